@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- BioEn log-weights theta-sweep on MI355X (BASELINE.json metric).
+
+One "step" = one complete pass of the hot path over the workload: the 8-point
+theta series (np.logspace(3, -0.5, 8), every theta cold-started, liblbfgs yaml
+defaults) of the log-weights optimizer on a synthetic N = 1e6 x M = 1024 ensemble
+(BASELINE.json configs[2]; the matrix is generated in HBM, so inputs are resident
+when the timed region starts).  With --gpus N the thetas are sharded over the N
+ranks (one process per GPU, launched by torch.distributed.run; this script itself
+is torch-free) and the per-theta results are all-gathered over RCCL/xGMI.
+
+value = (L-BFGS iterations of the whole job) * N * M / wall-clock, max over ranks.
+
+    python bench.py                      # 1 GPU, 1 warm-up + 1 timed sweep
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29511 bench.py --gpus 8 --steps 1 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LBFGS_DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9,
+                      wolfe=0.9, past=10, max_linesearch=100)   # bioen_optimize.yaml:33-46
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+SEED = 12345
+
+
+def synthetic_targets(M, seed=SEED):
+    """Per-observable vectors of the SURVEY 8(d) recipe (after forces.py:19-68)."""
+    rng = np.random.default_rng(seed)
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp = 0.1 * YTrue
+    sig_sim = 0.5 * YTrue
+    YTilde = rng.normal(YTrue, sig_exp) / sig_exp
+    return YTrue, sig_sim, sig_exp, YTilde
+
+
+def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
+    """Time the CPU path on a bounded sample of the SAME matrix (a column block read back
+    from HBM): the reference's own C + liblbfgs code when oracle/_ref travelled here
+    ("reference"), else the oracle's C restatement ("port")."""
+    cols = int(min(N, budget_cols))
+    sample = ctx.read_ytilde(0, M, 0, cols)
+    G = np.zeros(cols)
+    params = dict(LBFGS_DEFAULTS, max_iterations=cap_iterations)
+    cores = len(os.sched_getaffinity(0))
+    from oracle import ref_binding as R
+    if R.available():
+        kind = "reference"
+        R.set_fast_openmp_flag(1)
+        R.omp_set_num_threads(cores)
+        # warm the thread pool / page in
+        R.logw_f(G, G, sample[:, :1024].copy(), YTilde, theta)
+        import ctypes as C
+        g0, Gc, yT, YT = R._a(G).copy(), R._a(G), R._a(sample), R._a(YTilde)
+        w = np.empty(cols); tmp_n = np.empty(cols); tmp_m = np.empty(M); result = np.empty(cols)
+        yTT = np.ascontiguousarray(yT.T)            # the reference's transposed cache (c_bioen.pyx:471-473)
+        p = R.params_t()
+        p.g, p.G, p.yTilde, p.YTilde, p.w, p.result = R._p(g0), R._p(Gc), R._p(yT), R._p(YT), R._p(w), R._p(result)
+        p.theta, p.yTildeT, p.caching = float(theta), R._p(yTT), 1
+        p.tmp_n, p.tmp_m, p.m, p.n = R._p(tmp_n), R._p(tmp_m), M, cols
+        err = C.c_int(0)
+        t0 = time.perf_counter()
+        R.lib()._opt_lbfgs_logw(p, R._lbfgs_cfg(params), R.visual_params(0, 0), C.byref(err))
+        dt = time.perf_counter() - t0
+        # liblbfgs stops with -997 after exactly cap_iterations accepted steps, or earlier on convergence;
+        # the reference counts iterations only in a verbose printf, so re-derive: code -997 <=> cap reached
+        iters = cap_iterations if err.value == -997 else None
+        if iters is None:
+            from oracle import oracle_binding as O
+            iters = O.opt_lbfgs_logw(G, G, sample, YTilde, theta, params)[3]
+    else:
+        kind = "port"
+        from oracle import oracle_binding as O
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        t0 = time.perf_counter()
+        res = O.opt_lbfgs_logw(G, G, sample, YTilde, theta, params)
+        dt = time.perf_counter() - t0
+        iters = res[3]
+    return {
+        "value": iters * float(cols) * M / dt,
+        "unit": "iter*N*M/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": "columns [0,%d) of the same %dx%d matrix (M unchanged), theta=%g, yaml-default liblbfgs, "
+                  "%d iterations in %.2f s (%.1f ms/iteration), %s OpenMP threads, transposed cache on"
+                  % (cols, M, N, theta, iters, dt, 1e3 * dt / max(iters, 1), cores),
+        "ms_per_iteration": 1e3 * dt / max(iters, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1000000, help="structures (default: BASELINE configs[2])")
+    ap.add_argument("--m", type=int, default=1024, help="observables")
+    ap.add_argument("--nthetas", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cols", type=int, default=65536)
+    ap.add_argument("--cpu-iters", type=int, default=40)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import bioen_amd
+    from bioen_amd import sweep
+
+    N, M = args.n, args.m
+    thetas = np.logspace(3, -0.5, args.nthetas)
+    YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
+
+    comm = sweep.SocketComm() if world > 1 else sweep.SingleComm()
+    ndev = bioen_amd.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no MI355X visible to HIP -- this benchmark has no CPU path")
+    ctx = bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED, device=local_rank % ndev)
+    gather = "none"
+    rccl = False
+    if world > 1:
+        try:
+            rccl = sweep.init_rccl(ctx, comm)
+            gather = "rccl-allgather"
+        except bioen_amd.BioenHipError as e:   # report, keep the control-plane gather
+            gather = "tcp-allgather (RCCL unavailable: %s)" % e
+            rccl = False
+        ok = comm.allgather_object(rccl)
+        if not all(ok):
+            rccl = False
+            gather = "tcp-allgather (RCCL init failed on some rank)"
+
+    G = np.zeros(N)          # w0 = 1/N  =>  G = 0 ; GInit = G
+    g0 = np.zeros(N)
+
+    def step():
+        return sweep.sweep_log_weights(ctx, thetas, G, g0, LBFGS_DEFAULTS, comm=comm, rccl=rccl)
+
+    results = None
+    for _ in range(args.warmup):
+        results = step()
+
+    ctx.kernel_stats_enable(True)
+    ctx.kernel_stats_reset()
+    comm.barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        results = step()
+    ctx.synchronize()
+    comm.barrier()
+    dt = comm.max(time.perf_counter() - t0)
+    stats = ctx.kernel_stats()
+    ctx.kernel_stats_enable(False)
+
+    iters_per_sweep = sum(r["iterations"] for r in results)
+    evals_per_sweep = sum(r["evaluations"] for r in results)
+    total_iters = iters_per_sweep * args.steps
+    value = total_iters * float(N) * M / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant (slower) matrix-streaming kernel, rank 0's launches ----
+        mat_bytes = float(M) * N * 8
+        alg = {"forward": mat_bytes + 8.0 * N + 8.0 * M,        # read yTilde + w, write ybar
+               "adjoint": mat_bytes + 8.0 * M + 8.0 * N}        # read yTilde + r, write a
+        kern = {}
+        for name in ("forward", "adjoint"):
+            s = stats[name]
+            avg_ms = s["total_ms"] / max(s["launches"], 1)
+            kern[name] = {"kernel": "k_fwd_partial" if name == "forward" else "k_adj",
+                          "launches": s["launches"], "avg_ms": avg_ms,
+                          "algorithmic_bytes": alg[name],
+                          "achieved_GBs": alg[name] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
+        dom = max(kern, key=lambda k: kern[k]["avg_ms"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                with open(tpath) as fp:
+                    tj = json.load(fp)
+                key = "%s_N%d_M%d" % (kern[dom]["kernel"], N, M)
+                traffic = tj.get(key)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernels": kern}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(ctx, M, N, YTilde, 10.0, args.cpu_cols, args.cpu_iters)
+            except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+                cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
+
+        line = {
+            "metric": "L-BFGS iterations/sec x (N structures * M observables), log-weights theta sweep",
+            "value": value,
+            "unit": "iter*N*M/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "log-weights theta sweep, N=%d structures x M=%d observables, %d thetas "
+                                   "logspace(3,-0.5), cold starts, liblbfgs yaml defaults" % (N, M, len(thetas)),
+                       "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
+                       "sharding": "theta round-robin over %d rank(s)" % world, "gather": gather},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "sweep_wall_s": dt / max(args.steps, 1),
+            "iterations_per_sweep": iters_per_sweep,
+            "evaluations_per_sweep": evals_per_sweep,
+            "per_theta": [{"theta": r["theta"], "rank": r["rank"], "iterations": r["iterations"],
+                           "evaluations": r["evaluations"], "code": r["code"], "fmin": r["fmin"],
+                           "chi2": r["chi2"], "S": r["S"], "seconds": r["seconds"]} for r in results],
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+
+    ctx.close()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,307 @@
+"""ctypes loader for ``libbioen_hip.so`` (C ABI: ``include/bioen_hip.h``).
+
+There is deliberately NO CPU fallback: if the HIP library is missing, or no
+MI355X is visible, every compute entry point raises.  No torch, no numpy
+compute -- this module only moves pointers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbioen_hip.so")
+
+dp = C.POINTER(C.c_double)
+ctx_p = C.c_void_p
+
+
+class LbfgsConfig(C.Structure):
+    # field order = reference lbfgs_config_params (c_bioen_common.h:69-79)
+    _fields_ = [("linesearch", C.c_int), ("max_iterations", C.c_int),
+                ("delta", C.c_double), ("epsilon", C.c_double),
+                ("ftol", C.c_double), ("gtol", C.c_double),
+                ("wolfe", C.c_double), ("past", C.c_int),
+                ("max_linesearch", C.c_int)]
+
+
+class VisualParams(C.Structure):
+    # reference visual_params (c_bioen_common.h:89-92)
+    _fields_ = [("debug", C.c_size_t), ("verbose", C.c_size_t)]
+
+
+class OptResult(C.Structure):
+    _fields_ = [("fmin", C.c_double), ("chi2", C.c_double), ("kl", C.c_double),
+                ("seconds", C.c_double), ("lbfgs_code", C.c_int), ("iterations", C.c_int),
+                ("evaluations", C.c_int), ("reserved", C.c_int)]
+
+
+class BioenHipError(RuntimeError):
+    """Failure inside libbioen_hip (HIP runtime, allocation, bad argument)."""
+
+
+# every symbol include/bioen_hip.h declares: name -> (restype, argtypes)
+_SIGNATURES = {
+    "bioen_hip_version": (C.c_char_p, []),
+    "bioen_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bioen_hip_strerror": (C.c_char_p, [C.c_int]),
+    "bioen_hip_last_error": (C.c_char_p, []),
+    "bioen_hip_lbfgs_strerror": (C.c_char_p, [C.c_int]),
+    "bioen_hip_set_fast_openmp_flag": (None, [C.c_int]),
+    "bioen_hip_get_fast_openmp_flag": (C.c_int, []),
+    "bioen_hip_ctx_create": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_int, C.POINTER(ctx_p)]),
+    "bioen_hip_ctx_create_synthetic": (C.c_int, [C.c_int, C.c_int, dp, dp, dp, dp, C.c_ulonglong, C.c_int,
+                                                 C.POINTER(ctx_p)]),
+    "bioen_hip_ctx_destroy": (C.c_int, [ctx_p]),
+    "bioen_hip_ctx_shape": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bioen_hip_ctx_read_ytilde": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
+    "bioen_hip_ctx_set_ytilde_target": (C.c_int, [ctx_p, dp]),
+    "bioen_hip_synchronize": (C.c_int, [ctx_p]),
+    "bioen_hip_logw_weights": (C.c_int, [ctx_p, dp, dp, dp]),
+    "bioen_hip_logw_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
+    "bioen_hip_opt_lbfgs_logw": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(LbfgsConfig),
+                                           C.POINTER(VisualParams), dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_forces_weights": (C.c_int, [ctx_p, dp, dp, dp]),
+    "bioen_hip_forces_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
+    "bioen_hip_opt_lbfgs_forces": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(LbfgsConfig),
+                                             C.POINTER(VisualParams), dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_chi_squared": (C.c_int, [ctx_p, dp, dp, dp]),
+    "bioen_hip_kernel_stats": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong)]),
+    "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
+    "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
+    "bioen_hip_comm_allgather": (C.c_int, [ctx_p, dp, C.c_size_t, dp]),
+    "bioen_hip_comm_destroy": (C.c_int, [ctx_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libbioen_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise BioenHipError(
+                "bioen_amd: %s not found -- build it with `make -C bioen_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as e; e.build()'`). "
+                "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        raise BioenHipError("libbioen_hip: %s (%d): %s" % (L.bioen_hip_strerror(rc).decode(), rc,
+                                                          L.bioen_hip_last_error().decode()))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().bioen_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def as_f64(x, shape=None):
+    """float64, C-contiguous, np.matrix-safe view/copy of x (the reference's pyx reads
+    `.data` unchecked, c_bioen.pyx:274-290; we normalise instead)."""
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def ptr(a):
+    return a.ctypes.data_as(dp)
+
+
+def lbfgs_config(params):
+    c = LbfgsConfig()
+    for k in ("linesearch", "max_iterations", "past", "max_linesearch"):
+        setattr(c, k, int(params[k]))
+    for k in ("delta", "epsilon", "ftol", "gtol", "wolfe"):
+        setattr(c, k, float(params[k]))
+    return c
+
+
+class Context(object):
+    """Device-resident problem: yTilde (M x N) lives in HBM until close()."""
+
+    def __init__(self, yTilde=None, YTilde=None, device=0, _handle=None, _shape=None):
+        L = lib()
+        self._h = None
+        if _handle is not None:
+            self._h = _handle
+            self.m, self.n = _shape
+            return
+        yT = as_f64(yTilde)
+        if yT.ndim != 2:
+            raise ValueError("yTilde must be a 2-D (M x N) array")
+        self.m, self.n = yT.shape
+        YT = as_f64(YTilde).ravel()
+        if YT.size != self.m:
+            raise ValueError("YTilde must have M = %d entries" % self.m)
+        h = ctx_p()
+        check(L.bioen_hip_ctx_create(self.m, self.n, ptr(yT), ptr(YT), int(device), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def synthetic(cls, m, n, YTrue, sig_sim, sig_exp, YTilde, seed=12345, device=0):
+        L = lib()
+        a = [as_f64(v).ravel() for v in (YTrue, sig_sim, sig_exp, YTilde)]
+        for v in a:
+            if v.size != m:
+                raise ValueError("synthetic(): every per-observable vector needs M entries")
+        h = ctx_p()
+        check(L.bioen_hip_ctx_create_synthetic(int(m), int(n), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]),
+                                               C.c_ulonglong(seed), int(device), C.byref(h)))
+        return cls(_handle=h, _shape=(int(m), int(n)))
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if self._h is not None:
+            lib().bioen_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _nvec(self, x, name):
+        a = as_f64(x).ravel()
+        if a.size != self.n:
+            raise ValueError("%s must have N = %d entries, got %d" % (name, self.n, a.size))
+        return a
+
+    def _mvec(self, x, name):
+        a = as_f64(x).ravel()
+        if a.size != self.m:
+            raise ValueError("%s must have M = %d entries, got %d" % (name, self.m, a.size))
+        return a
+
+    # -- data ---------------------------------------------------------------------
+    def read_ytilde(self, row0=0, rows=None, col0=0, cols=None):
+        rows = self.m - row0 if rows is None else rows
+        cols = self.n - col0 if cols is None else cols
+        out = np.empty((rows, cols))
+        check(lib().bioen_hip_ctx_read_ytilde(self._h, row0, rows, col0, cols, ptr(out)))
+        return out
+
+    def set_target(self, YTilde):
+        check(lib().bioen_hip_ctx_set_ytilde_target(self._h, ptr(self._mvec(YTilde, "YTilde"))))
+
+    def synchronize(self):
+        check(lib().bioen_hip_synchronize(self._h))
+
+    # -- log-weights --------------------------------------------------------------
+    def logw_weights(self, g):
+        g = self._nvec(g, "g")
+        w = np.empty(self.n)
+        logs = C.c_double(0.0)
+        check(lib().bioen_hip_logw_weights(self._h, ptr(g), ptr(w), C.byref(logs)))
+        return w, logs.value
+
+    def logw_fdf(self, g, G, theta, need_f=True, need_grad=True):
+        g, G = self._nvec(g, "g"), self._nvec(G, "G")
+        f = C.c_double(0.0)
+        grad = np.empty(self.n) if need_grad else None
+        check(lib().bioen_hip_logw_fdf(self._h, ptr(g), ptr(G), float(theta), C.byref(f),
+                                       ptr(grad) if need_grad else None))
+        return (f.value if need_f else None), grad
+
+    def opt_lbfgs_logw(self, g0, G, theta, params, verbose=False, debug=False, want_weights=True):
+        g0, G = self._nvec(g0, "g0"), self._nvec(G, "G")
+        cfg = lbfgs_config(params)
+        vis = VisualParams(int(bool(debug)), int(bool(verbose)))
+        res = np.empty(self.n)
+        w = np.empty(self.n) if want_weights else None
+        info = OptResult()
+        check(lib().bioen_hip_opt_lbfgs_logw(self._h, ptr(g0), ptr(G), float(theta), C.byref(cfg), C.byref(vis),
+                                             ptr(res), ptr(w) if want_weights else None, C.byref(info)))
+        return res, w, info
+
+    # -- forces -------------------------------------------------------------------
+    def forces_weights(self, forces, w0):
+        f, w0 = self._mvec(forces, "forces"), self._nvec(w0, "w0")
+        w = np.empty(self.n)
+        check(lib().bioen_hip_forces_weights(self._h, ptr(f), ptr(w0), ptr(w)))
+        return w
+
+    def forces_fdf(self, forces, w0, theta, need_f=True, need_grad=True):
+        fo, w0 = self._mvec(forces, "forces"), self._nvec(w0, "w0")
+        f = C.c_double(0.0)
+        grad = np.empty(self.m) if need_grad else None
+        check(lib().bioen_hip_forces_fdf(self._h, ptr(fo), ptr(w0), float(theta), C.byref(f),
+                                         ptr(grad) if need_grad else None))
+        return (f.value if need_f else None), grad
+
+    def opt_lbfgs_forces(self, forces0, w0, theta, params, verbose=False, debug=False, want_weights=True):
+        f0, w0 = self._mvec(forces0, "forces0"), self._nvec(w0, "w0")
+        cfg = lbfgs_config(params)
+        vis = VisualParams(int(bool(debug)), int(bool(verbose)))
+        res = np.empty(self.m)
+        w = np.empty(self.n) if want_weights else None
+        info = OptResult()
+        check(lib().bioen_hip_opt_lbfgs_forces(self._h, ptr(f0), ptr(w0), float(theta), C.byref(cfg), C.byref(vis),
+                                               ptr(res), ptr(w) if want_weights else None, C.byref(info)))
+        return res, w, info
+
+    # -- shared -------------------------------------------------------------------
+    def chi_squared(self, w):
+        w = self._nvec(w, "w")
+        yave = np.empty(self.m)
+        chi2 = C.c_double(0.0)
+        check(lib().bioen_hip_chi_squared(self._h, ptr(w), ptr(yave), C.byref(chi2)))
+        return chi2.value, yave
+
+    # -- measurement ---------------------------------------------------------------
+    def kernel_stats_enable(self, on=True):
+        check(lib().bioen_hip_kernel_stats_enable(self._h, 1 if on else 0))
+
+    def kernel_stats_reset(self):
+        check(lib().bioen_hip_kernel_stats_reset(self._h))
+
+    def kernel_stats(self):
+        out = {}
+        for which, name in ((0, "forward"), (1, "adjoint")):
+            ms = C.c_double(0.0)
+            cnt = C.c_longlong(0)
+            check(lib().bioen_hip_kernel_stats(self._h, which, C.byref(ms), C.byref(cnt)))
+            out[name] = {"total_ms": ms.value, "launches": cnt.value}
+        return out
+
+    # -- RCCL ------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * 128)()
+        check(lib().bioen_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        check(lib().bioen_hip_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_allgather(self, send, nranks):
+        send = as_f64(send).ravel()
+        recv = np.empty(send.size * nranks)
+        check(lib().bioen_hip_comm_allgather(self._h, ptr(send), send.size, ptr(recv)))
+        return recv.reshape(nranks, send.size)

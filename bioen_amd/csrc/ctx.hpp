@@ -1,0 +1,118 @@
+// Context and device-buffer layout of the MI355X BioEn hot path.
+//
+// HBM layout
+//   Y      : yTilde, row-major, padded to  mp x ld  doubles
+//              ld = round_up(n, 128)   (every row starts on a 1 KiB boundary, so a
+//                                       wave's 64 x 16 B load is one aligned KiB)
+//              mp = round_up(m, 32)    (4 waves x 8 rows per forward block; 4 x 8
+//                                       unrolled rows per adjoint block)
+//            padding is zero, so no matrix kernel needs an edge branch.
+//   N-vectors (x, xp, g, gp, d, w, G/w0, a, t, S[6], Y[6]) : ld doubles, pad = 0
+//   M-vectors (YT, ybar, r, um, gm)                         : mp doubles, pad = 0
+//   scal   : a few dozen device-resident doubles (dot products, alphas, f, ...)
+//            so that only line-search decisions ever cross PCIe.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/bioen_hip.h"
+
+namespace bioen {
+
+constexpr int kHistory = 6;        // liblbfgs default m (lbfgs.c:113), never overridden by BioEn
+constexpr int kColAlign = 128;     // doubles: one wave x 16 B
+constexpr int kRowAlign = 32;
+constexpr int kMaxPartials = 1024; // upper bound on any reduction grid
+
+// device-resident scalar slots
+enum Slot : int {
+    S_F = 0,      // objective
+    S_DG,         // grad . d   at the trial point
+    S_GG,         // grad . grad
+    S_XX,         // x . x
+    S_DGINIT,     // gp . d     at the accepted point (for the next line search)
+    S_LOGS,       // log sum exp(x)
+    S_P,          // sum_j w_j (x_j - G_j)
+    S_CHI,        // sum_i r_i^2
+    S_C,          // sum_i ybar_i r_i
+    S_LOGS0,      // log sum exp(G)
+    S_KL,         // forces: sum_j w_j log(w_j / w0_j)
+    S_TSUM,       // forces: sum_j t_j
+    S_YS,         // y.s of the newest pair
+    S_YY,         // y.y of the newest pair
+    S_THETA,
+    S_SPARE,
+    S_YSH,                         // [kHistory] y.s per history slot
+    S_ALPHA = S_YSH + kHistory,    // [kHistory]
+    S_COUNT = S_ALPHA + kHistory
+};
+
+struct KernelTimer {
+    bool enabled = false;
+    double total_ms[2] = {0.0, 0.0};
+    long long launches[2] = {0, 0};
+    struct Pair { hipEvent_t a, b; int which; };
+    std::vector<Pair> pending;
+    std::vector<Pair> pool;
+};
+
+}  // namespace bioen
+
+struct bioen_hip_ctx {
+    int device = 0;
+    int m = 0, n = 0;
+    int mp = 0;
+    size_t ld = 0;
+    hipStream_t stream = nullptr;
+
+    double* Y = nullptr;      // mp x ld
+    double* YT = nullptr;     // mp   experimental targets (YTilde)
+    double* ybar = nullptr;   // mp
+    double* r = nullptr;      // mp
+    double* um = nullptr;     // mp   M-vector input  (forces)
+    double* gm = nullptr;     // mp   M-vector output (forces gradient)
+
+    // N-vectors
+    double *x = nullptr, *xp = nullptr, *g = nullptr, *gp = nullptr, *d = nullptr;
+    double *w = nullptr, *fixed = nullptr /* G or w0 */, *a = nullptr, *t = nullptr;
+    double* S[bioen::kHistory] = {};
+    double* Yh[bioen::kHistory] = {};
+    bool history_allocated = false;
+
+    double* fwd_partial = nullptr;   // mp x fwd_ctiles
+    int fwd_ctiles = 0;              // column tiles of the forward pass
+    int fwd_steps = 0;               // 128-column steps per tile
+    double* part = nullptr;          // 8 x kMaxPartials reduction partials
+    double* scal = nullptr;          // S_COUNT device scalars
+    double* host_scal = nullptr;     // pinned mirror
+
+    int rec_flip = 0;                // ping-pong index of the recursion's dot partials
+    bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)
+    bioen::KernelTimer timer;
+
+    // RCCL (lazy, dlopen)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
+    double* comm_buf = nullptr;
+    size_t comm_buf_count = 0;
+};
+
+namespace bioen {
+
+void set_last_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define BIOEN_HIP_CHECK(expr)                                                      \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) return ::bioen::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace bioen

@@ -1,0 +1,292 @@
+"""theta-series (confidence-parameter sweep) sharded over the GPUs of one node.
+
+The reference runs the series serially (``bioen/analyze/procedure.py:62-83``:
+``for theta in options.thetas``).  Every theta is an independent L-BFGS problem
+over the same read-only (yTilde, YTilde, G), so the series shards with no
+communication inside the loop: rank r solves its thetas against its own
+HBM-resident copy of yTilde, and ONE all-gather at the end ships
+(theta, fmin, chi2, S, iterations, evaluations, status, seconds, w[N]) per theta
+to every rank -- over RCCL/xGMI when the context has an RCCL communicator,
+else over the control-plane communicator (which is what the CPU tests use).
+
+Control plane (rendezvous, barrier, max-over-ranks): ``SocketComm`` (pure-Python
+TCP, no torch -- the GPU processes stay torch-free) or ``TorchComm`` (any
+``torch.distributed`` process group, e.g. gloo in the tests).
+"""
+import os
+import pickle
+import socket
+import struct
+import time
+
+import numpy as np
+
+HEADER = 8   # doubles in front of w[N]: theta, fmin, chi2, kl, iterations, evaluations, code, seconds
+
+
+# ------------------------------------------------------------------------------------
+# sharding
+# ------------------------------------------------------------------------------------
+def shard_thetas(thetas, rank, world):
+    """Indices (into `thetas`) that `rank` solves.
+
+    Small theta = weak prior = more L-BFGS iterations, so the thetas are dealt
+    round-robin in ascending order: the expensive ones land on different ranks."""
+    order = np.argsort(np.asarray(thetas, dtype=np.float64), kind="stable")
+    return [int(i) for k, i in enumerate(order) if k % world == rank]
+
+
+# ------------------------------------------------------------------------------------
+# communicators (control plane)
+# ------------------------------------------------------------------------------------
+class SingleComm(object):
+    rank, world = 0, 1
+
+    def allgather_array(self, a):
+        return np.asarray(a, dtype=np.float64).reshape(1, -1).copy()
+
+    def allgather_object(self, obj):
+        return [obj]
+
+    def barrier(self):
+        pass
+
+    def max(self, x):
+        return float(x)
+
+    def close(self):
+        pass
+
+
+class TorchComm(object):
+    """Adapter over an initialised ``torch.distributed`` process group (CPU tests: gloo)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self._group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allgather_array(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(-1))
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(out, t, group=self._group)
+        return np.stack([o.numpy() for o in out])
+
+    def allgather_object(self, obj):
+        out = [None] * self.world
+        self._dist.all_gather_object(out, obj, group=self._group)
+        return out
+
+    def barrier(self):
+        self._dist.barrier(group=self._group)
+
+    def max(self, x):
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
+        return float(t[0])
+
+    def close(self):
+        pass
+
+
+class SocketComm(object):
+    """Star-topology TCP communicator for the ranks of ONE node, driven by the
+    torchrun environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT).
+
+    Rank 0 listens on an ephemeral port and publishes it in a rendezvous file under
+    /tmp keyed by MASTER_PORT (torchrun's own store owns MASTER_PORT itself)."""
+
+    MAGIC = b"BIOENAMD"
+
+    def __init__(self, rank=None, world=None, timeout=300.0):
+        self.rank = int(os.environ.get("RANK", 0) if rank is None else rank)
+        self.world = int(os.environ.get("WORLD_SIZE", 1) if world is None else world)
+        self._peers = []
+        self._sock = None
+        if self.world == 1:
+            return
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = os.environ.get("MASTER_PORT", "29500")
+        run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+        path = os.path.join("/tmp", "bioen_amd_rdzv_%s_%s_%d" % (port, run_id, os.getuid()))
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", 0))
+            srv.listen(self.world)
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as fp:
+                fp.write("%d %d\n" % (srv.getsockname()[1], os.getpid()))
+            os.replace(tmp, path)
+            self._path = path
+            peers = {}
+            srv.settimeout(timeout)
+            while len(peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                hello = self._recv_exact(conn, len(self.MAGIC) + 4)
+                if hello[:len(self.MAGIC)] != self.MAGIC:
+                    conn.close()
+                    continue
+                r = struct.unpack("<i", hello[len(self.MAGIC):])[0]
+                conn.sendall(self.MAGIC)
+                peers[r] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            host = addr if addr not in ("localhost",) else "127.0.0.1"
+            while True:
+                try:
+                    with open(path) as fp:
+                        p = int(fp.read().split()[0])
+                    s = socket.create_connection((host, p), timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.sendall(self.MAGIC + struct.pack("<i", self.rank))
+                    s.settimeout(timeout)
+                    if self._recv_exact(s, len(self.MAGIC)) == self.MAGIC:
+                        self._sock = s
+                        break
+                    s.close()
+                except (OSError, ValueError, IndexError):
+                    pass
+                if time.time() > deadline:
+                    raise RuntimeError("SocketComm: rendezvous with rank 0 timed out (%s)" % path)
+                time.sleep(0.05)
+
+    @staticmethod
+    def _recv_exact(s, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = s.recv(min(1 << 20, n - len(buf)))
+            if not chunk:
+                raise RuntimeError("SocketComm: peer closed the connection")
+            buf += chunk
+        return bytes(buf)
+
+    def _send_msg(self, s, payload):
+        s.sendall(struct.pack("<q", len(payload)) + payload)
+
+    def _recv_msg(self, s):
+        n = struct.unpack("<q", self._recv_exact(s, 8))[0]
+        return self._recv_exact(s, n)
+
+    def _allgather_bytes(self, payload):
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [self._recv_msg(p) for p in self._peers]
+            blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+            for p in self._peers:
+                self._send_msg(p, blob)
+            return parts
+        self._send_msg(self._sock, payload)
+        return pickle.loads(self._recv_msg(self._sock))
+
+    def allgather_array(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(-1)
+        parts = self._allgather_bytes(a.tobytes())
+        return np.stack([np.frombuffer(p, dtype=np.float64) for p in parts])
+
+    def allgather_object(self, obj):
+        return [pickle.loads(p) for p in self._allgather_bytes(pickle.dumps(obj))]
+
+    def barrier(self):
+        self._allgather_bytes(b"")
+
+    def max(self, x):
+        return float(max(self.allgather_object(float(x))))
+
+    def close(self):
+        for p in self._peers:
+            p.close()
+        if self._sock is not None:
+            self._sock.close()
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.remove(self._path)
+            except OSError:
+                pass
+        self._peers, self._sock = [], None
+
+
+def init_rccl(ctx, comm):
+    """Create the RCCL communicator of `ctx` (one rank per GPU): rank 0 draws the
+    ncclUniqueId, the control plane ships its 128 bytes."""
+    if comm.world == 1:
+        return False
+    uid = ctx.comm_unique_id() if comm.rank == 0 else None
+    uid = comm.allgather_object(uid)[0]
+    ctx.comm_init(uid, comm.rank, comm.world)
+    return True
+
+
+# ------------------------------------------------------------------------------------
+# the sweep
+# ------------------------------------------------------------------------------------
+def _pack(theta, w, info, n):
+    rec = np.zeros(HEADER + n)
+    rec[:HEADER] = (theta, info.fmin, info.chi2, info.kl, info.iterations, info.evaluations,
+                    info.lbfgs_code, info.seconds)
+    rec[HEADER:] = w
+    return rec
+
+
+def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None):
+    """Solve every theta of the series, sharded over comm.world ranks, and gather.
+
+    ctx    : bioen_amd.Context (may be None when `solve` does not need one and rccl is False)
+    solve  : callable(theta) -> (w[n], info) with info.{fmin,chi2,kl,iterations,evaluations,
+             lbfgs_code,seconds}; the product passes a closure over ctx.opt_lbfgs_logw /
+             ctx.opt_lbfgs_forces, the CPU tests inject their checker.
+    rccl   : gather through ctx.comm_allgather (RCCL over xGMI) instead of `comm`.
+    Returns a list (in the order of `thetas`) of dicts, identical on every rank.
+    """
+    comm = comm or SingleComm()
+    thetas = [float(t) for t in thetas]
+    n = ctx.n if n is None else n
+    mine = shard_thetas(thetas, comm.rank, comm.world)
+    per_rank = -(-len(thetas) // comm.world)          # ceil: fixed-size gather payload
+    buf = np.zeros((per_rank, HEADER + n))
+    buf[:, 0] = np.nan                                 # unused slots are marked by theta = NaN
+    for slot, idx in enumerate(mine):
+        w, info = solve(thetas[idx])
+        buf[slot] = _pack(thetas[idx], np.asarray(w, dtype=np.float64).reshape(-1), info, n)
+
+    if comm.world == 1:
+        gathered = buf.reshape(1, -1)
+    elif rccl:
+        gathered = ctx.comm_allgather(buf.reshape(-1), comm.world)
+    else:
+        gathered = comm.allgather_array(buf.reshape(-1))
+    gathered = gathered.reshape(comm.world, per_rank, HEADER + n)
+
+    out = [None] * len(thetas)
+    for r in range(comm.world):
+        for slot, idx in enumerate(shard_thetas(thetas, r, comm.world)):
+            rec = gathered[r, slot]
+            out[idx] = {"theta": rec[0], "fmin": rec[1], "chi2": rec[2], "S": -rec[3],
+                        "iterations": int(rec[4]), "evaluations": int(rec[5]), "code": int(rec[6]),
+                        "seconds": rec[7], "rank": r, "w": rec[HEADER:].copy()}
+    return out
+
+
+def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=False, verbose=False):
+    """Cold-started log-weights series (every theta starts from g_init, as
+    procedure.py:46,66 does for generic data)."""
+    def solve(theta):
+        _, w, info = ctx.opt_lbfgs_logw(g_init, G, theta, lbfgs_params, verbose=verbose)
+        return w, info
+    return theta_sweep(ctx, thetas, solve, comm=comm, rccl=rccl)
+
+
+def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=False, verbose=False):
+    """Cold-started forces series (the ala5 notebook's protocol)."""
+    def solve(theta):
+        _, w, info = ctx.opt_lbfgs_forces(forces_init, w0, theta, lbfgs_params, verbose=verbose)
+        return w, info
+    return theta_sweep(ctx, thetas, solve, comm=comm, rccl=rccl)

@@ -1,0 +1,154 @@
+/* bioen_hip.h -- C ABI of the MI355X (gfx950) BioEn optimizer hot path.
+ *
+ * This is the boundary a BioEn maintainer binds instead of the Cython module
+ * bioen/optimize/ext/c_bioen.pyx (ctypes stub: bioen_amd/optimize/ext/c_bioen.py,
+ * walk-through: INTEGRATION.md).  Plain C: pointers, sizes, PODs.  No torch
+ * types, no C++ types.  All arithmetic is IEEE double.
+ *
+ * Ownership: every `const double*` / `double*` argument is a HOST buffer owned
+ * by the caller and only read (inputs) or written (outputs) during the call;
+ * nothing is retained after return.  Device memory belongs to the context and
+ * is released by bioen_hip_ctx_destroy().  A context is not re-entrant (one
+ * HIP stream, one scratch set); distinct contexts are independent.
+ *
+ * Return value: 0 on success, a negative BIOEN_HIP_E* code otherwise
+ * (bioen_hip_strerror() gives the text; bioen_hip_last_error() the detail).
+ * The L-BFGS drivers additionally report the liblbfgs status code through
+ * `lbfgs_code` (0,1,2 = success; negative = liblbfgs error numbering,
+ * third-party/liblbfgs-1.10/include/lbfgs.h:76-147), which the Python shim
+ * turns into the reference's RuntimeError("... return code ...").
+ */
+#ifndef BIOEN_HIP_H
+#define BIOEN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIOEN_HIP_OK 0
+#define BIOEN_HIP_EINVAL (-1)    /* bad argument (NULL, non-positive size, ...) */
+#define BIOEN_HIP_ENODEV (-2)    /* no usable HIP device */
+#define BIOEN_HIP_EHIP (-3)      /* a HIP runtime call failed */
+#define BIOEN_HIP_ENOMEM (-4)    /* device or host allocation failed */
+#define BIOEN_HIP_ERCCL (-5)     /* RCCL unavailable or an RCCL call failed */
+#define BIOEN_HIP_ESTATE (-6)    /* call not valid in the context's state */
+
+typedef struct bioen_hip_ctx bioen_hip_ctx;
+
+/* Same fields, same order as the reference's lbfgs_config_params
+ * (bioen/optimize/ext/c_bioen_common.h:69-79) so the shim mirrors its packing. */
+typedef struct bioen_lbfgs_config {
+    int linesearch;      /* 0 More-Thuente, 1 Armijo, 2 Wolfe (yaml default), 3 strong Wolfe */
+    int max_iterations;
+    double delta;
+    double epsilon;
+    double ftol;
+    double gtol;
+    double wolfe;
+    int past;
+    int max_linesearch;
+} bioen_lbfgs_config;
+
+/* reference visual_params, c_bioen_common.h:89-92 */
+typedef struct bioen_visual_params {
+    size_t debug;
+    size_t verbose;
+} bioen_visual_params;
+
+/* What the reference only prints (c_bioen_kernels_logw.c:646-653) is returned. */
+typedef struct bioen_opt_result {
+    double fmin;          /* final negative log-posterior                        */
+    double chi2;          /* 0.5 * |yTilde w - YTilde|^2 at the optimum          */
+    double kl;            /* KL(w || w0) = -S at the optimum (S: utils.py:83-106) */
+    double seconds;       /* wall time inside the minimiser (device-synchronised) */
+    int lbfgs_code;       /* liblbfgs status                                      */
+    int iterations;       /* progress-callback count (accepted line searches)     */
+    int evaluations;      /* objective+gradient evaluations                       */
+    int reserved;
+} bioen_opt_result;
+
+/* ---- library / device ------------------------------------------------------ */
+const char* bioen_hip_version(void);
+int bioen_hip_device_count(int* count);
+const char* bioen_hip_strerror(int code);
+const char* bioen_hip_last_error(void);
+/* replaces lbfgs_strerror(), bioen/optimize/ext/c_bioen_error.c:23-115 */
+const char* bioen_hip_lbfgs_strerror(int lbfgs_code);
+/* replace _set_fast_openmp_flag/_get_fast_openmp_flag (c_bioen_common.c:46-55):
+ * accepted and stored; device reductions are fixed-order either way. */
+void bioen_hip_set_fast_openmp_flag(int flag);
+int bioen_hip_get_fast_openmp_flag(void);
+
+/* ---- context: yTilde (m x n, row-major, host) is uploaded once and stays
+ *      resident in HBM across evaluations, thetas and minimiser runs.
+ *      Replaces the per-call pointer bag params_t (c_bioen_common.h:44-60) and
+ *      the host-side transposed copy of c_bioen.pyx:471-473 (not needed). ---- */
+int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTilde,
+                         int device, bioen_hip_ctx** ctx);
+/* Synthetic ensemble generated directly in HBM (bench / scale tests):
+ *   yTilde[i][j] = (YTrue[i] + sig_sim[i] * z_ij) / sig_exp[i],  z_ij ~ N(0,1)
+ * with z_ij a counter-based Box-Muller stream of (seed, i, j); recipe after
+ * forces.gen_sythetic_ensemble (bioen/optimize/forces.py:44-68). */
+int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const double* sig_sim,
+                                   const double* sig_exp, const double* YTilde,
+                                   unsigned long long seed, int device, bioen_hip_ctx** ctx);
+int bioen_hip_ctx_destroy(bioen_hip_ctx* ctx);
+int bioen_hip_ctx_shape(const bioen_hip_ctx* ctx, int* m, int* n);
+/* copy rows [row0,row0+rows) x cols [col0,col0+cols) of the resident matrix to host (row-major) */
+int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, int cols, double* out);
+int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
+int bioen_hip_synchronize(bioen_hip_ctx* ctx);
+
+/* ---- log-weights method ---------------------------------------------------- */
+/* _get_weights, c_bioen_kernels_logw.c:55-94: w = softmax(g); *log_s = log sum exp(g) */
+int bioen_hip_logw_weights(bioen_hip_ctx* ctx, const double* g, double* w, double* log_s);
+/* interface_lbfgs_logw, c_bioen_kernels_logw.c:525-561 (= _get_weights +
+ * _bioen_log_posterior_logw :131-147 + _grad_bioen_log_posterior_logw :151-268).
+ * `f` and/or `grad` may be NULL (f-only skips the adjoint pass). */
+int bioen_hip_logw_fdf(bioen_hip_ctx* ctx, const double* g, const double* G, double theta,
+                       double* f, double* grad);
+/* _opt_lbfgs_logw, c_bioen_kernels_logw.c:581-669, with the liblbfgs loop
+ * (lbfgs.c:245-641) device-resident.  result[n] = optimal log-weights;
+ * w_opt[n] (optional, may be NULL) = softmax(result). */
+int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* ctx, const double* g0, const double* G, double theta,
+                             const bioen_lbfgs_config* config, const bioen_visual_params* visual,
+                             double* result, double* w_opt, bioen_opt_result* info);
+
+/* ---- forces method --------------------------------------------------------- */
+/* _get_weights_from_forces, c_bioen_kernels_forces.c:111-224 */
+int bioen_hip_forces_weights(bioen_hip_ctx* ctx, const double* forces, const double* w0, double* w);
+/* interface_lbfgs_forces, c_bioen_kernels_forces.c:43-76 (= F1 + :227-277 + :280-340) */
+int bioen_hip_forces_fdf(bioen_hip_ctx* ctx, const double* forces, const double* w0, double theta,
+                         double* f, double* grad);
+/* _opt_lbfgs_forces, c_bioen_kernels_forces.c:574-662.  result[m] = optimal forces. */
+int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* ctx, const double* forces0, const double* w0,
+                               double theta, const bioen_lbfgs_config* config,
+                               const bioen_visual_params* visual, double* result, double* w_opt,
+                               bioen_opt_result* info);
+
+/* ---- shared pieces --------------------------------------------------------- */
+/* _bioen_chi_squared (c_bioen_common.c:70-108) / _getAve (c_bioen_kernels_forces.c:93-109):
+ * yave[m] = yTilde . w ; *chi2 = 0.5 |yave - YTilde|^2.  Either output may be NULL. */
+int bioen_hip_chi_squared(bioen_hip_ctx* ctx, const double* w, double* yave, double* chi2);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------- */
+/* Average device time (HIP events on the context's stream) and launch count of the
+ * two matrix-streaming kernels since the last reset. which: 0 = forward, 1 = adjoint. */
+int bioen_hip_kernel_stats(bioen_hip_ctx* ctx, int which, double* total_ms, long long* launches);
+int bioen_hip_kernel_stats_reset(bioen_hip_ctx* ctx);
+int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
+
+/* ---- theta-sweep gather over RCCL (multi-GPU; one process per GPU) ----------------- */
+/* rank 0 obtains the 128-byte ncclUniqueId; the host side ships it to the other ranks */
+int bioen_hip_comm_unique_id(unsigned char id[128]);
+int bioen_hip_comm_init(bioen_hip_ctx* ctx, const unsigned char id[128], int rank, int nranks);
+/* all-gather of `count` doubles per rank, host in / host out (staged through HBM, RCCL over xGMI) */
+int bioen_hip_comm_allgather(bioen_hip_ctx* ctx, const double* send, size_t count, double* recv);
+int bioen_hip_comm_destroy(bioen_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOEN_HIP_H */

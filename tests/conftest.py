@@ -1,0 +1,53 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    for k in ("theta", "kind"):
+        if k in d:
+            d[k] = d[k].item()
+    if "y" in d and d["y"].size == 0:
+        d["y"] = d["yTilde"]
+    return d
+
+
+def golden_files(kind):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        b = os.path.basename(p)
+        if b == "error_codes.npz":
+            continue
+        z = np.load(p, allow_pickle=False)
+        if z["kind"].item() == kind:
+            out.append(b)
+    return out
+
+
+LOGW_GOLDEN = golden_files("logw")
+FORCES_GOLDEN = golden_files("forces")
+
+LBFGS_DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9,
+                      wolfe=0.9, past=10, max_linesearch=100)
+LBFGS_TIGHT = dict(LBFGS_DEFAULTS, epsilon=1e-7, delta=1e-11)
+
+
+@pytest.fixture(scope="session")
+def have_ref():
+    from oracle import ref_binding
+    return ref_binding.available()
