@@ -52,8 +52,9 @@ def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
     sample = ctx.read_ytilde(0, M, 0, cols)
     G = np.zeros(cols)
     params = dict(LBFGS_DEFAULTS, max_iterations=cap_iterations)
-    cores = len(os.sched_getaffinity(0))
     from oracle import ref_binding as R
+    from oracle import cpus
+    cores = cpus.usable_cpus()
     if R.available():
         kind = "reference"
         R.set_fast_openmp_flag(1)

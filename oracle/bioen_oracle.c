@@ -73,8 +73,11 @@ double oracle_logw_weights(const double* g, double* w, size_t n) {
 
 /* forward pass: out[i] = sum_j yTilde[i,j] v[j]   (c_bioen_common.c:76-86,
  * c_bioen_kernels_forces.c:93-109) */
+/* small problems run serially: a 256-thread team costs more than the loop */
+#define PAR_MIN ((size_t)1 << 20)
+
 static void matvec(const double* yTilde, const double* v, double* out, size_t m, size_t n) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m * n >= PAR_MIN)
     for (size_t i = 0; i < m; ++i) {
         const double* row = yTilde + i * n;
         double acc = 0.0;
@@ -87,7 +90,7 @@ static void matvec(const double* yTilde, const double* v, double* out, size_t m,
  * by rows (the reference walks a transposed copy instead,
  * c_bioen_kernels_logw.c:185-195; same sums, different order). */
 static void matvec_t(const double* yTilde, const double* u, double* out, size_t m, size_t n) {
-#pragma omp parallel
+#pragma omp parallel if (m * n >= PAR_MIN)
     {
         const size_t chunk = 2048;
 #pragma omp for schedule(static)

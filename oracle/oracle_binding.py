@@ -10,6 +10,8 @@ import subprocess
 
 import numpy as np
 
+from . import cpus
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "libbioen_oracle.so")
 
@@ -43,6 +45,7 @@ def lib():
     if _lib is None:
         if not os.path.isfile(_PATH):
             build()
+        cpus.default_omp_threads()
         L = C.CDLL(_PATH)
         L.oracle_logw_weights.restype = C.c_double
         L.oracle_logw_weights.argtypes = [dp, dp, C.c_size_t]

@@ -16,6 +16,8 @@ import os
 
 import numpy as np
 
+from . import cpus
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "_ref", "libbioen_ref.so")
 
@@ -54,6 +56,7 @@ def available():
 def lib():
     global _lib
     if _lib is None:
+        cpus.default_omp_threads()
         L = C.CDLL(_PATH)
         L._get_weights.restype = C.c_double
         L._get_weights.argtypes = [dp, dp, C.c_size_t]

@@ -26,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import ref_binding as R  # noqa: E402
+from oracle import oracle_binding as O  # noqa: E402
 
 REFDATA = "/root/reference/test/optimize/data"
 
@@ -62,6 +63,13 @@ def logw_case(GInit, G, y, yTilde, YTilde, theta, ref_value=None):
         out["lbfgs_%s_fmin" % tag] = fmin
         out["lbfgs_%s_code" % tag] = code
         out["lbfgs_%s_wopt" % tag] = R.get_weights(gopt)[0]
+        # How well do these settings pin the optimum?  The same algorithm restated with a
+        # different summation order (oracle/bioen_oracle.c) stops at a slightly different point;
+        # the spread between the two is the conditioning of the stopping point itself and
+        # bounds what ANY implementation can be held to on this case.
+        g_o = O.opt_lbfgs_logw(GInit, G, yTilde, YTilde, theta, cfg)[0]
+        w_o = O.logw_weights(g_o)[0]
+        out["lbfgs_%s_wspread" % tag] = np.abs(w_o - out["lbfgs_%s_wopt" % tag]).max() / out["lbfgs_%s_wopt" % tag].max()
     if ref_value is not None:
         out["ref_fmin_scipy_bfgs"] = float(ref_value)
     return out
@@ -89,6 +97,9 @@ def forces_case(forces_init, w0, y, yTilde, YTilde, theta, ref_value=None):
         out["lbfgs_%s_code" % tag] = code
         out["lbfgs_%s_fopt" % tag] = fopt
         out["lbfgs_%s_wopt" % tag] = R.forces_weights(fopt, w0, yTilde)
+        f_o = O.opt_lbfgs_forces(forces_init, w0, yTilde, YTilde, theta, cfg)[0]
+        w_o = O.forces_weights(f_o, w0, yTilde)
+        out["lbfgs_%s_wspread" % tag] = np.abs(w_o - out["lbfgs_%s_wopt" % tag]).max() / out["lbfgs_%s_wopt" % tag].max()
     if ref_value is not None:
         out["ref_fmin_scipy_bfgs"] = float(ref_value)
     return out

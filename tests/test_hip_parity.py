@@ -97,9 +97,12 @@ def test_logw_lbfgs_vs_reference(hip, name, tag, params):
         # trajectories that differ in the last bits may stop an iteration apart
         tol = FMIN_RTOL if tag == "tight" else 5e-6
         assert rel(info.fmin, float(d["lbfgs_%s_fmin" % tag])) < tol, (name, info.fmin)
-        if tag == "tight":
-            wref = d["lbfgs_tight_wopt"]
-            assert np.abs(w - wref).max() <= W_RTOL * wref.max(), name
+        # weights: 1e-5 where the settings pin the optimum that well; where the reference and
+        # its own restatement (different summation order) already stop further apart than
+        # that (stored as *_wspread by make_golden.py) the bound is that spread
+        wref = d["lbfgs_%s_wopt" % tag]
+        wtol = max(W_RTOL, 3.0 * float(d["lbfgs_%s_wspread" % tag]))
+        assert np.abs(w - wref).max() <= wtol * wref.max(), (name, np.abs(w - wref).max() / wref.max(), wtol)
         # self-consistency (test_find_opt_analytical_grad_logw.py:181-188): fmin == L(gopt)
         f_again, _ = ctx.logw_fdf(gopt, d["G"], d["theta"], need_grad=False)
         assert rel(f_again, info.fmin) < 5e-14
@@ -117,7 +120,8 @@ def test_forces_lbfgs_vs_reference(hip, name):
         assert info.lbfgs_code in (0, 1, 2)
         assert rel(info.fmin, float(d["lbfgs_def_fmin"])) < 5e-6, (name, info.fmin)
         wref = d["lbfgs_def_wopt"]
-        assert np.abs(w - wref).max() <= 1e-3 * wref.max()
+        wtol = max(W_RTOL, 3.0 * float(d["lbfgs_def_wspread"]))
+        assert np.abs(w - wref).max() <= wtol * wref.max(), (name, np.abs(w - wref).max() / wref.max(), wtol)
         f_again, _ = ctx.forces_fdf(fopt, d["w0"], d["theta"], need_grad=False)
         assert rel(f_again, info.fmin) < 5e-14
         if "ref_fmin_scipy_bfgs" in d:
