@@ -69,6 +69,7 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_selftest_lbfgs": (C.c_int, [C.c_int, C.c_int, dp, C.POINTER(LbfgsConfig), dp, C.POINTER(OptResult)]),
     "bioen_hip_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
     "bioen_hip_comm_allgather": (C.c_int, [ctx_p, dp, C.c_size_t, dp]),
@@ -133,6 +134,16 @@ def lbfgs_config(params):
     for k in ("delta", "epsilon", "ftol", "gtol", "wolfe"):
         setattr(c, k, float(params[k]))
     return c
+
+
+def selftest_lbfgs(kind, x0, params):
+    """Run the library's L-BFGS driver on a built-in host objective (no GPU). -> (x, OptResult)"""
+    x0 = as_f64(x0).ravel()
+    cfg = lbfgs_config(params)
+    out = np.empty_like(x0)
+    info = OptResult()
+    check(lib().bioen_hip_selftest_lbfgs(int(kind), x0.size, ptr(x0), C.byref(cfg), ptr(out), C.byref(info)))
+    return out, info
 
 
 class Context(object):

@@ -156,6 +156,9 @@ def find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg):
     cfg["cache_ytilde_transposed"] = caching
 
     minimizer = cfg["minimizer"].upper()
+    if minimizer not in ('LIBLBFGS', 'LBFGS', 'GSL', 'SCIPY'):
+        raise RuntimeError("Library " + cfg["minimizer"] +
+                           " not recognized (valid values =  'LIBLBFGS', 'GSL', 'scipy', 'scipy' ) ")
     use_c = bool(cfg["use_c_functions"])
     use_device = not (minimizer == 'SCIPY' and not use_c)
 
@@ -182,13 +185,10 @@ def find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg):
             res = _run_scipy(cfg, dev.f, dev.fprime, forces, (), "c", True)
         finally:
             dev.close()
-    elif minimizer == 'SCIPY':
+    else:
         common.print_highlighted("FORCES -- Library scipy/PY", cfg["verbose"])
         res = _run_scipy(cfg, bioen_log_posterior_base, grad_bioen_log_posterior_base, forces,
                          (w0, yTilde, YTilde, theta), "py", False)
-    else:
-        raise RuntimeError("Library " + cfg["minimizer"] +
-                           " not recognized (valid values =  'LIBLBFGS', 'GSL', 'scipy', 'scipy' ) ")
     end = time.time()
     if cfg["verbose"]:
         print('time elapsed ', (end - start))

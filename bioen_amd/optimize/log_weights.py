@@ -61,20 +61,20 @@ def bioen_log_prior(w, s, g, G, theta):
     """theta * ( g.w - G.w - log s + log s0 )  (log_weights.py:18-68)."""
     _, s0 = getWeights(G)
     w, g, G = _col(w), _col(g), _col(G)
-    return float(theta * (float(g.T.dot(w)) - float(G.T.dot(w)) - np.log(s) + np.log(s0)))
+    return float(theta * ((g.T.dot(w)).item() - (G.T.dot(w)).item() - np.log(s) + np.log(s0)))
 
 
 def grad_chiSqrTerm(gPrime, g, G, yTilde, YTilde, theta):
     """Gradient of the chi^2 term w.r.t. the first n-1 log-weights, the last one pinned
     to zero (legacy parametrisation, log_weights.py:164-188)."""
-    g[:-1, 0] = np.asarray(gPrime).reshape(-1)
-    g[-1, 0] = 0
+    np.asarray(g)[:-1, 0] = np.asarray(gPrime).reshape(-1)
+    np.asarray(g)[-1, 0] = 0
     w, _ = getWeights(g)
     w = _col(w)
     yT = np.asarray(yTilde, dtype=np.float64)
     ybar = yT.dot(w)
     r = ybar - _col(YTilde)
-    tmp = w[:, 0] * (yT.T.dot(r)[:, 0] - float(ybar.T.dot(r)))
+    tmp = w[:, 0] * (yT.T.dot(r)[:, 0] - ybar.T.dot(r).item())
     return tmp[:-1]
 
 
@@ -110,7 +110,7 @@ def grad_bioen_log_posterior(gPrime, g, G, yTilde, YTilde, theta, use_c=True, ca
 def bioen_log_posterior_base(gPrime, g, G, yTilde, YTilde, theta):
     """Pure-numpy objective (log_weights.py:289-328).  Like the reference it writes the
     current point into `g` in place."""
-    g[:, 0] = np.asarray(gPrime, dtype=np.float64).reshape(-1)
+    np.asarray(g)[:, 0] = np.asarray(gPrime, dtype=np.float64).reshape(-1)   # view: works for np.matrix too
     w, s = getWeights(g)
     return bioen_log_prior(w, s, g, G, theta) + common.chiSqrTerm(w, yTilde, YTilde)
 
@@ -129,9 +129,9 @@ def grad_bioen_log_posterior_base(gPrime, g, G, yTilde, YTilde, theta):
     yT = np.asarray(yTilde, dtype=np.float64)
     ybar = yT.dot(w)
     r = ybar - _col(YTilde)
-    t = w * (yT.T.dot(r) - float(ybar.T.dot(r)))
+    t = w * (yT.T.dot(r) - ybar.T.dot(r).item())
     dev = gp - Gc
-    grad = theta * w * (dev - float(w.T.dot(dev))) + t
+    grad = theta * w * (dev - w.T.dot(dev).item()) + t
     return grad[:, 0]
 
 
@@ -222,6 +222,9 @@ def find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
     cfg["cache_ytilde_transposed"] = caching      # the reference writes this back, :440
 
     minimizer = cfg["minimizer"].upper()
+    if minimizer not in ('LIBLBFGS', 'LBFGS', 'GSL', 'SCIPY'):
+        raise RuntimeError("Library " + cfg["minimizer"] +
+                           " not recognized (valid values =  'LIBLBFGS', 'GSL', 'scipy', 'scipy' ) ")
     use_c = bool(cfg["use_c_functions"])
     use_device = not (minimizer == 'SCIPY' and not use_c)
 
@@ -249,13 +252,10 @@ def find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
             res = _run_scipy(cfg, dev.f, dev.fprime, gPrime, (), "c", True)
         finally:
             dev.close()
-    elif minimizer == 'SCIPY':
+    else:
         common.print_highlighted("LOGW -- Library scipy/PY", cfg["verbose"])
         res = _run_scipy(cfg, bioen_log_posterior_base, grad_bioen_log_posterior_base, gPrime,
                          (g, G, yTilde, YTilde, theta), "py", False)
-    else:
-        raise RuntimeError("Library " + cfg["minimizer"] +
-                           " not recognized (valid values =  'LIBLBFGS', 'GSL', 'scipy', 'scipy' ) ")
     end = time.time()
     if cfg["verbose"]:
         print('time elapsed ', (end - start))

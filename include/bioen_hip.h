@@ -140,6 +140,14 @@ int bioen_hip_kernel_stats(bioen_hip_ctx* ctx, int which, double* total_ms, long
 int bioen_hip_kernel_stats_reset(bioen_hip_ctx* ctx);
 int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
 
+/* ---- host self-test of the L-BFGS driver (no GPU needed) ------------------------------
+ * Runs the SAME driver + line-search code as the optimizers above on a built-in analytic
+ * objective evaluated on the host: kind 0 = extended Rosenbrock, kind 1 = ill-conditioned
+ * convex quadratic + quartic.  Lets the CPU test-suite pin the control flow
+ * (lbfgs.c:245-641, 645-734, 812-1296) without a device. */
+int bioen_hip_selftest_lbfgs(int kind, int n, const double* x0, const bioen_lbfgs_config* config,
+                             double* x_out, bioen_opt_result* info);
+
 /* ---- theta-sweep gather over RCCL (multi-GPU; one process per GPU) ----------------- */
 /* rank 0 obtains the 128-byte ncclUniqueId; the host side ships it to the other ranks */
 int bioen_hip_comm_unique_id(unsigned char id[128]);

@@ -624,3 +624,46 @@ int oracle_opt_lbfgs_forces(int m, int n, const double* yTilde, const double* YT
     if (stats) stats->iterations = stats->evaluations = 0;
     return lbfgs_minimize(&p, result, fmin, stats);
 }
+
+/* ------------------------------------------------------------------ */
+/* analytic self-test objectives                                       */
+/* ------------------------------------------------------------------ */
+typedef struct { int kind, n; } selftest_t;
+
+static double eval_selftest(void* ctx, const double* x, double* g) {
+    const selftest_t* q = (const selftest_t*)ctx;
+    const int n = q->n;
+    double f = 0.0;
+    for (int i = 0; i < n; ++i) g[i] = 0.0;
+    if (q->kind == 0) {
+        for (int i = 0; i + 1 < n; i += 2) {
+            const double t1 = 1.0 - x[i];
+            const double t2 = 10.0 * (x[i + 1] - x[i] * x[i]);
+            g[i + 1] = 20.0 * t2;
+            g[i] = -2.0 * (x[i] * g[i + 1] + t1);
+            f += t1 * t1 + t2 * t2;
+        }
+        if (n & 1) {
+            f += x[n - 1] * x[n - 1];
+            g[n - 1] = 2.0 * x[n - 1];
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const double c = pow(10.0, 4.0 * i / (n > 1 ? n - 1 : 1) - 2.0);
+            const double d = x[i] - 1.0;
+            f += c * d * d + 0.01 * d * d * d * d;
+            g[i] = 2.0 * c * d + 0.04 * d * d * d;
+        }
+    }
+    return f;
+}
+
+int oracle_selftest_lbfgs(int kind, int n, const double* x0, const oracle_lbfgs_config* cfg,
+                          double* x_out, double* fmin, oracle_lbfgs_stats* stats) {
+    selftest_t q = {kind, n};
+    problem_t p = {n, eval_selftest, &q, cfg, 0};
+    memcpy(x_out, x0, sizeof(double) * (size_t)n);
+    *fmin = 0.0;
+    if (stats) stats->iterations = stats->evaluations = 0;
+    return lbfgs_minimize(&p, x_out, fmin, stats);
+}

@@ -72,6 +72,12 @@ int oracle_opt_lbfgs_forces(int m, int n, const double* yTilde, const double* YT
                             const oracle_lbfgs_config* cfg, double* result, double* fmin,
                             oracle_lbfgs_stats* stats);
 
+/* The oracle's L-BFGS on built-in analytic objectives (kind 0: extended Rosenbrock,
+ * kind 1: ill-conditioned quadratic + quartic) -- the counterpart of
+ * bioen_hip_selftest_lbfgs, used by the CPU tests to pin the product's driver. */
+int oracle_selftest_lbfgs(int kind, int n, const double* x0, const oracle_lbfgs_config* cfg,
+                          double* x_out, double* fmin, oracle_lbfgs_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

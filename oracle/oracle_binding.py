@@ -62,6 +62,9 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, C.c_double, C.POINTER(lbfgs_config), dp, dp,
                            C.POINTER(lbfgs_stats)]
+        L.oracle_selftest_lbfgs.restype = C.c_int
+        L.oracle_selftest_lbfgs.argtypes = [C.c_int, C.c_int, dp, C.POINTER(lbfgs_config), dp, dp,
+                                            C.POINTER(lbfgs_stats)]
         _lib = L
     return _lib
 
@@ -146,3 +149,12 @@ def opt_lbfgs_forces(f0, w0, yTilde, YTilde, theta, params=None):
     code = lib().oracle_opt_lbfgs_forces(m, n, _p(yTilde), _p(YTilde), _p(f0), _p(w0), float(theta),
                                          C.byref(cfg), _p(res), C.byref(fmin), C.byref(st))
     return res, fmin.value, code, st.iterations, st.evaluations
+
+
+def selftest_lbfgs(kind, x0, params=None):
+    """-> (x, fmin, code, iterations, evaluations) for the built-in analytic objectives"""
+    x0 = _a(x0).ravel()
+    out = np.empty_like(x0); fmin = C.c_double(0.0); st = lbfgs_stats()
+    cfg = _cfg(params)
+    code = lib().oracle_selftest_lbfgs(int(kind), x0.size, _p(x0), C.byref(cfg), _p(out), C.byref(fmin), C.byref(st))
+    return out, fmin.value, code, st.iterations, st.evaluations

@@ -1,0 +1,123 @@
+"""CPU tests of the ORACLE itself: the C restatement (oracle/bioen_oracle.c) against the
+committed golden vectors -- values produced by the reference's own C code -- and against
+the reference's known answers (test/optimize/data/*.ref).  Where oracle/_ref (the
+reference built from source) is present, the two are also compared live."""
+import numpy as np
+import pytest
+
+from conftest import LOGW_GOLDEN, FORCES_GOLDEN, LBFGS_DEFAULTS, LBFGS_TIGHT, load_golden
+from oracle import oracle_binding as O
+from oracle import ref_binding as R
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def maxrel(a, b):
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", LOGW_GOLDEN)
+def test_oracle_logw_eval_vs_reference_values(name):
+    d = load_golden(name)
+    # reference tolerances between its C and Python paths: 5e-14 / 5e-12 (test_func_gradient_logw.py:9-10)
+    for gkey, fkey, grkey in (("GInit", "f_init", "grad_init"), ("g_pert", "f_pert", "grad_pert")):
+        f, grad, w = O.logw_fdf(d[gkey], d["G"], d["yTilde"], d["YTilde"], d["theta"])
+        assert rel(f, d[fkey]) < 5e-14
+        assert maxrel(grad, d[grkey]) < 5e-12
+    w, logs = O.logw_weights(d["GInit"])
+    assert maxrel(w, d["w_init"]) < 1e-14
+    assert abs(logs - np.log(d["s_init"])) < 1e-13 * max(1.0, abs(logs))
+
+
+@pytest.mark.parametrize("name", FORCES_GOLDEN)
+def test_oracle_forces_eval_vs_reference_values(name):
+    d = load_golden(name)
+    for xkey, wkey, fkey, grkey in (("forces_init", "w_init", "f_init", "grad_init"),
+                                    ("forces_pert", "w_pert", "f_pert", "grad_pert")):
+        f, grad, w = O.forces_fdf(d[xkey], d["w0"], d["yTilde"], d["YTilde"], d["theta"])
+        assert rel(f, d[fkey]) < 5e-14
+        assert maxrel(w, d[wkey]) < 1e-13
+        assert maxrel(grad, d[grkey]) < 5e-8        # test_func_gradient_forces.py:10
+
+
+@pytest.mark.parametrize("name", LOGW_GOLDEN)
+@pytest.mark.parametrize("tag,params", [("def", LBFGS_DEFAULTS), ("tight", LBFGS_TIGHT),
+                                        ("mt", dict(LBFGS_DEFAULTS, linesearch=0)),
+                                        ("strong", dict(LBFGS_DEFAULTS, linesearch=3))])
+def test_oracle_logw_lbfgs_vs_reference_runs(name, tag, params):
+    d = load_golden(name)
+    g, fmin, code, it, ev = O.opt_lbfgs_logw(d["GInit"], d["G"], d["yTilde"], d["YTilde"], d["theta"], params)
+    code_ref = int(d["lbfgs_%s_code" % tag])
+    if code_ref in (0, 1, 2):
+        assert code in (0, 1, 2)
+        # yaml-default runs stop on a 1e-6 relative plateau over 10 iterations, so fmin itself is
+        # only pinned to ~1e-5 on the flattest case; the tight runs are held to the north-star 1e-6
+        assert rel(fmin, float(d["lbfgs_%s_fmin" % tag])) < (1e-6 if tag == "tight" else 5e-5)
+    else:
+        # the reference's own line search gives up here; a restatement may or may not at the same ulp
+        assert code < 0 or rel(fmin, float(d["lbfgs_%s_fmin" % tag])) < 1e-6
+    if "ref_fmin_scipy_bfgs" in d and code in (0, 1, 2):
+        assert rel(fmin, float(d["ref_fmin_scipy_bfgs"])) < 1e-1     # the reference's regression tolerance
+
+
+@pytest.mark.parametrize("name", FORCES_GOLDEN)
+def test_oracle_forces_lbfgs_vs_reference_runs(name):
+    d = load_golden(name)
+    fo, fmin, code, it, ev = O.opt_lbfgs_forces(d["forces_init"], d["w0"], d["yTilde"], d["YTilde"], d["theta"],
+                                                LBFGS_DEFAULTS)
+    assert code == int(d["lbfgs_def_code"])
+    assert rel(fmin, float(d["lbfgs_def_fmin"])) < 5e-6
+    w = O.forces_weights(fo, d["w0"], d["yTilde"])
+    assert np.abs(w - d["lbfgs_def_wopt"]).max() <= max(1e-5, 3 * float(d["lbfgs_def_wspread"])) * d["lbfgs_def_wopt"].max()
+    if "ref_fmin_scipy_bfgs" in d:
+        assert rel(fmin, float(d["ref_fmin_scipy_bfgs"])) < 1e-1
+
+
+def test_oracle_error_codes():
+    import os
+    from conftest import GOLDEN
+    e = np.load(os.path.join(GOLDEN, "error_codes.npz"))
+    G = np.zeros(e["yTilde"].shape[1])
+    _, _, code, it, ev = O.opt_lbfgs_logw(G, G, e["yTilde"], e["YTilde"], 1.0, dict(LBFGS_DEFAULTS, delta=-1.0))
+    assert code == int(e["code_delta_neg"]) == -1015 and ev == 0
+    _, f, code, it, ev = O.opt_lbfgs_logw(G, G, e["yTilde"], e["YTilde"], 1.0, dict(LBFGS_DEFAULTS, max_iterations=3))
+    assert code == int(e["code_maxiter"]) == -997 and it == 3
+    assert rel(f, float(e["f_maxiter"])) < 1e-12
+
+
+def test_known_answers_table():
+    """'f at init' and liblbfgs fmin measured on the real reference."""
+    table = {
+        "ref_data_16x15.npz": (5.767871756737714, 5.35657174307813),
+        "ref_data_deer_test_logw_M808xN10.npz": (4082.625060300343, 2282.28625639876),
+        "ref_data_potra_part_2_logw_M205xN10.npz": (1774.720221370775, 847.311552054163),
+        "ref_data_deer_test_forces_M808xN10.npz": (27141.27841165691, 25538.7702661363),
+        "ref_data_forces_M64xN64.npz": (40.05921503438893, 36.8906810151493),
+    }
+    for name, (f0, fmin) in table.items():
+        d = load_golden(name)
+        assert rel(float(d["f_init"]), f0) < 1e-13
+        assert rel(float(d["lbfgs_def_fmin"]), fmin) < 1e-12
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("name", ["synth_logw_M37xN500.npz", "ref_data_potra_part_2_logw_M808xN10.npz"])
+def test_oracle_vs_live_reference(name):
+    d = load_golden(name)
+    rng = np.random.default_rng(11)
+    g = d["GInit"].ravel() + 0.5 * rng.standard_normal(d["GInit"].size)
+    R.set_fast_openmp_flag(0)
+    f_ref = R.logw_f(g, d["G"], d["yTilde"], d["YTilde"], d["theta"])
+    grad_ref = R.logw_df(g, d["G"], d["yTilde"], d["YTilde"], d["theta"])
+    f, grad, _ = O.logw_fdf(g, d["G"], d["yTilde"], d["YTilde"], d["theta"])
+    assert rel(f, f_ref) < 5e-14 and maxrel(grad, grad_ref) < 5e-12
+    # the two historical slips of the reference's Python layer are NOT in its C kernels:
+    # finite differences agree with the C gradient (and hence with the oracle)
+    h = 1e-6
+    dirn = rng.standard_normal(g.size)
+    fd = (O.logw_fdf(g + h * dirn, d["G"], d["yTilde"], d["YTilde"], d["theta"])[0] -
+          O.logw_fdf(g - h * dirn, d["G"], d["yTilde"], d["YTilde"], d["theta"])[0]) / (2 * h)
+    assert abs(fd - grad.dot(dirn)) < 1e-6 * max(1.0, abs(fd))
