@@ -99,14 +99,29 @@ def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
     }
 
 
+class stdout_to_stderr(object):
+    """librccl prints a version banner on stdout when a communicator is created; keep this
+    process' stdout for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1000000, help="structures (default: BASELINE configs[2])")
-    ap.add_argument("--m", type=int, default=1024, help="observables")
-    ap.add_argument("--nthetas", type=int, default=8)
+    ap.add_argument("--structures", type=int, default=1000000, help="N (default: BASELINE configs[2])")
+    ap.add_argument("--observables", type=int, default=1024, help="M")
+    ap.add_argument("--thetas", type=int, default=8, help="points of the theta series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols", type=int, default=65536)
     ap.add_argument("--cpu-iters", type=int, default=40)
@@ -121,8 +136,8 @@ def main():
     import bioen_amd
     from bioen_amd import sweep
 
-    N, M = args.n, args.m
-    thetas = np.logspace(3, -0.5, args.nthetas)
+    N, M = args.structures, args.observables
+    thetas = np.logspace(3, -0.5, args.thetas)
     YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
 
     comm = sweep.SocketComm() if world > 1 else sweep.SingleComm()
@@ -134,7 +149,8 @@ def main():
     rccl = False
     if world > 1:
         try:
-            rccl = sweep.init_rccl(ctx, comm)
+            with stdout_to_stderr():
+                rccl = sweep.init_rccl(ctx, comm)
             gather = "rccl-allgather"
         except bioen_amd.BioenHipError as e:   # report, keep the control-plane gather
             gather = "tcp-allgather (RCCL unavailable: %s)" % e

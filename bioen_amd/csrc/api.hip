@@ -151,7 +151,7 @@ static void enqueue_logw_eval(bioen_hip_ctx* c, double theta, bool with_grad) {
     launch_fwd_rows_residual(c);        //     r, chi^2, ybar . r
     launch_logw_scalars(c, theta);      // A5: f
     if (with_grad) {
-        launch_adj(c, c->r, c->a);      // A6: a = yTilde^T . r             [matrix pass 2]
+        launch_adj(c, c->r, c->a, true); // A6: a_k = sum_i r_i (yTilde_ik - ybar_i) [matrix pass 2]
         launch_logw_grad(c, theta);     //     gradient epilogue + g.d, g.g, x.x
         launch_finish_eval(c);
     }
@@ -173,8 +173,8 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, double theta, bool with_grad) 
     if (with_grad) {
         launch_adj(c, c->r, c->a);      // F3: b = yTilde^T r                [matrix pass 3]
         launch_forces_t(c, theta);      //     t_j, sum t
-        launch_fwd_partial(c, c->t);    //     yTilde . t                    [matrix pass 4]
-        launch_fwd_rows_forces_grad(c); //     gm = yTilde.t - ybar sum(t)
+        launch_fwd_partial(c, c->t, true); //  gm_i = sum_j (yTilde_ij - ybar_i) t_j [matrix pass 4]
+        launch_fwd_rows_forces_grad(c);
     }
 }
 

@@ -82,9 +82,13 @@ __device__ __forceinline__ d2 ldg2(const double* p) {
 //   block = 4 waves stacked over rows, R rows per wave; a wave walks its column
 //   tile in 128-column (1 KiB) steps, two steps in flight (2*R loads of 1 KiB).
 // ------------------------------------------------------------------------------
-template <int R, bool NT>
+// CENTER: sum_j (Y[row][j] - ybar[row]) v[j] -- the centred form the reference uses for the
+// forces gradient (c_bioen_kernels_forces.c:330-338); avoids the cancellation of
+// (Y v) - ybar (1.v) when a gradient component is small against its two terms.
+template <int R, bool NT, bool CENTER>
 __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict__ Y, size_t ld,
                                                         const double* __restrict__ v,
+                                                        const double* __restrict__ ybar,
                                                         double* __restrict__ partial, int ctiles,
                                                         int steps_per_tile, int total_steps) {
     const int lane = threadIdx.x & 63;
@@ -98,9 +102,12 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
     const double* yp = Y + (size_t)row0 * ld + (size_t)s * 128 + lane * 2;
     const double* vp = v + (size_t)s * 128 + lane * 2;
 
-    double acc[R];
+    double acc[R], yb[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int r = 0; r < R; ++r) {
+        acc[r] = 0.0;
+        yb[r] = CENTER ? ybar[row0 + r] : 0.0;
+    }
 
     for (; s + 2 <= s_end; s += 2) {
         d2 y0[R], y1[R];
@@ -113,10 +120,17 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
         const d2 v1 = *reinterpret_cast<const d2*>(vp + 128);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc[r] = fma(y0[r].x, v0.x, acc[r]);
-            acc[r] = fma(y0[r].y, v0.y, acc[r]);
-            acc[r] = fma(y1[r].x, v1.x, acc[r]);
-            acc[r] = fma(y1[r].y, v1.y, acc[r]);
+            if (CENTER) {
+                acc[r] = fma(y0[r].x - yb[r], v0.x, acc[r]);
+                acc[r] = fma(y0[r].y - yb[r], v0.y, acc[r]);
+                acc[r] = fma(y1[r].x - yb[r], v1.x, acc[r]);
+                acc[r] = fma(y1[r].y - yb[r], v1.y, acc[r]);
+            } else {
+                acc[r] = fma(y0[r].x, v0.x, acc[r]);
+                acc[r] = fma(y0[r].y, v0.y, acc[r]);
+                acc[r] = fma(y1[r].x, v1.x, acc[r]);
+                acc[r] = fma(y1[r].y, v1.y, acc[r]);
+            }
         }
         yp += 256;
         vp += 256;
@@ -128,8 +142,13 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
         const d2 v0 = *reinterpret_cast<const d2*>(vp);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc[r] = fma(y0[r].x, v0.x, acc[r]);
-            acc[r] = fma(y0[r].y, v0.y, acc[r]);
+            if (CENTER) {
+                acc[r] = fma(y0[r].x - yb[r], v0.x, acc[r]);
+                acc[r] = fma(y0[r].y - yb[r], v0.y, acc[r]);
+            } else {
+                acc[r] = fma(y0[r].x, v0.x, acc[r]);
+                acc[r] = fma(y0[r].y, v0.y, acc[r]);
+            }
         }
     }
 #pragma unroll
@@ -173,14 +192,10 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_residual(const double* __re
     }
 }
 
-// mode 1 (forces gradient, c_bioen_kernels_forces.c:330-338):
-//   gm_i = sum_j Y_ij t_j - ybar_i * sum_j t_j
+// mode 1 (forces gradient, c_bioen_kernels_forces.c:330-338): the partials already hold the
+// centred sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* __restrict__ partial, int ctiles,
-                                                                 int mp, const double* __restrict__ ybar,
-                                                                 const double* __restrict__ ptsum, int np,
-                                                                 double* __restrict__ gm) {
-    __shared__ double sh[kWaves];
-    const double tsum = sum_partials(ptsum, np, sh);
+                                                                 int mp, double* __restrict__ gm) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* _
         double s = 0.0;
         for (int k = lane; k < ctiles; k += 64) s += p[k];
         s = wave_sum(s);
-        if (lane == 0) gm[row] = s - ybar[row] * tsum;
+        if (lane == 0) gm[row] = s;
     }
 }
 
@@ -198,9 +213,12 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* _
 //   waves split the rows; U rows (U KiB) in flight per wave; u[i] is wave-uniform
 //   and comes through the scalar cache.
 // ------------------------------------------------------------------------------
-template <int U, bool NT>
+// CENTER: out[j] = sum_i u[i] (Y[i][j] - ybar[i]) -- the reference's centred gradient sum
+// (c_bioen_kernels_logw.c:185-195); padded columns then hold -u.ybar, which nobody reads.
+template <int U, bool NT, bool CENTER>
 __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, size_t ld, int rows_per_wave,
-                                                const double* __restrict__ u, double* __restrict__ out) {
+                                                const double* __restrict__ u, const double* __restrict__ ybar,
+                                                double* __restrict__ out) {
     __shared__ d2 red[kWaves][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -208,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, si
     const int r0 = wave * rows_per_wave;
     const double* yp = Y + (size_t)r0 * ld + col;
     const double* up = u + r0;
+    const double* bp = ybar + r0;
 
     d2 acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
     for (int i = 0; i < rows_per_wave; i += U) {
@@ -217,10 +236,18 @@ __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, si
 #pragma unroll
         for (int k = 0; k < U; k += 2) {
             const double u0 = up[i + k], u1 = up[i + k + 1];
-            acc0.x = fma(y[k].x, u0, acc0.x);
-            acc0.y = fma(y[k].y, u0, acc0.y);
-            acc1.x = fma(y[k + 1].x, u1, acc1.x);
-            acc1.y = fma(y[k + 1].y, u1, acc1.y);
+            if (CENTER) {
+                const double b0 = bp[i + k], b1 = bp[i + k + 1];
+                acc0.x = fma(y[k].x - b0, u0, acc0.x);
+                acc0.y = fma(y[k].y - b0, u0, acc0.y);
+                acc1.x = fma(y[k + 1].x - b1, u1, acc1.x);
+                acc1.y = fma(y[k + 1].y - b1, u1, acc1.y);
+            } else {
+                acc0.x = fma(y[k].x, u0, acc0.x);
+                acc0.y = fma(y[k].y, u0, acc0.y);
+                acc1.x = fma(y[k + 1].x, u1, acc1.x);
+                acc1.y = fma(y[k + 1].y, u1, acc1.y);
+            }
         }
         yp += (size_t)U * ld;
     }
@@ -331,8 +358,8 @@ __global__ __launch_bounds__(kBlock) void k_logw_scalars(const double* __restric
     }
 }
 
-// gradient epilogue (c_bioen_kernels_logw.c:207-218 in closed form):
-//   g_k = w_k [ theta (x_k - G_k - P) + a_k - c ],  a = yTilde^T r, c = ybar . r
+// gradient epilogue (c_bioen_kernels_logw.c:207-218):
+//   g_k = w_k [ theta (x_k - G_k - P) + a_k ],  a_k = sum_i r_i (yTilde_ik - ybar_i)  (centred adjoint)
 // plus the three dot products the line search / convergence test needs.
 __global__ __launch_bounds__(kBlock) void k_logw_grad(const double* __restrict__ x, const double* __restrict__ G,
                                                       const double* __restrict__ w, const double* __restrict__ a,
@@ -341,11 +368,11 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(const double* __restrict__
                                                       double* __restrict__ g, double* __restrict__ pdg,
                                                       double* __restrict__ pgg, double* __restrict__ pxx) {
     __shared__ double sh[kWaves];
-    const double P = scal[S_P], c = scal[S_C];
+    const double P = scal[S_P];
     double dg = 0.0, gg = 0.0, xx = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double xv = x[j];
-        const double gv = w[j] * (theta * ((xv - G[j]) - P) + (a[j] - c));
+        const double gv = w[j] * (theta * ((xv - G[j]) - P) + a[j]);
         g[j] = gv;
         dg = fma(gv, d[j], dg);
         gg = fma(gv, gv, gg);
@@ -603,16 +630,21 @@ struct TimedLaunch {
     }
 };
 
-void launch_fwd_partial(bioen_hip_ctx* c, const double* v) {
-    TimedLaunch tl(c, 0);
+template <bool NT, bool CENTER>
+static void launch_fwd_t(bioen_hip_ctx* c, const double* v) {
     const int total_steps = (int)(c->ld / 128);
     dim3 grid(c->fwd_ctiles, c->mp / kRowAlign);
-    if (c->nontemporal)
-        hipLaunchKernelGGL((k_fwd_partial<8, true>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v,
-                           c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
-    else
-        hipLaunchKernelGGL((k_fwd_partial<8, false>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v,
-                           c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
+    hipLaunchKernelGGL((k_fwd_partial<8, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v, c->ybar,
+                       c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
+}
+
+void launch_fwd_partial(bioen_hip_ctx* c, const double* v, bool centred) {
+    TimedLaunch tl(c, 0);
+    if (c->nontemporal) {
+        if (centred) launch_fwd_t<true, true>(c, v); else launch_fwd_t<true, false>(c, v);
+    } else {
+        if (centred) launch_fwd_t<false, true>(c, v); else launch_fwd_t<false, false>(c, v);
+    }
 }
 
 void launch_fwd_rows_residual(bioen_hip_ctx* c) {
@@ -622,17 +654,23 @@ void launch_fwd_rows_residual(bioen_hip_ctx* c) {
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c) {
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c)), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       c->fwd_ctiles, c->mp, c->ybar, part(c, P_TSUM), vec_grid(c), c->gm);
+                       c->fwd_ctiles, c->mp, c->gm);
 }
 
-void launch_adj(bioen_hip_ctx* c, const double* u, double* out) {
-    TimedLaunch tl(c, 1);
+template <bool NT, bool CENTER>
+static void launch_adj_t(bioen_hip_ctx* c, const double* u, double* out) {
     dim3 grid((unsigned)(c->ld / 128));
-    const int rpw = c->mp / kWaves;
-    if (c->nontemporal)
-        hipLaunchKernelGGL((k_adj<8, true>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, rpw, u, out);
-    else
-        hipLaunchKernelGGL((k_adj<8, false>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, rpw, u, out);
+    hipLaunchKernelGGL((k_adj<8, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp / kWaves, u,
+                       c->ybar, out);
+}
+
+void launch_adj(bioen_hip_ctx* c, const double* u, double* out, bool centred) {
+    TimedLaunch tl(c, 1);
+    if (c->nontemporal) {
+        if (centred) launch_adj_t<true, true>(c, u, out); else launch_adj_t<true, false>(c, u, out);
+    } else {
+        if (centred) launch_adj_t<false, true>(c, u, out); else launch_adj_t<false, false>(c, u, out);
+    }
 }
 
 void launch_trial(bioen_hip_ctx* c, double stp) {

@@ -17,13 +17,13 @@ inline double* part(bioen_hip_ctx* c, int slot) { return c->part + (size_t)slot 
 int vec_grid(const bioen_hip_ctx* c);   // blocks used by every N-vector kernel of this context
 
 // ---- matrix streaming kernels ------------------------------------------------
-// forward:  partial[row][ctile] = sum_{j in tile} Y[row][j] * v[j]
-void launch_fwd_partial(bioen_hip_ctx* c, const double* v);
+// forward:  partial[row][ctile] = sum_{j in tile} (Y[row][j] - [centred] ybar[row]) * v[j]
+void launch_fwd_partial(bioen_hip_ctx* c, const double* v, bool centred = false);
 // reduce the column tiles; mode 0: ybar,r,chi/c partials; mode 1: gm = rowsum - ybar * tsum
 void launch_fwd_rows_residual(bioen_hip_ctx* c);
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c);
-// adjoint:  out[j] = sum_i Y[i][j] * u[i]
-void launch_adj(bioen_hip_ctx* c, const double* u, double* out);
+// adjoint:  out[j] = sum_i (Y[i][j] - [centred] ybar[i]) * u[i]
+void launch_adj(bioen_hip_ctx* c, const double* u, double* out, bool centred = false);
 
 // ---- log-weights N-vector kernels ------------------------------------------------
 // x = xp + stp * d ; block maxima of x -> P_MAX

@@ -112,7 +112,7 @@ def grad_bioen_log_posterior_base(forces, w0, yTilde, YTilde, theta, use_c=True)
     b = yT.T.dot(ybar - np.asarray(YTilde, dtype=np.float64).reshape(-1))
     ratio = np.where(w > 0, w / w0v, 1.0)
     t = ((np.log(ratio) + 1.0) * theta + b) * w
-    return yT.dot(t) - ybar * t.sum()
+    return (yT - ybar[:, None]).dot(t)        # centred, as forces.py:329-332 (no cancellation)
 
 
 # ------------------------------------------------------------------ optimizer

@@ -204,7 +204,8 @@ def test_ragged_shapes_vs_oracle(hip, M, N):
     assert rel(f, f_o) < F_RTOL and maxrel(w, w_o) < 1e-13
     assert np.abs(grad - grad_o).max() <= G_RTOL * max(np.abs(grad_o).max(), 1e-12)
     assert rel(ff, ff_o) < F_RTOL and maxrel(fw, fw_o) < 1e-12
-    assert np.abs(fg - fg_o).max() <= 1e-9 * max(np.abs(fg_o).max(), 1e-12)
+    # the forces gradient is a difference of O(|yTilde| |t|) terms: absolute scale, not its own size
+    assert np.abs(fg - fg_o).max() <= 1e-9 * max(np.abs(fg_o).max(), 1e-12) + 1e-13 * np.abs(yTilde).max() * (abs(ff_o) + 1)
 
 
 def test_extreme_log_weights_do_not_overflow(hip):
