@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--structures", type=int, default=1000000, help="N (default: BASELINE configs[2])")
     ap.add_argument("--observables", type=int, default=1024, help="M")
     ap.add_argument("--thetas", type=int, default=8, help="points of the theta series")
+    ap.add_argument("--max-batch", type=int, default=8, help="thetas sharing one matrix pass (1 = unbatched)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols", type=int, default=65536)
     ap.add_argument("--cpu-iters", type=int, default=40)
@@ -164,7 +165,8 @@ def main():
     g0 = np.zeros(N)
 
     def step():
-        return sweep.sweep_log_weights(ctx, thetas, G, g0, LBFGS_DEFAULTS, comm=comm, rccl=rccl)
+        return sweep.sweep_log_weights(ctx, thetas, G, g0, LBFGS_DEFAULTS, comm=comm, rccl=rccl,
+                                       max_batch=args.max_batch)
 
     results = None
     for _ in range(args.warmup):
@@ -190,17 +192,20 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant (slower) matrix-streaming kernel, rank 0's launches ----
+        # algorithmic bytes of ONE launch serving K thetas: the matrix once, plus per theta one
+        # N-vector and one M-vector in, one out (matrix bytes are shared by the batch)
         mat_bytes = float(M) * N * 8
-        alg = {"forward": mat_bytes + 8.0 * N + 8.0 * M,        # read yTilde + w, write ybar
-               "adjoint": mat_bytes + 8.0 * M + 8.0 * N}        # read yTilde + r, write a
         kern = {}
         for name in ("forward", "adjoint"):
             s = stats[name]
-            avg_ms = s["total_ms"] / max(s["launches"], 1)
+            launches = max(s["launches"], 1)
+            avg_ms = s["total_ms"] / launches
+            avg_k = s["problem_passes"] / launches
+            alg = mat_bytes + avg_k * (8.0 * N + 8.0 * M)
             kern[name] = {"kernel": "k_fwd_partial" if name == "forward" else "k_adj",
-                          "launches": s["launches"], "avg_ms": avg_ms,
-                          "algorithmic_bytes": alg[name],
-                          "achieved_GBs": alg[name] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
+                          "launches": s["launches"], "avg_ms": avg_ms, "avg_batch_width": avg_k,
+                          "algorithmic_bytes": alg,
+                          "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -239,7 +244,8 @@ def main():
             "config": {"workload": "log-weights theta sweep, N=%d structures x M=%d observables, %d thetas "
                                    "logspace(3,-0.5), cold starts, liblbfgs yaml defaults" % (N, M, len(thetas)),
                        "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
-                       "sharding": "theta round-robin over %d rank(s)" % world, "gather": gather},
+                       "sharding": "theta round-robin over %d rank(s)" % world, "gather": gather,
+                       "max_batch": args.max_batch},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "sweep_wall_s": dt / max(args.steps, 1),

@@ -61,12 +61,15 @@ _SIGNATURES = {
     "bioen_hip_logw_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
     "bioen_hip_opt_lbfgs_logw": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(LbfgsConfig),
                                            C.POINTER(VisualParams), dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_opt_lbfgs_logw_batch": (C.c_int, [ctx_p, C.c_int, dp, dp, C.c_size_t, dp, C.POINTER(LbfgsConfig),
+                                                 C.POINTER(VisualParams), C.c_int, dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_forces_weights": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_forces_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
     "bioen_hip_opt_lbfgs_forces": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(LbfgsConfig),
                                              C.POINTER(VisualParams), dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_chi_squared": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_kernel_stats": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong)]),
+    "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_selftest_lbfgs": (C.c_int, [C.c_int, C.c_int, dp, C.POINTER(LbfgsConfig), dp, C.POINTER(OptResult)]),
@@ -250,6 +253,31 @@ class Context(object):
                                              ptr(res), ptr(w) if want_weights else None, C.byref(info)))
         return res, w, info
 
+    def opt_lbfgs_logw_batch(self, thetas, g0, G, params, max_batch=8, verbose=False, debug=False,
+                             want_weights=True):
+        """Solve a whole theta series; up to `max_batch` (<= 8) thetas share every pass over yTilde.
+        g0: (n,) shared start or (ntheta, n) one start per theta.
+        -> (results[ntheta, n], weights[ntheta, n] or None, [OptResult] * ntheta)"""
+        thetas = as_f64(thetas).ravel()
+        nt = thetas.size
+        g0 = as_f64(g0)
+        if g0.size == self.n:
+            g0, stride = g0.ravel(), 0
+        elif g0.shape == (nt, self.n):
+            stride = self.n
+        else:
+            raise ValueError("g0 must have shape (n,) or (ntheta, n)")
+        G = self._nvec(G, "G")
+        cfg = lbfgs_config(params)
+        vis = VisualParams(int(bool(debug)), int(bool(verbose)))
+        res = np.empty((nt, self.n))
+        w = np.empty((nt, self.n)) if want_weights else None
+        infos = (OptResult * nt)()
+        check(lib().bioen_hip_opt_lbfgs_logw_batch(self._h, nt, ptr(thetas), ptr(g0), stride, ptr(G), C.byref(cfg),
+                                                   C.byref(vis), int(max_batch), ptr(res),
+                                                   ptr(w) if want_weights else None, infos))
+        return res, w, list(infos)
+
     # -- forces -------------------------------------------------------------------
     def forces_weights(self, forces, w0):
         f, w0 = self._mvec(forces, "forces"), self._nvec(w0, "w0")
@@ -296,8 +324,9 @@ class Context(object):
         for which, name in ((0, "forward"), (1, "adjoint")):
             ms = C.c_double(0.0)
             cnt = C.c_longlong(0)
-            check(lib().bioen_hip_kernel_stats(self._h, which, C.byref(ms), C.byref(cnt)))
-            out[name] = {"total_ms": ms.value, "launches": cnt.value}
+            pp = C.c_longlong(0)
+            check(lib().bioen_hip_kernel_stats_ex(self._h, which, C.byref(ms), C.byref(cnt), C.byref(pp)))
+            out[name] = {"total_ms": ms.value, "launches": cnt.value, "problem_passes": pp.value}
         return out
 
     # -- RCCL ------------------------------------------------------------------------

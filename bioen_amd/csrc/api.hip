@@ -61,6 +61,31 @@ static void choose_fwd_tiling(bioen_hip_ctx* c) {
     c->fwd_ctiles = (total_steps + spt - 1) / spt;
 }
 
+static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history) {
+    ProblemSlot& sl = c->slot[s];
+    int rc = 0;
+    if (!sl.allocated) {
+        double** vecs[] = {&sl.xa, &sl.xb, &sl.ga, &sl.gb, &sl.d, &sl.w, &sl.a};
+        for (double** p : vecs)
+            if ((rc = dalloc_zero(p, c->ld, c->stream)) != 0) return rc;
+        sl.x = sl.xa;
+        sl.xp = sl.xb;
+        sl.g = sl.ga;
+        sl.gp = sl.gb;
+        sl.scal = c->scal + (size_t)s * kScalStride;
+        sl.part = c->part + (size_t)s * P_COUNT * kMaxPartials;
+        sl.allocated = true;
+    }
+    if (with_history && !sl.history) {
+        for (int i = 0; i < kHistory; ++i) {
+            if ((rc = dalloc_zero(&sl.S[i], c->ld, c->stream)) != 0) return rc;
+            if ((rc = dalloc_zero(&sl.Yh[i], c->ld, c->stream)) != 0) return rc;
+        }
+        sl.history = true;
+    }
+    return 0;
+}
+
 static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
     if (!out) return fail(BIOEN_HIP_EINVAL, "ctx pointer is NULL");
     *out = nullptr;
@@ -91,17 +116,19 @@ static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
 #define TRY(x) if ((rc = (x)) != 0) { bioen_hip_ctx_destroy(c); return rc; }
     TRY(dalloc_zero(&c->Y, (size_t)c->mp * c->ld, c->stream));
     TRY(dalloc_zero(&c->YT, c->mp, c->stream));
-    TRY(dalloc_zero(&c->ybar, c->mp, c->stream));
-    TRY(dalloc_zero(&c->r, c->mp, c->stream));
+    TRY(dalloc_zero(&c->ybar_c, (size_t)c->mp * kMaxBatch, c->stream));
+    TRY(dalloc_zero(&c->r_c, (size_t)c->mp * kMaxBatch, c->stream));
     TRY(dalloc_zero(&c->um, c->mp, c->stream));
     TRY(dalloc_zero(&c->gm, c->mp, c->stream));
-    double** nvecs[] = {&c->x, &c->xp, &c->g, &c->gp, &c->d, &c->w, &c->fixed, &c->a, &c->t};
-    for (double** p : nvecs) TRY(dalloc_zero(p, c->ld, c->stream));
-    TRY(dalloc_zero(&c->fwd_partial, (size_t)c->mp * c->fwd_ctiles, c->stream));
-    TRY(dalloc_zero(&c->part, (size_t)P_COUNT * kMaxPartials, c->stream));
-    TRY(dalloc_zero(&c->scal, 64, c->stream));
+    TRY(dalloc_zero(&c->fixed, c->ld, c->stream));
+    TRY(dalloc_zero(&c->t, c->ld, c->stream));
+    TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * c->fwd_ctiles, c->stream));
+    TRY(dalloc_zero(&c->part, (size_t)kMaxBatch * P_COUNT * kMaxPartials, c->stream));
+    TRY(dalloc_zero(&c->scal, (size_t)kMaxBatch * kScalStride, c->stream));
+    TRY(alloc_slot(c, 0, false));
 #undef TRY
-    e = hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), 64 * sizeof(double), hipHostMallocDefault);
+    e = hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), (size_t)kMaxBatch * kScalStride * sizeof(double),
+                      hipHostMallocDefault);
     if (e != hipSuccess) {
         bioen_hip_ctx_destroy(c);
         return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
@@ -110,26 +137,14 @@ static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
     return 0;
 }
 
-static int ensure_history(bioen_hip_ctx* c) {
-    if (c->history_allocated) return 0;
-    for (int i = 0; i < kHistory; ++i) {
-        int rc = dalloc_zero(&c->S[i], c->ld, c->stream);
-        if (rc) return rc;
-        rc = dalloc_zero(&c->Yh[i], c->ld, c->stream);
-        if (rc) return rc;
-    }
-    c->history_allocated = true;
-    return 0;
-}
-
 static int upload_n(bioen_hip_ctx* c, double* dst, const double* src) {
     BIOEN_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 
-static int read_scalars(bioen_hip_ctx* c) {
-    BIOEN_HIP_CHECK(hipMemcpyAsync(c->host_scal, c->scal, S_COUNT * sizeof(double), hipMemcpyDeviceToHost,
-                                   c->stream));
+static int read_scalars(bioen_hip_ctx* c, int nslots = 1) {
+    BIOEN_HIP_CHECK(hipMemcpyAsync(c->host_scal, c->scal, (size_t)nslots * kScalStride * sizeof(double),
+                                   hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -140,137 +155,353 @@ static int check_launch() {
     return 0;
 }
 
+static void print_config(const bioen_lbfgs_config& p);
+static void print_summary(const bioen_hip_ctx* c, const bioen_opt_result& r);
+
 // ---------------------------------------------------------------------------------
 // evaluation pipelines (all asynchronous on c->stream)
 // ---------------------------------------------------------------------------------
-// log-weights: x must hold the point and P_MAX its block maxima (launch_trial does both).
-static void enqueue_logw_eval(bioen_hip_ctx* c, double theta, bool with_grad) {
-    launch_logw_exp(c);                 // A1 first half + prior partials
-    launch_logw_norm(c);                // A1 second half -> w, log s, P
-    launch_fwd_partial(c, c->w);        // A4: ybar = yTilde . w            [matrix pass 1]
-    launch_fwd_rows_residual(c);        //     r, chi^2, ybar . r
-    launch_logw_scalars(c, theta);      // A5: f
+static Round make_round(bioen_hip_ctx* c, const int* slots, int k, const double* stp, const double* theta) {
+    Round r{};
+    r.n = k;
+    for (int a = 0; a < k; ++a) {
+        ProblemSlot& sl = c->slot[slots[a]];
+        r.x[a] = sl.x;
+        r.xp[a] = sl.xp;
+        r.g[a] = sl.g;
+        r.gp[a] = sl.gp;
+        r.d[a] = sl.d;
+        r.w[a] = sl.w;
+        r.a[a] = sl.a;
+        r.scal[a] = sl.scal;
+        r.part[a] = sl.part;
+        r.stp[a] = stp ? stp[a] : 0.0;
+        r.theta[a] = theta ? theta[a] : 0.0;
+    }
+    return r;
+}
+
+// log-weights: r.x must hold the points and P_MAX their block maxima (launch_trial does both).
+static void enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
+    launch_logw_exp(c, r);                 // A1 first half + prior partials
+    launch_logw_norm(c, r);                // A1 second half -> w, log s, P
+    Vec8 w{};
+    for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
+    launch_fwd_partial(c, r.n, w);         // A4: ybar_a = yTilde . w_a          [matrix pass 1]
+    launch_fwd_rows_residual(c, r);        //     r, chi^2, ybar . r
+    launch_logw_scalars(c, r);             // A5: f
     if (with_grad) {
-        launch_adj(c, c->r, c->a, true); // A6: a_k = sum_i r_i (yTilde_ik - ybar_i) [matrix pass 2]
-        launch_logw_grad(c, theta);     //     gradient epilogue + g.d, g.g, x.x
-        launch_finish_eval(c);
+        MVec8 out{};
+        for (int a = 0; a < r.n; ++a) out.p[a] = r.a[a];
+        launch_adj(c, r.n, c->r_c, out, true);   // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
+        launch_logw_grad(c, r);            //     gradient epilogue + g.d, g.g, x.x
+        launch_finish_eval(c, r);
     }
 }
 
-// forces: um holds the forces
+// forces (single problem, slot 0): um holds the forces
 static void enqueue_forces_weights(bioen_hip_ctx* c) {
-    launch_adj(c, c->um, c->a);         // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
-    launch_max(c, c->a);
-    launch_forces_exp(c, c->a);
-    launch_forces_norm(c);              // w ; KL partials
+    ProblemSlot& s0 = c->slot[0];
+    MVec8 out{};
+    out.p[0] = s0.a;
+    launch_adj(c, 1, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
+    launch_max_vec(c, s0.a, s0.part + (size_t)P_MAX * kMaxPartials);
+    launch_forces_exp(c, s0.a);
+    launch_forces_norm(c);                 // w ; KL partials
 }
 
 static void enqueue_forces_eval(bioen_hip_ctx* c, double theta, bool with_grad) {
+    ProblemSlot& s0 = c->slot[0];
+    const int slots[1] = {0};
+    const Round r = make_round(c, slots, 1, nullptr, &theta);
     enqueue_forces_weights(c);
-    launch_fwd_partial(c, c->w);        // F2: ybar                         [matrix pass 2]
-    launch_fwd_rows_residual(c);
-    launch_forces_scalars(c, theta);    //     f = theta KL + 0.5 chi^2
+    Vec8 v{};
+    v.p[0] = s0.w;
+    launch_fwd_partial(c, 1, v);           // F2: ybar                         [matrix pass 2]
+    launch_fwd_rows_residual(c, r);
+    launch_forces_scalars(c, theta);       //     f = theta KL + 0.5 chi^2
     if (with_grad) {
-        launch_adj(c, c->r, c->a);      // F3: b = yTilde^T r                [matrix pass 3]
-        launch_forces_t(c, theta);      //     t_j, sum t
-        launch_fwd_partial(c, c->t, true); //  gm_i = sum_j (yTilde_ij - ybar_i) t_j [matrix pass 4]
+        MVec8 out{};
+        out.p[0] = s0.a;
+        launch_adj(c, 1, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
+        launch_forces_t(c, theta);         //     t_j
+        v.p[0] = c->t;
+        launch_fwd_partial(c, 1, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
         launch_fwd_rows_forces_grad(c);
     }
 }
 
 // ---------------------------------------------------------------------------------
-// L-BFGS backends
+// lock-step batch engine for the log-weights method: up to kMaxBatch thetas advance one
+// evaluation per round and share both matrix passes of that round.
 // ---------------------------------------------------------------------------------
-struct DeviceLogwBackend {
+struct BatchProblem {
+    int id = -1;                 // index into the caller's theta list
+    double theta = 0.0;
+    LbfgsMachine* machine = nullptr;
+    bool initial = true;         // next evaluation is the one at the start point
+    bool need_direction = false; // build d before the next trial
+    bool accept = false;         //   ... after committing the (s, y) pair
+    int end = 0, bound = 0;
+    std::chrono::steady_clock::time_point t0;
+};
+
+struct LogwBatchEngine {
     bioen_hip_ctx* c;
-    double theta;
-    bool result_is_trial = false;
-    int rc = 0;   // first HIP failure, if any
+    const bioen_lbfgs_config& cfg;
+    bool verbose;
+    int rc = 0;
 
-    int fetch(TrialResult* t) {
-        int e = read_scalars(c);
-        if (e && !rc) rc = e;
-        const double* h = c->host_scal;
-        t->f = h[S_F];
-        t->dg = h[S_DG];
-        t->gg = h[S_GG];
-        t->xx = h[S_XX];
-        t->dginit = h[S_DGINIT];
-        return e;
-    }
+    LogwBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
+        : c(ctx), cfg(config), verbose(verb) {}
 
-    void direction(int end_after, int bound, bool finalize_pair, int newest) {
-        // lbfgs.c:571-598 as 1 + 2*bound fused launches
-        RecurArgs a{};
-        a.mode = 0;
-        a.hist = newest;
-        a.finalize_sy = finalize_pair ? 1 : 0;
-        if (bound == 0) {
-            a.vdot = c->gp;
-            a.out_slot = P_DGINIT;
-            launch_recur(c, a);
-            return;
+    void note(int e) { if (e && !rc) rc = e; }
+    void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
+
+    // d = -H gp for the problems in `list` (lbfgs.c:571-598): 1 + 2*bound fused launches each,
+    // issued together (a problem with a shorter history idles in the surplus launches)
+    void directions(BatchProblem* slots, const std::vector<int>& list) {
+        if (list.empty()) return;
+        const int k = (int)list.size();
+        // commit the new pairs first
+        PairArgs pa{};
+        int np = 0;
+        for (int s : list) {
+            BatchProblem& p = slots[s];
+            if (!p.accept) continue;
+            ProblemSlot& sl = c->slot[s];
+            pa.x[np] = sl.x; pa.xp[np] = sl.xp; pa.g[np] = sl.g; pa.gp[np] = sl.gp;
+            pa.s[np] = sl.S[p.end]; pa.y[np] = sl.Yh[p.end]; pa.part[np] = sl.part;
+            ++np;
         }
-        int j = end_after;
-        int order[kHistory];
-        for (int b = 0; b < bound; ++b) {
-            j = (j + kHistory - 1) % kHistory;
-            order[b] = j;   // newest -> oldest
+        if (np) {
+            pa.n = np;
+            launch_update_sy(c, pa);
         }
-        a.vdot = c->S[order[0]];
-        a.out_slot = P_REC;
-        launch_recur(c, a);
-        for (int b = 0; b < bound; ++b) {   // first loop
-            RecurArgs s{};
-            s.mode = 1;
-            s.hist = order[b];
-            s.vaxpy = c->Yh[order[b]];
-            const bool last = (b == bound - 1);
-            s.scale = last ? 1 : 0;
-            s.vdot = last ? c->Yh[order[b]] : c->S[order[b + 1]];
-            s.out_slot = P_REC;
-            launch_recur(c, s);
+        int order[kMaxBatch][kHistory];
+        int maxb = 0;
+        for (int a = 0; a < k; ++a) {
+            BatchProblem& p = slots[list[a]];
+            ProblemSlot& sl = c->slot[list[a]];
+            if (p.accept) {   // the trial point becomes the accepted point
+                std::swap(sl.x, sl.xp);
+                std::swap(sl.g, sl.gp);
+            }
+            int j = (p.end + 1) % kHistory;
+            for (int b = 0; b < p.bound; ++b) {
+                j = (j + kHistory - 1) % kHistory;
+                order[a][b] = j;   // newest -> oldest
+            }
+            maxb = std::max(maxb, p.bound);
         }
-        for (int b = bound - 1; b >= 0; --b) {   // second loop, oldest -> newest
-            RecurArgs s{};
-            s.mode = 2;
-            s.hist = order[b];
-            s.vaxpy = c->S[order[b]];
-            const bool last = (b == 0);
-            s.vdot = last ? c->gp : c->Yh[order[b - 1]];
-            s.out_slot = last ? P_DGINIT : P_REC;
-            launch_recur(c, s);
+        const int nlaunch = 1 + 2 * maxb;
+        for (int step = 0; step < nlaunch; ++step) {
+            RecurArgs q{};
+            q.n = k;
+            for (int a = 0; a < k; ++a) {
+                BatchProblem& p = slots[list[a]];
+                ProblemSlot& sl = c->slot[list[a]];
+                const int bound = p.bound;
+                q.d[a] = sl.d; q.gp[a] = sl.gp; q.part[a] = sl.part; q.scal[a] = sl.scal;
+                q.mode[a] = -1;
+                if (step >= 1 + 2 * bound) continue;
+                double* pin = sl.part + (size_t)(sl.rec_flip ? P_REC2 : P_REC) * kMaxPartials;
+                const double* vdot = nullptr;
+                bool to_dginit = false;
+                if (step == 0) {
+                    q.mode[a] = 0;
+                    q.hist[a] = p.end;
+                    q.finalize_sy[a] = p.accept ? 1 : 0;
+                    if (bound == 0) { vdot = sl.gp; to_dginit = true; }
+                    else vdot = sl.S[order[a][0]];
+                } else if (step <= bound) {          // first loop, newest -> oldest
+                    const int b = step - 1;
+                    const bool last = (b == bound - 1);
+                    q.mode[a] = 1;
+                    q.hist[a] = order[a][b];
+                    q.vaxpy[a] = sl.Yh[order[a][b]];
+                    q.scale[a] = last ? 1 : 0;
+                    vdot = last ? sl.Yh[order[a][b]] : sl.S[order[a][b + 1]];
+                } else {                             // second loop, oldest -> newest
+                    const int b = bound - 1 - (step - 1 - bound);
+                    const bool last = (b == 0);
+                    q.mode[a] = 2;
+                    q.hist[a] = order[a][b];
+                    q.vaxpy[a] = sl.S[order[a][b]];
+                    if (last) { vdot = sl.gp; to_dginit = true; }
+                    else vdot = sl.Yh[order[a][b - 1]];
+                }
+                q.pin[a] = pin;
+                q.vdot[a] = vdot;
+                if (to_dginit) {
+                    q.pout[a] = sl.part + (size_t)P_DGINIT * kMaxPartials;
+                } else {
+                    sl.rec_flip ^= 1;   // a step reads its predecessor's partials while writing its own
+                    q.pout[a] = sl.part + (size_t)(sl.rec_flip ? P_REC2 : P_REC) * kMaxPartials;
+                }
+            }
+            launch_recur(c, q);
+        }
+        for (int s : list) {
+            slots[s].need_direction = false;
+            slots[s].accept = false;
         }
     }
 
-    void initial(double* f, double* gg, double* xx) {
-        // x0 is in xp; d is zero.  trial(0) evaluates there.
-        launch_trial(c, 0.0);
-        enqueue_logw_eval(c, theta, true);
-        TrialResult t{};
-        fetch(&t);
-        *f = t.f;
-        *gg = t.gg;
-        *xx = t.xx;
-        std::swap(c->g, c->gp);   // gradient at the accepted point
-        direction(0, 0, false, 0);
-    }
+    int run(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride, const double* G_host,
+            int max_batch, double* results, double* w_opt, bioen_opt_result* infos) {
+        for (int i = 0; i < ntheta; ++i) std::memset(&infos[i], 0, sizeof(bioen_opt_result));
+        LbfgsMachine probe(c->n, cfg);
+        const int bad = probe.validate();
+        if (bad != 0) {   // liblbfgs rejects the parameters before touching x (lbfgs.c:285-331)
+            for (int i = 0; i < ntheta; ++i) {
+                infos[i].lbfgs_code = bad;
+                std::memcpy(results + (size_t)i * c->n, g0_host + (size_t)i * g0_stride, (size_t)c->n * sizeof(double));
+            }
+            return 0;
+        }
+        int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
+        for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, true));
+        if (rc) return rc;
+        note(upload_n(c, c->fixed, G_host));
+        const bool shared_start = (g0_stride == 0) || ntheta == 1;
+        if (shared_start) {
+            if (!c->g0) note(dalloc_zero(&c->g0, c->ld, c->stream));
+            if (rc) return rc;
+            note(upload_n(c, c->g0, g0_host));
+        }
+        {   // log sum exp(G) once, written into every slot of the batch
+            int all[kMaxBatch];
+            for (int s = 0; s < kb; ++s) all[s] = s;
+            const Round r = make_round(c, all, kb, nullptr, nullptr);
+            launch_logw_logs0(c, r);
+        }
 
-    void trial(double stp, TrialResult* t) {
-        launch_trial(c, stp);
-        enqueue_logw_eval(c, theta, true);
-        fetch(t);
-    }
+        BatchProblem slots[kMaxBatch];
+        std::vector<LbfgsMachine> machines;
+        machines.reserve(ntheta);
+        for (int i = 0; i < ntheta; ++i) machines.emplace_back(c->n, cfg);
+        int next = 0, active = 0;
+        bool occupied[kMaxBatch] = {};
 
-    void accept(int end, int bound) {
-        launch_update_sy(c, c->S[end], c->Yh[end]);
-        std::swap(c->x, c->xp);
-        std::swap(c->g, c->gp);
-        direction((end + 1) % kHistory, bound, true, end);
-    }
+        auto start_problem = [&](int s) {
+            BatchProblem& p = slots[s];
+            p = BatchProblem();
+            p.id = next;
+            p.theta = thetas[next];
+            p.machine = &machines[next];
+            p.t0 = std::chrono::steady_clock::now();
+            ProblemSlot& sl = c->slot[s];
+            sl.rec_flip = 0;
+            if (shared_start)
+                note(hipMemcpyAsync(sl.xp, c->g0, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "copy g0");
+            else
+                note(upload_n(c, sl.xp, g0_host + (size_t)next * g0_stride));
+            note(hipMemsetAsync(sl.d, 0, c->ld * sizeof(double), c->stream), "memset d");
+            note(hipMemsetAsync(sl.part + (size_t)P_DGINIT * kMaxPartials, 0, kMaxPartials * sizeof(double), c->stream),
+                 "memset dginit");
+            occupied[s] = true;
+            ++active;
+            ++next;
+        };
+        auto finish_problem = [&](int s, int code, bool keep_trial) {
+            BatchProblem& p = slots[s];
+            ProblemSlot& sl = c->slot[s];
+            bioen_opt_result& info = infos[p.id];
+            info.lbfgs_code = code;
+            info.iterations = p.machine->iterations();
+            info.evaluations = p.machine->evaluations();
+            info.fmin = p.machine->fx();
+            const double* res = keep_trial ? sl.x : sl.xp;
+            if (!keep_trial && !p.initial) {
+                // line search failed: liblbfgs returns the previous point; re-establish w, chi^2, KL there
+                note(hipMemcpyAsync(sl.x, sl.xp, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "revert");
+                const int one[1] = {s};
+                const Round r = make_round(c, one, 1, nullptr, &p.theta);
+                launch_max(c, r);
+                enqueue_logw_eval(c, r, false);
+                note(read_scalars(c, kMaxBatch));
+                res = sl.x;
+            }
+            const double* h = c->host_scal + (size_t)s * kScalStride;
+            info.chi2 = 0.5 * h[S_CHI];
+            info.kl = h[S_P] - h[S_LOGS] + h[S_LOGS0];
+            note(hipMemcpyAsync(results + (size_t)p.id * c->n, res, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
+                                c->stream), "result D2H");
+            if (w_opt)
+                note(hipMemcpyAsync(w_opt + (size_t)p.id * c->n, sl.w, (size_t)c->n * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream), "weights D2H");
+            note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
+            info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
+            if (verbose) {
+                std::printf("\ttheta = %g\n", p.theta);
+                print_summary(c, info);
+            }
+            occupied[s] = false;
+            --active;
+        };
 
-    void revert() { result_is_trial = false; }
-    void keep_trial() { result_is_trial = true; }
+        for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
+
+        while (active > 0 && !rc) {
+            // ---- one round: every active problem evaluates its next point -------------------------
+            int list[kMaxBatch];
+            double stp[kMaxBatch], th[kMaxBatch];
+            int k = 0;
+            for (int s = 0; s < kb; ++s) {
+                if (!occupied[s]) continue;
+                list[k] = s;
+                stp[k] = slots[s].initial ? 0.0 : slots[s].machine->trial_step();
+                th[k] = slots[s].theta;
+                ++k;
+            }
+            const Round r = make_round(c, list, k, stp, th);
+            launch_trial(c, r);
+            enqueue_logw_eval(c, r, true);
+            note(read_scalars(c, kMaxBatch));
+            note(check_launch());
+            if (rc) break;
+
+            std::vector<int> dir_list;
+            for (int a = 0; a < k; ++a) {
+                const int s = list[a];
+                BatchProblem& p = slots[s];
+                ProblemSlot& sl = c->slot[s];
+                const double* h = c->host_scal + (size_t)s * kScalStride;
+                LbfgsMachine::Action act;
+                if (p.initial) {
+                    act = p.machine->on_initial(h[S_F], h[S_GG], h[S_XX]);
+                    if (act.kind != LbfgsMachine::DONE) {
+                        std::swap(sl.g, sl.gp);      // gradient at the accepted (= start) point
+                        p.initial = false;
+                        p.need_direction = true;
+                        p.accept = false;
+                        p.end = 0;
+                        p.bound = 0;
+                        dir_list.push_back(s);
+                    }
+                } else {
+                    TrialResult t{h[S_F], h[S_DG], h[S_GG], h[S_XX], h[S_DGINIT]};
+                    act = p.machine->on_trial(t);
+                    if (act.kind == LbfgsMachine::ACCEPT) {
+                        p.need_direction = true;
+                        p.accept = true;
+                        p.end = act.end;
+                        p.bound = act.bound;
+                        dir_list.push_back(s);
+                    }
+                }
+                if (act.kind == LbfgsMachine::DONE) {
+                    finish_problem(s, act.code, act.keep_trial);
+                    if (next < ntheta && !rc) start_problem(s);
+                }
+            }
+            directions(slots, dir_list);
+        }
+        note(hipStreamSynchronize(c->stream), "sync");
+        note(check_launch());
+        return rc;
+    }
 };
 
 // forces: M variables live on the host, evaluations on the device
@@ -481,6 +712,7 @@ static void resolve_timers(bioen_hip_ctx* c) {
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             t.total_ms[p.which] += ms;
             t.launches[p.which] += 1;
+            t.problem_passes[p.which] += p.k;
         }
         t.pool.push_back(p);
     }
@@ -550,20 +782,20 @@ int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const doub
     bioen_hip_ctx* c = nullptr;
     int rc = ctx_alloc(m, n, device, &c);
     if (rc) return rc;
-    // stage the three M-vectors in ybar / r / um (all mp long), then generate in place
-    hipError_t e = hipMemcpyAsync(c->ybar, YTrue, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    // stage the three M-vectors in ybar_c / r_c / um (all >= mp long), then generate in place
+    hipError_t e = hipMemcpyAsync(c->ybar_c, YTrue, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
-        e = hipMemcpyAsync(c->r, sig_sim, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(c->r_c, sig_sim, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->um, sig_exp, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->YT, YTilde, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        launch_generate(c, c->ybar, c->r, c->um, seed);
+        launch_generate(c, c->ybar_c, c->r_c, c->um, seed);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemsetAsync(c->ybar, 0, c->mp * sizeof(double), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->r, 0, c->mp * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->ybar_c, 0, c->mp * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->r_c, 0, c->mp * sizeof(double), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->um, 0, c->mp * sizeof(double), c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
@@ -584,13 +816,19 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    double* bufs[] = {c->Y, c->YT, c->ybar, c->r, c->um, c->gm, c->x, c->xp, c->g, c->gp, c->d, c->w,
-                      c->fixed, c->a, c->t, c->fwd_partial, c->part, c->scal};
+    double* bufs[] = {c->Y, c->YT, c->ybar_c, c->r_c, c->um, c->gm, c->fixed, c->t, c->g0, c->fwd_partial,
+                      c->part, c->scal};
     for (double* p : bufs)
         if (p) hipFree(p);
-    for (int i = 0; i < kHistory; ++i) {
-        if (c->S[i]) hipFree(c->S[i]);
-        if (c->Yh[i]) hipFree(c->Yh[i]);
+    for (int s = 0; s < kMaxBatch; ++s) {
+        ProblemSlot& sl = c->slot[s];
+        double* v[] = {sl.xa, sl.xb, sl.ga, sl.gb, sl.d, sl.w, sl.a};
+        for (double* p : v)
+            if (p) hipFree(p);
+        for (int i = 0; i < kHistory; ++i) {
+            if (sl.S[i]) hipFree(sl.S[i]);
+            if (sl.Yh[i]) hipFree(sl.Yh[i]);
+        }
     }
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -636,14 +874,17 @@ int bioen_hip_synchronize(bioen_hip_ctx* c) {
 int bioen_hip_logw_weights(bioen_hip_ctx* c, const double* g, double* w, double* log_s) {
     if (!c || !g) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    int rc = upload_n(c, c->xp, g);
+    ProblemSlot& s0 = c->slot[0];
+    int rc = upload_n(c, s0.x, g);
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipMemsetAsync(c->fixed, 0, c->ld * sizeof(double), c->stream));
-    launch_trial(c, 0.0);
-    launch_logw_exp(c);
-    launch_logw_norm(c);
+    const int one[1] = {0};
+    const Round r = make_round(c, one, 1, nullptr, nullptr);
+    launch_max(c, r);
+    launch_logw_exp(c, r);
+    launch_logw_norm(c, r);
     if ((rc = check_launch())) return rc;
-    if (w) BIOEN_HIP_CHECK(hipMemcpyAsync(w, c->w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (w) BIOEN_HIP_CHECK(hipMemcpyAsync(w, s0.w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if ((rc = read_scalars(c))) return rc;
     if (log_s) *log_s = c->host_scal[S_LOGS];
     return 0;
@@ -653,72 +894,47 @@ int bioen_hip_logw_fdf(bioen_hip_ctx* c, const double* g, const double* G, doubl
                        double* grad) {
     if (!c || !g || !G) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    ProblemSlot& s0 = c->slot[0];
     int rc;
-    if ((rc = upload_n(c, c->xp, g))) return rc;
+    if ((rc = upload_n(c, s0.x, g))) return rc;
     if ((rc = upload_n(c, c->fixed, G))) return rc;
-    launch_logw_logs0(c);
-    launch_trial(c, 0.0);
-    enqueue_logw_eval(c, theta, grad != nullptr);
+    if (grad) BIOEN_HIP_CHECK(hipMemsetAsync(s0.d, 0, c->ld * sizeof(double), c->stream));
+    const int one[1] = {0};
+    const Round r = make_round(c, one, 1, nullptr, &theta);
+    launch_logw_logs0(c, r);
+    launch_max(c, r);
+    enqueue_logw_eval(c, r, grad != nullptr);
     if ((rc = check_launch())) return rc;
     if (grad)
-        BIOEN_HIP_CHECK(hipMemcpyAsync(grad, c->g, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        BIOEN_HIP_CHECK(hipMemcpyAsync(grad, s0.g, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if ((rc = read_scalars(c))) return rc;
     if (f) *f = c->host_scal[S_F];
     return 0;
 }
 
+int bioen_hip_opt_lbfgs_logw_batch(bioen_hip_ctx* c, int ntheta, const double* thetas, const double* g0,
+                                   size_t g0_stride, const double* G, const bioen_lbfgs_config* config,
+                                   const bioen_visual_params* visual, int max_batch, double* results,
+                                   double* w_opt, bioen_opt_result* infos) {
+    if (!c || !thetas || !g0 || !G || !config || !results || !infos || ntheta <= 0)
+        return fail(BIOEN_HIP_EINVAL, "NULL argument or ntheta <= 0");
+    if (g0_stride != 0 && g0_stride < (size_t)c->n) return fail(BIOEN_HIP_EINVAL, "g0_stride must be 0 or >= n");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    const bool verbose = visual && visual->verbose;
+    if (verbose) {
+        std::printf("L-BFGS minimizer (%d theta value%s, up to %d per matrix pass)\n", ntheta, ntheta > 1 ? "s" : "",
+                    std::max(1, std::min(max_batch, (int)kMaxBatch)));
+        print_config(*config);
+    }
+    LogwBatchEngine eng(c, *config, verbose);
+    return eng.run(ntheta, thetas, g0, g0_stride, G, max_batch, results, w_opt, infos);
+}
+
 int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* c, const double* g0, const double* G, double theta,
                              const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                              double* result, double* w_opt, bioen_opt_result* info) {
-    if (!c || !g0 || !G || !config || !result || !info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    const bool verbose = visual && visual->verbose;
-    std::memset(info, 0, sizeof *info);
-    int rc;
-    if ((rc = ensure_history(c))) return rc;
-    if ((rc = upload_n(c, c->xp, g0))) return rc;
-    if ((rc = upload_n(c, c->fixed, G))) return rc;
-    BIOEN_HIP_CHECK(hipMemsetAsync(c->d, 0, c->ld * sizeof(double), c->stream));
-    BIOEN_HIP_CHECK(hipMemsetAsync(bioen::part(c, P_DGINIT), 0, kMaxPartials * sizeof(double), c->stream));
-    launch_logw_logs0(c);
-    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
-
-    if (verbose) {
-        std::printf("L-BFGS minimizer\n");
-        print_config(*config);
-    }
-    DeviceLogwBackend B{c, theta};
-    const auto t0 = std::chrono::steady_clock::now();
-    double fx = 0.0;
-    info->lbfgs_code = lbfgs_run(B, c->n, *config, &fx, &info->iterations, &info->evaluations);
-    hipStreamSynchronize(c->stream);
-    info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    info->fmin = fx;
-    if (B.rc) return B.rc;
-    if ((rc = check_launch())) return rc;
-
-    const double* res = B.result_is_trial ? c->x : c->xp;
-    if (info->evaluations > 0) {
-        if (!B.result_is_trial) {
-            // re-establish w, chi^2, KL at the accepted point (one forward pass, outside the timing)
-            BIOEN_HIP_CHECK(hipMemcpyAsync(c->x, c->xp, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            launch_max(c, c->x);
-            enqueue_logw_eval(c, theta, false);
-            res = c->x;
-        }
-        if ((rc = read_scalars(c))) return rc;
-        info->chi2 = 0.5 * c->host_scal[S_CHI];
-        info->kl = c->host_scal[S_P] - c->host_scal[S_LOGS] + c->host_scal[S_LOGS0];
-        if (w_opt)
-            BIOEN_HIP_CHECK(hipMemcpyAsync(w_opt, c->w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
-                                           c->stream));
-    } else {
-        res = c->xp;
-    }
-    BIOEN_HIP_CHECK(hipMemcpyAsync(result, res, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (verbose) print_summary(c, *info);
-    return 0;
+    if (!info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    return bioen_hip_opt_lbfgs_logw_batch(c, 1, &theta, g0, 0, G, config, visual, 1, result, w_opt, info);
 }
 
 // ---- forces ---------------------------------------------------------------------------
@@ -734,7 +950,7 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
     if ((rc = upload_forces_inputs(c, forces, w0))) return rc;
     enqueue_forces_weights(c);
     if ((rc = check_launch())) return rc;
-    BIOEN_HIP_CHECK(hipMemcpyAsync(w, c->w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BIOEN_HIP_CHECK(hipMemcpyAsync(w, c->slot[0].w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -785,7 +1001,7 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
         enqueue_forces_eval(c, theta, false);
         if ((rc = check_launch())) return rc;
         if (w_opt)
-            BIOEN_HIP_CHECK(hipMemcpyAsync(w_opt, c->w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
+            BIOEN_HIP_CHECK(hipMemcpyAsync(w_opt, c->slot[0].w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
                                            c->stream));
         if ((rc = read_scalars(c))) return rc;
         info->chi2 = 0.5 * c->host_scal[S_CHI];
@@ -799,14 +1015,19 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
 int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, double* chi2) {
     if (!c || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    ProblemSlot& s0 = c->slot[0];
     int rc;
-    if ((rc = upload_n(c, c->w, w))) return rc;
-    launch_fwd_partial(c, c->w);
-    launch_fwd_rows_residual(c);
+    if ((rc = upload_n(c, s0.w, w))) return rc;
+    const int one[1] = {0};
+    const Round r = make_round(c, one, 1, nullptr, nullptr);
+    Vec8 v{};
+    v.p[0] = s0.w;
+    launch_fwd_partial(c, 1, v);
+    launch_fwd_rows_residual(c, r);
     launch_forces_scalars(c, 0.0);   // S_CHI (the KL partials it also sums are irrelevant here)
     if ((rc = check_launch())) return rc;
-    if (yave)
-        BIOEN_HIP_CHECK(hipMemcpyAsync(yave, c->ybar, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (yave)   // K = 1: the compact layout is the plain M-vector
+        BIOEN_HIP_CHECK(hipMemcpyAsync(yave, c->ybar_c, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if ((rc = read_scalars(c))) return rc;
     if (chi2) *chi2 = 0.5 * c->host_scal[S_CHI];
     return 0;
@@ -838,6 +1059,14 @@ int bioen_hip_kernel_stats(bioen_hip_ctx* c, int which, double* total_ms, long l
     return 0;
 }
 
+int bioen_hip_kernel_stats_ex(bioen_hip_ctx* c, int which, double* total_ms, long long* launches,
+                              long long* problem_passes) {
+    int rc = bioen_hip_kernel_stats(c, which, total_ms, launches);
+    if (rc) return rc;
+    if (problem_passes) *problem_passes = c->timer.problem_passes[which];
+    return 0;
+}
+
 int bioen_hip_kernel_stats_reset(bioen_hip_ctx* c) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
     hipSetDevice(c->device);
@@ -845,6 +1074,7 @@ int bioen_hip_kernel_stats_reset(bioen_hip_ctx* c) {
     resolve_timers(c);
     c->timer.total_ms[0] = c->timer.total_ms[1] = 0.0;
     c->timer.launches[0] = c->timer.launches[1] = 0;
+    c->timer.problem_passes[0] = c->timer.problem_passes[1] = 0;
     return 0;
 }
 

@@ -7,10 +7,15 @@
 //              mp = round_up(m, 32)    (4 waves x 8 rows per forward block; 4 x 8
 //                                       unrolled rows per adjoint block)
 //            padding is zero, so no matrix kernel needs an edge branch.
-//   N-vectors (x, xp, g, gp, d, w, G/w0, a, t, S[6], Y[6]) : ld doubles, pad = 0
-//   M-vectors (YT, ybar, r, um, gm)                         : mp doubles, pad = 0
-//   scal   : a few dozen device-resident doubles (dot products, alphas, f, ...)
-//            so that only line-search decisions ever cross PCIe.
+//   slots  : up to kMaxBatch optimisation problems (thetas) live side by side and share
+//            every pass over Y ("lock-step batch").  Per slot: N-vectors x, xp, g, gp,
+//            d, w, a and the L-BFGS history S[6], Y[6] (ld doubles each, pad = 0), 32
+//            device-resident scalars and 16 x 1024 reduction partials.
+//   M-side : YT (targets), and per round the COMPACT interleaved arrays
+//            ybar_c[row*K + a], r_c[row*K + a] (a = position in the round's batch), so
+//            the adjoint kernel fetches the K wave-uniform operands of a row with one
+//            scalar load.
+//   Only line-search decisions ever cross PCIe (kMaxBatch x 32 doubles per round).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,9 +33,11 @@ constexpr int kHistory = 6;        // liblbfgs default m (lbfgs.c:113), never ov
 constexpr int kColAlign = 128;     // doubles: one wave x 16 B
 constexpr int kRowAlign = 32;
 constexpr int kMaxPartials = 1024; // upper bound on any reduction grid
+constexpr int kMaxBatch = 8;       // thetas sharing one matrix pass
+constexpr int kScalStride = 32;    // doubles per slot in `scal`
 
-// device-resident scalar slots
-enum Slot : int {
+// device-resident scalar slots (per problem slot)
+enum ScalarSlot : int {
     S_F = 0,      // objective
     S_DG,         // grad . d   at the trial point
     S_GG,         // grad . grad
@@ -45,20 +52,41 @@ enum Slot : int {
     S_TSUM,       // forces: sum_j t_j
     S_YS,         // y.s of the newest pair
     S_YY,         // y.y of the newest pair
-    S_THETA,
-    S_SPARE,
+    S_SPARE0,
+    S_SPARE1,
     S_YSH,                         // [kHistory] y.s per history slot
     S_ALPHA = S_YSH + kHistory,    // [kHistory]
     S_COUNT = S_ALPHA + kHistory
+};
+static_assert(S_COUNT <= kScalStride, "scalar slots");
+
+// partial-reduction arrays (each kMaxPartials doubles, per problem slot)
+enum PartSlot : int {
+    P_MAX = 0, P_SUM, P_PP, P_CHI, P_C, P_DG, P_GG, P_XX, P_DGINIT, P_REC, P_REC2, P_YS, P_YY, P_KL, P_TSUM,
+    P_COUNT = 16
 };
 
 struct KernelTimer {
     bool enabled = false;
     double total_ms[2] = {0.0, 0.0};
     long long launches[2] = {0, 0};
-    struct Pair { hipEvent_t a, b; int which; };
+    long long problem_passes[2] = {0, 0};   // sum over launches of the batch width K
+    struct Pair { hipEvent_t a, b; int which; int k; };
     std::vector<Pair> pending;
     std::vector<Pair> pool;
+};
+
+struct ProblemSlot {
+    bool allocated = false;
+    bool history = false;
+    double *xa = nullptr, *xb = nullptr, *ga = nullptr, *gb = nullptr;   // storage
+    double *x = nullptr, *xp = nullptr, *g = nullptr, *gp = nullptr;     // current roles
+    double *d = nullptr, *w = nullptr, *a = nullptr;
+    double* S[kHistory] = {};
+    double* Yh[kHistory] = {};
+    double* scal = nullptr;   // kScalStride doubles inside ctx->scal
+    double* part = nullptr;   // P_COUNT * kMaxPartials doubles inside ctx->part
+    int rec_flip = 0;         // ping-pong index of the recursion's dot partials
 };
 
 }  // namespace bioen
@@ -70,28 +98,25 @@ struct bioen_hip_ctx {
     size_t ld = 0;
     hipStream_t stream = nullptr;
 
-    double* Y = nullptr;      // mp x ld
-    double* YT = nullptr;     // mp   experimental targets (YTilde)
-    double* ybar = nullptr;   // mp
-    double* r = nullptr;      // mp
-    double* um = nullptr;     // mp   M-vector input  (forces)
-    double* gm = nullptr;     // mp   M-vector output (forces gradient)
+    double* Y = nullptr;       // mp x ld
+    double* YT = nullptr;      // mp   experimental targets (YTilde)
+    double* ybar_c = nullptr;  // mp * kMaxBatch, compact per round
+    double* r_c = nullptr;     // mp * kMaxBatch
+    double* um = nullptr;      // mp   M-vector input  (forces)
+    double* gm = nullptr;      // mp   M-vector output (forces gradient)
+    double* fixed = nullptr;   // ld   G (log-weights) or w0 (forces), shared by all slots
+    double* t = nullptr;       // ld   forces scratch
+    double* g0 = nullptr;      // ld   shared start vector of a batch run (lazy)
 
-    // N-vectors
-    double *x = nullptr, *xp = nullptr, *g = nullptr, *gp = nullptr, *d = nullptr;
-    double *w = nullptr, *fixed = nullptr /* G or w0 */, *a = nullptr, *t = nullptr;
-    double* S[bioen::kHistory] = {};
-    double* Yh[bioen::kHistory] = {};
-    bool history_allocated = false;
+    bioen::ProblemSlot slot[bioen::kMaxBatch];
 
-    double* fwd_partial = nullptr;   // mp x fwd_ctiles
+    double* fwd_partial = nullptr;   // kMaxBatch * mp * fwd_ctiles, compact per round
     int fwd_ctiles = 0;              // column tiles of the forward pass
     int fwd_steps = 0;               // 128-column steps per tile
-    double* part = nullptr;          // 8 x kMaxPartials reduction partials
-    double* scal = nullptr;          // S_COUNT device scalars
+    double* part = nullptr;          // kMaxBatch * P_COUNT * kMaxPartials
+    double* scal = nullptr;          // kMaxBatch * kScalStride
     double* host_scal = nullptr;     // pinned mirror
 
-    int rec_flip = 0;                // ping-pong index of the recursion's dot partials
     bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)
     bioen::KernelTimer timer;
 

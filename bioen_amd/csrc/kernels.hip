@@ -1,18 +1,22 @@
 // gfx950 (CDNA4, wave64) kernels of the BioEn log-weights / forces hot path.
 //
 // Two kernels touch the M x N matrix and carry >99 % of the bytes:
-//   k_fwd_partial : ybar = yTilde . v      (replaces _bioen_chi_squared's GEMV,
-//                                           c_bioen_common.c:76-86, and _getAve,
-//                                           c_bioen_kernels_forces.c:93-109)
-//   k_adj         : a    = yTilde^T . u    (replaces the transposed-cache walks of
-//                                           c_bioen_kernels_logw.c:185-205 and
-//                                           c_bioen_kernels_forces.c:127-150,300-320)
-// Both stream the row-major matrix exactly once with 16-byte-per-lane loads
-// (one aligned KiB per wave instruction) straight into registers -- the operand
-// is read once and not shared across waves, so an LDS round trip would be pure
-// overhead -- and reduce in a fixed order (bitwise reproducible run to run).
-// Everything else is O(N) or O(M) glue that keeps all vectors and scalars in
-// HBM so that only line-search decisions cross PCIe.
+//   k_fwd_partial : ybar_a = yTilde . v_a    (replaces _bioen_chi_squared's GEMV,
+//                                             c_bioen_common.c:76-86, and _getAve,
+//                                             c_bioen_kernels_forces.c:93-109)
+//   k_adj         : out_a  = yTilde^T . u_a  (replaces the transposed-cache walks of
+//                                             c_bioen_kernels_logw.c:185-205 and
+//                                             c_bioen_kernels_forces.c:127-150,300-320)
+// for a = 0..K-1: up to K = 8 optimisation problems (thetas of a series) share one pass,
+// so the matrix bytes per problem drop by K while the arithmetic per problem -- and its
+// order -- is exactly that of a K = 1 launch (batched runs are bitwise equal to single
+// runs).  Both kernels stream the row-major matrix once with 16-byte-per-lane loads (one
+// aligned KiB per wave instruction) straight into registers: the operand is read once and
+// not shared across waves, so an LDS round trip would be pure overhead.  FP64 FMA issue
+// stays far below the HBM-bound budget up to K = 8 (2K flop per 8 bytes), which is why the
+// batch runs on the vector ALU rather than on v_mfma_f64 (whose 16x16x4 shape would also
+// force 64-byte row fragments instead of KiB-wide coalesced loads).
+// Every reduction has a fixed shape => results are bitwise reproducible run to run.
 #include "kernels.hpp"
 
 #include <cfloat>
@@ -39,6 +43,36 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// Butterfly-reduce NV (power of two, <= 64) per-lane values at once: at every stage the two
+// lanes of a pair split the remaining values between them, so the whole thing costs NV-1
+// shuffles instead of 6*NV.  Each value's sum is formed in the same pair order
+// (32,16,8,4,2,1) as wave_sum, hence bitwise equal to it.  On return v[0] of lane l is the
+// total of value number  l >> (6 - log2 NV).
+template <int CNT, int O, int NV>
+__device__ __forceinline__ void multi_stage(double (&v)[NV], int lane) {
+    if constexpr (O >= 1) {
+        if constexpr (CNT > 1) {
+            const bool upper = (lane & O) != 0;
+            constexpr int half = CNT / 2;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const double send = upper ? v[i] : v[i + half];
+                const double keep = upper ? v[i + half] : v[i];
+                v[i] = keep + __shfl_xor(send, O, 64);
+            }
+            multi_stage<half, O / 2, NV>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], O, 64);
+            multi_stage<1, O / 2, NV>(v, lane);
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void wave_multi_reduce(double (&v)[NV], int lane) {
+    multi_stage<NV, 32, NV>(v, lane);
+}
+
 // sum over the 256 threads of a block; result in every thread
 __device__ __forceinline__ double block_sum(double v, double* sh /* [kWaves] */) {
     v = wave_sum(v);
@@ -56,9 +90,9 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 
-// Sum an array of per-block partials written by the PREVIOUS kernel.  Every
-// block of the consumer kernel does this redundantly in its prologue (<= 8 KiB,
-// L2 resident), which replaces a separate 1-block "finalise" launch.
+// Sum an array of per-block partials written by the PREVIOUS kernel.  Every block of the
+// consumer kernel does this redundantly in its prologue (<= 8 KiB, L2 resident), which
+// replaces a separate 1-block "finalise" launch.
 __device__ __forceinline__ double sum_partials(const double* __restrict__ p, int np, double* sh) {
     double s = 0.0;
     for (int k = threadIdx.x; k < np; k += kBlock) s += p[k];
@@ -77,106 +111,116 @@ __device__ __forceinline__ d2 ldg2(const double* p) {
     return *reinterpret_cast<const d2*>(p);
 }
 
+constexpr int next_pow2(int v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : 8)); }
+
 // ------------------------------------------------------------------------------
-// forward pass: partial[row * ctiles + tile] = sum_{j in tile} Y[row][j] v[j]
-//   block = 4 waves stacked over rows, R rows per wave; a wave walks its column
-//   tile in 128-column (1 KiB) steps, two steps in flight (2*R loads of 1 KiB).
+// forward pass: partial[(row*K + a)*ctiles + tile] = sum_{j in tile} Y[row][j] v_a[j]
+//   block = 4 waves stacked over rows, R rows per wave; a wave walks its column tile in
+//   128-column (1 KiB) steps, STEPS steps in flight, K x R accumulators.
+//   CENTER (K = 1 only): sum_j (Y[row][j] - ybar[row]) v[j] -- the centred form the reference
+//   uses for the forces gradient (c_bioen_kernels_forces.c:330-338).
 // ------------------------------------------------------------------------------
-// CENTER: sum_j (Y[row][j] - ybar[row]) v[j] -- the centred form the reference uses for the
-// forces gradient (c_bioen_kernels_forces.c:330-338); avoids the cancellation of
-// (Y v) - ybar (1.v) when a gradient component is small against its two terms.
-template <int R, bool NT, bool CENTER>
-__global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict__ Y, size_t ld,
-                                                        const double* __restrict__ v,
-                                                        const double* __restrict__ ybar,
+template <int R, int K, int STEPS, bool NT, bool CENTER>
+__global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict__ Y, size_t ld, Vec8 v,
+                                                        const double* __restrict__ ybar_c,
                                                         double* __restrict__ partial, int ctiles,
                                                         int steps_per_tile, int total_steps) {
+    static_assert(!CENTER || K == 1, "centred forward pass is single-problem");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x;
-    const int row0 = (blockIdx.y * kWaves + wave) * R;
+    // blockIdx.x = row block (fast index): consecutive blocks share the column tile, so the
+    // tile's slice of v_a is fetched from HBM once per XCD and then served by L2
+    const int tile = blockIdx.y;
+    const int row0 = (blockIdx.x * kWaves + wave) * R;
     int s = tile * steps_per_tile;
     int s_end = s + steps_per_tile;
     if (s_end > total_steps) s_end = total_steps;
 
-    const double* yp = Y + (size_t)row0 * ld + (size_t)s * 128 + lane * 2;
-    const double* vp = v + (size_t)s * 128 + lane * 2;
+    const size_t col = (size_t)s * 128 + lane * 2;
+    const double* yp = Y + (size_t)row0 * ld + col;
 
-    double acc[R], yb[R];
+    constexpr int KP = next_pow2(K);
+    double acc[KP * R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc[r] = 0.0;
-        yb[r] = CENTER ? ybar[row0 + r] : 0.0;
-    }
+    for (int i = 0; i < KP * R; ++i) acc[i] = 0.0;
+    double yb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) yb[r] = CENTER ? ybar_c[row0 + r] : 0.0;
 
-    for (; s + 2 <= s_end; s += 2) {
-        d2 y0[R], y1[R];
+    size_t off = col;
+    for (; s + STEPS <= s_end; s += STEPS) {
+        d2 y[STEPS][R];
+        d2 vv[STEPS][K];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            y0[r] = ldg2<NT>(yp + (size_t)r * ld);
-            y1[r] = ldg2<NT>(yp + (size_t)r * ld + 128);
+        for (int t = 0; t < STEPS; ++t) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) y[t][r] = ldg2<NT>(yp + (size_t)r * ld + t * 128);
+#pragma unroll
+            for (int k = 0; k < K; ++k) vv[t][k] = *reinterpret_cast<const d2*>(v.p[k] + off + t * 128);
         }
-        const d2 v0 = *reinterpret_cast<const d2*>(vp);
-        const d2 v1 = *reinterpret_cast<const d2*>(vp + 128);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (CENTER) {
-                acc[r] = fma(y0[r].x - yb[r], v0.x, acc[r]);
-                acc[r] = fma(y0[r].y - yb[r], v0.y, acc[r]);
-                acc[r] = fma(y1[r].x - yb[r], v1.x, acc[r]);
-                acc[r] = fma(y1[r].y - yb[r], v1.y, acc[r]);
-            } else {
-                acc[r] = fma(y0[r].x, v0.x, acc[r]);
-                acc[r] = fma(y0[r].y, v0.y, acc[r]);
-                acc[r] = fma(y1[r].x, v1.x, acc[r]);
-                acc[r] = fma(y1[r].y, v1.y, acc[r]);
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int t = 0; t < STEPS; ++t) {
+                    acc[k * R + r] = fma(y[t][r].x - yb[r], vv[t][k].x, acc[k * R + r]);
+                    acc[k * R + r] = fma(y[t][r].y - yb[r], vv[t][k].y, acc[k * R + r]);
+                }
             }
         }
-        yp += 256;
-        vp += 256;
+        yp += STEPS * 128;
+        off += STEPS * 128;
     }
-    if (s < s_end) {
-        d2 y0[R];
+    for (; s < s_end; ++s) {   // tail (only when STEPS = 2 and the tile has an odd step count)
+        d2 y[R];
+        d2 vv[K];
 #pragma unroll
-        for (int r = 0; r < R; ++r) y0[r] = ldg2<NT>(yp + (size_t)r * ld);
-        const d2 v0 = *reinterpret_cast<const d2*>(vp);
+        for (int r = 0; r < R; ++r) y[r] = ldg2<NT>(yp + (size_t)r * ld);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (CENTER) {
-                acc[r] = fma(y0[r].x - yb[r], v0.x, acc[r]);
-                acc[r] = fma(y0[r].y - yb[r], v0.y, acc[r]);
-            } else {
-                acc[r] = fma(y0[r].x, v0.x, acc[r]);
-                acc[r] = fma(y0[r].y, v0.y, acc[r]);
+        for (int k = 0; k < K; ++k) vv[k] = *reinterpret_cast<const d2*>(v.p[k] + off);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[k * R + r] = fma(y[r].x - yb[r], vv[k].x, acc[k * R + r]);
+                acc[k * R + r] = fma(y[r].y - yb[r], vv[k].y, acc[k * R + r]);
             }
         }
+        yp += 128;
+        off += 128;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const double tot = wave_sum(acc[r]);
-        if (lane == r) partial[(size_t)(row0 + r) * ctiles + tile] = tot;
+
+    constexpr int NV = KP * R;
+    wave_multi_reduce<NV>(acc, lane);
+    constexpr int SHIFT = (NV == 8) ? 3 : (NV == 16) ? 2 : (NV == 32) ? 1 : 0;   // 6 - log2(NV)
+    if ((lane & ((1 << SHIFT) - 1)) == 0) {
+        const int idx = lane >> SHIFT;
+        const int k = idx / R, r = idx % R;
+        if (k < K) partial[((size_t)(row0 + r) * K + k) * ctiles + tile] = acc[0];
     }
 }
 
-// reduce the column tiles of one row per wave (fixed order), mode 0:
-//   ybar_i, r_i = ybar_i - YT_i ; per-block partials of sum r^2 and sum ybar r
+// reduce the column tiles of one (row, problem) per wave (fixed order):
+//   ybar, r = ybar - YT (compact layout [row*K + a]) ; per-block partials of sum r^2 and sum ybar r
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_residual(const double* __restrict__ partial, int ctiles,
-                                                              int mp, const double* __restrict__ YT,
-                                                              double* __restrict__ ybar, double* __restrict__ r,
-                                                              double* __restrict__ pchi, double* __restrict__ pc) {
+                                                              int mp, int K, const double* __restrict__ YT,
+                                                              double* __restrict__ ybar_c,
+                                                              double* __restrict__ r_c, MVec8 part) {
     __shared__ double sh[2][kWaves];
+    const int a = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double chi = 0.0, cc = 0.0;
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
-        const double* p = partial + (size_t)row * ctiles;
+        const double* p = partial + ((size_t)row * K + a) * ctiles;
         double s = 0.0;
         for (int k = lane; k < ctiles; k += 64) s += p[k];
         s = wave_sum(s);
         const double res = s - YT[row];
         if (lane == 0) {
-            ybar[row] = s;
-            r[row] = res;
+            ybar_c[(size_t)row * K + a] = s;
+            r_c[(size_t)row * K + a] = res;
         }
         chi += res * res;
         cc += s * res;
@@ -187,13 +231,14 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_residual(const double* __re
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        pchi[blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        pc[blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        double* pa = part.p[a];
+        pa[(size_t)P_CHI * kMaxPartials + blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        pa[(size_t)P_C * kMaxPartials + blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     }
 }
 
-// mode 1 (forces gradient, c_bioen_kernels_forces.c:330-338): the partials already hold the
-// centred sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.
+// forces gradient (c_bioen_kernels_forces.c:330-338): the partials already hold the centred
+// sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* __restrict__ partial, int ctiles,
                                                                  int mp, double* __restrict__ gm) {
     const int lane = threadIdx.x & 63;
@@ -208,67 +253,72 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* _
 }
 
 // ------------------------------------------------------------------------------
-// adjoint pass: out[j] = sum_i Y[i][j] u[i]
-//   block = one 128-column strip (a lane owns 2 adjacent columns = 16 B), the 4
-//   waves split the rows; U rows (U KiB) in flight per wave; u[i] is wave-uniform
-//   and comes through the scalar cache.
+// adjoint pass: out_a[j] = sum_i Y[i][j] u_a[i]      (u, ybar compact: [i*K + a])
+//   block = one 128-column strip (a lane owns 2 adjacent columns = 16 B), the 4 waves split
+//   the rows; U rows (U KiB) in flight per wave; the K operands of a row are wave-uniform
+//   and come through the scalar cache with one load.
+//   CENTER: out_a[j] = sum_i u_a[i] (Y[i][j] - ybar_a[i]) -- the reference's centred gradient
+//   sum (c_bioen_kernels_logw.c:185-195); padded columns then hold -u.ybar, which nobody reads.
 // ------------------------------------------------------------------------------
-// CENTER: out[j] = sum_i u[i] (Y[i][j] - ybar[i]) -- the reference's centred gradient sum
-// (c_bioen_kernels_logw.c:185-195); padded columns then hold -u.ybar, which nobody reads.
-template <int U, bool NT, bool CENTER>
+template <int U, int K, bool NT, bool CENTER>
 __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, size_t ld, int rows_per_wave,
-                                                const double* __restrict__ u, const double* __restrict__ ybar,
-                                                double* __restrict__ out) {
-    __shared__ d2 red[kWaves][64];
+                                                const double* __restrict__ u_c,
+                                                const double* __restrict__ ybar_c, MVec8 out) {
+    __shared__ d2 red[kWaves][K][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t col = (size_t)blockIdx.x * 128 + lane * 2;
     const int r0 = wave * rows_per_wave;
     const double* yp = Y + (size_t)r0 * ld + col;
-    const double* up = u + r0;
-    const double* bp = ybar + r0;
+    const double* up = u_c + (size_t)r0 * K;
+    const double* bp = ybar_c + (size_t)r0 * K;
 
-    d2 acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+    d2 acc0[K], acc1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        acc0[k] = d2{0.0, 0.0};
+        acc1[k] = d2{0.0, 0.0};
+    }
     for (int i = 0; i < rows_per_wave; i += U) {
         d2 y[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) y[k] = ldg2<NT>(yp + (size_t)k * ld);
+        for (int q = 0; q < U; ++q) y[q] = ldg2<NT>(yp + (size_t)q * ld);
 #pragma unroll
-        for (int k = 0; k < U; k += 2) {
-            const double u0 = up[i + k], u1 = up[i + k + 1];
-            if (CENTER) {
-                const double b0 = bp[i + k], b1 = bp[i + k + 1];
-                acc0.x = fma(y[k].x - b0, u0, acc0.x);
-                acc0.y = fma(y[k].y - b0, u0, acc0.y);
-                acc1.x = fma(y[k + 1].x - b1, u1, acc1.x);
-                acc1.y = fma(y[k + 1].y - b1, u1, acc1.y);
-            } else {
-                acc0.x = fma(y[k].x, u0, acc0.x);
-                acc0.y = fma(y[k].y, u0, acc0.y);
-                acc1.x = fma(y[k + 1].x, u1, acc1.x);
-                acc1.y = fma(y[k + 1].y, u1, acc1.y);
+        for (int q = 0; q < U; q += 2) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double u0 = up[(size_t)(i + q) * K + k], u1 = up[(size_t)(i + q + 1) * K + k];
+                const double b0 = CENTER ? bp[(size_t)(i + q) * K + k] : 0.0;
+                const double b1 = CENTER ? bp[(size_t)(i + q + 1) * K + k] : 0.0;
+                acc0[k].x = fma(y[q].x - b0, u0, acc0[k].x);
+                acc0[k].y = fma(y[q].y - b0, u0, acc0[k].y);
+                acc1[k].x = fma(y[q + 1].x - b1, u1, acc1[k].x);
+                acc1[k].y = fma(y[q + 1].y - b1, u1, acc1[k].y);
             }
         }
         yp += (size_t)U * ld;
     }
-    d2 acc = {acc0.x + acc1.x, acc0.y + acc1.y};
-    red[wave][lane] = acc;
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave][k][lane] = d2{acc0[k].x + acc1[k].x, acc0[k].y + acc1[k].y};
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const d2 a0 = red[0][lane], a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
+    for (int k = wave; k < K; k += kWaves) {
+        const d2 a0 = red[0][k][lane], a1 = red[1][k][lane], a2 = red[2][k][lane], a3 = red[3][k][lane];
         d2 o = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
-        *reinterpret_cast<d2*>(out + col) = o;
+        *reinterpret_cast<d2*>(out.p[k] + col) = o;
     }
 }
 
 // ------------------------------------------------------------------------------
-// log-weights N-vector kernels
+// log-weights N-vector kernels (blockIdx.y = position a in the round's batch)
 // ------------------------------------------------------------------------------
 // x = xp + stp * d ; block maxima of x
-__global__ __launch_bounds__(kBlock) void k_trial(double* __restrict__ x, const double* __restrict__ xp,
-                                                  const double* __restrict__ d, double stp, int n,
-                                                  double* __restrict__ pmax) {
+__global__ __launch_bounds__(kBlock) void k_trial(Round r, int n) {
     __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    double* __restrict__ x = r.x[a];
+    const double* __restrict__ xp = r.xp[a];
+    const double* __restrict__ d = r.d[a];
+    const double stp = r.stp[a];
     double mx = -DBL_MAX;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double v = fma(stp, d[j], xp[j]);
@@ -276,10 +326,20 @@ __global__ __launch_bounds__(kBlock) void k_trial(double* __restrict__ x, const 
         mx = fmax(mx, v);
     }
     mx = block_max(mx, sh);
-    if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
+    if (threadIdx.x == 0) r.part[a][(size_t)P_MAX * kMaxPartials + blockIdx.x] = mx;
 }
 
-__global__ __launch_bounds__(kBlock) void k_max(const double* __restrict__ v, int n, double* __restrict__ pmax) {
+__global__ __launch_bounds__(kBlock) void k_max(Round r, int n) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = r.x[a];
+    double mx = -DBL_MAX;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, x[j]);
+    mx = block_max(mx, sh);
+    if (threadIdx.x == 0) r.part[a][(size_t)P_MAX * kMaxPartials + blockIdx.x] = mx;
+}
+
+__global__ __launch_bounds__(kBlock) void k_max_vec(const double* __restrict__ v, int n, double* __restrict__ pmax) {
     __shared__ double sh[kWaves];
     double mx = -DBL_MAX;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, v[j]);
@@ -289,12 +349,13 @@ __global__ __launch_bounds__(kBlock) void k_max(const double* __restrict__ v, in
 
 // _get_weights (c_bioen_kernels_logw.c:55-94) with a max shift, first half:
 //   e_j = exp(x_j - max) ; partials of sum e and sum e (x - G)   (prior, :96-127)
-__global__ __launch_bounds__(kBlock) void k_logw_exp(const double* __restrict__ x, const double* __restrict__ G,
-                                                     int n, const double* __restrict__ pmax, int np,
-                                                     double* __restrict__ e, double* __restrict__ psum,
-                                                     double* __restrict__ ppp) {
+__global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, int np) {
     __shared__ double sh[kWaves];
-    const double gmax = max_partials(pmax, np, sh);
+    const int a = blockIdx.y;
+    const double* __restrict__ x = r.x[a];
+    double* __restrict__ e = r.w[a];
+    double* pa = r.part[a];
+    const double gmax = max_partials(pa + (size_t)P_MAX * kMaxPartials, np, sh);
     double s = 0.0, pp = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double xv = x[j];
@@ -306,34 +367,34 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(const double* __restrict__ 
     s = block_sum(s, sh);
     pp = block_sum(pp, sh);
     if (threadIdx.x == 0) {
-        psum[blockIdx.x] = s;
-        ppp[blockIdx.x] = pp;
+        pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = s;
+        pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = pp;
     }
 }
 
 // second half: w = e / S ; scal[S_LOGS] = max + log S ; scal[S_P] = sum e (x-G) / S
-__global__ __launch_bounds__(kBlock) void k_logw_norm(double* __restrict__ w, int n, const double* __restrict__ pmax,
-                                                      const double* __restrict__ psum,
-                                                      const double* __restrict__ ppp, int np,
-                                                      double* __restrict__ scal) {
+__global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, int np) {
     __shared__ double sh[kWaves];
-    const double S = sum_partials(psum, np, sh);
+    const int a = blockIdx.y;
+    double* __restrict__ w = r.w[a];
+    const double* pa = r.part[a];
+    const double S = sum_partials(pa + (size_t)P_SUM * kMaxPartials, np, sh);
     const double inv = 1.0 / S;
     if (blockIdx.x == 0) {
-        const double gmax = max_partials(pmax, np, sh);
-        const double PP = sum_partials(ppp, np, sh);
+        const double gmax = max_partials(pa + (size_t)P_MAX * kMaxPartials, np, sh);
+        const double PP = sum_partials(pa + (size_t)P_PP * kMaxPartials, np, sh);
         if (threadIdx.x == 0) {
-            scal[S_LOGS] = gmax + log(S);
-            scal[S_P] = PP * inv;
+            r.scal[a][S_LOGS] = gmax + log(S);
+            r.scal[a][S_P] = PP * inv;
         }
     }
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] *= inv;
 }
 
-// log s0 = log sum exp(G): constant per problem, computed once (the reference
-// recomputes it at every evaluation, c_bioen_kernels_logw.c:122)
-__global__ __launch_bounds__(kBlock) void k_logsumexp1(const double* __restrict__ G, int n, double* __restrict__ scal,
-                                                       int slot) {
+// log s0 = log sum exp(G): constant per problem, computed once (the reference recomputes it
+// at every evaluation, c_bioen_kernels_logw.c:122).  One block; every problem of the round
+// gets the value.
+__global__ __launch_bounds__(kBlock) void k_logsumexp1(const double* __restrict__ G, int n, Round r) {
     __shared__ double sh[kWaves];
     double mx = -DBL_MAX;
     for (int j = threadIdx.x; j < n; j += kBlock) mx = fmax(mx, G[j]);
@@ -341,38 +402,44 @@ __global__ __launch_bounds__(kBlock) void k_logsumexp1(const double* __restrict_
     double s = 0.0;
     for (int j = threadIdx.x; j < n; j += kBlock) s += exp(G[j] - mx);
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) scal[slot] = mx + log(s);
+    if (threadIdx.x == 0) {
+        const double v = mx + log(s);
+        for (int a = 0; a < r.n; ++a) r.scal[a][S_LOGS0] = v;
+    }
 }
 
 // f = theta (P - log s + log s0) + 0.5 sum r^2       (c_bioen_kernels_logw.c:124-147)
-__global__ __launch_bounds__(kBlock) void k_logw_scalars(const double* __restrict__ pchi,
-                                                         const double* __restrict__ pc, int np, double theta,
-                                                         double* __restrict__ scal) {
+__global__ __launch_bounds__(kBlock) void k_logw_scalars(Round r, int np) {
     __shared__ double sh[kWaves];
-    const double chi = sum_partials(pchi, np, sh);
-    const double c = sum_partials(pc, np, sh);
+    const int a = blockIdx.y;
+    const double* pa = r.part[a];
+    const double chi = sum_partials(pa + (size_t)P_CHI * kMaxPartials, np, sh);
+    const double c = sum_partials(pa + (size_t)P_C * kMaxPartials, np, sh);
     if (threadIdx.x == 0) {
-        scal[S_CHI] = chi;
-        scal[S_C] = c;
-        scal[S_F] = theta * (scal[S_P] - scal[S_LOGS] + scal[S_LOGS0]) + 0.5 * chi;
+        double* sc = r.scal[a];
+        sc[S_CHI] = chi;
+        sc[S_C] = c;
+        sc[S_F] = r.theta[a] * (sc[S_P] - sc[S_LOGS] + sc[S_LOGS0]) + 0.5 * chi;
     }
 }
 
 // gradient epilogue (c_bioen_kernels_logw.c:207-218):
 //   g_k = w_k [ theta (x_k - G_k - P) + a_k ],  a_k = sum_i r_i (yTilde_ik - ybar_i)  (centred adjoint)
 // plus the three dot products the line search / convergence test needs.
-__global__ __launch_bounds__(kBlock) void k_logw_grad(const double* __restrict__ x, const double* __restrict__ G,
-                                                      const double* __restrict__ w, const double* __restrict__ a,
-                                                      const double* __restrict__ d, double theta,
-                                                      const double* __restrict__ scal, int n,
-                                                      double* __restrict__ g, double* __restrict__ pdg,
-                                                      double* __restrict__ pgg, double* __restrict__ pxx) {
+__global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __restrict__ G, int n) {
     __shared__ double sh[kWaves];
-    const double P = scal[S_P];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = r.x[a];
+    const double* __restrict__ w = r.w[a];
+    const double* __restrict__ av = r.a[a];
+    const double* __restrict__ d = r.d[a];
+    double* __restrict__ g = r.g[a];
+    const double theta = r.theta[a];
+    const double P = r.scal[a][S_P];
     double dg = 0.0, gg = 0.0, xx = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double xv = x[j];
-        const double gv = w[j] * (theta * ((xv - G[j]) - P) + a[j]);
+        const double gv = w[j] * (theta * ((xv - G[j]) - P) + av[j]);
         g[j] = gv;
         dg = fma(gv, d[j], dg);
         gg = fma(gv, gv, gg);
@@ -382,31 +449,32 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(const double* __restrict__
     gg = block_sum(gg, sh);
     xx = block_sum(xx, sh);
     if (threadIdx.x == 0) {
-        pdg[blockIdx.x] = dg;
-        pgg[blockIdx.x] = gg;
-        pxx[blockIdx.x] = xx;
+        double* pa = r.part[a];
+        pa[(size_t)P_DG * kMaxPartials + blockIdx.x] = dg;
+        pa[(size_t)P_GG * kMaxPartials + blockIdx.x] = gg;
+        pa[(size_t)P_XX * kMaxPartials + blockIdx.x] = xx;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_finish_eval(const double* __restrict__ pdg, const double* __restrict__ pgg,
-                                                        const double* __restrict__ pxx,
-                                                        const double* __restrict__ pdginit, int np,
-                                                        double* __restrict__ scal) {
+__global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, int np) {
     __shared__ double sh[kWaves];
-    const double dg = sum_partials(pdg, np, sh);
-    const double gg = sum_partials(pgg, np, sh);
-    const double xx = sum_partials(pxx, np, sh);
-    const double di = sum_partials(pdginit, np, sh);
+    const int a = blockIdx.y;
+    const double* pa = r.part[a];
+    const double dg = sum_partials(pa + (size_t)P_DG * kMaxPartials, np, sh);
+    const double gg = sum_partials(pa + (size_t)P_GG * kMaxPartials, np, sh);
+    const double xx = sum_partials(pa + (size_t)P_XX * kMaxPartials, np, sh);
+    const double di = sum_partials(pa + (size_t)P_DGINIT * kMaxPartials, np, sh);
     if (threadIdx.x == 0) {
-        scal[S_DG] = dg;
-        scal[S_GG] = gg;
-        scal[S_XX] = xx;
-        scal[S_DGINIT] = di;
+        double* sc = r.scal[a];
+        sc[S_DG] = dg;
+        sc[S_GG] = gg;
+        sc[S_XX] = xx;
+        sc[S_DGINIT] = di;
     }
 }
 
 // ------------------------------------------------------------------------------
-// forces N-vector kernels
+// forces N-vector kernels (single problem)
 // ------------------------------------------------------------------------------
 // _get_weights_from_forces (c_bioen_kernels_forces.c:152-176), first half
 __global__ __launch_bounds__(kBlock) void k_forces_exp(const double* __restrict__ xj, const double* __restrict__ w0,
@@ -444,19 +512,13 @@ __global__ __launch_bounds__(kBlock) void k_forces_norm(double* __restrict__ w, 
 // t_j = (theta (1 + log w_j - log w0_j) + b_j) w_j     (c_bioen_kernels_forces.c:320-328)
 __global__ __launch_bounds__(kBlock) void k_forces_t(const double* __restrict__ w, const double* __restrict__ w0,
                                                      const double* __restrict__ b, double theta, int n,
-                                                     double* __restrict__ t, double* __restrict__ ptsum) {
-    __shared__ double sh[kWaves];
-    double ts = 0.0;
+                                                     double* __restrict__ t) {
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double wv = w[j], w0v = w0[j];
         double dd = 1.0;
         if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += log(wv) - log(w0v);
-        const double tv = (dd * theta + b[j]) * wv;
-        t[j] = tv;
-        ts += tv;
+        t[j] = (dd * theta + b[j]) * wv;
     }
-    ts = block_sum(ts, sh);
-    if (threadIdx.x == 0) ptsum[blockIdx.x] = ts;
 }
 
 __global__ __launch_bounds__(kBlock) void k_forces_scalars(const double* __restrict__ pchi, int npchi,
@@ -476,11 +538,15 @@ __global__ __launch_bounds__(kBlock) void k_forces_scalars(const double* __restr
 // L-BFGS vector kernels (liblbfgs lbfgs.c:543-615 with every scalar device-resident)
 // ------------------------------------------------------------------------------
 // s = x - xp, y = g - gp (lbfgs.c:549-551); partials of y.s and y.y (:559-561)
-__global__ __launch_bounds__(kBlock) void k_update_sy(const double* __restrict__ x, const double* __restrict__ xp,
-                                                      const double* __restrict__ g, const double* __restrict__ gp,
-                                                      int n, double* __restrict__ s, double* __restrict__ y,
-                                                      double* __restrict__ pys, double* __restrict__ pyy) {
+__global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n) {
     __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = p.x[a];
+    const double* __restrict__ xp = p.xp[a];
+    const double* __restrict__ g = p.g[a];
+    const double* __restrict__ gp = p.gp[a];
+    double* __restrict__ s = p.s[a];
+    double* __restrict__ y = p.y[a];
     double ys = 0.0, yy = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double sv = x[j] - xp[j];
@@ -493,32 +559,37 @@ __global__ __launch_bounds__(kBlock) void k_update_sy(const double* __restrict__
     ys = block_sum(ys, sh);
     yy = block_sum(yy, sh);
     if (threadIdx.x == 0) {
-        pys[blockIdx.x] = ys;
-        pyy[blockIdx.x] = yy;
+        p.part[a][(size_t)P_YS * kMaxPartials + blockIdx.x] = ys;
+        p.part[a][(size_t)P_YY * kMaxPartials + blockIdx.x] = yy;
     }
 }
 
-// One fused step of the two-loop recursion (lbfgs.c:571-598).  The dot product a
-// step needs was left as per-block partials by the previous step; every block
-// re-reduces them (fixed order) in its prologue, so a step is ONE launch:
+// One fused step of the two-loop recursion (lbfgs.c:571-598).  The dot product a step needs
+// was left as per-block partials by the previous step; every block re-reduces them (fixed
+// order) in its prologue, so a step is ONE launch:
 //   mode 0: d = -gp                                   [+ finalise y.s, y.y of slot `hist`]
 //   mode 1: alpha_h = (S_h . d) / ys_h ; d -= alpha_h Y_h        (first loop)
 //   mode 2: beta = (Y_h . d) / ys_h ; d += (alpha_h - beta) S_h  (second loop)
 //   scale : d *= ys / yy   after the update (last step of the first loop)
-// and in the same sweep  out_partials = vdot . d  for the next step (or gp . d,
-// the next line search's initial slope).
-__global__ __launch_bounds__(kBlock) void k_recur(int mode, int hist, int scale, int finalize_sy,
-                                                  double* __restrict__ d, const double* __restrict__ gp,
-                                                  const double* __restrict__ vaxpy, const double* __restrict__ vdot,
-                                                  const double* __restrict__ pin, const double* __restrict__ pys,
-                                                  const double* __restrict__ pyy, int np, int n,
-                                                  double* __restrict__ scal, double* __restrict__ pout) {
+// and in the same sweep  out_partials = vdot . d  for the next step (or gp . d, the next
+// line search's initial slope).  mode -1: this problem has no step in this launch.
+__global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int np, int n) {
     __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const int mode = q.mode[a];
+    if (mode < 0) return;
+    const int hist = q.hist[a];
+    const int scale = q.scale[a];
+    double* __restrict__ d = q.d[a];
+    const double* __restrict__ gp = q.gp[a];
+    const double* __restrict__ vaxpy = q.vaxpy[a];
+    const double* __restrict__ vdot = q.vdot[a];
+    double* scal = q.scal[a];
     double coef = 0.0, sc = 1.0;
     if (mode == 0) {
-        if (finalize_sy && blockIdx.x == 0) {
-            const double ys = sum_partials(pys, np, sh);
-            const double yy = sum_partials(pyy, np, sh);
+        if (q.finalize_sy[a] && blockIdx.x == 0) {
+            const double ys = sum_partials(q.part[a] + (size_t)P_YS * kMaxPartials, np, sh);
+            const double yy = sum_partials(q.part[a] + (size_t)P_YY * kMaxPartials, np, sh);
             if (threadIdx.x == 0) {
                 scal[S_YSH + hist] = ys;
                 scal[S_YS] = ys;
@@ -526,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_recur(int mode, int hist, int scale,
             }
         }
     } else {
-        const double dot = sum_partials(pin, np, sh);
+        const double dot = sum_partials(q.pin[a], np, sh);
         const double ysh = scal[S_YSH + hist];
         if (mode == 1) {
             const double alpha = dot / ysh;
@@ -550,7 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_recur(int mode, int hist, int scale,
         if (vdot) acc = fma(vdot[j], dv, acc);
     }
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0 && pout) pout[blockIdx.x] = acc;
+    if (threadIdx.x == 0 && q.pout[a]) q.pout[a][blockIdx.x] = acc;
 }
 
 // ------------------------------------------------------------------------------
@@ -600,7 +671,7 @@ int vec_grid(const bioen_hip_ctx* c) {
     return (int)b;
 }
 
-static int rows_grid(const bioen_hip_ctx* c) {
+int rows_grid(const bioen_hip_ctx* c) {
     int b = c->mp / kWaves;
     if (b > kMaxPartials) b = kMaxPartials;
     return b;
@@ -610,46 +681,64 @@ struct TimedLaunch {
     bioen_hip_ctx* c;
     KernelTimer::Pair pr;
     bool on;
-    TimedLaunch(bioen_hip_ctx* ctx, int which) : c(ctx), on(ctx->timer.enabled) {
+    TimedLaunch(bioen_hip_ctx* ctx, int which, int k) : c(ctx), on(ctx->timer.enabled) {
         if (!on) return;
         KernelTimer& t = c->timer;
         if (!t.pool.empty()) {
             pr = t.pool.back();
             t.pool.pop_back();
         } else {
-            hipEventCreate(&pr.a);
-            hipEventCreate(&pr.b);
+            (void)hipEventCreate(&pr.a);
+            (void)hipEventCreate(&pr.b);
         }
         pr.which = which;
-        hipEventRecord(pr.a, c->stream);
+        pr.k = k;
+        (void)hipEventRecord(pr.a, c->stream);
     }
     ~TimedLaunch() {
         if (!on) return;
-        hipEventRecord(pr.b, c->stream);
+        (void)hipEventRecord(pr.b, c->stream);
         c->timer.pending.push_back(pr);
     }
 };
 
-template <bool NT, bool CENTER>
-static void launch_fwd_t(bioen_hip_ctx* c, const double* v) {
+// ---- forward ---------------------------------------------------------------------------
+template <int K, int STEPS, bool NT, bool CENTER>
+static void fwd_launch(bioen_hip_ctx* c, const Vec8& v) {
     const int total_steps = (int)(c->ld / 128);
-    dim3 grid(c->fwd_ctiles, c->mp / kRowAlign);
-    hipLaunchKernelGGL((k_fwd_partial<8, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v, c->ybar,
-                       c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
+    dim3 grid(c->mp / kRowAlign, c->fwd_ctiles);
+    hipLaunchKernelGGL((k_fwd_partial<8, K, STEPS, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v,
+                       c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
 }
 
-void launch_fwd_partial(bioen_hip_ctx* c, const double* v, bool centred) {
-    TimedLaunch tl(c, 0);
-    if (c->nontemporal) {
-        if (centred) launch_fwd_t<true, true>(c, v); else launch_fwd_t<true, false>(c, v);
-    } else {
-        if (centred) launch_fwd_t<false, true>(c, v); else launch_fwd_t<false, false>(c, v);
+template <bool NT>
+static void fwd_dispatch(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
+    if (centred) {
+        fwd_launch<1, 2, NT, true>(c, v);
+        return;
+    }
+    switch (K) {
+        case 1: fwd_launch<1, 2, NT, false>(c, v); break;
+        case 2: fwd_launch<2, 2, NT, false>(c, v); break;
+        case 3: fwd_launch<3, 1, NT, false>(c, v); break;
+        case 4: fwd_launch<4, 1, NT, false>(c, v); break;
+        case 5: fwd_launch<5, 1, NT, false>(c, v); break;
+        case 6: fwd_launch<6, 1, NT, false>(c, v); break;
+        case 7: fwd_launch<7, 1, NT, false>(c, v); break;
+        default: fwd_launch<8, 1, NT, false>(c, v); break;
     }
 }
 
-void launch_fwd_rows_residual(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_fwd_rows_residual, dim3(rows_grid(c)), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       c->fwd_ctiles, c->mp, c->YT, c->ybar, c->r, part(c, P_CHI), part(c, P_C));
+void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
+    TimedLaunch tl(c, 0, K);
+    if (c->nontemporal) fwd_dispatch<true>(c, K, v, centred); else fwd_dispatch<false>(c, K, v, centred);
+}
+
+void launch_fwd_rows_residual(bioen_hip_ctx* c, const Round& r) {
+    MVec8 part;
+    for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
+    hipLaunchKernelGGL(k_fwd_rows_residual, dim3(rows_grid(c), r.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       c->fwd_ctiles, c->mp, r.n, c->YT, c->ybar_c, c->r_c, part);
 }
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c) {
@@ -657,101 +746,105 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c) {
                        c->fwd_ctiles, c->mp, c->gm);
 }
 
-template <bool NT, bool CENTER>
-static void launch_adj_t(bioen_hip_ctx* c, const double* u, double* out) {
+// ---- adjoint ---------------------------------------------------------------------------
+template <int K, bool NT, bool CENTER>
+static void adj_launch(bioen_hip_ctx* c, const double* u_c, const MVec8& out) {
     dim3 grid((unsigned)(c->ld / 128));
-    hipLaunchKernelGGL((k_adj<8, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp / kWaves, u,
-                       c->ybar, out);
+    hipLaunchKernelGGL((k_adj<8, K, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp / kWaves,
+                       u_c, c->ybar_c, out);
 }
 
-void launch_adj(bioen_hip_ctx* c, const double* u, double* out, bool centred) {
-    TimedLaunch tl(c, 1);
-    if (c->nontemporal) {
-        if (centred) launch_adj_t<true, true>(c, u, out); else launch_adj_t<true, false>(c, u, out);
-    } else {
-        if (centred) launch_adj_t<false, true>(c, u, out); else launch_adj_t<false, false>(c, u, out);
+template <bool NT, bool CENTER>
+static void adj_dispatch(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out) {
+    switch (K) {
+        case 1: adj_launch<1, NT, CENTER>(c, u_c, out); break;
+        case 2: adj_launch<2, NT, CENTER>(c, u_c, out); break;
+        case 3: adj_launch<3, NT, CENTER>(c, u_c, out); break;
+        case 4: adj_launch<4, NT, CENTER>(c, u_c, out); break;
+        case 5: adj_launch<5, NT, CENTER>(c, u_c, out); break;
+        case 6: adj_launch<6, NT, CENTER>(c, u_c, out); break;
+        case 7: adj_launch<7, NT, CENTER>(c, u_c, out); break;
+        default: adj_launch<8, NT, CENTER>(c, u_c, out); break;
     }
 }
 
-void launch_trial(bioen_hip_ctx* c, double stp) {
-    hipLaunchKernelGGL(k_trial, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->x, c->xp, c->d, stp, c->n,
-                       part(c, P_MAX));
+void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred) {
+    TimedLaunch tl(c, 1, K);
+    if (c->nontemporal) {
+        if (centred) adj_dispatch<true, true>(c, K, u_c, out); else adj_dispatch<true, false>(c, K, u_c, out);
+    } else {
+        if (centred) adj_dispatch<false, true>(c, K, u_c, out); else adj_dispatch<false, false>(c, K, u_c, out);
+    }
 }
 
-void launch_max(bioen_hip_ctx* c, const double* v) {
-    hipLaunchKernelGGL(k_max, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, v, c->n, part(c, P_MAX));
+// ---- log-weights vector kernels -----------------------------------------------------------
+void launch_trial(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_trial, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
 }
 
-void launch_logw_exp(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_logw_exp, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->x, c->fixed, c->n,
-                       part(c, P_MAX), vec_grid(c), c->w, part(c, P_SUM), part(c, P_PP));
+void launch_max(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_max, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
 }
 
-void launch_logw_norm(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->w, c->n, part(c, P_MAX),
-                       part(c, P_SUM), part(c, P_PP), vec_grid(c), c->scal);
+void launch_logw_exp(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       vec_grid(c));
 }
 
-void launch_logw_logs0(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_logsumexp1, dim3(1), dim3(kBlock), 0, c->stream, c->fixed, c->n, c->scal, (int)S_LOGS0);
+void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n, vec_grid(c));
 }
 
-void launch_logw_scalars(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_logw_scalars, dim3(1), dim3(kBlock), 0, c->stream, part(c, P_CHI), part(c, P_C),
-                       rows_grid(c), theta, c->scal);
+void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logsumexp1, dim3(1), dim3(kBlock), 0, c->stream, c->fixed, c->n, r);
 }
 
-void launch_logw_grad(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_logw_grad, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->x, c->fixed, c->w, c->a,
-                       c->d, theta, c->scal, c->n, c->g, part(c, P_DG), part(c, P_GG), part(c, P_XX));
+void launch_logw_scalars(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, rows_grid(c));
 }
 
-void launch_finish_eval(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_finish_eval, dim3(1), dim3(kBlock), 0, c->stream, part(c, P_DG), part(c, P_GG),
-                       part(c, P_XX), part(c, P_DGINIT), vec_grid(c), c->scal);
+void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_grad, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n);
+}
+
+void launch_finish_eval(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_finish_eval, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, vec_grid(c));
+}
+
+// ---- forces (slot 0) -------------------------------------------------------------------------
+static double* part0(bioen_hip_ctx* c, int which) { return c->slot[0].part + (size_t)which * kMaxPartials; }
+
+void launch_max_vec(bioen_hip_ctx* c, const double* v, double* pmax) {
+    hipLaunchKernelGGL(k_max_vec, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, v, c->n, pmax);
 }
 
 void launch_forces_exp(bioen_hip_ctx* c, const double* xj) {
     hipLaunchKernelGGL(k_forces_exp, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, xj, c->fixed, c->n,
-                       part(c, P_MAX), vec_grid(c), c->w, part(c, P_SUM));
+                       part0(c, P_MAX), vec_grid(c), c->slot[0].w, part0(c, P_SUM));
 }
 
 void launch_forces_norm(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_forces_norm, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->w, c->fixed, c->n,
-                       part(c, P_SUM), vec_grid(c), part(c, P_KL));
+    hipLaunchKernelGGL(k_forces_norm, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->slot[0].w, c->fixed, c->n,
+                       part0(c, P_SUM), vec_grid(c), part0(c, P_KL));
 }
 
 void launch_forces_t(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_forces_t, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->w, c->fixed, c->a, theta,
-                       c->n, c->t, part(c, P_TSUM));
+    hipLaunchKernelGGL(k_forces_t, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->slot[0].w, c->fixed,
+                       c->slot[0].a, theta, c->n, c->t);
 }
 
 void launch_forces_scalars(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_forces_scalars, dim3(1), dim3(kBlock), 0, c->stream, part(c, P_CHI), rows_grid(c),
-                       part(c, P_KL), vec_grid(c), theta, c->scal);
+    hipLaunchKernelGGL(k_forces_scalars, dim3(1), dim3(kBlock), 0, c->stream, part0(c, P_CHI), rows_grid(c),
+                       part0(c, P_KL), vec_grid(c), theta, c->slot[0].scal);
 }
 
-void launch_update_sy(bioen_hip_ctx* c, double* s, double* y) {
-    hipLaunchKernelGGL(k_update_sy, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->x, c->xp, c->g, c->gp,
-                       c->n, s, y, part(c, P_YS), part(c, P_YY));
+// ---- L-BFGS vector kernels ----------------------------------------------------------------------
+void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a) {
+    hipLaunchKernelGGL(k_update_sy, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
 }
 
 void launch_recur(bioen_hip_ctx* c, const RecurArgs& a) {
-    // The running dot product ping-pongs between two partial arrays: a step reads the
-    // partials of its predecessor in its prologue while its own blocks already write new ones.
-    const double* pin = part(c, c->rec_flip ? P_REC2 : P_REC);
-    double* pout = nullptr;
-    if (a.vdot) {
-        if (a.out_slot == P_DGINIT) {
-            pout = part(c, P_DGINIT);
-        } else {
-            c->rec_flip ^= 1;
-            pout = part(c, c->rec_flip ? P_REC2 : P_REC);
-        }
-    }
-    hipLaunchKernelGGL(k_recur, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a.mode, a.hist, a.scale,
-                       a.finalize_sy, c->d, c->gp, a.vaxpy, a.vdot, pin, part(c, P_YS), part(c, P_YY), vec_grid(c),
-                       c->n, c->scal, pout);
+    hipLaunchKernelGGL(k_recur, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, vec_grid(c), c->n);
 }
 
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,

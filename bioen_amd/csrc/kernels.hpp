@@ -1,65 +1,99 @@
 // Host-side launch API of the gfx950 kernels (definitions: kernels.hip).
 // Every function enqueues on ctx->stream and returns without synchronising.
+//
+// All kernels are batched: a launch serves the K (<= kMaxBatch) problems listed in a
+// `Round`, in "batch order" a = 0..K-1.  Each problem performs exactly the arithmetic,
+// in exactly the order, it would perform alone (K = 1), so a batched run is bitwise
+// identical to K separate runs.
 #pragma once
 
 #include "ctx.hpp"
 
 namespace bioen {
 
-// partial-reduction arrays inside ctx->part (each kMaxPartials doubles)
-enum PartSlot : int {
-    P_MAX = 0, P_SUM, P_PP, P_CHI, P_C, P_DG, P_GG, P_XX, P_DGINIT, P_REC, P_REC2, P_YS, P_YY, P_KL, P_TSUM,
-    P_COUNT = 16
+// Per-round, per-batch-position device pointers and scalars (passed by value).
+struct Round {
+    int n;                        // K: problems in this round
+    double* x[kMaxBatch];         // trial point
+    double* xp[kMaxBatch];        // accepted point
+    double* g[kMaxBatch];         // trial gradient
+    double* gp[kMaxBatch];        // accepted gradient
+    double* d[kMaxBatch];         // search direction
+    double* w[kMaxBatch];         // weights
+    double* a[kMaxBatch];         // adjoint output
+    double* scal[kMaxBatch];
+    double* part[kMaxBatch];
+    double stp[kMaxBatch];
+    double theta[kMaxBatch];
 };
 
-inline double* part(bioen_hip_ctx* c, int slot) { return c->part + (size_t)slot * kMaxPartials; }
+struct Vec8 {
+    const double* p[kMaxBatch];
+};
+struct MVec8 {
+    double* p[kMaxBatch];
+};
+
+inline double* part_of(const Round& r, int a, int which) { return r.part[a] + (size_t)which * kMaxPartials; }
 
 int vec_grid(const bioen_hip_ctx* c);   // blocks used by every N-vector kernel of this context
+int rows_grid(const bioen_hip_ctx* c);
 
 // ---- matrix streaming kernels ------------------------------------------------
-// forward:  partial[row][ctile] = sum_{j in tile} (Y[row][j] - [centred] ybar[row]) * v[j]
-void launch_fwd_partial(bioen_hip_ctx* c, const double* v, bool centred = false);
-// reduce the column tiles; mode 0: ybar,r,chi/c partials; mode 1: gm = rowsum - ybar * tsum
-void launch_fwd_rows_residual(bioen_hip_ctx* c);
+// forward: fwd_partial[(row*K + a)*ctiles + tile] = sum_{j in tile} (Y[row][j] - [centred] ybar_c[row*K+a]) v_a[j]
+void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred = false);
+// reduce the column tiles -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
+void launch_fwd_rows_residual(bioen_hip_ctx* c, const Round& r);
+// forces gradient (K = 1): gm = reduced centred sums
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c);
-// adjoint:  out[j] = sum_i (Y[i][j] - [centred] ybar[i]) * u[i]
-void launch_adj(bioen_hip_ctx* c, const double* u, double* out, bool centred = false);
+// adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
+void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);
 
-// ---- log-weights N-vector kernels ------------------------------------------------
-// x = xp + stp * d ; block maxima of x -> P_MAX
-void launch_trial(bioen_hip_ctx* c, double stp);
-// e = exp(x - max) -> w (unnormalised), partial sums -> P_SUM, P_PP
-void launch_logw_exp(bioen_hip_ctx* c);
-// w /= S ; scal[S_LOGS], scal[S_P]
-void launch_logw_norm(bioen_hip_ctx* c);
-// scal[S_LOGS0] = log sum exp(fixed)     (once per problem)
-void launch_logw_logs0(bioen_hip_ctx* c);
-// scal[S_CHI], scal[S_C], scal[S_F] for log-weights
-void launch_logw_scalars(bioen_hip_ctx* c, double theta);
-// g = w (theta (x - G - P) + a - c) ; partials of g.d, g.g, x.x
-void launch_logw_grad(bioen_hip_ctx* c, double theta);
-// scal[S_DG], scal[S_GG], scal[S_XX], scal[S_DGINIT] from their partials
-void launch_finish_eval(bioen_hip_ctx* c);
+// ---- log-weights N-vector kernels (blockIdx.y = batch position) ------------------------
+void launch_trial(bioen_hip_ctx* c, const Round& r);        // x = xp + stp d ; block maxima
+void launch_max(bioen_hip_ctx* c, const Round& r);          // block maxima of x only
+void launch_logw_exp(bioen_hip_ctx* c, const Round& r);     // e = exp(x - max) -> w ; partial sums
+void launch_logw_norm(bioen_hip_ctx* c, const Round& r);    // w /= S ; log s, P
+void launch_logw_logs0(bioen_hip_ctx* c, const Round& r);   // scal[S_LOGS0] = log sum exp(fixed)
+void launch_logw_scalars(bioen_hip_ctx* c, const Round& r); // chi^2, c, f
+void launch_logw_grad(bioen_hip_ctx* c, const Round& r);    // gradient epilogue + g.d, g.g, x.x
+void launch_finish_eval(bioen_hip_ctx* c, const Round& r);  // scal[S_DG..S_DGINIT]
 
-// ---- forces N-vector kernels ---------------------------------------------------
-void launch_max(bioen_hip_ctx* c, const double* v);                 // block maxima of v -> P_MAX
-void launch_forces_exp(bioen_hip_ctx* c, const double* xj);          // w = w0 exp(xj - max), P_SUM
-void launch_forces_norm(bioen_hip_ctx* c);                           // w /= S ; KL partials
-void launch_forces_t(bioen_hip_ctx* c, double theta);                // t, tsum partials
-void launch_forces_scalars(bioen_hip_ctx* c, double theta);          // scal[S_F], S_KL, S_CHI
+// ---- forces N-vector kernels (single problem, slot 0) -------------------------------------
+void launch_max_vec(bioen_hip_ctx* c, const double* v, double* pmax);
+void launch_forces_exp(bioen_hip_ctx* c, const double* xj);
+void launch_forces_norm(bioen_hip_ctx* c);
+void launch_forces_t(bioen_hip_ctx* c, double theta);
+void launch_forces_scalars(bioen_hip_ctx* c, double theta);
 
 // ---- L-BFGS vector kernels (device-resident scalars) -------------------------------
-// s = x - xp ; y = g - gp ; partials y.s -> P_YS, y.y -> P_YY
-void launch_update_sy(bioen_hip_ctx* c, double* s, double* y);
-// One fused step of the two-loop recursion on d (see kernels.hip: k_recur).
+struct PairArgs {      // s = x - xp ; y = g - gp for the accepting problems
+    int n;
+    const double* x[kMaxBatch];
+    const double* xp[kMaxBatch];
+    const double* g[kMaxBatch];
+    const double* gp[kMaxBatch];
+    double* s[kMaxBatch];
+    double* y[kMaxBatch];
+    double* part[kMaxBatch];
+};
+void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a);
+
+// One fused step of the two-loop recursion per problem (see kernels.hip: k_recur).
 struct RecurArgs {
-    int mode;            // 0 init (d = -gp), 1 first loop, 2 second loop
-    int hist;            // history slot whose alpha / ys this step uses (modes 1,2)
-    const double* vaxpy; // Y[hist] (mode 1) or S[hist] (mode 2)
-    const double* vdot;  // vector dotted with the updated d for the NEXT step (may be null)
-    int scale;           // 1: multiply the updated d by ys/yy (end of first loop / bound==0 never)
-    int finalize_sy;     // 1 (mode 0 only): block 0 finalises y.s,y.y of slot `hist` from partials
-    int out_slot;        // partial slot receiving vdot . d (P_REC or P_DGINIT)
+    int n;
+    int mode[kMaxBatch];          // -1 idle, 0 init (d = -gp), 1 first loop, 2 second loop
+    int hist[kMaxBatch];          // history slot whose alpha / ys this step uses
+    int scale[kMaxBatch];         // multiply the updated d by ys/yy (last step of the first loop)
+    int finalize_sy[kMaxBatch];   // mode 0: block 0 finalises y.s, y.y of slot `hist` from partials
+    double* d[kMaxBatch];
+    const double* gp[kMaxBatch];
+    const double* vaxpy[kMaxBatch];
+    const double* vdot[kMaxBatch];
+    const double* pin[kMaxBatch];
+    double* pout[kMaxBatch];
+    double* part[kMaxBatch];
+    double* scal[kMaxBatch];
 };
 void launch_recur(bioen_hip_ctx* c, const RecurArgs& a);
 

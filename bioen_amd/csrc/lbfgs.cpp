@@ -286,4 +286,69 @@ int LineSearch::report_morethuente(const TrialResult& t, double* stp) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// LbfgsMachine: the control flow of lbfgs() (lbfgs.c:412-616)
+// ---------------------------------------------------------------------------------------
+void LbfgsMachine::begin_linesearch(double step0) {
+    double stp = 0.0;
+    ls_error_ = ls_.begin(fx_, step0, &stp);
+    stp_ = stp;
+}
+
+LbfgsMachine::Action LbfgsMachine::on_initial(double f, double gg, double xx) {
+    ++evaluations_;
+    fx_ = f;
+    pf_.assign(cfg_.past > 0 ? cfg_.past : 0, 0.0);
+    if (!pf_.empty()) pf_[0] = f;
+    double xnorm = std::sqrt(xx);
+    const double gnorm = std::sqrt(gg);
+    if (xnorm < 1.0) xnorm = 1.0;
+    if (gnorm / xnorm <= cfg_.epsilon) return Action{DONE, 0, 0, LBFGS_ALREADY_MINIMIZED, false};
+    k_ = 1;
+    end_ = 0;
+    begin_linesearch(1.0 / gnorm);   // d = -g  =>  |d| = |g|   (lbfgs.c:456)
+    if (ls_error_ < 0) return Action{DONE, 0, 0, ls_error_, false};
+    return Action{TRIAL, 0, 0, 0, false};
+}
+
+LbfgsMachine::Action LbfgsMachine::on_trial(const TrialResult& t) {
+    ++evaluations_;
+    double stp = stp_;
+    const int st = ls_.report(t, &stp);
+    if (st == 0) {          // line search wants another point
+        stp_ = stp;
+        return Action{TRIAL, 0, 0, 0, false};
+    }
+    if (st < 0) {
+        // liblbfgs reverts to the previous point and returns the code; *ptr_fx keeps the
+        // last trial's value (lbfgs.c:476-481,622-624)
+        fx_ = t.f;
+        return Action{DONE, 0, 0, st, false};
+    }
+    // accepted
+    fx_ = t.f;
+    double xnorm = std::sqrt(t.xx);
+    const double gnorm = std::sqrt(t.gg);
+    ++iterations_;   // progress callback, c_bioen_kernels_logw.c:565-576
+    if (xnorm < 1.0) xnorm = 1.0;
+    if (gnorm / xnorm <= cfg_.epsilon) return Action{DONE, 0, 0, LBFGS_CONVERGED, true};
+    if (!pf_.empty()) {
+        if (cfg_.past <= k_) {
+            const double rate = (pf_[k_ % cfg_.past] - fx_) / fx_;
+            if (rate < cfg_.delta) return Action{DONE, 0, 0, LBFGS_STOPPED, true};
+        }
+        pf_[k_ % cfg_.past] = fx_;
+    }
+    if (cfg_.max_iterations != 0 && cfg_.max_iterations < k_ + 1)
+        return Action{DONE, 0, 0, LBFGSERR_MAXIMUMITERATION, true};
+
+    const int bound = (kLbfgsM <= k_) ? kLbfgsM : k_;
+    const int end = end_;
+    ++k_;
+    end_ = (end_ + 1) % kLbfgsM;
+    begin_linesearch(1.0);           // "now the search direction d is ready. We try step = 1 first."
+    if (ls_error_ < 0) return Action{DONE, 0, 0, ls_error_, true};
+    return Action{ACCEPT, end, bound, 0, false};
+}
+
 }  // namespace bioen

@@ -99,7 +99,7 @@ class LineSearch {
     int report_morethuente(const TrialResult& t, double* stp);
     void mt_prepare(double* stp);
 
-    const bioen_lbfgs_config& c_;
+    bioen_lbfgs_config c_;   // by value: machines are stored in containers
     int count_ = 0;
     bool have_dginit_ = false;
     double finit_ = 0, dginit_ = 0, dgtest_ = 0;
@@ -110,6 +110,53 @@ class LineSearch {
 };
 
 int validate_lbfgs_config(int n, const bioen_lbfgs_config& c);
+
+// ------------------------------------------------------------------------------------
+// One L-BFGS problem as a state machine (lbfgs.c:245-641 without the vector work).
+// The owner evaluates points and builds directions; the machine decides.  Used by the
+// single-problem loop below AND by the lock-step batch engine (several thetas advancing
+// one evaluation per round against the same matrix pass).
+// ------------------------------------------------------------------------------------
+class LbfgsMachine {
+  public:
+    enum Kind { TRIAL, ACCEPT, DONE };
+    struct Action {
+        Kind kind;
+        int end;          // ACCEPT: history slot receiving the new (s, y) pair
+        int bound;        // ACCEPT: number of pairs the two-loop recursion uses
+        int code;         // DONE: liblbfgs status
+        bool keep_trial;  // DONE: result is the trial point (else the accepted point)
+    };
+
+    LbfgsMachine(int n, const bioen_lbfgs_config& cfg) : n_(n), cfg_(cfg), ls_(cfg_) {}
+
+    // 0 = parameters fine, else the liblbfgs error code (no evaluation happens)
+    int validate() const { return validate_lbfgs_config(n_, cfg_); }
+
+    // Result of the evaluation at the start point (d = -g is built by the owner afterwards
+    // unless the answer is DONE).  Returns TRIAL (go on) or DONE (already minimal).
+    Action on_initial(double f, double gg, double xx);
+    // Step length of the next point to evaluate: x = xp + step * d
+    double trial_step() const { return stp_; }
+    // Result of that evaluation.
+    Action on_trial(const TrialResult& t);
+
+    double fx() const { return fx_; }
+    int iterations() const { return iterations_; }
+    int evaluations() const { return evaluations_; }
+
+  private:
+    void begin_linesearch(double step0);
+
+    int n_;
+    bioen_lbfgs_config cfg_;
+    LineSearch ls_;
+    std::vector<double> pf_;
+    double fx_ = 0.0, stp_ = 0.0;
+    int k_ = 1, end_ = 0;
+    int iterations_ = 0, evaluations_ = 0;
+    int ls_error_ = 0;
+};
 
 // Backend concept (xp/gp = accepted point and gradient, x/g = trial point and gradient):
 //   void initial(double* f, double* gg, double* xx); // evaluate at x0 (= xp); d = -gp
@@ -125,77 +172,24 @@ int lbfgs_run(Backend& B, int n, const bioen_lbfgs_config& cfg, double* fx_out, 
     *iterations_out = 0;
     *evaluations_out = 0;
     *fx_out = 0.0;
-    int code = validate_lbfgs_config(n, cfg);
+    LbfgsMachine m(n, cfg);
+    int code = m.validate();
     if (code != 0) return code;
 
-    std::vector<double> pf(cfg.past > 0 ? cfg.past : 0);
-
-    double fx, gg, xx;
-    B.initial(&fx, &gg, &xx);
-    ++*evaluations_out;
-    if (!pf.empty()) pf[0] = fx;
-
-    double xnorm = std::sqrt(xx), gnorm = std::sqrt(gg);
-    if (xnorm < 1.0) xnorm = 1.0;
-    if (gnorm / xnorm <= cfg.epsilon) {
-        *fx_out = fx;
-        return LBFGS_ALREADY_MINIMIZED;
-    }
-    // d = -g, so |d| = |g|
-    double step = 1.0 / gnorm;
-    int k = 1, end = 0;
-
-    for (;;) {
-        LineSearch ls(cfg);
-        double stp;
-        int st = ls.begin(fx, step, &stp);
+    double f0, gg, xx;
+    B.initial(&f0, &gg, &xx);
+    LbfgsMachine::Action a = m.on_initial(f0, gg, xx);
+    while (a.kind != LbfgsMachine::DONE) {
+        if (a.kind == LbfgsMachine::ACCEPT) B.accept(a.end, a.bound);
         TrialResult tr{};
-        while (st == 0) {
-            B.trial(stp, &tr);
-            ++*evaluations_out;
-            st = ls.report(tr, &stp);
-        }
-        if (st < 0) {
-            // liblbfgs reverts to the previous point and returns the code; *ptr_fx keeps
-            // the last trial's value (lbfgs.c:476-481,622-624).
-            *fx_out = tr.f;
-            B.revert();
-            return st;
-        }
-        step = stp;
-        fx = tr.f;
-        xnorm = std::sqrt(tr.xx);
-        gnorm = std::sqrt(tr.gg);
-        ++*iterations_out;   // progress callback, c_bioen_kernels_logw.c:565-576
-
-        if (xnorm < 1.0) xnorm = 1.0;
-        if (gnorm / xnorm <= cfg.epsilon) {
-            code = LBFGS_CONVERGED;
-            break;
-        }
-        if (!pf.empty()) {
-            if (cfg.past <= k) {
-                const double rate = (pf[k % cfg.past] - fx) / fx;
-                if (rate < cfg.delta) {
-                    code = LBFGS_STOPPED;
-                    break;
-                }
-            }
-            pf[k % cfg.past] = fx;
-        }
-        if (cfg.max_iterations != 0 && cfg.max_iterations < k + 1) {
-            code = LBFGSERR_MAXIMUMITERATION;
-            break;
-        }
-        const int bound = (kLbfgsM <= k) ? kLbfgsM : k;
-        B.accept(end, bound);
-        ++k;
-        end = (end + 1) % kLbfgsM;
-        step = 1.0;
+        B.trial(m.trial_step(), &tr);
+        a = m.on_trial(tr);
     }
-    B.keep_trial();
-    *fx_out = fx;
-    return code;
+    if (a.keep_trial) B.keep_trial(); else B.revert();
+    *fx_out = m.fx();
+    *iterations_out = m.iterations();
+    *evaluations_out = m.evaluations();
+    return a.code;
 }
 
 }  // namespace bioen

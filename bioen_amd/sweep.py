@@ -236,7 +236,7 @@ def _pack(theta, w, info, n):
     return rec
 
 
-def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None):
+def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None, presolved=None):
     """Solve every theta of the series, sharded over comm.world ranks, and gather.
 
     ctx    : bioen_amd.Context (may be None when `solve` does not need one and rccl is False)
@@ -244,6 +244,8 @@ def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None):
              lbfgs_code,seconds}; the product passes a closure over ctx.opt_lbfgs_logw /
              ctx.opt_lbfgs_forces, the CPU tests inject their checker.
     rccl   : gather through ctx.comm_allgather (RCCL over xGMI) instead of `comm`.
+    presolved : optional {index into thetas: (w, info)} for this rank's thetas (a rank that
+             solved its shard as one lock-step batch); `solve` is then not called.
     Returns a list (in the order of `thetas`) of dicts, identical on every rank.
     """
     comm = comm or SingleComm()
@@ -254,7 +256,7 @@ def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None):
     buf = np.zeros((per_rank, HEADER + n))
     buf[:, 0] = np.nan                                 # unused slots are marked by theta = NaN
     for slot, idx in enumerate(mine):
-        w, info = solve(thetas[idx])
+        w, info = presolved[idx] if presolved is not None else solve(thetas[idx])
         buf[slot] = _pack(thetas[idx], np.asarray(w, dtype=np.float64).reshape(-1), info, n)
 
     if comm.world == 1:
@@ -275,13 +277,20 @@ def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None):
     return out
 
 
-def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=False, verbose=False):
+def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=False, verbose=False, max_batch=8):
     """Cold-started log-weights series (every theta starts from g_init, as
-    procedure.py:46,66 does for generic data)."""
-    def solve(theta):
-        _, w, info = ctx.opt_lbfgs_logw(g_init, G, theta, lbfgs_params, verbose=verbose)
-        return w, info
-    return theta_sweep(ctx, thetas, solve, comm=comm, rccl=rccl)
+    procedure.py:46,66 does for generic data).  The thetas of a rank run as ONE lock-step
+    batch (ctx.opt_lbfgs_logw_batch): up to `max_batch` of them share every pass over yTilde."""
+    comm = comm or SingleComm()
+    thetas = [float(t) for t in thetas]
+    mine = shard_thetas(thetas, comm.rank, comm.world)
+    solved = {}
+    if mine:
+        _, w, infos = ctx.opt_lbfgs_logw_batch([thetas[i] for i in mine], g_init, G, lbfgs_params,
+                                               max_batch=max_batch, verbose=verbose)
+        for k, i in enumerate(mine):
+            solved[i] = (w[k], infos[k])
+    return theta_sweep(ctx, thetas, None, comm=comm, rccl=rccl, presolved=solved)
 
 
 def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=False, verbose=False):

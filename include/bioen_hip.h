@@ -116,6 +116,20 @@ int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* ctx, const double* g0, const double*
                              const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                              double* result, double* w_opt, bioen_opt_result* info);
 
+/* A whole theta series in one call.  Up to `max_batch` (<= 8) thetas advance in lock step --
+ * one evaluation each per round -- and SHARE every pass over yTilde, so the matrix bytes per
+ * theta drop by the batch width; finished thetas hand their slot to the next one.  Each theta
+ * does exactly the arithmetic of a single run (results are bitwise identical to
+ * bioen_hip_opt_lbfgs_logw called per theta).  This replaces the serial loop of
+ * bioen/analyze/procedure.py:62-83 for cold-started series.
+ *   thetas[ntheta]; g0: start log-weights, shared (g0_stride = 0) or per theta (stride >= n);
+ *   results[ntheta][n]; w_opt[ntheta][n] or NULL; infos[ntheta]. */
+int bioen_hip_opt_lbfgs_logw_batch(bioen_hip_ctx* ctx, int ntheta, const double* thetas,
+                                   const double* g0, size_t g0_stride, const double* G,
+                                   const bioen_lbfgs_config* config, const bioen_visual_params* visual,
+                                   int max_batch, double* results, double* w_opt,
+                                   bioen_opt_result* infos);
+
 /* ---- forces method --------------------------------------------------------- */
 /* _get_weights_from_forces, c_bioen_kernels_forces.c:111-224 */
 int bioen_hip_forces_weights(bioen_hip_ctx* ctx, const double* forces, const double* w0, double* w);
@@ -137,6 +151,9 @@ int bioen_hip_chi_squared(bioen_hip_ctx* ctx, const double* w, double* yave, dou
 /* Average device time (HIP events on the context's stream) and launch count of the
  * two matrix-streaming kernels since the last reset. which: 0 = forward, 1 = adjoint. */
 int bioen_hip_kernel_stats(bioen_hip_ctx* ctx, int which, double* total_ms, long long* launches);
+/* as above, plus the sum over launches of the batch width (problems served per matrix pass) */
+int bioen_hip_kernel_stats_ex(bioen_hip_ctx* ctx, int which, double* total_ms, long long* launches,
+                              long long* problem_passes);
 int bioen_hip_kernel_stats_reset(bioen_hip_ctx* ctx);
 int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
 

@@ -226,3 +226,46 @@ def test_extreme_log_weights_do_not_overflow(hip):
         w1, _ = ctx.logw_weights(g)
         w2, _ = ctx.logw_weights(g - 800.0)
     assert maxrel(w1, w2) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------
+# lock-step batch: K thetas share every matrix pass and must reproduce K single runs bitwise
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,max_batch", [("synth_logw_M37xN500.npz", 8), ("synth_logw_M37xN500.npz", 3),
+                                            ("synth_logw_M129xN257.npz", 5), ("ref_data_potra_part_2_logw_M808xN10.npz", 8)])
+def test_batched_theta_series_equals_single_runs_bitwise(hip, name, max_batch):
+    d = load_golden(name)
+    thetas = [200.0, 0.3, 50.0, 7.0, 1.0, 20.0, 2.0, 0.7, 100.0, 3.0, 0.5]      # 11 thetas: slots get refilled
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        single = [ctx.opt_lbfgs_logw(d["GInit"], d["G"], th, LBFGS_DEFAULTS) for th in thetas]
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=max_batch)
+        # per-theta start vectors
+        starts = np.stack([d["GInit"].ravel() + 0.01 * i for i in range(len(thetas))])
+        res2, w2, infos2 = ctx.opt_lbfgs_logw_batch(thetas, starts, d["G"], LBFGS_DEFAULTS, max_batch=max_batch)
+        single2 = [ctx.opt_lbfgs_logw(starts[i], d["G"], th, LBFGS_DEFAULTS) for i, th in enumerate(thetas)]
+    for i, (g1, w1, i1) in enumerate(single):
+        assert infos[i].lbfgs_code == i1.lbfgs_code and infos[i].iterations == i1.iterations
+        assert infos[i].evaluations == i1.evaluations
+        assert infos[i].fmin == i1.fmin and infos[i].chi2 == i1.chi2 and infos[i].kl == i1.kl
+        assert np.array_equal(res[i], g1) and np.array_equal(w[i], w1)
+    for i, (g1, w1, i1) in enumerate(single2):
+        assert infos2[i].fmin == i1.fmin and infos2[i].iterations == i1.iterations
+        assert np.array_equal(res2[i], g1) and np.array_equal(w2[i], w1)
+
+
+def test_batched_series_with_failing_and_trivial_members(hip):
+    """A batch whose members end differently: converged, stopped, max_iterations hit."""
+    d = load_golden("synth_logw_M64xN2000.npz")
+    thetas = [1e6, 10.0, 0.05]
+    params = dict(LBFGS_DEFAULTS, max_iterations=60)
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, d["G"], d["G"], params, max_batch=8)
+        single = [ctx.opt_lbfgs_logw(d["G"], d["G"], th, params) for th in thetas]
+        bad = ctx.opt_lbfgs_logw_batch(thetas, d["G"], d["G"], dict(LBFGS_DEFAULTS, delta=-1.0))
+    assert [i.lbfgs_code for i in infos] == [s[2].lbfgs_code for s in single]
+    assert infos[2].lbfgs_code == -997 and infos[2].iterations == 60
+    for i in range(3):
+        assert infos[i].fmin == single[i][2].fmin and np.array_equal(res[i], single[i][0])
+        assert abs(w[i].sum() - 1.0) < 1e-12
+    assert all(i.lbfgs_code == -1015 and i.evaluations == 0 for i in bad[2])
+    assert np.array_equal(bad[0][1], d["G"].ravel())
