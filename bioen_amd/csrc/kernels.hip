@@ -320,10 +320,15 @@ __global__ __launch_bounds__(kBlock) void k_trial(Round r, int n) {
     const double* __restrict__ d = r.d[a];
     const double stp = r.stp[a];
     double mx = -DBL_MAX;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const double v = fma(stp, d[j], xp[j]);
-        x[j] = v;
-        mx = fmax(mx, v);
+    const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 dv = *reinterpret_cast<const d2*>(d + j);
+        const d2 pv = *reinterpret_cast<const d2*>(xp + j);
+        d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
+        *reinterpret_cast<d2*>(x + j) = v;
+        mx = fmax(mx, v.x);
+        if (j + 1 < n) mx = fmax(mx, v.y);
     }
     mx = block_max(mx, sh);
     if (threadIdx.x == 0) r.part[a][(size_t)P_MAX * kMaxPartials + blockIdx.x] = mx;
@@ -357,12 +362,19 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
     double* pa = r.part[a];
     const double gmax = max_partials(pa + (size_t)P_MAX * kMaxPartials, np, sh);
     double s = 0.0, pp = 0.0;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const double xv = x[j];
-        const double ev = exp(xv - gmax);
-        e[j] = ev;
-        s += ev;
-        pp = fma(ev, xv - G[j], pp);
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 xv = *reinterpret_cast<const d2*>(x + j);
+        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        d2 ev;
+        ev.x = exp(xv.x - gmax);
+        ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
+        *reinterpret_cast<d2*>(e + j) = ev;
+        s += ev.x;
+        pp = fma(ev.x, xv.x - Gv.x, pp);
+        s += ev.y;
+        pp = fma(ev.y, xv.y - Gv.y, pp);
     }
     s = block_sum(s, sh);
     pp = block_sum(pp, sh);
@@ -388,7 +400,13 @@ __global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, int np) {
             r.scal[a][S_P] = PP * inv;
         }
     }
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] *= inv;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        d2 v = *reinterpret_cast<const d2*>(w + 2 * p);
+        v.x *= inv;
+        v.y *= inv;
+        *reinterpret_cast<d2*>(w + 2 * p) = v;
+    }
 }
 
 // log s0 = log sum exp(G): constant per problem, computed once (the reference recomputes it
@@ -437,13 +455,24 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     const double theta = r.theta[a];
     const double P = r.scal[a][S_P];
     double dg = 0.0, gg = 0.0, xx = 0.0;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const double xv = x[j];
-        const double gv = w[j] * (theta * ((xv - G[j]) - P) + av[j]);
-        g[j] = gv;
-        dg = fma(gv, d[j], dg);
-        gg = fma(gv, gv, gg);
-        xx = fma(xv, xv, xx);
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 xv = *reinterpret_cast<const d2*>(x + j);
+        const d2 wv = *reinterpret_cast<const d2*>(w + j);     // pad: w = 0  =>  g = 0
+        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        const d2 aa = *reinterpret_cast<const d2*>(av + j);
+        const d2 dv = *reinterpret_cast<const d2*>(d + j);
+        d2 gv;
+        gv.x = wv.x * (theta * ((xv.x - Gv.x) - P) + aa.x);
+        gv.y = wv.y * (theta * ((xv.y - Gv.y) - P) + aa.y);
+        *reinterpret_cast<d2*>(g + j) = gv;
+        dg = fma(gv.x, dv.x, dg);
+        gg = fma(gv.x, gv.x, gg);
+        xx = fma(xv.x, xv.x, xx);
+        dg = fma(gv.y, dv.y, dg);
+        gg = fma(gv.y, gv.y, gg);
+        xx = fma(xv.y, xv.y, xx);
     }
     dg = block_sum(dg, sh);
     gg = block_sum(gg, sh);
@@ -548,13 +577,19 @@ __global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n) {
     double* __restrict__ s = p.s[a];
     double* __restrict__ y = p.y[a];
     double ys = 0.0, yy = 0.0;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const double sv = x[j] - xp[j];
-        const double yv = g[j] - gp[j];
-        s[j] = sv;
-        y[j] = yv;
-        ys = fma(yv, sv, ys);
-        yy = fma(yv, yv, yy);
+    const int n2 = (n + 1) >> 1;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < n2; q += gridDim.x * kBlock) {
+        const int j = 2 * q;
+        const d2 xa = *reinterpret_cast<const d2*>(x + j), xb = *reinterpret_cast<const d2*>(xp + j);
+        const d2 ga = *reinterpret_cast<const d2*>(g + j), gb = *reinterpret_cast<const d2*>(gp + j);
+        const d2 sv = {xa.x - xb.x, xa.y - xb.y};
+        const d2 yv = {ga.x - gb.x, ga.y - gb.y};
+        *reinterpret_cast<d2*>(s + j) = sv;
+        *reinterpret_cast<d2*>(y + j) = yv;
+        ys = fma(yv.x, sv.x, ys);
+        yy = fma(yv.x, yv.x, yy);
+        ys = fma(yv.y, sv.y, ys);
+        yy = fma(yv.y, yv.y, yy);
     }
     ys = block_sum(ys, sh);
     yy = block_sum(yy, sh);
@@ -609,16 +644,30 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int np, int n) {
         if (scale) sc = scal[S_YS] / scal[S_YY];
     }
     double acc = 0.0;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        double dv;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        d2 dv;
         if (mode == 0) {
-            dv = -gp[j];
+            const d2 gv = *reinterpret_cast<const d2*>(gp + j);
+            dv.x = -gv.x;
+            dv.y = -gv.y;
         } else {
-            dv = fma(coef, vaxpy[j], d[j]);
-            if (scale) dv *= sc;
+            const d2 av = *reinterpret_cast<const d2*>(vaxpy + j);
+            const d2 old = *reinterpret_cast<const d2*>(d + j);
+            dv.x = fma(coef, av.x, old.x);
+            dv.y = fma(coef, av.y, old.y);
+            if (scale) {
+                dv.x *= sc;
+                dv.y *= sc;
+            }
         }
-        d[j] = dv;
-        if (vdot) acc = fma(vdot[j], dv, acc);
+        *reinterpret_cast<d2*>(d + j) = dv;
+        if (vdot) {
+            const d2 vv = *reinterpret_cast<const d2*>(vdot + j);
+            acc = fma(vv.x, dv.x, acc);
+            acc = fma(vv.y, dv.y, acc);
+        }
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0 && q.pout[a]) q.pout[a][blockIdx.x] = acc;
@@ -665,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(double* __restrict__ Y, siz
 // host-side launchers
 // ==============================================================================
 int vec_grid(const bioen_hip_ctx* c) {
-    long long b = ((long long)c->n + 4 * kBlock - 1) / (4 * kBlock);
+    long long b = ((long long)c->n + 4 * kBlock - 1) / (4 * kBlock);   // 2 pairs (4 elements) per thread
     if (b < 1) b = 1;
     if (b > kMaxPartials) b = kMaxPartials;
     return (int)b;
