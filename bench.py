@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--observables", type=int, default=1024, help="M")
     ap.add_argument("--thetas", type=int, default=8, help="points of the theta series")
     ap.add_argument("--max-batch", type=int, default=8, help="thetas sharing one matrix pass (1 = unbatched)")
+    ap.add_argument("--shard", choices=("structures", "thetas"), default="structures",
+                    help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal thetas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols", type=int, default=65536)
     ap.add_argument("--cpu-iters", type=int, default=40)
@@ -145,7 +147,9 @@ def main():
     ndev = bioen_amd.device_count()
     if ndev < 1:
         raise SystemExit("bench.py: no MI355X visible to HIP -- this benchmark has no CPU path")
-    ctx = bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED, device=local_rank % ndev)
+    nshard = world > 1 and args.shard == "structures"
+    ctx = bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED, device=local_rank % ndev,
+                                      rank=rank if nshard else 0, world=world if nshard else 1)
     gather = "none"
     rccl = False
     if world > 1:
@@ -153,18 +157,25 @@ def main():
             with stdout_to_stderr():
                 rccl = sweep.init_rccl(ctx, comm)
             gather = "rccl-allgather"
-        except bioen_amd.BioenHipError as e:   # report, keep the control-plane gather
+        except bioen_amd.BioenHipError as e:   # report, keep the control-plane path
             gather = "tcp-allgather (RCCL unavailable: %s)" % e
             rccl = False
         ok = comm.allgather_object(rccl)
         if not all(ok):
             rccl = False
             gather = "tcp-allgather (RCCL init failed on some rank)"
+            if nshard:
+                ctx.comm_destroy()
+        if nshard and not rccl:
+            ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (e.g. ranks sharing one GPU)
 
     G = np.zeros(N)          # w0 = 1/N  =>  G = 0 ; GInit = G
     g0 = np.zeros(N)
 
     def step():
+        if nshard:
+            # every rank holds a column block of yTilde and takes part in every theta of the batch
+            return sweep.sweep_log_weights_sharded(ctx, thetas, G, g0, LBFGS_DEFAULTS, max_batch=args.max_batch)
         return sweep.sweep_log_weights(ctx, thetas, G, g0, LBFGS_DEFAULTS, comm=comm, rccl=rccl,
                                        max_batch=args.max_batch)
 
@@ -194,14 +205,15 @@ def main():
         # ---- roofline of the dominant (slower) matrix-streaming kernel, rank 0's launches ----
         # algorithmic bytes of ONE launch serving K thetas: the matrix once, plus per theta one
         # N-vector and one M-vector in, one out (matrix bytes are shared by the batch)
-        mat_bytes = float(M) * N * 8
+        n_rank = ctx.n_local if nshard else N            # columns streamed by one launch on rank 0
+        mat_bytes = float(M) * n_rank * 8
         kern = {}
         for name in ("forward", "adjoint"):
             s = stats[name]
             launches = max(s["launches"], 1)
             avg_ms = s["total_ms"] / launches
             avg_k = s["problem_passes"] / launches
-            alg = mat_bytes + avg_k * (8.0 * N + 8.0 * M)
+            alg = mat_bytes + avg_k * (8.0 * n_rank + 8.0 * M)
             kern[name] = {"kernel": "k_fwd_partial" if name == "forward" else "k_adj",
                           "launches": s["launches"], "avg_ms": avg_ms, "avg_batch_width": avg_k,
                           "algorithmic_bytes": alg,
@@ -213,7 +225,7 @@ def main():
             try:
                 with open(tpath) as fp:
                     tj = json.load(fp)
-                key = "%s_N%d_M%d" % (kern[dom]["kernel"], N, M)
+                key = "%s_N%d_M%d" % (kern[dom]["kernel"], n_rank, M)
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
@@ -244,7 +256,8 @@ def main():
             "config": {"workload": "log-weights theta sweep, N=%d structures x M=%d observables, %d thetas "
                                    "logspace(3,-0.5), cold starts, liblbfgs yaml defaults" % (N, M, len(thetas)),
                        "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
-                       "sharding": "theta round-robin over %d rank(s)" % world, "gather": gather,
+                       "sharding": ("structures (columns) split over %d rank(s), all thetas batched on every rank" % world)
+                       if nshard else ("theta round-robin over %d rank(s)" % world), "gather": gather,
                        "max_batch": args.max_batch},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -52,6 +52,13 @@ _SIGNATURES = {
     "bioen_hip_ctx_create": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_int, C.POINTER(ctx_p)]),
     "bioen_hip_ctx_create_synthetic": (C.c_int, [C.c_int, C.c_int, dp, dp, dp, dp, C.c_ulonglong, C.c_int,
                                                  C.POINTER(ctx_p)]),
+    "bioen_hip_ctx_create_sharded": (C.c_int, [C.c_int, C.c_longlong, dp, dp, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(ctx_p)]),
+    "bioen_hip_ctx_create_synthetic_sharded": (C.c_int, [C.c_int, C.c_longlong, dp, dp, dp, dp, C.c_ulonglong,
+                                                         C.c_int, C.c_int, C.c_int, C.POINTER(ctx_p)]),
+    "bioen_hip_ctx_set_exchange_callback": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p]),
+    "bioen_hip_ctx_shard": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong),
+                                      C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "bioen_hip_ctx_destroy": (C.c_int, [ctx_p]),
     "bioen_hip_ctx_shape": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bioen_hip_ctx_read_ytilde": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
@@ -149,15 +156,26 @@ def selftest_lbfgs(kind, x0, params):
     return out, info
 
 
-class Context(object):
-    """Device-resident problem: yTilde (M x N) lives in HBM until close()."""
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_size_t)
 
-    def __init__(self, yTilde=None, YTilde=None, device=0, _handle=None, _shape=None):
+
+class Context(object):
+    """Device-resident problem: yTilde (M x N) lives in HBM until close().
+
+    rank/world > 1: the structures (columns) are sharded over `world` GPUs, one process each;
+    this process keeps block `rank`.  N-vector arguments stay GLOBAL on every rank.  Before the
+    first evaluation give the context a communicator: ``comm_init`` (RCCL) or ``set_exchange``
+    (host-staged through any object with ``allgather_array``)."""
+
+    def __init__(self, yTilde=None, YTilde=None, device=0, rank=0, world=1, _handle=None, _shape=None):
         L = lib()
         self._h = None
+        self._exchange_keepalive = None
+        self.rank, self.world = int(rank), int(world)
         if _handle is not None:
             self._h = _handle
             self.m, self.n = _shape
+            self._query_shard()
             return
         yT = as_f64(yTilde)
         if yT.ndim != 2:
@@ -167,20 +185,51 @@ class Context(object):
         if YT.size != self.m:
             raise ValueError("YTilde must have M = %d entries" % self.m)
         h = ctx_p()
-        check(L.bioen_hip_ctx_create(self.m, self.n, ptr(yT), ptr(YT), int(device), C.byref(h)))
+        check(L.bioen_hip_ctx_create_sharded(self.m, self.n, ptr(yT), ptr(YT), int(device), self.rank, self.world,
+                                             C.byref(h)))
         self._h = h
+        self._query_shard()
+
+    def _query_shard(self):
+        r, w, nl = C.c_int(0), C.c_int(1), C.c_int(0)
+        ng, c0 = C.c_longlong(0), C.c_longlong(0)
+        check(lib().bioen_hip_ctx_shard(self._h, C.byref(r), C.byref(w), C.byref(ng), C.byref(c0), C.byref(nl)))
+        self.rank, self.world, self.col0, self.n_local = r.value, w.value, c0.value, nl.value
 
     @classmethod
-    def synthetic(cls, m, n, YTrue, sig_sim, sig_exp, YTilde, seed=12345, device=0):
+    def synthetic(cls, m, n, YTrue, sig_sim, sig_exp, YTilde, seed=12345, device=0, rank=0, world=1):
         L = lib()
         a = [as_f64(v).ravel() for v in (YTrue, sig_sim, sig_exp, YTilde)]
         for v in a:
             if v.size != m:
                 raise ValueError("synthetic(): every per-observable vector needs M entries")
         h = ctx_p()
-        check(L.bioen_hip_ctx_create_synthetic(int(m), int(n), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]),
-                                               C.c_ulonglong(seed), int(device), C.byref(h)))
-        return cls(_handle=h, _shape=(int(m), int(n)))
+        check(L.bioen_hip_ctx_create_synthetic_sharded(int(m), int(n), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]),
+                                                       C.c_ulonglong(seed), int(device), int(rank), int(world),
+                                                       C.byref(h)))
+        return cls(rank=rank, world=world, _handle=h, _shape=(int(m), int(n)))
+
+    def set_exchange(self, comm):
+        """Complete cross-rank reductions through `comm.allgather_array` (host-staged; for ranks
+        that cannot share an RCCL communicator).  `comm` = None removes the hook."""
+        if comm is None:
+            self._exchange_keepalive = None
+            check(lib().bioen_hip_ctx_set_exchange_callback(self._h, None, None))
+            return
+        world, rank = self.world, self.rank
+
+        def _cb(user, buf, count):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(world * count,)).reshape(world, count)
+                arr[:] = comm.allgather_array(arr[rank].copy())
+                return 0
+            except Exception:            # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = EXCHANGE_FN(_cb)
+        self._exchange_keepalive = fn
+        check(lib().bioen_hip_ctx_set_exchange_callback(self._h, C.cast(fn, C.c_void_p), None))
 
     # -- lifetime ---------------------------------------------------------------
     def close(self):
@@ -214,8 +263,9 @@ class Context(object):
 
     # -- data ---------------------------------------------------------------------
     def read_ytilde(self, row0=0, rows=None, col0=0, cols=None):
+        """Block of the resident matrix; on a sharded context columns are relative to this rank's block."""
         rows = self.m - row0 if rows is None else rows
-        cols = self.n - col0 if cols is None else cols
+        cols = self.n_local - col0 if cols is None else cols
         out = np.empty((rows, cols))
         check(lib().bioen_hip_ctx_read_ytilde(self._h, row0, rows, col0, cols, ptr(out)))
         return out
@@ -339,6 +389,9 @@ class Context(object):
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(lib().bioen_hip_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        check(lib().bioen_hip_comm_destroy(self._h))
 
     def comm_allgather(self, send, nranks):
         send = as_f64(send).ravel()

@@ -86,10 +86,32 @@ static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history) {
     return 0;
 }
 
-static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
+// columns [col0, col0 + n_local) of an n_global-column matrix go to `rank` of `world`
+static void shard_columns(long long n_global, int rank, int world, long long* col0, long long* n_local,
+                          long long* cols_per_rank) {
+    const long long per = (long long)round_up((size_t)((n_global + world - 1) / world), kColAlign);
+    *cols_per_rank = per;
+    *col0 = per * rank;
+    long long nl = n_global - *col0;
+    if (nl > per) nl = per;
+    if (nl < 0) nl = 0;
+    *n_local = nl;
+}
+
+static int ctx_alloc(int m, long long n_global, int device, int rank, int world, bioen_hip_ctx** out) {
     if (!out) return fail(BIOEN_HIP_EINVAL, "ctx pointer is NULL");
     *out = nullptr;
-    if (m <= 0 || n <= 0) return fail(BIOEN_HIP_EINVAL, "m and n must be positive");
+    if (m <= 0 || n_global <= 0) return fail(BIOEN_HIP_EINVAL, "m and n must be positive");
+    if (world < 1 || world > kMaxPartials / 8 || rank < 0 || rank >= world)
+        return fail(BIOEN_HIP_EINVAL, "bad rank / world");
+    long long col0 = 0, n_local = n_global, per = 0;
+    if (world > 1) {
+        shard_columns(n_global, rank, world, &col0, &n_local, &per);
+        if (n_global < (long long)world * kColAlign || n_local <= 0)
+            return fail(BIOEN_HIP_EINVAL, "too few structures to shard: need n >= 128 * world");
+    }
+    if (n_local > 0x7fffffff) return fail(BIOEN_HIP_EINVAL, "n per GPU exceeds 2^31-1");
+    const int n = (int)n_local;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(BIOEN_HIP_ENODEV, "no HIP device visible (libbioen_hip has no CPU fallback)");
@@ -101,8 +123,12 @@ static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
     c->device = device;
     c->m = m;
     c->n = n;
+    c->rank = rank;
+    c->world = world;
+    c->n_global = n_global;
+    c->col0 = col0;
     c->mp = (int)round_up((size_t)m, kRowAlign);
-    c->ld = round_up((size_t)n, kColAlign);
+    c->ld = world > 1 ? (size_t)per : round_up((size_t)n, kColAlign);   // identical on every rank
     choose_fwd_tiling(c);
     // stream yTilde with non-temporal loads once it no longer fits the 256 MiB Infinity Cache
     c->nontemporal = (size_t)c->mp * c->ld * sizeof(double) > (size_t)192 * 1024 * 1024;
@@ -125,6 +151,17 @@ static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
     TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * c->fwd_ctiles, c->stream));
     TRY(dalloc_zero(&c->part, (size_t)kMaxBatch * P_COUNT * kMaxPartials, c->stream));
     TRY(dalloc_zero(&c->scal, (size_t)kMaxBatch * kScalStride, c->stream));
+    {   // exchange stages: [world][capacity]
+        const size_t npl = (size_t)vec_grid(c);
+        const size_t arrays[X_COUNT] = {1, 2, 0, 3, 2, 1, 1, 1, 0};
+        for (int st = 0; st < X_COUNT; ++st) {
+            size_t cap = arrays[st] * kMaxBatch * npl;
+            if (st == X_YBAR) cap = (size_t)c->mp * kMaxBatch;
+            if (st == X_VEC) cap = world > 1 ? c->ld : 0;
+            c->xcap[st] = cap;
+            if (cap) TRY(dalloc_zero(&c->xbuf[st], cap * world, c->stream));
+        }
+    }
     TRY(alloc_slot(c, 0, false));
 #undef TRY
     e = hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), (size_t)kMaxBatch * kScalStride * sizeof(double),
@@ -137,8 +174,60 @@ static int ctx_alloc(int m, int n, int device, bioen_hip_ctx** out) {
     return 0;
 }
 
+// host N-vectors are always GLOBAL (n_global long); a sharded context takes its slice
 static int upload_n(bioen_hip_ctx* c, double* dst, const double* src) {
-    BIOEN_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BIOEN_HIP_CHECK(hipMemcpyAsync(dst, src + c->col0, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice,
+                                   c->stream));
+    return 0;
+}
+
+static int rccl_allgather_inplace(bioen_hip_ctx* c, double* base, size_t count);   // defined with the RCCL glue
+
+// One in-place all-gather of an exchange stage ([world][payload] doubles).  world == 1: nothing.
+static int exchange(bioen_hip_ctx* c, int stage, size_t payload) {
+    if (c->world == 1) return 0;
+    double* base = c->xbuf[stage];
+    if (c->comm) return rccl_allgather_inplace(c, base, payload);
+    if (!c->exchange_cb) return fail(BIOEN_HIP_ESTATE, "sharded context without a communicator");
+    // host-staged path (processes that cannot share an RCCL communicator, e.g. tests on one GPU)
+    const size_t total = payload * c->world;
+    if (c->exchange_host_count < total) {
+        if (c->exchange_host) hipHostFree(c->exchange_host);
+        c->exchange_host = nullptr;
+        BIOEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c->exchange_host), total * sizeof(double),
+                                      hipHostMallocDefault));
+        c->exchange_host_count = total;
+    }
+    BIOEN_HIP_CHECK(hipMemcpyAsync(c->exchange_host + (size_t)c->rank * payload, base + (size_t)c->rank * payload,
+                                   payload * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->exchange_cb(c->exchange_user, c->exchange_host, payload) != 0) {
+        c->exchange_error = 1;
+        return fail(BIOEN_HIP_ERCCL, "exchange callback failed");
+    }
+    BIOEN_HIP_CHECK(hipMemcpyAsync(base, c->exchange_host, total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// gather a sharded device N-vector into a GLOBAL host vector (world == 1: plain download)
+static int download_n(bioen_hip_ctx* c, double* dst_global, const double* src_local) {
+    if (c->world == 1) {
+        BIOEN_HIP_CHECK(hipMemcpyAsync(dst_global, src_local, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
+                                       c->stream));
+        return 0;
+    }
+    double* base = c->xbuf[X_VEC];
+    BIOEN_HIP_CHECK(hipMemcpyAsync(base + (size_t)c->rank * c->ld, src_local, c->ld * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
+    int rc = exchange(c, X_VEC, c->ld);
+    if (rc) return rc;
+    for (int r = 0; r < c->world; ++r) {
+        long long col0, nl, per;
+        shard_columns(c->n_global, r, c->world, &col0, &nl, &per);
+        if (nl > 0)
+            BIOEN_HIP_CHECK(hipMemcpyAsync(dst_global + col0, base + (size_t)r * c->ld, (size_t)nl * sizeof(double),
+                                           hipMemcpyDeviceToHost, c->stream));
+    }
     return 0;
 }
 
@@ -147,6 +236,14 @@ static int read_scalars(bioen_hip_ctx* c, int nslots = 1) {
                                    hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+static double host_logsumexp(const double* v, long long n) {
+    double mx = -1.7976931348623157e308;
+    for (long long j = 0; j < n; ++j) mx = std::max(mx, v[j]);
+    double s = 0.0;
+    for (long long j = 0; j < n; ++j) s += std::exp(v[j] - mx);
+    return mx + std::log(s);
 }
 
 static int check_launch() {
@@ -182,21 +279,30 @@ static Round make_round(bioen_hip_ctx* c, const int* slots, int k, const double*
 }
 
 // log-weights: r.x must hold the points and P_MAX their block maxima (launch_trial does both).
-static void enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
+// (the caller has produced X_MAX; its all-gather is the first thing done here)
+static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
+    const size_t g = (size_t)vec_grid(c);
+    int rc;
+    if ((rc = exchange(c, X_MAX, r.n * g))) return rc;
     launch_logw_exp(c, r);                 // A1 first half + prior partials
+    if ((rc = exchange(c, X_EXP, 2 * r.n * g))) return rc;
     launch_logw_norm(c, r);                // A1 second half -> w, log s, P
     Vec8 w{};
     for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
-    launch_fwd_partial(c, r.n, w);         // A4: ybar_a = yTilde . w_a          [matrix pass 1]
-    launch_fwd_rows_residual(c, r);        //     r, chi^2, ybar . r
+    launch_fwd_partial(c, r.n, w);         // A4: this rank's share of ybar_a = yTilde . w_a   [matrix pass 1]
+    launch_fwd_rows_local(c, r.n);
+    if ((rc = exchange(c, X_YBAR, (size_t)c->mp * r.n))) return rc;
+    launch_rows_combine(c, r);             //     ybar, r, chi^2, ybar . r (identical on every rank)
     launch_logw_scalars(c, r);             // A5: f
     if (with_grad) {
         MVec8 out{};
         for (int a = 0; a < r.n; ++a) out.p[a] = r.a[a];
         launch_adj(c, r.n, c->r_c, out, true);   // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
         launch_logw_grad(c, r);            //     gradient epilogue + g.d, g.g, x.x
+        if ((rc = exchange(c, X_GRAD, 3 * r.n * g))) return rc;
         launch_finish_eval(c, r);
     }
+    return 0;
 }
 
 // forces (single problem, slot 0): um holds the forces
@@ -218,7 +324,8 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, double theta, bool with_grad) 
     Vec8 v{};
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);           // F2: ybar                         [matrix pass 2]
-    launch_fwd_rows_residual(c, r);
+    launch_fwd_rows_local(c, 1);
+    launch_rows_combine(c, r);
     launch_forces_scalars(c, theta);       //     f = theta KL + 0.5 chi^2
     if (with_grad) {
         MVec8 out{};
@@ -259,24 +366,28 @@ struct LogwBatchEngine {
     void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
 
     // d = -H gp for the problems in `list` (lbfgs.c:571-598): 1 + 2*bound fused launches each,
-    // issued together (a problem with a shorter history idles in the surplus launches)
+    // issued together.  A problem with a shorter history starts later, so that all of them
+    // finish in the same launch (one X_DGI exchange for everybody).
     void directions(BatchProblem* slots, const std::vector<int>& list) {
         if (list.empty()) return;
         const int k = (int)list.size();
+        const size_t g = (size_t)vec_grid(c);
         // commit the new pairs first
         PairArgs pa{};
         int np = 0;
-        for (int s : list) {
+        for (int a = 0; a < k; ++a) {
+            const int s = list[a];
             BatchProblem& p = slots[s];
             if (!p.accept) continue;
             ProblemSlot& sl = c->slot[s];
             pa.x[np] = sl.x; pa.xp[np] = sl.xp; pa.g[np] = sl.g; pa.gp[np] = sl.gp;
-            pa.s[np] = sl.S[p.end]; pa.y[np] = sl.Yh[p.end]; pa.part[np] = sl.part;
+            pa.s[np] = sl.S[p.end]; pa.y[np] = sl.Yh[p.end]; pa.xpos[np] = a;
             ++np;
         }
         if (np) {
             pa.n = np;
-            launch_update_sy(c, pa);
+            launch_update_sy(c, pa, k);
+            note(exchange(c, X_SY, 2 * k * g));
         }
         int order[kMaxBatch][kHistory];
         int maxb = 0;
@@ -302,20 +413,20 @@ struct LogwBatchEngine {
                 BatchProblem& p = slots[list[a]];
                 ProblemSlot& sl = c->slot[list[a]];
                 const int bound = p.bound;
-                q.d[a] = sl.d; q.gp[a] = sl.gp; q.part[a] = sl.part; q.scal[a] = sl.scal;
+                const int my = step - 2 * (maxb - bound);   // this problem's own step index
+                q.d[a] = sl.d; q.gp[a] = sl.gp; q.scal[a] = sl.scal;
                 q.mode[a] = -1;
-                if (step >= 1 + 2 * bound) continue;
-                double* pin = sl.part + (size_t)(sl.rec_flip ? P_REC2 : P_REC) * kMaxPartials;
+                if (my < 0) continue;
                 const double* vdot = nullptr;
                 bool to_dginit = false;
-                if (step == 0) {
+                if (my == 0) {
                     q.mode[a] = 0;
                     q.hist[a] = p.end;
                     q.finalize_sy[a] = p.accept ? 1 : 0;
                     if (bound == 0) { vdot = sl.gp; to_dginit = true; }
                     else vdot = sl.S[order[a][0]];
-                } else if (step <= bound) {          // first loop, newest -> oldest
-                    const int b = step - 1;
+                } else if (my <= bound) {            // first loop, newest -> oldest
+                    const int b = my - 1;
                     const bool last = (b == bound - 1);
                     q.mode[a] = 1;
                     q.hist[a] = order[a][b];
@@ -323,7 +434,7 @@ struct LogwBatchEngine {
                     q.scale[a] = last ? 1 : 0;
                     vdot = last ? sl.Yh[order[a][b]] : sl.S[order[a][b + 1]];
                 } else {                             // second loop, oldest -> newest
-                    const int b = bound - 1 - (step - 1 - bound);
+                    const int b = bound - 1 - (my - 1 - bound);
                     const bool last = (b == 0);
                     q.mode[a] = 2;
                     q.hist[a] = order[a][b];
@@ -331,17 +442,16 @@ struct LogwBatchEngine {
                     if (last) { vdot = sl.gp; to_dginit = true; }
                     else vdot = sl.Yh[order[a][b - 1]];
                 }
-                q.pin[a] = pin;
                 q.vdot[a] = vdot;
-                if (to_dginit) {
-                    q.pout[a] = sl.part + (size_t)P_DGINIT * kMaxPartials;
-                } else {
-                    sl.rec_flip ^= 1;   // a step reads its predecessor's partials while writing its own
-                    q.pout[a] = sl.part + (size_t)(sl.rec_flip ? P_REC2 : P_REC) * kMaxPartials;
-                }
+                q.to_dginit[a] = to_dginit ? 1 : 0;
             }
-            launch_recur(c, q);
+            launch_recur(c, q, step);
+            if (step + 1 < nlaunch) note(exchange(c, (step & 1) ? X_REC1 : X_REC0, k * g));
+            else note(exchange(c, X_DGI, k * g));
         }
+        MVec8 sc{};
+        for (int a = 0; a < k; ++a) sc.p[a] = c->slot[list[a]].scal;
+        launch_store_dginit(c, k, sc);
         for (int s : list) {
             slots[s].need_direction = false;
             slots[s].accept = false;
@@ -351,12 +461,13 @@ struct LogwBatchEngine {
     int run(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride, const double* G_host,
             int max_batch, double* results, double* w_opt, bioen_opt_result* infos) {
         for (int i = 0; i < ntheta; ++i) std::memset(&infos[i], 0, sizeof(bioen_opt_result));
-        LbfgsMachine probe(c->n, cfg);
+        LbfgsMachine probe((int)std::min<long long>(c->n_global, 0x7fffffff), cfg);
         const int bad = probe.validate();
         if (bad != 0) {   // liblbfgs rejects the parameters before touching x (lbfgs.c:285-331)
             for (int i = 0; i < ntheta; ++i) {
                 infos[i].lbfgs_code = bad;
-                std::memcpy(results + (size_t)i * c->n, g0_host + (size_t)i * g0_stride, (size_t)c->n * sizeof(double));
+                std::memcpy(results + (size_t)i * c->n_global, g0_host + (size_t)i * g0_stride,
+                            (size_t)c->n_global * sizeof(double));
             }
             return 0;
         }
@@ -374,13 +485,21 @@ struct LogwBatchEngine {
             int all[kMaxBatch];
             for (int s = 0; s < kb; ++s) all[s] = s;
             const Round r = make_round(c, all, kb, nullptr, nullptr);
-            launch_logw_logs0(c, r);
+            if (c->world == 1) {
+                launch_logw_logs0(c, r);
+            } else {   // G is sharded on the device but whole on the host: same value on every rank
+                const double v = host_logsumexp(G_host, c->n_global);
+                for (int s = 0; s < kb; ++s)
+                    note(hipMemcpyAsync(c->slot[s].scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream),
+                         "logs0");
+                note(hipStreamSynchronize(c->stream), "sync");
+            }
         }
 
         BatchProblem slots[kMaxBatch];
         std::vector<LbfgsMachine> machines;
         machines.reserve(ntheta);
-        for (int i = 0; i < ntheta; ++i) machines.emplace_back(c->n, cfg);
+        for (int i = 0; i < ntheta; ++i) machines.emplace_back((int)std::min<long long>(c->n_global, 0x7fffffff), cfg);
         int next = 0, active = 0;
         bool occupied[kMaxBatch] = {};
 
@@ -392,14 +511,11 @@ struct LogwBatchEngine {
             p.machine = &machines[next];
             p.t0 = std::chrono::steady_clock::now();
             ProblemSlot& sl = c->slot[s];
-            sl.rec_flip = 0;
             if (shared_start)
                 note(hipMemcpyAsync(sl.xp, c->g0, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "copy g0");
             else
                 note(upload_n(c, sl.xp, g0_host + (size_t)next * g0_stride));
             note(hipMemsetAsync(sl.d, 0, c->ld * sizeof(double), c->stream), "memset d");
-            note(hipMemsetAsync(sl.part + (size_t)P_DGINIT * kMaxPartials, 0, kMaxPartials * sizeof(double), c->stream),
-                 "memset dginit");
             occupied[s] = true;
             ++active;
             ++next;
@@ -419,18 +535,15 @@ struct LogwBatchEngine {
                 const int one[1] = {s};
                 const Round r = make_round(c, one, 1, nullptr, &p.theta);
                 launch_max(c, r);
-                enqueue_logw_eval(c, r, false);
+                note(enqueue_logw_eval(c, r, false));
                 note(read_scalars(c, kMaxBatch));
                 res = sl.x;
             }
             const double* h = c->host_scal + (size_t)s * kScalStride;
             info.chi2 = 0.5 * h[S_CHI];
             info.kl = h[S_P] - h[S_LOGS] + h[S_LOGS0];
-            note(hipMemcpyAsync(results + (size_t)p.id * c->n, res, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
-                                c->stream), "result D2H");
-            if (w_opt)
-                note(hipMemcpyAsync(w_opt + (size_t)p.id * c->n, sl.w, (size_t)c->n * sizeof(double),
-                                    hipMemcpyDeviceToHost, c->stream), "weights D2H");
+            note(download_n(c, results + (size_t)p.id * c->n_global, res));
+            if (w_opt) note(download_n(c, w_opt + (size_t)p.id * c->n_global, sl.w));
             note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
             info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
             if (verbose) {
@@ -457,7 +570,7 @@ struct LogwBatchEngine {
             }
             const Round r = make_round(c, list, k, stp, th);
             launch_trial(c, r);
-            enqueue_logw_eval(c, r, true);
+            note(enqueue_logw_eval(c, r, true));
             note(read_scalars(c, kMaxBatch));
             note(check_launch());
             if (rc) break;
@@ -756,14 +869,15 @@ const char* bioen_hip_lbfgs_strerror(int code) { return lbfgs_code_string(code);
 void bioen_hip_set_fast_openmp_flag(int flag) { g_fast_openmp_flag = flag; }
 int bioen_hip_get_fast_openmp_flag(void) { return g_fast_openmp_flag; }
 
-int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTilde, int device,
-                         bioen_hip_ctx** ctx) {
+int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const double* YTilde, int device,
+                                 int rank, int world, bioen_hip_ctx** ctx) {
     if (!yTilde || !YTilde) return fail(BIOEN_HIP_EINVAL, "yTilde / YTilde is NULL");
     bioen_hip_ctx* c = nullptr;
-    int rc = ctx_alloc(m, n, device, &c);
+    int rc = ctx_alloc(m, n, device, rank, world, &c);
     if (rc) return rc;
-    hipError_t e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), yTilde, (size_t)n * sizeof(double),
-                                    (size_t)n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->stream);
+    // this rank's column block [col0, col0 + n_local) of the host matrix
+    hipError_t e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), yTilde + c->col0, (size_t)n * sizeof(double),
+                                    (size_t)c->n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->YT, YTilde, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -775,12 +889,17 @@ int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTild
     return 0;
 }
 
-int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const double* sig_sim,
-                                   const double* sig_exp, const double* YTilde, unsigned long long seed,
-                                   int device, bioen_hip_ctx** ctx) {
+int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTilde, int device,
+                         bioen_hip_ctx** ctx) {
+    return bioen_hip_ctx_create_sharded(m, n, yTilde, YTilde, device, 0, 1, ctx);
+}
+
+int bioen_hip_ctx_create_synthetic_sharded(int m, long long n, const double* YTrue, const double* sig_sim,
+                                           const double* sig_exp, const double* YTilde, unsigned long long seed,
+                                           int device, int rank, int world, bioen_hip_ctx** ctx) {
     if (!YTrue || !sig_sim || !sig_exp || !YTilde) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     bioen_hip_ctx* c = nullptr;
-    int rc = ctx_alloc(m, n, device, &c);
+    int rc = ctx_alloc(m, n, device, rank, world, &c);
     if (rc) return rc;
     // stage the three M-vectors in ybar_c / r_c / um (all >= mp long), then generate in place
     hipError_t e = hipMemcpyAsync(c->ybar_c, YTrue, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
@@ -803,6 +922,30 @@ int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const doub
         return hip_fail(e, "synthetic generation", __FILE__, __LINE__);
     }
     *ctx = c;
+    return 0;
+}
+
+int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const double* sig_sim,
+                                   const double* sig_exp, const double* YTilde, unsigned long long seed,
+                                   int device, bioen_hip_ctx** ctx) {
+    return bioen_hip_ctx_create_synthetic_sharded(m, n, YTrue, sig_sim, sig_exp, YTilde, seed, device, 0, 1, ctx);
+}
+
+int bioen_hip_ctx_set_exchange_callback(bioen_hip_ctx* c, bioen_hip_exchange_fn fn, void* user) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    c->exchange_cb = fn;
+    c->exchange_user = user;
+    return 0;
+}
+
+int bioen_hip_ctx_shard(const bioen_hip_ctx* c, int* rank, int* world, long long* n_global, long long* col0,
+                        int* n_local) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (n_global) *n_global = c->n_global;
+    if (col0) *col0 = c->col0;
+    if (n_local) *n_local = c->n;
     return 0;
 }
 
@@ -830,6 +973,9 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
             if (sl.Yh[i]) hipFree(sl.Yh[i]);
         }
     }
+    for (int st = 0; st < X_COUNT; ++st)
+        if (c->xbuf[st]) hipFree(c->xbuf[st]);
+    if (c->exchange_host) hipHostFree(c->exchange_host);
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -845,6 +991,7 @@ int bioen_hip_ctx_shape(const bioen_hip_ctx* c, int* m, int* n) {
 
 int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* c, int row0, int rows, int col0, int cols, double* out) {
     if (!c || !out) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    // (col0 is relative to this context's own column block when the matrix is sharded)
     if (row0 < 0 || col0 < 0 || rows <= 0 || cols <= 0 || row0 + rows > c->m || col0 + cols > c->n)
         return fail(BIOEN_HIP_EINVAL, "block out of range");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
@@ -880,11 +1027,14 @@ int bioen_hip_logw_weights(bioen_hip_ctx* c, const double* g, double* w, double*
     BIOEN_HIP_CHECK(hipMemsetAsync(c->fixed, 0, c->ld * sizeof(double), c->stream));
     const int one[1] = {0};
     const Round r = make_round(c, one, 1, nullptr, nullptr);
+    const size_t gsz = (size_t)vec_grid(c);
     launch_max(c, r);
+    if ((rc = exchange(c, X_MAX, gsz))) return rc;
     launch_logw_exp(c, r);
+    if ((rc = exchange(c, X_EXP, 2 * gsz))) return rc;
     launch_logw_norm(c, r);
     if ((rc = check_launch())) return rc;
-    if (w) BIOEN_HIP_CHECK(hipMemcpyAsync(w, s0.w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (w && (rc = download_n(c, w, s0.w))) return rc;
     if ((rc = read_scalars(c))) return rc;
     if (log_s) *log_s = c->host_scal[S_LOGS];
     return 0;
@@ -901,12 +1051,17 @@ int bioen_hip_logw_fdf(bioen_hip_ctx* c, const double* g, const double* G, doubl
     if (grad) BIOEN_HIP_CHECK(hipMemsetAsync(s0.d, 0, c->ld * sizeof(double), c->stream));
     const int one[1] = {0};
     const Round r = make_round(c, one, 1, nullptr, &theta);
-    launch_logw_logs0(c, r);
+    if (c->world == 1) {
+        launch_logw_logs0(c, r);
+    } else {
+        const double v = host_logsumexp(G, c->n_global);
+        BIOEN_HIP_CHECK(hipMemcpyAsync(s0.scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     launch_max(c, r);
-    enqueue_logw_eval(c, r, grad != nullptr);
+    if ((rc = enqueue_logw_eval(c, r, grad != nullptr))) return rc;
     if ((rc = check_launch())) return rc;
-    if (grad)
-        BIOEN_HIP_CHECK(hipMemcpyAsync(grad, s0.g, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (grad && (rc = download_n(c, grad, s0.g))) return rc;
     if ((rc = read_scalars(c))) return rc;
     if (f) *f = c->host_scal[S_F];
     return 0;
@@ -918,7 +1073,8 @@ int bioen_hip_opt_lbfgs_logw_batch(bioen_hip_ctx* c, int ntheta, const double* t
                                    double* w_opt, bioen_opt_result* infos) {
     if (!c || !thetas || !g0 || !G || !config || !results || !infos || ntheta <= 0)
         return fail(BIOEN_HIP_EINVAL, "NULL argument or ntheta <= 0");
-    if (g0_stride != 0 && g0_stride < (size_t)c->n) return fail(BIOEN_HIP_EINVAL, "g0_stride must be 0 or >= n");
+    if (g0_stride != 0 && g0_stride < (size_t)c->n_global)
+        return fail(BIOEN_HIP_EINVAL, "g0_stride must be 0 or >= n");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     const bool verbose = visual && visual->verbose;
     if (verbose) {
@@ -945,6 +1101,7 @@ static int upload_forces_inputs(bioen_hip_ctx* c, const double* forces, const do
 
 int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const double* w0, double* w) {
     if (!c || !forces || !w0 || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     int rc;
     if ((rc = upload_forces_inputs(c, forces, w0))) return rc;
@@ -958,6 +1115,7 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
 int bioen_hip_forces_fdf(bioen_hip_ctx* c, const double* forces, const double* w0, double theta, double* f,
                          double* grad) {
     if (!c || !forces || !w0) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     int rc;
     if ((rc = upload_forces_inputs(c, forces, w0))) return rc;
@@ -974,6 +1132,7 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
                                const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                                double* result, double* w_opt, bioen_opt_result* info) {
     if (!c || !forces0 || !w0 || !config || !result || !info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     const bool verbose = visual && visual->verbose;
     std::memset(info, 0, sizeof *info);
@@ -1014,6 +1173,7 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
 // ---- shared ---------------------------------------------------------------------------
 int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, double* chi2) {
     if (!c || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     ProblemSlot& s0 = c->slot[0];
     int rc;
@@ -1023,7 +1183,8 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     Vec8 v{};
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);
-    launch_fwd_rows_residual(c, r);
+    launch_fwd_rows_local(c, 1);
+    launch_rows_combine(c, r);
     launch_forces_scalars(c, 0.0);   // S_CHI (the KL partials it also sums are irrelevant here)
     if ((rc = check_launch())) return rc;
     if (yave)   // K = 1: the compact layout is the plain M-vector
@@ -1128,6 +1289,19 @@ int rccl_fail(ncclResult_t r, const char* what) {
 }
 }  // namespace
 
+}  // extern "C" (reopened below)
+
+namespace bioen {
+static int rccl_allgather_inplace(bioen_hip_ctx* c, double* base, size_t count) {
+    ncclResult_t r = g_rccl.AllGather(base + (size_t)c->rank * count, base, count, ncclDouble,
+                                      static_cast<ncclComm_t>(c->comm), c->stream);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather");
+    return 0;
+}
+}  // namespace bioen
+
+extern "C" {
+
 int bioen_hip_comm_unique_id(unsigned char id[128]) {
     if (!id) return fail(BIOEN_HIP_EINVAL, "id is NULL");
     int rc = load_rccl();
@@ -1142,6 +1316,8 @@ int bioen_hip_comm_unique_id(unsigned char id[128]) {
 int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank, int nranks) {
     if (!c || !id || nranks <= 0 || rank < 0 || rank >= nranks) return fail(BIOEN_HIP_EINVAL, "bad argument");
     if (c->comm) return fail(BIOEN_HIP_ESTATE, "communicator already initialised");
+    if (c->world > 1 && (rank != c->rank || nranks != c->world))
+        return fail(BIOEN_HIP_EINVAL, "communicator rank/size must match the context's shard");
     int rc = load_rccl();
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipSetDevice(c->device));

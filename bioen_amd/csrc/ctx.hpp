@@ -60,10 +60,38 @@ enum ScalarSlot : int {
 };
 static_assert(S_COUNT <= kScalStride, "scalar slots");
 
-// partial-reduction arrays (each kMaxPartials doubles, per problem slot)
+// local (never exchanged) partial-reduction arrays, each kMaxPartials doubles, per problem slot
 enum PartSlot : int {
-    P_MAX = 0, P_SUM, P_PP, P_CHI, P_C, P_DG, P_GG, P_XX, P_DGINIT, P_REC, P_REC2, P_YS, P_YY, P_KL, P_TSUM,
-    P_COUNT = 16
+    P_MAX = 0, P_SUM, P_PP, P_CHI, P_C, P_KL,
+    P_COUNT = 8
+};
+
+// Exchange stages.  A reduction over the N structures is produced as per-block partials and
+// consumed by the NEXT kernel, which re-sums them in a fixed order in its prologue.  With the
+// structures sharded over `world` GPUs the partials of a stage live in one buffer laid out
+// [rank][problem a][array q][block], every rank writes its own segment, and ONE in-place
+// all-gather per stage (RCCL over xGMI) makes all segments visible everywhere -- so every rank
+// sums the same numbers in the same order and takes bit-identical decisions without any host
+// communication.  world == 1: same code, no collective.
+enum XStage : int {
+    X_MAX = 0,   // 1 array : block maxima of the trial point
+    X_EXP,       // 2 arrays: sum e, sum e (x - G)
+    X_YBAR,      // mp values per problem: this rank's share of yTilde . w
+    X_GRAD,      // 3 arrays: g.d, g.g, x.x
+    X_SY,        // 2 arrays: y.s, y.y
+    X_REC0,      // 1 array : running dot of the two-loop recursion (ping)
+    X_REC1,      //                                                  (pong)
+    X_DGI,       // 1 array : gp . d
+    X_VEC,       // ld values per problem: result vectors at the end
+    X_COUNT
+};
+
+struct Xch {              // one stage, as the kernels see it
+    double* base;         // [world][payload]
+    int payload;          // doubles per rank in this launch
+    int world;
+    int rank;
+    int npl;              // blocks per array (= grid of the producing N-vector kernel)
 };
 
 struct KernelTimer {
@@ -85,17 +113,27 @@ struct ProblemSlot {
     double* S[kHistory] = {};
     double* Yh[kHistory] = {};
     double* scal = nullptr;   // kScalStride doubles inside ctx->scal
-    double* part = nullptr;   // P_COUNT * kMaxPartials doubles inside ctx->part
-    int rec_flip = 0;         // ping-pong index of the recursion's dot partials
+    double* part = nullptr;   // P_COUNT * kMaxPartials doubles inside ctx->part (local partials)
 };
 
 }  // namespace bioen
 
 struct bioen_hip_ctx {
     int device = 0;
-    int m = 0, n = 0;
+    int m = 0, n = 0;          // n = structures held by THIS rank
     int mp = 0;
     size_t ld = 0;
+    // structure (column) sharding over GPUs: this context holds columns [col0, col0 + n) of n_global
+    int rank = 0, world = 1;
+    long long n_global = 0, col0 = 0;
+    double* xbuf[bioen::X_COUNT] = {};   // exchange stage buffers, each world * capacity doubles
+    size_t xcap[bioen::X_COUNT] = {};    // capacity (doubles) per rank
+    // host-staged exchange for processes that cannot share an RCCL communicator (tests)
+    int (*exchange_cb)(void* user, double* host_buf, size_t count_per_rank) = nullptr;
+    void* exchange_user = nullptr;
+    double* exchange_host = nullptr;
+    size_t exchange_host_count = 0;
+    int exchange_error = 0;
     hipStream_t stream = nullptr;
 
     double* Y = nullptr;       // mp x ld

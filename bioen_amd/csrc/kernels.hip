@@ -105,6 +105,34 @@ __device__ __forceinline__ double max_partials(const double* __restrict__ p, int
     return block_max(s, sh);
 }
 
+// ---- exchange-stage accessors (ctx.hpp: XStage).  Layout [rank][problem a][array q][block].
+// put: this rank's block partial.  sum/max: over all ranks and blocks in a fixed order
+// (rank-major), identical on every rank.
+template <int A>
+__device__ __forceinline__ void xput(const Xch& x, int a, int q, double v) {
+    x.base[(size_t)x.rank * x.payload + (size_t)(a * A + q) * x.npl + blockIdx.x] = v;
+}
+
+template <int A>
+__device__ __forceinline__ double xsum(const Xch& x, int a, int q, double* sh) {
+    double s = 0.0;
+    for (int r = 0; r < x.world; ++r) {
+        const double* p = x.base + (size_t)r * x.payload + (size_t)(a * A + q) * x.npl;
+        for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
+    }
+    return block_sum(s, sh);
+}
+
+template <int A>
+__device__ __forceinline__ double xmax(const Xch& x, int a, int q, double* sh) {
+    double s = -DBL_MAX;
+    for (int r = 0; r < x.world; ++r) {
+        const double* p = x.base + (size_t)r * x.payload + (size_t)(a * A + q) * x.npl;
+        for (int k = threadIdx.x; k < x.npl; k += kBlock) s = fmax(s, p[k]);
+    }
+    return block_max(s, sh);
+}
+
 template <bool NT>
 __device__ __forceinline__ d2 ldg2(const double* p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
@@ -201,39 +229,46 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
     }
 }
 
-// reduce the column tiles of one (row, problem) per wave (fixed order):
-//   ybar, r = ybar - YT (compact layout [row*K + a]) ; per-block partials of sum r^2 and sum ybar r
-__global__ __launch_bounds__(kBlock) void k_fwd_rows_residual(const double* __restrict__ partial, int ctiles,
-                                                              int mp, int K, const double* __restrict__ YT,
-                                                              double* __restrict__ ybar_c,
-                                                              double* __restrict__ r_c, MVec8 part) {
-    __shared__ double sh[2][kWaves];
+// reduce the column tiles of one (row, problem) per wave (fixed order): this rank's share of
+// ybar, written into its segment of the X_YBAR stage (compact layout [row*K + a])
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restrict__ partial, int ctiles,
+                                                           int mp, int K, Xch xo) {
     const int a = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    double chi = 0.0, cc = 0.0;
+    double* out = xo.base + (size_t)xo.rank * xo.payload;
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
         const double* p = partial + ((size_t)row * K + a) * ctiles;
         double s = 0.0;
         for (int k = lane; k < ctiles; k += 64) s += p[k];
         s = wave_sum(s);
+        if (lane == 0) out[(size_t)row * K + a] = s;
+    }
+}
+
+// add the ranks' shares (rank order) -> ybar, r = ybar - YT (compact) ; per-block partials of
+// sum r^2 and sum ybar r.  Every rank computes the same numbers.
+__global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, const double* __restrict__ YT,
+                                                         double* __restrict__ ybar_c, double* __restrict__ r_c,
+                                                         MVec8 part) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    double chi = 0.0, cc = 0.0;
+    for (int row = blockIdx.x * kBlock + threadIdx.x; row < mp; row += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int r = 0; r < xi.world; ++r) s += xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
         const double res = s - YT[row];
-        if (lane == 0) {
-            ybar_c[(size_t)row * K + a] = s;
-            r_c[(size_t)row * K + a] = res;
-        }
-        chi += res * res;
-        cc += s * res;
+        ybar_c[(size_t)row * K + a] = s;
+        r_c[(size_t)row * K + a] = res;
+        chi = fma(res, res, chi);
+        cc = fma(s, res, cc);
     }
-    if (lane == 0) {
-        sh[0][wave] = chi;
-        sh[1][wave] = cc;
-    }
-    __syncthreads();
+    chi = block_sum(chi, sh);
+    cc = block_sum(cc, sh);
     if (threadIdx.x == 0) {
         double* pa = part.p[a];
-        pa[(size_t)P_CHI * kMaxPartials + blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        pa[(size_t)P_C * kMaxPartials + blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        pa[(size_t)P_CHI * kMaxPartials + blockIdx.x] = chi;
+        pa[(size_t)P_C * kMaxPartials + blockIdx.x] = cc;
     }
 }
 
@@ -312,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, si
 // log-weights N-vector kernels (blockIdx.y = position a in the round's batch)
 // ------------------------------------------------------------------------------
 // x = xp + stp * d ; block maxima of x
-__global__ __launch_bounds__(kBlock) void k_trial(Round r, int n) {
+__global__ __launch_bounds__(kBlock) void k_trial(Round r, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     double* __restrict__ x = r.x[a];
@@ -331,17 +366,17 @@ __global__ __launch_bounds__(kBlock) void k_trial(Round r, int n) {
         if (j + 1 < n) mx = fmax(mx, v.y);
     }
     mx = block_max(mx, sh);
-    if (threadIdx.x == 0) r.part[a][(size_t)P_MAX * kMaxPartials + blockIdx.x] = mx;
+    if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
 }
 
-__global__ __launch_bounds__(kBlock) void k_max(Round r, int n) {
+__global__ __launch_bounds__(kBlock) void k_max(Round r, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double* __restrict__ x = r.x[a];
     double mx = -DBL_MAX;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, x[j]);
     mx = block_max(mx, sh);
-    if (threadIdx.x == 0) r.part[a][(size_t)P_MAX * kMaxPartials + blockIdx.x] = mx;
+    if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
 }
 
 __global__ __launch_bounds__(kBlock) void k_max_vec(const double* __restrict__ v, int n, double* __restrict__ pmax) {
@@ -354,13 +389,13 @@ __global__ __launch_bounds__(kBlock) void k_max_vec(const double* __restrict__ v
 
 // _get_weights (c_bioen_kernels_logw.c:55-94) with a max shift, first half:
 //   e_j = exp(x_j - max) ; partials of sum e and sum e (x - G)   (prior, :96-127)
-__global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, int np) {
+__global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, Xch xmx,
+                                                     Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double* __restrict__ x = r.x[a];
     double* __restrict__ e = r.w[a];
-    double* pa = r.part[a];
-    const double gmax = max_partials(pa + (size_t)P_MAX * kMaxPartials, np, sh);
+    const double gmax = xmax<1>(xmx, a, 0, sh);
     double s = 0.0, pp = 0.0;
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
@@ -379,22 +414,21 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
     s = block_sum(s, sh);
     pp = block_sum(pp, sh);
     if (threadIdx.x == 0) {
-        pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = s;
-        pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = pp;
+        xput<2>(xo, a, 0, s);
+        xput<2>(xo, a, 1, pp);
     }
 }
 
 // second half: w = e / S ; scal[S_LOGS] = max + log S ; scal[S_P] = sum e (x-G) / S
-__global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, int np) {
+__global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xmx, Xch xe) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     double* __restrict__ w = r.w[a];
-    const double* pa = r.part[a];
-    const double S = sum_partials(pa + (size_t)P_SUM * kMaxPartials, np, sh);
+    const double S = xsum<2>(xe, a, 0, sh);
     const double inv = 1.0 / S;
     if (blockIdx.x == 0) {
-        const double gmax = max_partials(pa + (size_t)P_MAX * kMaxPartials, np, sh);
-        const double PP = sum_partials(pa + (size_t)P_PP * kMaxPartials, np, sh);
+        const double gmax = xmax<1>(xmx, a, 0, sh);
+        const double PP = xsum<2>(xe, a, 1, sh);
         if (threadIdx.x == 0) {
             r.scal[a][S_LOGS] = gmax + log(S);
             r.scal[a][S_P] = PP * inv;
@@ -444,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_logw_scalars(Round r, int np) {
 // gradient epilogue (c_bioen_kernels_logw.c:207-218):
 //   g_k = w_k [ theta (x_k - G_k - P) + a_k ],  a_k = sum_i r_i (yTilde_ik - ybar_i)  (centred adjoint)
 // plus the three dot products the line search / convergence test needs.
-__global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __restrict__ G, int n) {
+__global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __restrict__ G, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double* __restrict__ x = r.x[a];
@@ -478,28 +512,32 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     gg = block_sum(gg, sh);
     xx = block_sum(xx, sh);
     if (threadIdx.x == 0) {
-        double* pa = r.part[a];
-        pa[(size_t)P_DG * kMaxPartials + blockIdx.x] = dg;
-        pa[(size_t)P_GG * kMaxPartials + blockIdx.x] = gg;
-        pa[(size_t)P_XX * kMaxPartials + blockIdx.x] = xx;
+        xput<3>(xo, a, 0, dg);
+        xput<3>(xo, a, 1, gg);
+        xput<3>(xo, a, 2, xx);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, int np) {
+__global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
-    const double* pa = r.part[a];
-    const double dg = sum_partials(pa + (size_t)P_DG * kMaxPartials, np, sh);
-    const double gg = sum_partials(pa + (size_t)P_GG * kMaxPartials, np, sh);
-    const double xx = sum_partials(pa + (size_t)P_XX * kMaxPartials, np, sh);
-    const double di = sum_partials(pa + (size_t)P_DGINIT * kMaxPartials, np, sh);
+    const double dg = xsum<3>(xg, a, 0, sh);
+    const double gg = xsum<3>(xg, a, 1, sh);
+    const double xx = xsum<3>(xg, a, 2, sh);
     if (threadIdx.x == 0) {
         double* sc = r.scal[a];
         sc[S_DG] = dg;
         sc[S_GG] = gg;
         sc[S_XX] = xx;
-        sc[S_DGINIT] = di;
     }
+}
+
+// gp . d of the freshly built direction -> scal[S_DGINIT] (the next line search's initial slope)
+__global__ __launch_bounds__(kBlock) void k_store_dginit(MVec8 scal, Xch xd) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double di = xsum<1>(xd, a, 0, sh);
+    if (threadIdx.x == 0) scal.p[a][S_DGINIT] = di;
 }
 
 // ------------------------------------------------------------------------------
@@ -567,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_scalars(const double* __restr
 // L-BFGS vector kernels (liblbfgs lbfgs.c:543-615 with every scalar device-resident)
 // ------------------------------------------------------------------------------
 // s = x - xp, y = g - gp (lbfgs.c:549-551); partials of y.s and y.y (:559-561)
-__global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n) {
+__global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double* __restrict__ x = p.x[a];
@@ -594,8 +632,8 @@ __global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n) {
     ys = block_sum(ys, sh);
     yy = block_sum(yy, sh);
     if (threadIdx.x == 0) {
-        p.part[a][(size_t)P_YS * kMaxPartials + blockIdx.x] = ys;
-        p.part[a][(size_t)P_YY * kMaxPartials + blockIdx.x] = yy;
+        xput<2>(xo, p.xpos[a], 0, ys);
+        xput<2>(xo, p.xpos[a], 1, yy);
     }
 }
 
@@ -608,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n) {
 //   scale : d *= ys / yy   after the update (last step of the first loop)
 // and in the same sweep  out_partials = vdot . d  for the next step (or gp . d, the next
 // line search's initial slope).  mode -1: this problem has no step in this launch.
-__global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int np, int n) {
+__global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int n, Xch xin, Xch xsy, Xch xrec, Xch xdgi) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const int mode = q.mode[a];
@@ -623,8 +661,8 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int np, int n) {
     double coef = 0.0, sc = 1.0;
     if (mode == 0) {
         if (q.finalize_sy[a] && blockIdx.x == 0) {
-            const double ys = sum_partials(q.part[a] + (size_t)P_YS * kMaxPartials, np, sh);
-            const double yy = sum_partials(q.part[a] + (size_t)P_YY * kMaxPartials, np, sh);
+            const double ys = xsum<2>(xsy, a, 0, sh);
+            const double yy = xsum<2>(xsy, a, 1, sh);
             if (threadIdx.x == 0) {
                 scal[S_YSH + hist] = ys;
                 scal[S_YS] = ys;
@@ -632,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int np, int n) {
             }
         }
     } else {
-        const double dot = sum_partials(q.pin[a], np, sh);
+        const double dot = xsum<1>(xin, a, 0, sh);
         const double ysh = scal[S_YSH + hist];
         if (mode == 1) {
             const double alpha = dot / ysh;
@@ -670,7 +708,10 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int np, int n) {
         }
     }
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0 && q.pout[a]) q.pout[a][blockIdx.x] = acc;
+    if (threadIdx.x == 0) {
+        if (q.to_dginit[a]) xput<1>(xdgi, a, 0, acc);
+        else if (vdot) xput<1>(xrec, a, 0, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------
@@ -683,6 +724,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_generate(double* __restrict__ Y, size_t ld, int m, int n, int mp,
+                                                     unsigned long long col0, unsigned long long n_global,
                                                      const double* __restrict__ YTrue,
                                                      const double* __restrict__ sig_sim,
                                                      const double* __restrict__ sig_exp, unsigned long long seed) {
@@ -694,7 +736,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(double* __restrict__ Y, siz
         const size_t j = jp * 2;
         d2 out = {0.0, 0.0};
         if (i < m && j < (size_t)n) {
-            const unsigned long long ctr = (unsigned long long)i * (unsigned long long)((n + 1) / 2) + jp;
+            // counter = position of the column PAIR in the global (unsharded) matrix
+            const unsigned long long ctr = (unsigned long long)i * ((n_global + 1) / 2) + (col0 / 2 + jp);
             const unsigned long long h1 = mix64(seed + 0x9E3779B97F4A7C15ULL * (2 * ctr + 1));
             const unsigned long long h2 = mix64(seed + 0x9E3779B97F4A7C15ULL * (2 * ctr + 2));
             const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
@@ -714,10 +757,22 @@ __global__ __launch_bounds__(kBlock) void k_generate(double* __restrict__ Y, siz
 // host-side launchers
 // ==============================================================================
 int vec_grid(const bioen_hip_ctx* c) {
-    long long b = ((long long)c->n + 4 * kBlock - 1) / (4 * kBlock);   // 2 pairs (4 elements) per thread
+    // from ld (identical on every rank of a sharded context), 2 pairs (4 elements) per thread
+    long long b = ((long long)c->ld + 4 * kBlock - 1) / (4 * kBlock);
+    const long long cap = kMaxPartials / c->world;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
-    if (b > kMaxPartials) b = kMaxPartials;
     return (int)b;
+}
+
+Xch make_xch(const bioen_hip_ctx* c, int stage, int payload) {
+    Xch x;
+    x.base = c->xbuf[stage];
+    x.payload = payload;
+    x.world = c->world;
+    x.rank = c->rank;
+    x.npl = vec_grid(c);
+    return x;
 }
 
 int rows_grid(const bioen_hip_ctx* c) {
@@ -783,11 +838,21 @@ void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
     if (c->nontemporal) fwd_dispatch<true>(c, K, v, centred); else fwd_dispatch<false>(c, K, v, centred);
 }
 
-void launch_fwd_rows_residual(bioen_hip_ctx* c, const Round& r) {
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K) {
+    hipLaunchKernelGGL(k_fwd_rows_local, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       c->fwd_ctiles, c->mp, K, make_xch(c, X_YBAR, c->mp * K));
+}
+
+int combine_grid(const bioen_hip_ctx* c) {
+    int b = (c->mp + kBlock - 1) / kBlock;
+    return b > kMaxPartials ? kMaxPartials : b;
+}
+
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r) {
     MVec8 part;
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
-    hipLaunchKernelGGL(k_fwd_rows_residual, dim3(rows_grid(c), r.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       c->fwd_ctiles, c->mp, r.n, c->YT, c->ybar_c, c->r_c, part);
+    hipLaunchKernelGGL(k_rows_combine, dim3(combine_grid(c), r.n), dim3(kBlock), 0, c->stream,
+                       make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->ybar_c, c->r_c, part);
 }
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c) {
@@ -828,20 +893,23 @@ void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bo
 
 // ---- log-weights vector kernels -----------------------------------------------------------
 void launch_trial(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_trial, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
+    hipLaunchKernelGGL(k_trial, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_max(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_max, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
+    hipLaunchKernelGGL(k_max, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_logw_exp(bioen_hip_ctx* c, const Round& r) {
     hipLaunchKernelGGL(k_logw_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
-                       vec_grid(c));
+                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 2 * r.n * vec_grid(c)));
 }
 
 void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n, vec_grid(c));
+    hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 2 * r.n * vec_grid(c)));
 }
 
 void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
@@ -849,15 +917,22 @@ void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
 }
 
 void launch_logw_scalars(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, rows_grid(c));
+    hipLaunchKernelGGL(k_logw_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, combine_grid(c));
 }
 
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_grad, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n);
+    hipLaunchKernelGGL(k_logw_grad, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
 }
 
 void launch_finish_eval(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_finish_eval, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, vec_grid(c));
+    hipLaunchKernelGGL(k_finish_eval, dim3(1, r.n), dim3(kBlock), 0, c->stream, r,
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
+}
+
+void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal) {
+    hipLaunchKernelGGL(k_store_dginit, dim3(1, k), dim3(kBlock), 0, c->stream, scal,
+                       make_xch(c, X_DGI, k * vec_grid(c)));
 }
 
 // ---- forces (slot 0) -------------------------------------------------------------------------
@@ -883,23 +958,28 @@ void launch_forces_t(bioen_hip_ctx* c, double theta) {
 }
 
 void launch_forces_scalars(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_forces_scalars, dim3(1), dim3(kBlock), 0, c->stream, part0(c, P_CHI), rows_grid(c),
+    hipLaunchKernelGGL(k_forces_scalars, dim3(1), dim3(kBlock), 0, c->stream, part0(c, P_CHI), combine_grid(c),
                        part0(c, P_KL), vec_grid(c), theta, c->slot[0].scal);
 }
 
 // ---- L-BFGS vector kernels ----------------------------------------------------------------------
-void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a) {
-    hipLaunchKernelGGL(k_update_sy, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a, int kdir) {
+    hipLaunchKernelGGL(k_update_sy, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+                       make_xch(c, X_SY, 2 * kdir * vec_grid(c)));
 }
 
-void launch_recur(bioen_hip_ctx* c, const RecurArgs& a) {
-    hipLaunchKernelGGL(k_recur, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, vec_grid(c), c->n);
+void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step) {
+    const int k = a.n, g = vec_grid(c);
+    // step s reads the running dot its predecessor left in REC[(s-1)&1] and writes REC[s&1]
+    hipLaunchKernelGGL(k_recur, dim3(g, k), dim3(kBlock), 0, c->stream, a, c->n,
+                       make_xch(c, ((step - 1) & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_SY, 2 * k * g),
+                       make_xch(c, (step & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_DGI, k * g));
 }
 
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,
                      unsigned long long seed) {
-    hipLaunchKernelGGL(k_generate, dim3(256 * 16), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->m, c->n, c->mp, YTrue,
-                       sig_sim, sig_exp, seed);
+    hipLaunchKernelGGL(k_generate, dim3(256 * 16), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->m, c->n, c->mp,
+                       (unsigned long long)c->col0, (unsigned long long)c->n_global, YTrue, sig_sim, sig_exp, seed);
 }
 
 }  // namespace bioen

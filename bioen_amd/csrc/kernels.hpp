@@ -34,7 +34,7 @@ struct MVec8 {
     double* p[kMaxBatch];
 };
 
-inline double* part_of(const Round& r, int a, int which) { return r.part[a] + (size_t)which * kMaxPartials; }
+Xch make_xch(const bioen_hip_ctx* c, int stage, int payload);   // stage view for a launch
 
 int vec_grid(const bioen_hip_ctx* c);   // blocks used by every N-vector kernel of this context
 int rows_grid(const bioen_hip_ctx* c);
@@ -42,8 +42,11 @@ int rows_grid(const bioen_hip_ctx* c);
 // ---- matrix streaming kernels ------------------------------------------------
 // forward: fwd_partial[(row*K + a)*ctiles + tile] = sum_{j in tile} (Y[row][j] - [centred] ybar_c[row*K+a]) v_a[j]
 void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred = false);
-// reduce the column tiles -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
-void launch_fwd_rows_residual(bioen_hip_ctx* c, const Round& r);
+// reduce the column tiles -> this rank's share of ybar in its X_YBAR segment   [exchange X_YBAR]
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K);
+// add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r);
+int combine_grid(const bioen_hip_ctx* c);
 // forces gradient (K = 1): gm = reduced centred sums
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c);
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
@@ -57,7 +60,8 @@ void launch_logw_norm(bioen_hip_ctx* c, const Round& r);    // w /= S ; log s, P
 void launch_logw_logs0(bioen_hip_ctx* c, const Round& r);   // scal[S_LOGS0] = log sum exp(fixed)
 void launch_logw_scalars(bioen_hip_ctx* c, const Round& r); // chi^2, c, f
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r);    // gradient epilogue + g.d, g.g, x.x
-void launch_finish_eval(bioen_hip_ctx* c, const Round& r);  // scal[S_DG..S_DGINIT]
+void launch_finish_eval(bioen_hip_ctx* c, const Round& r);  // scal[S_DG], S_GG, S_XX
+void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal);   // scal[S_DGINIT] <- X_DGI
 
 // ---- forces N-vector kernels (single problem, slot 0) -------------------------------------
 void launch_max_vec(bioen_hip_ctx* c, const double* v, double* pmax);
@@ -75,9 +79,9 @@ struct PairArgs {      // s = x - xp ; y = g - gp for the accepting problems
     const double* gp[kMaxBatch];
     double* s[kMaxBatch];
     double* y[kMaxBatch];
-    double* part[kMaxBatch];
+    int xpos[kMaxBatch];   // position of the problem in the direction batch (X_SY index)
 };
-void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a);
+void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a, int kdir);
 
 // One fused step of the two-loop recursion per problem (see kernels.hip: k_recur).
 struct RecurArgs {
@@ -90,12 +94,10 @@ struct RecurArgs {
     const double* gp[kMaxBatch];
     const double* vaxpy[kMaxBatch];
     const double* vdot[kMaxBatch];
-    const double* pin[kMaxBatch];
-    double* pout[kMaxBatch];
-    double* part[kMaxBatch];
+    int to_dginit[kMaxBatch];     // this step's dot is gp . d (goes to X_DGI instead of X_REC)
     double* scal[kMaxBatch];
 };
-void launch_recur(bioen_hip_ctx* c, const RecurArgs& a);
+void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step);
 
 // ---- misc ---------------------------------------------------------------------------
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,

@@ -293,6 +293,19 @@ def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=Fals
     return theta_sweep(ctx, thetas, None, comm=comm, rccl=rccl, presolved=solved)
 
 
+def sweep_log_weights_sharded(ctx, thetas, G, g_init, lbfgs_params, verbose=False, max_batch=8):
+    """The same series on a STRUCTURE-sharded context (``Context(..., rank, world)``): every rank
+    keeps a column block of yTilde and all ranks work on every theta together -- each matrix
+    pass, each N-vector kernel and each L-BFGS vector lives 1/world per GPU, and the reductions
+    over structures are completed by one in-place all-gather per stage (RCCL over xGMI).  All
+    ranks return the same list (results are gathered inside the library)."""
+    thetas = [float(t) for t in thetas]
+    _, w, infos = ctx.opt_lbfgs_logw_batch(thetas, g_init, G, lbfgs_params, max_batch=max_batch, verbose=verbose)
+    return [{"theta": th, "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "iterations": i.iterations,
+             "evaluations": i.evaluations, "code": i.lbfgs_code, "seconds": i.seconds, "rank": -1, "w": w[k]}
+            for k, (th, i) in enumerate(zip(thetas, infos))]
+
+
 def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=False, verbose=False):
     """Cold-started forces series (the ala5 notebook's protocol)."""
     def solve(theta):

@@ -94,6 +94,27 @@ int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTild
 int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const double* sig_sim,
                                    const double* sig_exp, const double* YTilde,
                                    unsigned long long seed, int device, bioen_hip_ctx** ctx);
+/* Structure-sharded contexts (multi-GPU, one process per GPU): rank r of `world` keeps the
+ * column block [r*P, min(n, (r+1)*P)), P = ceil(n/world) rounded up to 128, of the n-column
+ * matrix -- `yTilde` is the caller's FULL row-major matrix, only the block is uploaded
+ * (resp. generated).  All N-vector arguments of the calls below stay GLOBAL (n long) on every
+ * rank; the library slices inputs and gathers outputs.  Reductions over structures are
+ * completed by one in-place all-gather per stage over RCCL (bioen_hip_comm_init) or, for
+ * processes that cannot share an RCCL communicator, through a host callback.  Every rank must
+ * issue the same calls in the same order.  Supported on sharded contexts: logw_weights,
+ * logw_fdf, opt_lbfgs_logw, opt_lbfgs_logw_batch. */
+int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const double* YTilde,
+                                 int device, int rank, int world, bioen_hip_ctx** ctx);
+int bioen_hip_ctx_create_synthetic_sharded(int m, long long n, const double* YTrue,
+                                           const double* sig_sim, const double* sig_exp,
+                                           const double* YTilde, unsigned long long seed, int device,
+                                           int rank, int world, bioen_hip_ctx** ctx);
+/* host_buf = [world][count_per_rank] doubles; on entry this rank's segment is filled, on
+ * return (0 = ok) all segments must be.  Called from the thread that called into the library. */
+typedef int (*bioen_hip_exchange_fn)(void* user, double* host_buf, size_t count_per_rank);
+int bioen_hip_ctx_set_exchange_callback(bioen_hip_ctx* ctx, bioen_hip_exchange_fn fn, void* user);
+int bioen_hip_ctx_shard(const bioen_hip_ctx* ctx, int* rank, int* world, long long* n_global,
+                        long long* col0, int* n_local);
 int bioen_hip_ctx_destroy(bioen_hip_ctx* ctx);
 int bioen_hip_ctx_shape(const bioen_hip_ctx* ctx, int* m, int* n);
 /* copy rows [row0,row0+rows) x cols [col0,col0+cols) of the resident matrix to host (row-major) */

@@ -1,0 +1,44 @@
+"""Worker of tests/test_hip_nshard.py: one rank of a structure-sharded (column-sharded) run.
+All ranks share the single GPU of the test box, so the cross-rank all-gathers go through the
+host-staged exchange hook (SocketComm); on a real multi-GPU node the same code path uses RCCL."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bioen_amd                      # noqa: E402
+from bioen_amd import sweep            # noqa: E402
+from conftest import load_golden, LBFGS_DEFAULTS   # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    comm = sweep.SocketComm()
+    d = load_golden("synth_logw_M64xN2000.npz")
+    thetas = [50.0, 5.0, 500.0, 1.0, 20.0]
+    rng = np.random.default_rng(99)
+    g = d["GInit"].ravel() + 0.2 * rng.standard_normal(d["GInit"].size)
+
+    ctx = bioen_amd.Context(d["yTilde"], d["YTilde"], device=0, rank=comm.rank, world=comm.world)
+    ctx.set_exchange(comm)
+    w, logs = ctx.logw_weights(g)
+    f, grad = ctx.logw_fdf(g, d["G"], d["theta"])
+    res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    block = ctx.read_ytilde()
+    col0, n_local = ctx.col0, ctx.n_local
+    ctx.close()
+    comm.barrier()
+    np.savez(out_path % comm.rank, w=w, logs=logs, f=f, grad=grad, res=res, wopt=wopt,
+             fmin=np.array([i.fmin for i in infos]), iters=np.array([i.iterations for i in infos]),
+             evals=np.array([i.evaluations for i in infos]), codes=np.array([i.lbfgs_code for i in infos]),
+             chi2=np.array([i.chi2 for i in infos]), kl=np.array([i.kl for i in infos]),
+             block=block, col0=col0, n_local=n_local)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
