@@ -123,8 +123,9 @@ def main():
     ap.add_argument("--observables", type=int, default=1024, help="M")
     ap.add_argument("--thetas", type=int, default=8, help="points of the theta series")
     ap.add_argument("--max-batch", type=int, default=8, help="thetas sharing one matrix pass (1 = unbatched)")
-    ap.add_argument("--shard", choices=("structures", "thetas"), default="structures",
-                    help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal thetas")
+    ap.add_argument("--shard", choices=("auto", "structures", "thetas"), default="auto",
+                    help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal "
+                         "thetas; auto = structures when the measured all-gather latency makes it the faster one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols", type=int, default=65536)
     ap.add_argument("--cpu-iters", type=int, default=40)
@@ -147,27 +148,44 @@ def main():
     ndev = bioen_amd.device_count()
     if ndev < 1:
         raise SystemExit("bench.py: no MI355X visible to HIP -- this benchmark has no CPU path")
-    nshard = world > 1 and args.shard == "structures"
-    ctx = bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED, device=local_rank % ndev,
-                                      rank=rank if nshard else 0, world=world if nshard else 1)
-    gather = "none"
-    rccl = False
-    if world > 1:
-        try:
-            with stdout_to_stderr():
-                rccl = sweep.init_rccl(ctx, comm)
-            gather = "rccl-allgather"
-        except bioen_amd.BioenHipError as e:   # report, keep the control-plane path
-            gather = "tcp-allgather (RCCL unavailable: %s)" % e
-            rccl = False
-        ok = comm.allgather_object(rccl)
-        if not all(ok):
-            rccl = False
-            gather = "tcp-allgather (RCCL init failed on some rank)"
-            if nshard:
+    def build(nshard):
+        """context + communicator for one of the two decompositions"""
+        ctx = bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED,
+                                          device=local_rank % ndev, rank=rank if nshard else 0,
+                                          world=world if nshard else 1)
+        gather, rccl = "none", False
+        if world > 1:
+            try:
+                with stdout_to_stderr():
+                    rccl = sweep.init_rccl(ctx, comm)
+                gather = "rccl-allgather"
+            except bioen_amd.BioenHipError as e:   # report, keep the control-plane path
+                gather = "tcp-allgather (RCCL unavailable: %s)" % e
+                rccl = False
+            if not all(comm.allgather_object(rccl)):
+                rccl = False
+                gather = "tcp-allgather (RCCL init failed on some rank)"
                 ctx.comm_destroy()
-        if nshard and not rccl:
-            ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (e.g. ranks sharing one GPU)
+            if nshard and not rccl:
+                ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
+        return ctx, gather, rccl
+
+    decision = None
+    nshard = world > 1 and args.shard in ("auto", "structures")
+    ctx, gather, rccl = build(nshard)
+    if world > 1 and args.shard == "auto":
+        # Splitting the structures pays when the per-pass saving beats the ~20 small all-gathers a
+        # round then needs: t_pass * (1 - 1/world)  vs  20 * t_exchange + launch overhead.
+        t_ex = max(comm.allgather_object(ctx.exchange_probe(count=M * min(8, len(thetas)), reps=40)))
+        t_pass_us = 2.0 * M * float(N) * 8 / 6.4e12 * 1e6
+        gain_us = t_pass_us * (1.0 - 1.0 / world)
+        cost_us = 20.0 * t_ex + 150.0
+        decision = {"exchange_us": t_ex, "pass_saving_us": gain_us, "exchange_cost_us": cost_us,
+                    "chosen": "structures" if gain_us > cost_us else "thetas"}
+        if gain_us <= cost_us:
+            ctx.close()
+            nshard = False
+            ctx, gather, rccl = build(False)
 
     G = np.zeros(N)          # w0 = 1/N  =>  G = 0 ; GInit = G (SURVEY 8d)
     g0 = np.zeros(N)
@@ -258,7 +276,7 @@ def main():
                        "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
                        "sharding": ("structures (columns) split over %d rank(s), all thetas batched on every rank" % world)
                        if nshard else ("theta round-robin over %d rank(s)" % world), "gather": gather,
-                       "max_batch": args.max_batch},
+                       "max_batch": args.max_batch, "shard_decision": decision},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "sweep_wall_s": dt / max(args.steps, 1),

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "bioen_hip_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
     "bioen_hip_comm_allgather": (C.c_int, [ctx_p, dp, C.c_size_t, dp]),
+    "bioen_hip_exchange_probe": (C.c_int, [ctx_p, C.c_size_t, C.c_int, dp]),
     "bioen_hip_comm_destroy": (C.c_int, [ctx_p]),
 }
 
@@ -389,6 +390,12 @@ class Context(object):
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(lib().bioen_hip_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def exchange_probe(self, count=1024, reps=50):
+        """microseconds per stage exchange (all-gather of `count` doubles per rank)"""
+        us = C.c_double(0.0)
+        check(lib().bioen_hip_exchange_probe(self._h, int(count), int(reps), C.byref(us)))
+        return us.value
 
     def comm_destroy(self):
         check(lib().bioen_hip_comm_destroy(self._h))

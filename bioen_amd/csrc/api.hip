@@ -1359,6 +1359,22 @@ int bioen_hip_comm_allgather(bioen_hip_ctx* c, const double* send, size_t count,
     return 0;
 }
 
+int bioen_hip_exchange_probe(bioen_hip_ctx* c, size_t count, int reps, double* usec_per_exchange) {
+    if (!c || !usec_per_exchange || reps <= 0 || count == 0) return fail(BIOEN_HIP_EINVAL, "bad argument");
+    if (count > c->xcap[X_YBAR]) count = c->xcap[X_YBAR];
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    int rc = 0;
+    for (int i = 0; i < 5 && !rc; ++i) rc = exchange(c, X_YBAR, count);   // warm-up (connection set-up)
+    if (rc) return rc;
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps && !rc; ++i) rc = exchange(c, X_YBAR, count);
+    if (rc) return rc;
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *usec_per_exchange = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+    return 0;
+}
+
 int bioen_hip_comm_destroy(bioen_hip_ctx* c) {
     if (!c) return 0;
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->comm));

@@ -192,6 +192,10 @@ int bioen_hip_comm_unique_id(unsigned char id[128]);
 int bioen_hip_comm_init(bioen_hip_ctx* ctx, const unsigned char id[128], int rank, int nranks);
 /* all-gather of `count` doubles per rank, host in / host out (staged through HBM, RCCL over xGMI) */
 int bioen_hip_comm_allgather(bioen_hip_ctx* ctx, const double* send, size_t count, double* recv);
+/* average wall time (microseconds) of one stage exchange of `count` doubles per rank on a sharded
+ * context, back to back on the context's stream: lets the host decide whether splitting the
+ * structures beats dealing thetas for a given problem size */
+int bioen_hip_exchange_probe(bioen_hip_ctx* ctx, size_t count, int reps, double* usec_per_exchange);
 int bioen_hip_comm_destroy(bioen_hip_ctx* ctx);
 
 #ifdef __cplusplus
