@@ -7,5 +7,6 @@
 from ._lib import Context, BioenHipError, device_count, LIB_PATH  # noqa: F401
 from . import optimize  # noqa: F401
 from . import sweep  # noqa: F401
+from . import nuisance  # noqa: F401
 
 __version__ = "0.1.0"

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "bioen_hip_ctx_shape": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bioen_hip_ctx_read_ytilde": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
     "bioen_hip_ctx_set_ytilde_target": (C.c_int, [ctx_p, dp]),
+    "bioen_hip_ctx_set_affine": (C.c_int, [ctx_p, dp, dp]),
     "bioen_hip_synchronize": (C.c_int, [ctx_p]),
     "bioen_hip_logw_weights": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_logw_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
@@ -273,6 +274,17 @@ class Context(object):
 
     def set_target(self, YTilde):
         check(lib().bioen_hip_ctx_set_ytilde_target(self._h, ptr(self._mvec(YTilde, "YTilde"))))
+
+    def set_affine(self, row_offset=None, row_scale=None):
+        """Optimise against row_offset[i] + row_scale[i] * yTilde[i][j] without touching the resident
+        matrix (DEER modulation depths, SAXS scaling factor).  None -> 0 resp. 1; a scalar
+        row_scale applies to every row."""
+        off = None if row_offset is None else self._mvec(row_offset, "row_offset")
+        if row_scale is not None and np.ndim(row_scale) == 0:
+            row_scale = np.full(self.m, float(row_scale))
+        sc = None if row_scale is None else self._mvec(row_scale, "row_scale")
+        check(lib().bioen_hip_ctx_set_affine(self._h, ptr(off) if off is not None else None,
+                                             ptr(sc) if sc is not None else None))
 
     def synchronize(self):
         check(lib().bioen_hip_synchronize(self._h))

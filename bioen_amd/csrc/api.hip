@@ -142,6 +142,18 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
 #define TRY(x) if ((rc = (x)) != 0) { bioen_hip_ctx_destroy(c); return rc; }
     TRY(dalloc_zero(&c->Y, (size_t)c->mp * c->ld, c->stream));
     TRY(dalloc_zero(&c->YT, c->mp, c->stream));
+    TRY(dalloc_zero(&c->row_offset, c->mp, c->stream));
+    TRY(dalloc_zero(&c->row_scale, c->mp, c->stream));
+    {
+        std::vector<double> ones(c->mp, 1.0);
+        hipError_t e1 = hipMemcpyAsync(c->row_scale, ones.data(), (size_t)c->mp * sizeof(double), hipMemcpyHostToDevice,
+                                       c->stream);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(c->stream);
+        if (e1 != hipSuccess) {
+            bioen_hip_ctx_destroy(c);
+            return hip_fail(e1, "row_scale init", __FILE__, __LINE__);
+        }
+    }
     TRY(dalloc_zero(&c->ybar_c, (size_t)c->mp * kMaxBatch, c->stream));
     TRY(dalloc_zero(&c->r_c, (size_t)c->mp * kMaxBatch, c->stream));
     TRY(dalloc_zero(&c->um, c->mp, c->stream));
@@ -959,7 +971,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    double* bufs[] = {c->Y, c->YT, c->ybar_c, c->r_c, c->um, c->gm, c->fixed, c->t, c->g0, c->fwd_partial,
+    double* bufs[] = {c->Y, c->YT, c->row_offset, c->row_scale, c->ybar_c, c->r_c, c->um, c->gm, c->fixed, c->t, c->g0, c->fwd_partial,
                       c->part, c->scal};
     for (double* p : bufs)
         if (p) hipFree(p);
@@ -1007,6 +1019,25 @@ int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* c, const double* YTilde) {
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     BIOEN_HIP_CHECK(hipMemcpyAsync(c->YT, YTilde, (size_t)c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bioen_hip_ctx_set_affine(bioen_hip_ctx* c, const double* row_offset, const double* row_scale) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> off(c->mp, 0.0), sc(c->mp, 1.0);
+    bool affine = false;
+    for (int i = 0; i < c->m; ++i) {
+        if (row_offset) off[i] = row_offset[i];
+        if (row_scale) sc[i] = row_scale[i];
+        affine = affine || off[i] != 0.0 || sc[i] != 1.0;
+    }
+    BIOEN_HIP_CHECK(hipMemcpyAsync(c->row_offset, off.data(), (size_t)c->mp * sizeof(double), hipMemcpyHostToDevice,
+                                   c->stream));
+    BIOEN_HIP_CHECK(hipMemcpyAsync(c->row_scale, sc.data(), (size_t)c->mp * sizeof(double), hipMemcpyHostToDevice,
+                                   c->stream));
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->affine = affine;
     return 0;
 }
 
@@ -1094,6 +1125,8 @@ int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* c, const double* g0, const double* G
 }
 
 // ---- forces ---------------------------------------------------------------------------
+static bool is_affine(const bioen_hip_ctx* c) { return c->affine; }
+
 static int upload_forces_inputs(bioen_hip_ctx* c, const double* forces, const double* w0) {
     BIOEN_HIP_CHECK(hipMemcpyAsync(c->um, forces, (size_t)c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return upload_n(c, c->fixed, w0);
@@ -1101,6 +1134,7 @@ static int upload_forces_inputs(bioen_hip_ctx* c, const double* forces, const do
 
 int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const double* w0, double* w) {
     if (!c || !forces || !w0 || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
     if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     int rc;
@@ -1115,6 +1149,7 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
 int bioen_hip_forces_fdf(bioen_hip_ctx* c, const double* forces, const double* w0, double theta, double* f,
                          double* grad) {
     if (!c || !forces || !w0) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
     if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     int rc;
@@ -1132,6 +1167,7 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
                                const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                                double* result, double* w_opt, bioen_opt_result* info) {
     if (!c || !forces0 || !w0 || !config || !result || !info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
     if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     const bool verbose = visual && visual->verbose;

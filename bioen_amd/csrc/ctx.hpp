@@ -138,6 +138,12 @@ struct bioen_hip_ctx {
 
     double* Y = nullptr;       // mp x ld
     double* YT = nullptr;      // mp   experimental targets (YTilde)
+    // affine observable model: yTilde_eff[i][j] = row_offset[i] + row_scale[i] * Y[i][j]
+    // (default 0, 1).  DEER / SAXS nuisance parameters enter exactly like this, so a refit never
+    // touches Y.
+    double* row_offset = nullptr;   // mp
+    double* row_scale = nullptr;    // mp
+    bool affine = false;            // anything but (0, 1)
     double* ybar_c = nullptr;  // mp * kMaxBatch, compact per round
     double* r_c = nullptr;     // mp * kMaxBatch
     double* um = nullptr;      // mp   M-vector input  (forces)

@@ -248,7 +248,13 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restr
 
 // add the ranks' shares (rank order) -> ybar, r = ybar - YT (compact) ; per-block partials of
 // sum r^2 and sum ybar r.  Every rank computes the same numbers.
+// Affine observable model (ctx.hpp): ybar_eff_i = off_i + sc_i (Y w)_i  (sum w = 1), while ybar_c
+// keeps the RAW Y w, which is what the centred passes subtract: the offset cancels in
+// sum_i r_i (yTilde_eff_ik - ybar_eff_i) = sum_i (r_i sc_i) (Y_ik - (Y w)_i), so the adjoint's
+// operand r_c is stored pre-multiplied by sc_i.  (off, sc) = (0, 1): the plain model, same bits.
 __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, const double* __restrict__ YT,
+                                                         const double* __restrict__ row_offset,
+                                                         const double* __restrict__ row_scale,
                                                          double* __restrict__ ybar_c, double* __restrict__ r_c,
                                                          MVec8 part) {
     __shared__ double sh[kWaves];
@@ -257,11 +263,13 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
     for (int row = blockIdx.x * kBlock + threadIdx.x; row < mp; row += gridDim.x * kBlock) {
         double s = 0.0;
         for (int r = 0; r < xi.world; ++r) s += xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
-        const double res = s - YT[row];
+        const double sc = row_scale[row];
+        const double eff = fma(sc, s, row_offset[row]);
+        const double res = eff - YT[row];
         ybar_c[(size_t)row * K + a] = s;
-        r_c[(size_t)row * K + a] = res;
+        r_c[(size_t)row * K + a] = res * sc;
         chi = fma(res, res, chi);
-        cc = fma(s, res, cc);
+        cc = fma(eff, res, cc);
     }
     chi = block_sum(chi, sh);
     cc = block_sum(cc, sh);
@@ -852,7 +860,8 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r) {
     MVec8 part;
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
     hipLaunchKernelGGL(k_rows_combine, dim3(combine_grid(c), r.n), dim3(kBlock), 0, c->stream,
-                       make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->ybar_c, c->r_c, part);
+                       make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale, c->ybar_c,
+                       c->r_c, part);
 }
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c) {

@@ -120,6 +120,15 @@ int bioen_hip_ctx_shape(const bioen_hip_ctx* ctx, int* m, int* n);
 /* copy rows [row0,row0+rows) x cols [col0,col0+cols) of the resident matrix to host (row-major) */
 int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, int cols, double* out);
 int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
+/* Affine observable model: the optimizer sees yTilde_eff[i][j] = row_offset[i] + row_scale[i] * yTilde[i][j]
+ * without the resident matrix being touched.  This is how DEER (modulation depth m:
+ * yTilde = 1/sigma + m (F-1)/sigma, bioen/analyze/observables/observables.py:133-134) and SAXS
+ * (scaling c: yTilde = c I/sigma, :141) nuisance parameters enter, so the refit loop of
+ * bioen/analyze/procedure.py:79-83 needs no rebuild / re-upload of yTilde (the reference rebuilds it
+ * on the host, observables.py:110-143).  row_offset = NULL means 0, row_scale = NULL means 1 (both m
+ * long; one value per DEER trace / data set, repeated over its rows).  Log-weights method;
+ * chi_squared() returns the raw yTilde . w and the chi^2 of the affine model. */
+int bioen_hip_ctx_set_affine(bioen_hip_ctx* ctx, const double* row_offset, const double* row_scale);
 int bioen_hip_synchronize(bioen_hip_ctx* ctx);
 
 /* ---- log-weights method ---------------------------------------------------- */

@@ -212,3 +212,102 @@ def test_synthetic_generator_statistics_and_large_property_checks(optimize):
         assert info.lbfgs_code in (0, 1) and code_o in (0, 1)
         assert rel(info.fmin, fmin_o) < 2e-5
         assert abs(info.iterations - it_o) <= max(5, it_o // 4)
+
+
+# ---------------------------------------------------------------------------------------
+# affine observable model + nuisance refits (BASELINE config 4 in miniature: DEER modulation depth)
+# ---------------------------------------------------------------------------------------
+def _deer_problem(M1=60, M2=45, N=400, seed=3):
+    """Two synthetic DEER traces F(d_j, t_i) in (0,1] with different modulation depths."""
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(2.0, 6.0, N)                      # nm
+    def trace(t):
+        return 0.5 * (1.0 + np.cos(2 * np.pi * 52.04 * t[:, None] / d[None, :] ** 3)) * np.exp(-0.2 * t[:, None])
+    F = np.vstack([trace(np.linspace(0.0, 2.5, M1)), trace(np.linspace(0.0, 3.5, M2))])
+    sigma = 0.01 * np.ones(M1 + M2)
+    groups = [np.arange(M1), np.arange(M1, M1 + M2)]
+    w_true = rng.dirichlet(np.ones(N) * 0.3)
+    m_true = [0.22, 0.31]
+    Y = np.empty(M1 + M2)
+    for mt, ix in zip(m_true, groups):
+        Y[ix] = 1 - mt + mt * F[ix].dot(w_true)
+    Y += sigma * rng.standard_normal(M1 + M2)
+    return F, sigma, groups, Y, m_true
+
+
+def test_affine_model_equals_explicit_matrix(optimize):
+    import bioen_amd
+    from oracle import oracle_binding as O
+    F, sigma, groups, Y, _ = _deer_problem()
+    Ft = (F - 1.0) / sigma[:, None]
+    YT = Y / sigma
+    off = 1.0 / sigma
+    sc = np.ones(F.shape[0])
+    sc[groups[0]], sc[groups[1]] = 0.15, 0.4
+    explicit = off[:, None] + sc[:, None] * Ft         # what the reference would rebuild on the host
+    rng = np.random.default_rng(1)
+    N = F.shape[1]
+    G = np.zeros(N)
+    g = 0.3 * rng.standard_normal(N)
+    theta = 100.0
+    f_o, grad_o, w_o = O.logw_fdf(g, G, explicit, YT, theta)
+    with bioen_amd.Context(Ft, YT) as ctx:
+        ctx.set_affine(off, sc)
+        f, grad = ctx.logw_fdf(g, G, theta)
+        chi2, yraw = ctx.chi_squared(w_o)
+        gopt, w, info = ctx.opt_lbfgs_logw(G, G, theta, dict(linesearch=2, max_iterations=5000, delta=1e-11,
+                                                             epsilon=1e-7, ftol=1e-5, gtol=0.9, wolfe=0.9, past=10,
+                                                             max_linesearch=100))
+        ctx.set_affine(None, None)
+        f_plain, _ = ctx.logw_fdf(g, G, theta)
+    assert rel(f, f_o) < 1e-12
+    assert np.abs(grad - grad_o).max() <= 1e-10 * np.abs(grad_o).max()
+    assert np.abs(yraw - Ft.dot(w_o)).max() <= 1e-12 * np.abs(Ft.dot(w_o)).max()
+    assert rel(chi2, 0.5 * np.sum((explicit.dot(w_o) - YT) ** 2)) < 1e-12
+    g2, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_logw(G, G, explicit, YT, theta, dict(epsilon=1e-7, delta=1e-11))
+    assert info.lbfgs_code in (0, 1) and rel(info.fmin, fmin_o) < 1e-6
+    f_plain_o, _, _ = O.logw_fdf(g, G, Ft, YT, theta)
+    assert rel(f_plain, f_plain_o) < 1e-12             # switched back to the plain model
+
+
+def test_nuisance_series_matches_host_rebuild_loop(optimize):
+    """The device loop (matrix resident, parameters through set_affine) against the reference's
+    protocol done the slow way: rebuild yTilde(m) on the host every iteration, optimise with the
+    oracle, refit m by scipy.leastsq on chi^2 like observables.py:205-210."""
+    import bioen_amd
+    from bioen_amd import nuisance
+    from oracle import oracle_binding as O
+    from scipy.optimize import leastsq
+    F, sigma, groups, Y, m_true = _deer_problem()
+    Ft = (F - 1.0) / sigma[:, None]
+    YT = Y / sigma
+    off = 1.0 / sigma
+    N = F.shape[1]
+    G = np.zeros(N)
+    params = dict(linesearch=2, max_iterations=5000, delta=1e-9, epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9,
+                  past=10, max_linesearch=100)
+    thetas = [1000.0, 100.0]
+    with bioen_amd.Context(Ft, YT) as ctx:
+        res = nuisance.series(ctx, thetas, G, G, params, YT, groups=groups, row_offset=off, scale0=0.15,
+                              iterations=6)
+    m = [0.15, 0.15]
+    for k, theta in enumerate(thetas):
+        for _ in range(6):
+            explicit = np.empty_like(Ft)
+            for mv, ix in zip(m, groups):
+                explicit[ix] = (1 - mv + mv * F[ix]) / sigma[ix, None]
+            g, fmin, code, it, ev = O.opt_lbfgs_logw(G, G, explicit, YT, theta, params)
+            w = O.logw_weights(g)[0]
+            new = []
+            for mv, ix in zip(m, groups):
+                def chi2_of(mm, ix=ix):
+                    sim = (1 - mm[0] + mm[0] * F[ix]) / sigma[ix, None]
+                    return 0.5 * np.sum((sim.dot(w) - YT[ix]) ** 2)
+                new.append(float(leastsq(chi2_of, mv)[0][0]))
+            m = new
+        assert rel(res[k]["fmin"], fmin) < 1e-5
+        # leastsq on the scalar chi^2 stops at its own tolerance; the closed form is the exact optimum
+        assert np.allclose(res[k]["scales"], m, rtol=2e-3)
+        assert np.abs(res[k]["w"] - w).max() <= 5e-3 * w.max()
+    # the refits recover the modulation depths the data were generated with
+    assert np.allclose(res[-1]["scales"], m_true, atol=0.03)
