@@ -64,6 +64,7 @@ _SIGNATURES = {
     "bioen_hip_ctx_read_ytilde": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
     "bioen_hip_ctx_set_ytilde_target": (C.c_int, [ctx_p, dp]),
     "bioen_hip_ctx_set_affine": (C.c_int, [ctx_p, dp, dp]),
+    "bioen_hip_ctx_set_direction_mode": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_synchronize": (C.c_int, [ctx_p]),
     "bioen_hip_logw_weights": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_logw_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
@@ -285,6 +286,12 @@ class Context(object):
         sc = None if row_scale is None else self._mvec(row_scale, "row_scale")
         check(lib().bioen_hip_ctx_set_affine(self._h, ptr(off) if off is not None else None,
                                              ptr(sc) if sc is not None else None))
+
+    def set_direction_mode(self, mode):
+        """'auto' (two-loop on one GPU, Gram form when sharded), 'twoloop' or 'gram'
+        (see include/bioen_hip.h: bioen_hip_ctx_set_direction_mode)."""
+        code = {"auto": 0, "twoloop": 1, "gram": 2}[mode]
+        check(lib().bioen_hip_ctx_set_direction_mode(self._h, code))
 
     def synchronize(self):
         check(lib().bioen_hip_synchronize(self._h))

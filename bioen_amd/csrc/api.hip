@@ -73,6 +73,7 @@ static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history) {
         sl.g = sl.ga;
         sl.gp = sl.gb;
         sl.scal = c->scal + (size_t)s * kScalStride;
+        sl.gram = c->gram + (size_t)s * kGramStride;
         sl.part = c->part + (size_t)s * P_COUNT * kMaxPartials;
         sl.allocated = true;
     }
@@ -163,9 +164,10 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * c->fwd_ctiles, c->stream));
     TRY(dalloc_zero(&c->part, (size_t)kMaxBatch * P_COUNT * kMaxPartials, c->stream));
     TRY(dalloc_zero(&c->scal, (size_t)kMaxBatch * kScalStride, c->stream));
+    TRY(dalloc_zero(&c->gram, (size_t)kMaxBatch * kGramStride, c->stream));
     {   // exchange stages: [world][capacity]
         const size_t npl = (size_t)vec_grid(c);
-        const size_t arrays[X_COUNT] = {1, 2, 0, 3, 2, 1, 1, 1, 0};
+        const size_t arrays[X_COUNT] = {1, 2, 0, 3, 2, 1, 1, 1, 0, kGramDots};
         for (int st = 0; st < X_COUNT; ++st) {
             size_t cap = arrays[st] * kMaxBatch * npl;
             if (st == X_YBAR) cap = (size_t)c->mp * kMaxBatch;
@@ -380,8 +382,48 @@ struct LogwBatchEngine {
     // d = -H gp for the problems in `list` (lbfgs.c:571-598): 1 + 2*bound fused launches each,
     // issued together.  A problem with a shorter history starts later, so that all of them
     // finish in the same launch (one X_DGI exchange for everybody).
-    void directions(BatchProblem* slots, const std::vector<int>& list) {
-        if (list.empty()) return;
+    bool use_gram() const {
+        return c->direction_mode == 2 || (c->direction_mode == 0 && c->world > 1);
+    }
+
+    // Gram form (see kernels.hpp: GramArgs): 3 launches and one exchange for all accepting problems
+    void directions_gram(BatchProblem* slots, const std::vector<int>& list) {
+        GramArgs ga{};
+        ga.n = (int)list.size();
+        for (int a = 0; a < ga.n; ++a) {
+            BatchProblem& p = slots[list[a]];
+            ProblemSlot& sl = c->slot[list[a]];
+            std::swap(sl.x, sl.xp);           // the trial point becomes the accepted point
+            std::swap(sl.g, sl.gp);
+            ga.xnew[a] = sl.xp; ga.xold[a] = sl.x; ga.gnew[a] = sl.gp; ga.gold[a] = sl.g;
+            for (int i = 0; i < kHistory; ++i) {
+                ga.S[a][i] = sl.S[i];
+                ga.Y[a][i] = sl.Yh[i];
+            }
+            ga.d[a] = sl.d; ga.gram[a] = sl.gram; ga.scal[a] = sl.scal;
+            ga.end[a] = p.end;
+            ga.bound[a] = p.bound;
+        }
+        launch_gram(c, ga);
+        note(exchange(c, X_GRAM, (size_t)kGramDots * ga.n * vec_grid(c)));
+        launch_gram_solve(c, ga);
+        launch_combine(c, ga);
+        for (int s : list) {
+            slots[s].need_direction = false;
+            slots[s].accept = false;
+        }
+    }
+
+    void directions(BatchProblem* slots, const std::vector<int>& all) {
+        if (all.empty()) return;
+        std::vector<int> list = all;
+        if (use_gram()) {     // first directions (d = -g) keep the plain path; the rest go through the Gram form
+            std::vector<int> first, rest;
+            for (int s : all) (slots[s].accept ? rest : first).push_back(s);
+            if (!rest.empty()) directions_gram(slots, rest);
+            if (first.empty()) return;
+            list = first;
+        }
         const int k = (int)list.size();
         const size_t g = (size_t)vec_grid(c);
         // commit the new pairs first
@@ -528,6 +570,7 @@ struct LogwBatchEngine {
             else
                 note(upload_n(c, sl.xp, g0_host + (size_t)next * g0_stride));
             note(hipMemsetAsync(sl.d, 0, c->ld * sizeof(double), c->stream), "memset d");
+            note(hipMemsetAsync(sl.gram, 0, kGramStride * sizeof(double), c->stream), "memset gram");
             occupied[s] = true;
             ++active;
             ++next;
@@ -971,7 +1014,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    double* bufs[] = {c->Y, c->YT, c->row_offset, c->row_scale, c->ybar_c, c->r_c, c->um, c->gm, c->fixed, c->t, c->g0, c->fwd_partial,
+    double* bufs[] = {c->Y, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed, c->t, c->g0, c->fwd_partial,
                       c->part, c->scal};
     for (double* p : bufs)
         if (p) hipFree(p);
@@ -1038,6 +1081,12 @@ int bioen_hip_ctx_set_affine(bioen_hip_ctx* c, const double* row_offset, const d
                                    c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->affine = affine;
+    return 0;
+}
+
+int bioen_hip_ctx_set_direction_mode(bioen_hip_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(BIOEN_HIP_EINVAL, "mode must be 0 (auto), 1 (two-loop) or 2 (Gram form)");
+    c->direction_mode = mode;
     return 0;
 }
 

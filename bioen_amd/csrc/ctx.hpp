@@ -35,6 +35,9 @@ constexpr int kRowAlign = 32;
 constexpr int kMaxPartials = 1024; // upper bound on any reduction grid
 constexpr int kMaxBatch = 8;       // thetas sharing one matrix pass
 constexpr int kScalStride = 32;    // doubles per slot in `scal`
+constexpr int kBasis = 2 * kHistory + 1;   // S[6], Y[6], g
+constexpr int kGramDots = 3 * kBasis;      // new s, new y, new g against the basis
+constexpr int kGramStride = 256;           // doubles per slot: 13x13 Gram matrix + 13 coefficients
 
 // device-resident scalar slots (per problem slot)
 enum ScalarSlot : int {
@@ -83,6 +86,7 @@ enum XStage : int {
     X_REC1,      //                                                  (pong)
     X_DGI,       // 1 array : gp . d
     X_VEC,       // ld values per problem: result vectors at the end
+    X_GRAM,      // kGramDots arrays: inner products of (s, y, g) with the 13 basis vectors
     X_COUNT
 };
 
@@ -114,6 +118,7 @@ struct ProblemSlot {
     double* Yh[kHistory] = {};
     double* scal = nullptr;   // kScalStride doubles inside ctx->scal
     double* part = nullptr;   // P_COUNT * kMaxPartials doubles inside ctx->part (local partials)
+    double* gram = nullptr;   // kGramStride doubles inside ctx->gram
 };
 
 }  // namespace bioen
@@ -159,6 +164,8 @@ struct bioen_hip_ctx {
     int fwd_steps = 0;               // 128-column steps per tile
     double* part = nullptr;          // kMaxBatch * P_COUNT * kMaxPartials
     double* scal = nullptr;          // kMaxBatch * kScalStride
+    double* gram = nullptr;          // kMaxBatch * kGramStride
+    int direction_mode = 0;          // 0 auto (two-loop on one GPU, Gram form when sharded), 1 two-loop, 2 Gram
     double* host_scal = nullptr;     // pinned mirror
 
     bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)

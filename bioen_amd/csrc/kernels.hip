@@ -723,6 +723,142 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int n, Xch xin, X
 }
 
 // ------------------------------------------------------------------------------
+// direction from inner products ("compact" two-loop recursion)
+// ------------------------------------------------------------------------------
+// One sweep: s = xnew - xold, y = gnew - gold -> history slot `end`; and the 39 inner products
+// of (s, y, gnew) with the basis B = {S_0..5, Y_0..5, gnew} (S_end = s, Y_end = y).
+__global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
+    __shared__ double sh[kWaves][64];
+    const int a = blockIdx.y;
+    const int e = q.end[a];
+    const double* __restrict__ xn = q.xnew[a];
+    const double* __restrict__ xo_ = q.xold[a];
+    const double* __restrict__ gn = q.gnew[a];
+    const double* __restrict__ go = q.gold[a];
+    double acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 a0 = *reinterpret_cast<const d2*>(xn + j), a1 = *reinterpret_cast<const d2*>(xo_ + j);
+        const d2 gv = *reinterpret_cast<const d2*>(gn + j), g1 = *reinterpret_cast<const d2*>(go + j);
+        const d2 sv = {a0.x - a1.x, a0.y - a1.y};
+        const d2 yv = {gv.x - g1.x, gv.y - g1.y};
+        d2 B[kBasis];
+#pragma unroll
+        for (int k = 0; k < kHistory; ++k) {
+            B[k] = (k == e) ? sv : *reinterpret_cast<const d2*>(q.S[a][k] + j);
+            B[kHistory + k] = (k == e) ? yv : *reinterpret_cast<const d2*>(q.Y[a][k] + j);
+        }
+        B[2 * kHistory] = gv;
+        *reinterpret_cast<d2*>(q.S[a][e] + j) = sv;
+        *reinterpret_cast<d2*>(q.Y[a][e] + j) = yv;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) {
+            acc[c] = fma(sv.x, B[c].x, acc[c]);
+            acc[c] = fma(sv.y, B[c].y, acc[c]);
+            acc[kBasis + c] = fma(yv.x, B[c].x, acc[kBasis + c]);
+            acc[kBasis + c] = fma(yv.y, B[c].y, acc[kBasis + c]);
+            acc[2 * kBasis + c] = fma(gv.x, B[c].x, acc[2 * kBasis + c]);
+            acc[2 * kBasis + c] = fma(gv.y, B[c].y, acc[2 * kBasis + c]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_multi_reduce<64>(acc, lane);          // lane l now holds the wave total of value l
+    sh[wave][lane] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < kGramDots) {
+        const double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        xo.base[(size_t)xo.rank * xo.payload + (size_t)(a * kGramDots + threadIdx.x) * xo.npl + blockIdx.x] = v;
+    }
+}
+
+// Per problem (one block): finish the 39 sums, update the Gram matrix, run the two-loop recursion
+// (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
+__global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
+    __shared__ double sh[kWaves];
+    __shared__ double dots[kGramDots];
+    const int a = blockIdx.y;
+    for (int c = 0; c < kGramDots; ++c) {
+        const double v = xsum<kGramDots>(xi, a, c, sh);
+        if (threadIdx.x == 0) dots[c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double* G = q.gram[a];
+    const int e = q.end[a], bound = q.bound[a];
+    const int rs = e, ry = kHistory + e, rg = 2 * kHistory;
+    for (int c = 0; c < kBasis; ++c) {
+        G[rs * kBasis + c] = G[c * kBasis + rs] = dots[c];
+        G[ry * kBasis + c] = G[c * kBasis + ry] = dots[kBasis + c];
+    }
+    for (int c = 0; c < kBasis; ++c) G[rg * kBasis + c] = G[c * kBasis + rg] = dots[2 * kBasis + c];
+    // q = -g as coefficients over {S, Y, g}
+    double coef[kBasis];
+    for (int c = 0; c < kBasis; ++c) coef[c] = 0.0;
+    coef[rg] = -1.0;
+    double alpha[kHistory];
+    int order[kHistory];
+    int j = (e + 1) % kHistory;
+    for (int b = 0; b < bound; ++b) {
+        j = (j + kHistory - 1) % kHistory;
+        order[b] = j;                         // newest -> oldest
+    }
+    for (int b = 0; b < bound; ++b) {         // first loop
+        const int i = order[b];
+        double sq = 0.0;
+        for (int c = 0; c < kBasis; ++c) sq = fma(coef[c], G[i * kBasis + c], sq);
+        alpha[i] = sq / G[(kHistory + i) * kBasis + i];
+        coef[kHistory + i] -= alpha[i];
+    }
+    const double scale = G[ry * kBasis + rs] / G[ry * kBasis + ry];   // ys / yy of the newest pair
+    for (int c = 0; c < kBasis; ++c) coef[c] *= scale;
+    for (int b = bound - 1; b >= 0; --b) {    // second loop
+        const int i = order[b];
+        double yq = 0.0;
+        for (int c = 0; c < kBasis; ++c) yq = fma(coef[c], G[(kHistory + i) * kBasis + c], yq);
+        const double beta = yq / G[(kHistory + i) * kBasis + i];
+        coef[i] += alpha[i] - beta;
+    }
+    double dg = 0.0;
+    for (int c = 0; c < kBasis; ++c) dg = fma(coef[c], G[rg * kBasis + c], dg);
+    for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = coef[c];
+    q.scal[a][S_DGINIT] = dg;
+}
+
+// d = sum_c coef_c B_c
+__global__ __launch_bounds__(kBlock) void k_combine(GramArgs q, int n) {
+    const int a = blockIdx.y;
+    const double* coef = q.gram[a] + kBasis * kBasis;
+    double cf[kBasis];
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] = coef[c];
+    double* __restrict__ d = q.d[a];
+    const double* __restrict__ gn = q.gnew[a];
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 gv = *reinterpret_cast<const d2*>(gn + j);
+        d2 dv = {cf[2 * kHistory] * gv.x, cf[2 * kHistory] * gv.y};
+#pragma unroll
+        for (int k = 0; k < kHistory; ++k) {
+            if (cf[k] != 0.0) {               // unused history slots may hold another problem's leftovers
+                const d2 v = *reinterpret_cast<const d2*>(q.S[a][k] + j);
+                dv.x = fma(cf[k], v.x, dv.x);
+                dv.y = fma(cf[k], v.y, dv.y);
+            }
+            if (cf[kHistory + k] != 0.0) {
+                const d2 v = *reinterpret_cast<const d2*>(q.Y[a][k] + j);
+                dv.x = fma(cf[kHistory + k], v.x, dv.x);
+                dv.y = fma(cf[kHistory + k], v.y, dv.y);
+            }
+        }
+        *reinterpret_cast<d2*>(d + j) = dv;
+    }
+}
+
+// ------------------------------------------------------------------------------
 // synthetic ensemble generated in HBM (bench): counter-based Box-Muller
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -983,6 +1119,20 @@ void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step) {
     hipLaunchKernelGGL(k_recur, dim3(g, k), dim3(kBlock), 0, c->stream, a, c->n,
                        make_xch(c, ((step - 1) & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_SY, 2 * k * g),
                        make_xch(c, (step & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_DGI, k * g));
+}
+
+void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
+    hipLaunchKernelGGL(k_gram, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+                       make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
+}
+
+void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
+    hipLaunchKernelGGL(k_gram_solve, dim3(1, a.n), dim3(kBlock), 0, c->stream, a,
+                       make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
+}
+
+void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {
+    hipLaunchKernelGGL(k_combine, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
 }
 
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,

@@ -99,6 +99,28 @@ struct RecurArgs {
 };
 void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step);
 
+// Direction from inner products (kernels.hip: k_gram / k_gram_solve / k_combine): the same
+// two-loop recursion carried out on coefficients over the basis {S_0..5, Y_0..5, g}.  One sweep
+// commits the new (s, y) pair and produces every inner product the recursion needs, so a direction
+// costs 3 launches and ONE stage exchange instead of 14 + 14.
+struct GramArgs {
+    int n;
+    const double* xnew[kMaxBatch];   // accepted (former trial) point
+    const double* xold[kMaxBatch];
+    const double* gnew[kMaxBatch];   // gradient at the accepted point
+    const double* gold[kMaxBatch];
+    double* S[kMaxBatch][kHistory];
+    double* Y[kMaxBatch][kHistory];
+    double* d[kMaxBatch];
+    double* gram[kMaxBatch];
+    double* scal[kMaxBatch];
+    int end[kMaxBatch];              // history slot of the new pair
+    int bound[kMaxBatch];            // pairs in use (including the new one)
+};
+void launch_gram(bioen_hip_ctx* c, const GramArgs& a);          // [exchange X_GRAM]
+void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a);
+void launch_combine(bioen_hip_ctx* c, const GramArgs& a);
+
 // ---- misc ---------------------------------------------------------------------------
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,
                      unsigned long long seed);

@@ -129,6 +129,15 @@ int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
  * long; one value per DEER trace / data set, repeated over its rows).  Log-weights method;
  * chi_squared() returns the raw yTilde . w and the chi^2 of the affine model. */
 int bioen_hip_ctx_set_affine(bioen_hip_ctx* ctx, const double* row_offset, const double* row_scale);
+/* How the L-BFGS direction d = -H g is formed on the device.
+ *   1  two-loop recursion on the vectors, liblbfgs' order of operations (lbfgs.c:571-598):
+ *      13 fused vector sweeps and 13 dependent reductions per direction;
+ *   2  the same recursion carried out on coefficients over {S_0..5, Y_0..5, g} from their
+ *      inner products: one sweep commits (s, y) and yields all 39 new products, one sweep forms
+ *      d -- half the vector traffic and ONE reduction stage instead of 14 (what matters when
+ *      every stage is an all-gather between GPUs).  Mathematically identical; rounding differs;
+ *   0  auto: 1 on a single GPU, 2 on a structure-sharded context (default). */
+int bioen_hip_ctx_set_direction_mode(bioen_hip_ctx* ctx, int mode);
 int bioen_hip_synchronize(bioen_hip_ctx* ctx);
 
 /* ---- log-weights method ---------------------------------------------------- */

@@ -269,3 +269,37 @@ def test_batched_series_with_failing_and_trivial_members(hip):
         assert abs(w[i].sum() - 1.0) < 1e-12
     assert all(i.lbfgs_code == -1015 and i.evaluations == 0 for i in bad[2])
     assert np.array_equal(bad[0][1], d["G"].ravel())
+
+
+# ---------------------------------------------------------------------------------------
+# direction from inner products ("Gram form"): same recursion, different rounding
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", LOGW_GOLDEN)
+def test_gram_direction_matches_two_loop(hip, name):
+    d = load_golden(name)
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        ref_def = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
+        ref_tight = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_TIGHT)
+        ctx.set_direction_mode("gram")
+        g_def = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
+        g_tight = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_TIGHT)
+        again = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
+        thetas = [30.0, 3.0, 300.0]
+        batch = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=8)
+        singles = [ctx.opt_lbfgs_logw(d["GInit"], d["G"], th, LBFGS_DEFAULTS) for th in thetas]
+        ctx.set_direction_mode("auto")
+    # deterministic, and batched == single also in this mode
+    assert again[2].fmin == g_def[2].fmin and np.array_equal(again[0], g_def[0])
+    for i, sgl in enumerate(singles):
+        assert batch[2][i].fmin == sgl[2].fmin and np.array_equal(batch[0][i], sgl[0])
+    for (r, g, tol) in ((ref_def, g_def, 5e-5), (ref_tight, g_tight, FMIN_RTOL)):   # 5e-5: plateau stop on the flattest case
+        if r[2].lbfgs_code in (0, 1, 2):
+            assert g[2].lbfgs_code in (0, 1, 2)
+            assert rel(g[2].fmin, r[2].fmin) < tol, (name, g[2].fmin, r[2].fmin)
+            assert abs(g[2].iterations - r[2].iterations) <= max(5, r[2].iterations // 3)
+    if ref_tight[2].lbfgs_code in (0, 1, 2):
+        wtol = max(W_RTOL, 3.0 * float(d["lbfgs_tight_wspread"]))
+        assert np.abs(g_tight[1] - ref_tight[1]).max() <= wtol * ref_tight[1].max()
+    # and against the reference's own run
+    if int(d["lbfgs_tight_code"]) in (0, 1, 2) and g_tight[2].lbfgs_code in (0, 1, 2):
+        assert rel(g_tight[2].fmin, float(d["lbfgs_tight_fmin"])) < FMIN_RTOL
