@@ -174,12 +174,13 @@ def main():
     nshard = world > 1 and args.shard in ("auto", "structures")
     ctx, gather, rccl = build(nshard)
     if world > 1 and args.shard == "auto":
-        # Splitting the structures pays when the per-pass saving beats the ~20 small all-gathers a
-        # round then needs: t_pass * (1 - 1/world)  vs  20 * t_exchange + launch overhead.
+        # Splitting the structures pays when the per-pass saving beats the 4 small all-gathers a
+        # round then needs (softmax sums, ybar, gradient dots, Gram update) plus launch overhead:
+        # t_pass * (1 - 1/world)  vs  5 * t_exchange + 0.15 ms.
         t_ex = max(comm.allgather_object(ctx.exchange_probe(count=M * min(8, len(thetas)), reps=40)))
         t_pass_us = 2.0 * M * float(N) * 8 / 6.4e12 * 1e6
         gain_us = t_pass_us * (1.0 - 1.0 / world)
-        cost_us = 20.0 * t_ex + 150.0
+        cost_us = 5.0 * t_ex + 150.0
         decision = {"exchange_us": t_ex, "pass_saving_us": gain_us, "exchange_cost_us": cost_us,
                     "chosen": "structures" if gain_us > cost_us else "thetas"}
         if gain_us <= cost_us:

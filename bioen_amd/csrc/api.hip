@@ -167,7 +167,7 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     TRY(dalloc_zero(&c->gram, (size_t)kMaxBatch * kGramStride, c->stream));
     {   // exchange stages: [world][capacity]
         const size_t npl = (size_t)vec_grid(c);
-        const size_t arrays[X_COUNT] = {1, 2, 0, 3, 2, 1, 1, 1, 0, kGramDots};
+        const size_t arrays[X_COUNT] = {1, 3, 0, 3, 2, 1, 1, 1, 0, kGramDots};
         for (int st = 0; st < X_COUNT; ++st) {
             size_t cap = arrays[st] * kMaxBatch * npl;
             if (st == X_YBAR) cap = (size_t)c->mp * kMaxBatch;
@@ -293,13 +293,12 @@ static Round make_round(bioen_hip_ctx* c, const int* slots, int k, const double*
 }
 
 // log-weights: r.x must hold the points and P_MAX their block maxima (launch_trial does both).
-// (the caller has produced X_MAX; its all-gather is the first thing done here)
+// (the caller has produced this rank's block maxima in its X_MAX segment; they are not exchanged)
 static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     const size_t g = (size_t)vec_grid(c);
     int rc;
-    if ((rc = exchange(c, X_MAX, r.n * g))) return rc;
-    launch_logw_exp(c, r);                 // A1 first half + prior partials
-    if ((rc = exchange(c, X_EXP, 2 * r.n * g))) return rc;
+    launch_logw_exp(c, r);                 // A1 first half + prior partials (shift: this rank's own maximum)
+    if ((rc = exchange(c, X_EXP, 3 * r.n * g))) return rc;
     launch_logw_norm(c, r);                // A1 second half -> w, log s, P
     Vec8 w{};
     for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
@@ -1109,9 +1108,8 @@ int bioen_hip_logw_weights(bioen_hip_ctx* c, const double* g, double* w, double*
     const Round r = make_round(c, one, 1, nullptr, nullptr);
     const size_t gsz = (size_t)vec_grid(c);
     launch_max(c, r);
-    if ((rc = exchange(c, X_MAX, gsz))) return rc;
     launch_logw_exp(c, r);
-    if ((rc = exchange(c, X_EXP, 2 * gsz))) return rc;
+    if ((rc = exchange(c, X_EXP, 3 * gsz))) return rc;
     launch_logw_norm(c, r);
     if ((rc = check_launch())) return rc;
     if (w && (rc = download_n(c, w, s0.w))) return rc;

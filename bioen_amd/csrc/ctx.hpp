@@ -77,8 +77,8 @@ enum PartSlot : int {
 // sums the same numbers in the same order and takes bit-identical decisions without any host
 // communication.  world == 1: same code, no collective.
 enum XStage : int {
-    X_MAX = 0,   // 1 array : block maxima of the trial point
-    X_EXP,       // 2 arrays: sum e, sum e (x - G)
+    X_MAX = 0,   // 1 array : block maxima of the trial point (consumed by the same rank: never exchanged)
+    X_EXP,       // 3 arrays: sum e, sum e (x - G), [0] = this rank's shift m_r
     X_YBAR,      // mp values per problem: this rank's share of yTilde . w
     X_GRAD,      // 3 arrays: g.d, g.g, x.x
     X_SY,        // 2 arrays: y.s, y.y

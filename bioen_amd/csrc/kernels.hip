@@ -133,6 +133,15 @@ __device__ __forceinline__ double xmax(const Xch& x, int a, int q, double* sh) {
     return block_max(s, sh);
 }
 
+// maximum over THIS rank's segment only (no exchange needed before it)
+template <int A>
+__device__ __forceinline__ double xmax_local(const Xch& x, int a, int q, double* sh) {
+    double s = -DBL_MAX;
+    const double* p = x.base + (size_t)x.rank * x.payload + (size_t)(a * A + q) * x.npl;
+    for (int k = threadIdx.x; k < x.npl; k += kBlock) s = fmax(s, p[k]);
+    return block_max(s, sh);
+}
+
 template <bool NT>
 __device__ __forceinline__ d2 ldg2(const double* p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
@@ -396,14 +405,17 @@ __global__ __launch_bounds__(kBlock) void k_max_vec(const double* __restrict__ v
 }
 
 // _get_weights (c_bioen_kernels_logw.c:55-94) with a max shift, first half:
-//   e_j = exp(x_j - max) ; partials of sum e and sum e (x - G)   (prior, :96-127)
+//   e_j = exp(x_j - m_r) ; partials of sum e and sum e (x - G)   (prior, :96-127)
+// m_r is the maximum over THIS rank's structures (its own block maxima need no exchange); it
+// travels with the sums (third array, entry 0) and k_logw_norm rescales by exp(m_r - max_r m_r),
+// which is exactly 1 on a single GPU.
 __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, Xch xmx,
                                                      Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double* __restrict__ x = r.x[a];
     double* __restrict__ e = r.w[a];
-    const double gmax = xmax<1>(xmx, a, 0, sh);
+    const double gmax = xmax_local<1>(xmx, a, 0, sh);
     double s = 0.0, pp = 0.0;
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
@@ -422,24 +434,46 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
     s = block_sum(s, sh);
     pp = block_sum(pp, sh);
     if (threadIdx.x == 0) {
-        xput<2>(xo, a, 0, s);
-        xput<2>(xo, a, 1, pp);
+        xput<3>(xo, a, 0, s);
+        xput<3>(xo, a, 1, pp);
+        if (blockIdx.x == 0) xput<3>(xo, a, 2, gmax);
     }
 }
 
 // second half: w = e / S ; scal[S_LOGS] = max + log S ; scal[S_P] = sum e (x-G) / S
-__global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xmx, Xch xe) {
+// sum over the blocks of ONE rank's segment
+template <int A>
+__device__ __forceinline__ double xsum_rank(const Xch& x, int rk, int a, int q, double* sh) {
+    double s = 0.0;
+    const double* p = x.base + (size_t)rk * x.payload + (size_t)(a * A + q) * x.npl;
+    for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
+    return block_sum(s, sh);
+}
+
+__global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     double* __restrict__ w = r.w[a];
-    const double S = xsum<2>(xe, a, 0, sh);
-    const double inv = 1.0 / S;
+    // global shift M = max_r m_r ; S = sum_r e^{m_r - M} S_r   (rank order; e^0 = 1 on one GPU)
+    double gmax = -DBL_MAX;
+    for (int rk = 0; rk < xe.world; ++rk)
+        gmax = fmax(gmax, xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl]);
+    double S = 0.0;
+    for (int rk = 0; rk < xe.world; ++rk) {
+        const double mr = xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+        S = fma(exp(mr - gmax), xsum_rank<3>(xe, rk, a, 0, sh), S);
+    }
+    const double mown = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+    const double inv = exp(mown - gmax) / S;
     if (blockIdx.x == 0) {
-        const double gmax = xmax<1>(xmx, a, 0, sh);
-        const double PP = xsum<2>(xe, a, 1, sh);
+        double PP = 0.0;
+        for (int rk = 0; rk < xe.world; ++rk) {
+            const double mr = xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+            PP = fma(exp(mr - gmax), xsum_rank<3>(xe, rk, a, 1, sh), PP);
+        }
         if (threadIdx.x == 0) {
             r.scal[a][S_LOGS] = gmax + log(S);
-            r.scal[a][S_P] = PP * inv;
+            r.scal[a][S_P] = PP * (1.0 / S);
         }
     }
     const int n2 = (n + 1) >> 1;
@@ -1049,12 +1083,12 @@ void launch_max(bioen_hip_ctx* c, const Round& r) {
 
 void launch_logw_exp(bioen_hip_ctx* c, const Round& r) {
     hipLaunchKernelGGL(k_logw_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
-                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 2 * r.n * vec_grid(c)));
+                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
 void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
     hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
-                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 2 * r.n * vec_grid(c)));
+                       make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
 void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
