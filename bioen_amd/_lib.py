@@ -76,6 +76,8 @@ _SIGNATURES = {
     "bioen_hip_forces_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
     "bioen_hip_opt_lbfgs_forces": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(LbfgsConfig),
                                              C.POINTER(VisualParams), dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_opt_lbfgs_forces_batch": (C.c_int, [ctx_p, C.c_int, dp, dp, C.c_size_t, dp, C.POINTER(LbfgsConfig),
+                                                   C.POINTER(VisualParams), C.c_int, dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_chi_squared": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_kernel_stats": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -373,6 +375,30 @@ class Context(object):
         check(lib().bioen_hip_opt_lbfgs_forces(self._h, ptr(f0), ptr(w0), float(theta), C.byref(cfg), C.byref(vis),
                                                ptr(res), ptr(w) if want_weights else None, C.byref(info)))
         return res, w, info
+
+    def opt_lbfgs_forces_batch(self, thetas, forces0, w0, params, max_batch=8, verbose=False, debug=False,
+                               want_weights=True):
+        """theta series of the forces method; up to `max_batch` (<= 8) thetas share every matrix pass.
+        forces0: (m,) shared start or (ntheta, m).  -> (forces[ntheta, m], weights[ntheta, n] or None, infos)"""
+        thetas = as_f64(thetas).ravel()
+        nt = thetas.size
+        f0 = as_f64(forces0)
+        if f0.size == self.m:
+            f0, stride = f0.ravel(), 0
+        elif f0.shape == (nt, self.m):
+            stride = self.m
+        else:
+            raise ValueError("forces0 must have shape (m,) or (ntheta, m)")
+        w0 = self._nvec(w0, "w0")
+        cfg = lbfgs_config(params)
+        vis = VisualParams(int(bool(debug)), int(bool(verbose)))
+        res = np.empty((nt, self.m))
+        w = np.empty((nt, self.n)) if want_weights else None
+        infos = (OptResult * nt)()
+        check(lib().bioen_hip_opt_lbfgs_forces_batch(self._h, nt, ptr(thetas), ptr(f0), stride, ptr(w0), C.byref(cfg),
+                                                     C.byref(vis), int(max_batch), ptr(res),
+                                                     ptr(w) if want_weights else None, infos))
+        return res, w, list(infos)
 
     # -- shared -------------------------------------------------------------------
     def chi_squared(self, w):

@@ -157,8 +157,8 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     }
     TRY(dalloc_zero(&c->ybar_c, (size_t)c->mp * kMaxBatch, c->stream));
     TRY(dalloc_zero(&c->r_c, (size_t)c->mp * kMaxBatch, c->stream));
-    TRY(dalloc_zero(&c->um, c->mp, c->stream));
-    TRY(dalloc_zero(&c->gm, c->mp, c->stream));
+    TRY(dalloc_zero(&c->um, (size_t)c->mp * kMaxBatch, c->stream));
+    TRY(dalloc_zero(&c->gm, (size_t)c->mp * kMaxBatch, c->stream));
     TRY(dalloc_zero(&c->fixed, c->ld, c->stream));
     TRY(dalloc_zero(&c->t, c->ld, c->stream));
     TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * c->fwd_ctiles, c->stream));
@@ -318,36 +318,47 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     return 0;
 }
 
-// forces (single problem, slot 0): um holds the forces
-static void enqueue_forces_weights(bioen_hip_ctx* c) {
-    ProblemSlot& s0 = c->slot[0];
-    MVec8 out{};
-    out.p[0] = s0.a;
-    launch_adj(c, 1, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
-    launch_max_vec(c, s0.a, s0.part + (size_t)P_MAX * kMaxPartials);
-    launch_forces_exp(c, s0.a);
-    launch_forces_norm(c);                 // w ; KL partials
+// forces: um holds the forces of the round's K problems, compact [row*K + a]
+static ForcesRound make_forces_round(bioen_hip_ctx* c, const int* slots, int k, const double* theta) {
+    ForcesRound r{};
+    r.n = k;
+    for (int a = 0; a < k; ++a) {
+        ProblemSlot& sl = c->slot[slots[a]];
+        r.a[a] = sl.a;
+        r.w[a] = sl.w;
+        r.t[a] = sl.d;
+        r.scal[a] = sl.scal;
+        r.part[a] = sl.part;
+        r.theta[a] = theta ? theta[a] : 0.0;
+    }
+    return r;
 }
 
-static void enqueue_forces_eval(bioen_hip_ctx* c, double theta, bool with_grad) {
-    ProblemSlot& s0 = c->slot[0];
-    const int slots[1] = {0};
-    const Round r = make_round(c, slots, 1, nullptr, &theta);
-    enqueue_forces_weights(c);
+static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
+    MVec8 out{};
+    for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
+    launch_adj(c, fr.n, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
+    launch_forces_max(c, fr);
+    launch_forces_exp(c, fr);
+    launch_forces_norm(c, fr);                // w ; KL partials
+}
+
+static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
+    enqueue_forces_weights(c, fr);
     Vec8 v{};
-    v.p[0] = s0.w;
-    launch_fwd_partial(c, 1, v);           // F2: ybar                         [matrix pass 2]
-    launch_fwd_rows_local(c, 1);
+    for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
+    launch_fwd_partial(c, fr.n, v);           // F2: ybar                         [matrix pass 2]
+    launch_fwd_rows_local(c, fr.n);
     launch_rows_combine(c, r);
-    launch_forces_scalars(c, theta);       //     f = theta KL + 0.5 chi^2
+    launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
         MVec8 out{};
-        out.p[0] = s0.a;
-        launch_adj(c, 1, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
-        launch_forces_t(c, theta);         //     t_j
-        v.p[0] = c->t;
-        launch_fwd_partial(c, 1, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
-        launch_fwd_rows_forces_grad(c);
+        for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
+        launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
+        launch_forces_t(c, fr);               //     t_j
+        for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
+        launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
+        launch_fwd_rows_forces_grad(c, fr.n);
     }
 }
 
@@ -671,67 +682,45 @@ struct LogwBatchEngine {
     }
 };
 
-// forces: M variables live on the host, evaluations on the device
-struct HostForcesBackend {
-    bioen_hip_ctx* c;
-    double theta;
-    int m;
+// ---------------------------------------------------------------------------------
+// forces method: the M variables of each problem live on the host (a few KB), the K problems of
+// a round share all four matrix passes of the evaluation.
+// ---------------------------------------------------------------------------------
+struct ForcesProblem {
+    int id = -1;
+    double theta = 0.0;
+    LbfgsMachine* machine = nullptr;
+    bool initial = true;
     std::vector<double> x, xp, g, gp, d;
     std::vector<double> S[kHistory], Y[kHistory];
     double ys[kHistory] = {}, alpha[kHistory] = {};
-    bool result_is_trial = false;
-    int rc = 0;
-
-    HostForcesBackend(bioen_hip_ctx* ctx, double th, const double* x0)
-        : c(ctx), theta(th), m(ctx->m), x(m), xp(x0, x0 + m), g(m), gp(m), d(m) {
-        for (int i = 0; i < kHistory; ++i) {
-            S[i].assign(m, 0.0);
-            Y[i].assign(m, 0.0);
-        }
-    }
+    std::chrono::steady_clock::time_point t0;
 
     static double dot(const std::vector<double>& a, const std::vector<double>& b) {
         double s = 0.0;
         for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
         return s;
     }
-
-    double evaluate(const std::vector<double>& at, std::vector<double>& grad) {
-        hipError_t e = hipMemcpyAsync(c->um, at.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice,
-                                      c->stream);
-        if (e != hipSuccess && !rc) rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
-        enqueue_forces_eval(c, theta, true);
-        e = hipMemcpyAsync(grad.data(), c->gm, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess && !rc) rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
-        int r2 = read_scalars(c);
-        if (r2 && !rc) rc = r2;
-        return c->host_scal[S_F];
-    }
-
-    void initial(double* f, double* gg, double* xx) {
-        *f = evaluate(xp, gp);
-        *gg = dot(gp, gp);
-        *xx = dot(xp, xp);
-        for (int i = 0; i < m; ++i) d[i] = -gp[i];
-    }
-
-    void trial(double stp, TrialResult* t) {
-        for (int i = 0; i < m; ++i) x[i] = xp[i] + stp * d[i];
-        t->f = evaluate(x, g);
-        t->dg = dot(g, d);
-        t->gg = dot(g, g);
-        t->xx = dot(x, x);
-        t->dginit = dot(gp, d);
-    }
-
-    void accept(int end, int bound) {
-        std::vector<double>& s = S[end];
-        std::vector<double>& y = Y[end];
-        for (int i = 0; i < m; ++i) {
-            s[i] = x[i] - xp[i];
-            y[i] = g[i] - gp[i];
+    void start(int m, const double* x0) {
+        x.assign(m, 0.0);
+        xp.assign(x0, x0 + m);
+        g.assign(m, 0.0);
+        gp.assign(m, 0.0);
+        d.assign(m, 0.0);
+        for (int i = 0; i < kHistory; ++i) {
+            S[i].assign(m, 0.0);
+            Y[i].assign(m, 0.0);
         }
-        const double ys_new = dot(y, s), yy = dot(y, y);
+        initial = true;
+    }
+    // lbfgs.c:543-598 on host vectors
+    void accept(int end, int bound) {
+        const int m = (int)x.size();
+        for (int i = 0; i < m; ++i) {
+            S[end][i] = x[i] - xp[i];
+            Y[end][i] = g[i] - gp[i];
+        }
+        const double ys_new = dot(Y[end], S[end]), yy = dot(Y[end], Y[end]);
         ys[end] = ys_new;
         x.swap(xp);
         g.swap(gp);
@@ -751,9 +740,155 @@ struct HostForcesBackend {
             j = (j + 1) % kHistory;
         }
     }
+};
 
-    void revert() { result_is_trial = false; }
-    void keep_trial() { result_is_trial = true; }
+struct ForcesBatchEngine {
+    bioen_hip_ctx* c;
+    const bioen_lbfgs_config& cfg;
+    bool verbose;
+    int rc = 0;
+    std::vector<double> um_h, gm_h;
+
+    ForcesBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
+        : c(ctx), cfg(config), verbose(verb), um_h((size_t)ctx->mp * kMaxBatch), gm_h((size_t)ctx->mp * kMaxBatch) {}
+
+    void note(int e) { if (e && !rc) rc = e; }
+    void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
+
+    // evaluate the K points pts[a] (each m long); f -> host_scal, gradients -> gm_h (compact)
+    void evaluate(const int* slots, int k, const double* const* pts, const double* thetas, bool with_grad) {
+        const int m = c->m;
+        std::fill(um_h.begin(), um_h.begin() + (size_t)c->mp * k, 0.0);
+        for (int a = 0; a < k; ++a)
+            for (int i = 0; i < m; ++i) um_h[(size_t)i * k + a] = pts[a][i];
+        note(hipMemcpyAsync(c->um, um_h.data(), (size_t)c->mp * k * sizeof(double), hipMemcpyHostToDevice, c->stream),
+             "forces H2D");
+        const ForcesRound fr = make_forces_round(c, slots, k, thetas);
+        const Round r = make_round(c, slots, k, nullptr, thetas);
+        enqueue_forces_eval(c, fr, r, with_grad);
+        if (with_grad)
+            note(hipMemcpyAsync(gm_h.data(), c->gm, (size_t)c->mp * k * sizeof(double), hipMemcpyDeviceToHost, c->stream),
+                 "gradient D2H");
+        note(read_scalars(c, kMaxBatch));
+        note(check_launch());
+    }
+
+    int run(int ntheta, const double* thetas, const double* f0, size_t f0_stride, const double* w0_host, int max_batch,
+            double* results, double* w_opt, bioen_opt_result* infos) {
+        const int m = c->m;
+        for (int i = 0; i < ntheta; ++i) std::memset(&infos[i], 0, sizeof(bioen_opt_result));
+        LbfgsMachine probe(m, cfg);
+        const int bad = probe.validate();
+        if (bad != 0) {
+            for (int i = 0; i < ntheta; ++i) {
+                infos[i].lbfgs_code = bad;
+                std::memcpy(results + (size_t)i * m, f0 + (size_t)i * f0_stride, (size_t)m * sizeof(double));
+            }
+            return 0;
+        }
+        const int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
+        for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, false));
+        if (rc) return rc;
+        note(upload_n(c, c->fixed, w0_host));
+
+        std::vector<LbfgsMachine> machines;
+        machines.reserve(ntheta);
+        for (int i = 0; i < ntheta; ++i) machines.emplace_back(m, cfg);
+        std::vector<ForcesProblem> probs(kb);
+        bool occupied[kMaxBatch] = {};
+        int next = 0, active = 0;
+
+        auto start_problem = [&](int s) {
+            ForcesProblem& p = probs[s];
+            p.id = next;
+            p.theta = thetas[next];
+            p.machine = &machines[next];
+            p.start(m, f0 + (size_t)next * f0_stride);
+            p.t0 = std::chrono::steady_clock::now();
+            occupied[s] = true;
+            ++active;
+            ++next;
+        };
+        auto finish_problem = [&](int s, int code, bool keep_trial) {
+            ForcesProblem& p = probs[s];
+            bioen_opt_result& info = infos[p.id];
+            info.lbfgs_code = code;
+            info.iterations = p.machine->iterations();
+            info.evaluations = p.machine->evaluations();
+            info.fmin = p.machine->fx();
+            const std::vector<double>& res = keep_trial ? p.x : p.xp;
+            std::memcpy(results + (size_t)p.id * m, res.data(), (size_t)m * sizeof(double));
+            // weights, chi^2 and KL at the returned forces (forces.py:535-548 recomputes them too)
+            const int one[1] = {s};
+            const double* pt[1] = {res.data()};
+            evaluate(one, 1, pt, &p.theta, false);
+            const double* h = c->host_scal + (size_t)s * kScalStride;
+            info.chi2 = 0.5 * h[S_CHI];
+            info.kl = h[S_KL];
+            if (w_opt) {
+                note(hipMemcpyAsync(w_opt + (size_t)p.id * c->n, c->slot[s].w, (size_t)c->n * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream), "weights D2H");
+                note(hipStreamSynchronize(c->stream), "sync");
+            }
+            info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
+            if (verbose) {
+                std::printf("\ttheta = %g\n", p.theta);
+                print_summary(c, info);
+            }
+            occupied[s] = false;
+            --active;
+        };
+
+        for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
+        while (active > 0 && !rc) {
+            int list[kMaxBatch];
+            double th[kMaxBatch];
+            const double* pts[kMaxBatch];
+            int k = 0;
+            for (int s = 0; s < kb; ++s) {
+                if (!occupied[s]) continue;
+                ForcesProblem& p = probs[s];
+                if (p.initial) {
+                    pts[k] = p.xp.data();
+                } else {
+                    const double stp = p.machine->trial_step();
+                    for (int i = 0; i < m; ++i) p.x[i] = p.xp[i] + stp * p.d[i];
+                    pts[k] = p.x.data();
+                }
+                list[k] = s;
+                th[k] = p.theta;
+                ++k;
+            }
+            evaluate(list, k, pts, th, true);
+            if (rc) break;
+            for (int a = 0; a < k; ++a) {
+                const int s = list[a];
+                ForcesProblem& p = probs[s];
+                const double f = c->host_scal[(size_t)s * kScalStride + S_F];
+                std::vector<double>& grad = p.initial ? p.gp : p.g;
+                for (int i = 0; i < m; ++i) grad[i] = gm_h[(size_t)i * k + a];
+                LbfgsMachine::Action act;
+                if (p.initial) {
+                    act = p.machine->on_initial(f, ForcesProblem::dot(p.gp, p.gp), ForcesProblem::dot(p.xp, p.xp));
+                    if (act.kind != LbfgsMachine::DONE) {
+                        for (int i = 0; i < m; ++i) p.d[i] = -p.gp[i];
+                        p.initial = false;
+                    }
+                } else {
+                    TrialResult t{f, ForcesProblem::dot(p.g, p.d), ForcesProblem::dot(p.g, p.g),
+                                  ForcesProblem::dot(p.x, p.x), ForcesProblem::dot(p.gp, p.d)};
+                    act = p.machine->on_trial(t);
+                    if (act.kind == LbfgsMachine::ACCEPT) p.accept(act.end, act.bound);
+                }
+                if (act.kind == LbfgsMachine::DONE) {
+                    finish_problem(s, act.code, act.keep_trial && !p.initial);
+                    if (next < ntheta && !rc) start_problem(s);
+                }
+            }
+        }
+        note(hipStreamSynchronize(c->stream), "sync");
+        return rc;
+    }
 };
 
 // analytic objectives of bioen_hip_selftest_lbfgs (host only, test hook)
@@ -1174,19 +1309,21 @@ int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* c, const double* g0, const double* G
 // ---- forces ---------------------------------------------------------------------------
 static bool is_affine(const bioen_hip_ctx* c) { return c->affine; }
 
-static int upload_forces_inputs(bioen_hip_ctx* c, const double* forces, const double* w0) {
-    BIOEN_HIP_CHECK(hipMemcpyAsync(c->um, forces, (size_t)c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    return upload_n(c, c->fixed, w0);
+static int forces_guard(const bioen_hip_ctx* c) {
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
+    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
+    return 0;
 }
 
 int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const double* w0, double* w) {
     if (!c || !forces || !w0 || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
+    int rc = forces_guard(c);
+    if (rc) return rc;
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    int rc;
-    if ((rc = upload_forces_inputs(c, forces, w0))) return rc;
-    enqueue_forces_weights(c);
+    if ((rc = upload_n(c, c->fixed, w0))) return rc;
+    BIOEN_HIP_CHECK(hipMemcpyAsync(c->um, forces, (size_t)c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int one[1] = {0};
+    enqueue_forces_weights(c, make_forces_round(c, one, 1, nullptr));
     if ((rc = check_launch())) return rc;
     BIOEN_HIP_CHECK(hipMemcpyAsync(w, c->slot[0].w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1196,61 +1333,46 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
 int bioen_hip_forces_fdf(bioen_hip_ctx* c, const double* forces, const double* w0, double theta, double* f,
                          double* grad) {
     if (!c || !forces || !w0) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
+    int rc = forces_guard(c);
+    if (rc) return rc;
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    int rc;
-    if ((rc = upload_forces_inputs(c, forces, w0))) return rc;
-    enqueue_forces_eval(c, theta, grad != nullptr);
-    if ((rc = check_launch())) return rc;
-    if (grad)
-        BIOEN_HIP_CHECK(hipMemcpyAsync(grad, c->gm, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if ((rc = read_scalars(c))) return rc;
+    if ((rc = upload_n(c, c->fixed, w0))) return rc;
+    bioen_lbfgs_config dummy{};
+    ForcesBatchEngine eng(c, dummy, false);
+    const int one[1] = {0};
+    const double* pt[1] = {forces};
+    eng.evaluate(one, 1, pt, &theta, grad != nullptr);
+    if (eng.rc) return eng.rc;
+    if (grad) std::memcpy(grad, eng.gm_h.data(), (size_t)c->m * sizeof(double));
     if (f) *f = c->host_scal[S_F];
     return 0;
+}
+
+int bioen_hip_opt_lbfgs_forces_batch(bioen_hip_ctx* c, int ntheta, const double* thetas, const double* forces0,
+                                     size_t f0_stride, const double* w0, const bioen_lbfgs_config* config,
+                                     const bioen_visual_params* visual, int max_batch, double* results,
+                                     double* w_opt, bioen_opt_result* infos) {
+    if (!c || !thetas || !forces0 || !w0 || !config || !results || !infos || ntheta <= 0)
+        return fail(BIOEN_HIP_EINVAL, "NULL argument or ntheta <= 0");
+    if (f0_stride != 0 && f0_stride < (size_t)c->m) return fail(BIOEN_HIP_EINVAL, "f0_stride must be 0 or >= m");
+    int rc = forces_guard(c);
+    if (rc) return rc;
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    const bool verbose = visual && visual->verbose;
+    if (verbose) {
+        std::printf("L-BFGS minimizer (forces, %d theta value%s, up to %d per matrix pass)\n", ntheta,
+                    ntheta > 1 ? "s" : "", std::max(1, std::min(max_batch, (int)kMaxBatch)));
+        print_config(*config);
+    }
+    ForcesBatchEngine eng(c, *config, verbose);
+    return eng.run(ntheta, thetas, forces0, f0_stride, w0, max_batch, results, w_opt, infos);
 }
 
 int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const double* w0, double theta,
                                const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                                double* result, double* w_opt, bioen_opt_result* info) {
-    if (!c || !forces0 || !w0 || !config || !result || !info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
-    BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    const bool verbose = visual && visual->verbose;
-    std::memset(info, 0, sizeof *info);
-    int rc;
-    if ((rc = upload_n(c, c->fixed, w0))) return rc;
-    if (verbose) {
-        std::printf("L-BFGS minimizer\n");
-        print_config(*config);
-    }
-    HostForcesBackend B(c, theta, forces0);
-    const auto t0 = std::chrono::steady_clock::now();
-    double fx = 0.0;
-    info->lbfgs_code = lbfgs_run(B, c->m, *config, &fx, &info->iterations, &info->evaluations);
-    hipStreamSynchronize(c->stream);
-    info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    info->fmin = fx;
-    if (B.rc) return B.rc;
-    if ((rc = check_launch())) return rc;
-
-    const std::vector<double>& res = B.result_is_trial ? B.x : B.xp;
-    std::memcpy(result, res.data(), (size_t)c->m * sizeof(double));
-    if (info->evaluations > 0) {
-        // weights, chi^2 and KL at the returned forces (forces.py:535-548 recomputes them too)
-        BIOEN_HIP_CHECK(hipMemcpyAsync(c->um, result, (size_t)c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        enqueue_forces_eval(c, theta, false);
-        if ((rc = check_launch())) return rc;
-        if (w_opt)
-            BIOEN_HIP_CHECK(hipMemcpyAsync(w_opt, c->slot[0].w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
-                                           c->stream));
-        if ((rc = read_scalars(c))) return rc;
-        info->chi2 = 0.5 * c->host_scal[S_CHI];
-        info->kl = c->host_scal[S_KL];
-    }
-    if (verbose) print_summary(c, *info);
-    return 0;
+    if (!info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    return bioen_hip_opt_lbfgs_forces_batch(c, 1, &theta, forces0, 0, w0, config, visual, 1, result, w_opt, info);
 }
 
 // ---- shared ---------------------------------------------------------------------------
@@ -1268,7 +1390,7 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     launch_fwd_partial(c, 1, v);
     launch_fwd_rows_local(c, 1);
     launch_rows_combine(c, r);
-    launch_forces_scalars(c, 0.0);   // S_CHI (the KL partials it also sums are irrelevant here)
+    launch_forces_scalars(c, make_forces_round(c, one, 1, nullptr));   // S_CHI (the KL part is irrelevant here)
     if ((rc = check_launch())) return rc;
     if (yave)   // K = 1: the compact layout is the plain M-vector
         BIOEN_HIP_CHECK(hipMemcpyAsync(yave, c->ybar_c, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -151,8 +151,8 @@ struct bioen_hip_ctx {
     bool affine = false;            // anything but (0, 1)
     double* ybar_c = nullptr;  // mp * kMaxBatch, compact per round
     double* r_c = nullptr;     // mp * kMaxBatch
-    double* um = nullptr;      // mp   M-vector input  (forces)
-    double* gm = nullptr;      // mp   M-vector output (forces gradient)
+    double* um = nullptr;      // mp * kMaxBatch  forces of the round's problems, compact [row*K + a]
+    double* gm = nullptr;      // mp * kMaxBatch  forces gradients, compact
     double* fixed = nullptr;   // ld   G (log-weights) or w0 (forces), shared by all slots
     double* t = nullptr;       // ld   forces scratch
     double* g0 = nullptr;      // ld   shared start vector of a batch run (lazy)

@@ -154,15 +154,15 @@ constexpr int next_pow2(int v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 :
 // forward pass: partial[(row*K + a)*ctiles + tile] = sum_{j in tile} Y[row][j] v_a[j]
 //   block = 4 waves stacked over rows, R rows per wave; a wave walks its column tile in
 //   128-column (1 KiB) steps, STEPS steps in flight, K x R accumulators.
-//   CENTER (K = 1 only): sum_j (Y[row][j] - ybar[row]) v[j] -- the centred form the reference
-//   uses for the forces gradient (c_bioen_kernels_forces.c:330-338).
+//   CENTER: sum_j (Y[row][j] - ybar_a[row]) v_a[j] -- the centred form the reference uses for the
+//   forces gradient (c_bioen_kernels_forces.c:330-338); ybar_a[row] is wave-uniform and read
+//   through the scalar cache (compact layout [row*K + a]).
 // ------------------------------------------------------------------------------
 template <int R, int K, int STEPS, bool NT, bool CENTER>
 __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict__ Y, size_t ld, Vec8 v,
                                                         const double* __restrict__ ybar_c,
                                                         double* __restrict__ partial, int ctiles,
                                                         int steps_per_tile, int total_steps) {
-    static_assert(!CENTER || K == 1, "centred forward pass is single-problem");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // blockIdx.x = row block (fast index): consecutive blocks share the column tile, so the
@@ -180,9 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
     double acc[KP * R];
 #pragma unroll
     for (int i = 0; i < KP * R; ++i) acc[i] = 0.0;
-    double yb[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) yb[r] = CENTER ? ybar_c[row0 + r] : 0.0;
+    const double* ybp = ybar_c + (size_t)row0 * K;   // [r*K + k], wave-uniform
 
     size_t off = col;
     for (; s + STEPS <= s_end; s += STEPS) {
@@ -199,10 +197,11 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
         for (int k = 0; k < K; ++k) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                const double yb = CENTER ? ybp[r * K + k] : 0.0;
 #pragma unroll
                 for (int t = 0; t < STEPS; ++t) {
-                    acc[k * R + r] = fma(y[t][r].x - yb[r], vv[t][k].x, acc[k * R + r]);
-                    acc[k * R + r] = fma(y[t][r].y - yb[r], vv[t][k].y, acc[k * R + r]);
+                    acc[k * R + r] = fma(y[t][r].x - yb, vv[t][k].x, acc[k * R + r]);
+                    acc[k * R + r] = fma(y[t][r].y - yb, vv[t][k].y, acc[k * R + r]);
                 }
             }
         }
@@ -220,8 +219,9 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
         for (int k = 0; k < K; ++k) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                acc[k * R + r] = fma(y[r].x - yb[r], vv[k].x, acc[k * R + r]);
-                acc[k * R + r] = fma(y[r].y - yb[r], vv[k].y, acc[k * R + r]);
+                const double yb = CENTER ? ybp[r * K + k] : 0.0;
+                acc[k * R + r] = fma(y[r].x - yb, vv[k].x, acc[k * R + r]);
+                acc[k * R + r] = fma(y[r].y - yb, vv[k].y, acc[k * R + r]);
             }
         }
         yp += 128;
@@ -292,15 +292,16 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
 // forces gradient (c_bioen_kernels_forces.c:330-338): the partials already hold the centred
 // sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* __restrict__ partial, int ctiles,
-                                                                 int mp, double* __restrict__ gm) {
+                                                                 int mp, int K, double* __restrict__ gm_c) {
+    const int a = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
-        const double* p = partial + (size_t)row * ctiles;
+        const double* p = partial + ((size_t)row * K + a) * ctiles;
         double s = 0.0;
         for (int k = lane; k < ctiles; k += 64) s += p[k];
         s = wave_sum(s);
-        if (lane == 0) gm[row] = s;
+        if (lane == 0) gm_c[(size_t)row * K + a] = s;
     }
 }
 
@@ -394,14 +395,6 @@ __global__ __launch_bounds__(kBlock) void k_max(Round r, int n, Xch xo) {
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, x[j]);
     mx = block_max(mx, sh);
     if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
-}
-
-__global__ __launch_bounds__(kBlock) void k_max_vec(const double* __restrict__ v, int n, double* __restrict__ pmax) {
-    __shared__ double sh[kWaves];
-    double mx = -DBL_MAX;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, v[j]);
-    mx = block_max(mx, sh);
-    if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
 }
 
 // _get_weights (c_bioen_kernels_logw.c:55-94) with a max shift, first half:
@@ -583,14 +576,27 @@ __global__ __launch_bounds__(kBlock) void k_store_dginit(MVec8 scal, Xch xd) {
 }
 
 // ------------------------------------------------------------------------------
-// forces N-vector kernels (single problem)
+// forces N-vector kernels (blockIdx.y = batch position; xj / b live in the slot's `a`,
+// t in the slot's `d`, which the forces method does not otherwise use)
 // ------------------------------------------------------------------------------
-// _get_weights_from_forces (c_bioen_kernels_forces.c:152-176), first half
-__global__ __launch_bounds__(kBlock) void k_forces_exp(const double* __restrict__ xj, const double* __restrict__ w0,
-                                                       int n, const double* __restrict__ pmax, int np,
-                                                       double* __restrict__ w, double* __restrict__ psum) {
+__global__ __launch_bounds__(kBlock) void k_forces_max(ForcesRound r, int n) {
     __shared__ double sh[kWaves];
-    const double xmax = max_partials(pmax, np, sh);
+    const int a = blockIdx.y;
+    const double* __restrict__ v = r.a[a];
+    double mx = -DBL_MAX;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, v[j]);
+    mx = block_max(mx, sh);
+    if (threadIdx.x == 0) r.part[a][(size_t)P_MAX * kMaxPartials + blockIdx.x] = mx;
+}
+
+// _get_weights_from_forces (c_bioen_kernels_forces.c:152-176), first half
+__global__ __launch_bounds__(kBlock) void k_forces_exp(ForcesRound r, const double* __restrict__ w0, int n, int np) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ xj = r.a[a];
+    double* __restrict__ w = r.w[a];
+    double* pa = r.part[a];
+    const double xmax = max_partials(pa + (size_t)P_MAX * kMaxPartials, np, sh);
     double s = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double ev = w0[j] * exp(xj[j] - xmax);
@@ -598,15 +604,16 @@ __global__ __launch_bounds__(kBlock) void k_forces_exp(const double* __restrict_
         s += ev;
     }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) psum[blockIdx.x] = s;
+    if (threadIdx.x == 0) pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = s;
 }
 
 // second half + relative entropy terms (c_bioen_kernels_forces.c:246-258)
-__global__ __launch_bounds__(kBlock) void k_forces_norm(double* __restrict__ w, const double* __restrict__ w0, int n,
-                                                        const double* __restrict__ psum, int np,
-                                                        double* __restrict__ pkl) {
+__global__ __launch_bounds__(kBlock) void k_forces_norm(ForcesRound r, const double* __restrict__ w0, int n, int np) {
     __shared__ double sh[kWaves];
-    const double inv = 1.0 / sum_partials(psum, np, sh);
+    const int a = blockIdx.y;
+    double* __restrict__ w = r.w[a];
+    double* pa = r.part[a];
+    const double inv = 1.0 / sum_partials(pa + (size_t)P_SUM * kMaxPartials, np, sh);
     double kl = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double wv = inv * w[j];
@@ -615,13 +622,16 @@ __global__ __launch_bounds__(kBlock) void k_forces_norm(double* __restrict__ w, 
         if (wv >= DBL_MIN && w0v >= DBL_MIN) kl = fma(log(wv) - log(w0v), wv, kl);
     }
     kl = block_sum(kl, sh);
-    if (threadIdx.x == 0) pkl[blockIdx.x] = kl;
+    if (threadIdx.x == 0) pa[(size_t)P_KL * kMaxPartials + blockIdx.x] = kl;
 }
 
 // t_j = (theta (1 + log w_j - log w0_j) + b_j) w_j     (c_bioen_kernels_forces.c:320-328)
-__global__ __launch_bounds__(kBlock) void k_forces_t(const double* __restrict__ w, const double* __restrict__ w0,
-                                                     const double* __restrict__ b, double theta, int n,
-                                                     double* __restrict__ t) {
+__global__ __launch_bounds__(kBlock) void k_forces_t(ForcesRound r, const double* __restrict__ w0, int n) {
+    const int a = blockIdx.y;
+    const double* __restrict__ w = r.w[a];
+    const double* __restrict__ b = r.a[a];
+    double* __restrict__ t = r.t[a];
+    const double theta = r.theta[a];
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double wv = w[j], w0v = w0[j];
         double dd = 1.0;
@@ -630,16 +640,17 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(const double* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_forces_scalars(const double* __restrict__ pchi, int npchi,
-                                                           const double* __restrict__ pkl, int npkl, double theta,
-                                                           double* __restrict__ scal) {
+__global__ __launch_bounds__(kBlock) void k_forces_scalars(ForcesRound r, int npchi, int npkl) {
     __shared__ double sh[kWaves];
-    const double chi = sum_partials(pchi, npchi, sh);
-    const double kl = sum_partials(pkl, npkl, sh);
+    const int a = blockIdx.y;
+    const double* pa = r.part[a];
+    const double chi = sum_partials(pa + (size_t)P_CHI * kMaxPartials, npchi, sh);
+    const double kl = sum_partials(pa + (size_t)P_KL * kMaxPartials, npkl, sh);
     if (threadIdx.x == 0) {
-        scal[S_CHI] = chi;
-        scal[S_KL] = kl;
-        scal[S_F] = kl * theta + 0.5 * chi;
+        double* sc = r.scal[a];
+        sc[S_CHI] = chi;
+        sc[S_KL] = kl;
+        sc[S_F] = kl * r.theta[a] + 0.5 * chi;
     }
 }
 
@@ -993,27 +1004,27 @@ static void fwd_launch(bioen_hip_ctx* c, const Vec8& v) {
                        c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
 }
 
-template <bool NT>
-static void fwd_dispatch(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
-    if (centred) {
-        fwd_launch<1, 2, NT, true>(c, v);
-        return;
-    }
+template <bool NT, bool CENTER>
+static void fwd_dispatch(bioen_hip_ctx* c, int K, const Vec8& v) {
     switch (K) {
-        case 1: fwd_launch<1, 2, NT, false>(c, v); break;
-        case 2: fwd_launch<2, 2, NT, false>(c, v); break;
-        case 3: fwd_launch<3, 1, NT, false>(c, v); break;
-        case 4: fwd_launch<4, 1, NT, false>(c, v); break;
-        case 5: fwd_launch<5, 1, NT, false>(c, v); break;
-        case 6: fwd_launch<6, 1, NT, false>(c, v); break;
-        case 7: fwd_launch<7, 1, NT, false>(c, v); break;
-        default: fwd_launch<8, 1, NT, false>(c, v); break;
+        case 1: fwd_launch<1, 2, NT, CENTER>(c, v); break;
+        case 2: fwd_launch<2, 2, NT, CENTER>(c, v); break;
+        case 3: fwd_launch<3, 1, NT, CENTER>(c, v); break;
+        case 4: fwd_launch<4, 1, NT, CENTER>(c, v); break;
+        case 5: fwd_launch<5, 1, NT, CENTER>(c, v); break;
+        case 6: fwd_launch<6, 1, NT, CENTER>(c, v); break;
+        case 7: fwd_launch<7, 1, NT, CENTER>(c, v); break;
+        default: fwd_launch<8, 1, NT, CENTER>(c, v); break;
     }
 }
 
 void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
     TimedLaunch tl(c, 0, K);
-    if (c->nontemporal) fwd_dispatch<true>(c, K, v, centred); else fwd_dispatch<false>(c, K, v, centred);
+    if (c->nontemporal) {
+        if (centred) fwd_dispatch<true, true>(c, K, v); else fwd_dispatch<true, false>(c, K, v);
+    } else {
+        if (centred) fwd_dispatch<false, true>(c, K, v); else fwd_dispatch<false, false>(c, K, v);
+    }
 }
 
 void launch_fwd_rows_local(bioen_hip_ctx* c, int K) {
@@ -1034,9 +1045,9 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r) {
                        c->r_c, part);
 }
 
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c)), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       c->fwd_ctiles, c->mp, c->gm);
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K) {
+    hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       c->fwd_ctiles, c->mp, K, c->gm);
 }
 
 // ---- adjoint ---------------------------------------------------------------------------
@@ -1114,31 +1125,27 @@ void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal) {
                        make_xch(c, X_DGI, k * vec_grid(c)));
 }
 
-// ---- forces (slot 0) -------------------------------------------------------------------------
-static double* part0(bioen_hip_ctx* c, int which) { return c->slot[0].part + (size_t)which * kMaxPartials; }
-
-void launch_max_vec(bioen_hip_ctx* c, const double* v, double* pmax) {
-    hipLaunchKernelGGL(k_max_vec, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, v, c->n, pmax);
+// ---- forces ------------------------------------------------------------------------------------
+void launch_forces_max(bioen_hip_ctx* c, const ForcesRound& r) {
+    hipLaunchKernelGGL(k_forces_max, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
 }
 
-void launch_forces_exp(bioen_hip_ctx* c, const double* xj) {
-    hipLaunchKernelGGL(k_forces_exp, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, xj, c->fixed, c->n,
-                       part0(c, P_MAX), vec_grid(c), c->slot[0].w, part0(c, P_SUM));
+void launch_forces_exp(bioen_hip_ctx* c, const ForcesRound& r) {
+    hipLaunchKernelGGL(k_forces_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       vec_grid(c));
 }
 
-void launch_forces_norm(bioen_hip_ctx* c) {
-    hipLaunchKernelGGL(k_forces_norm, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->slot[0].w, c->fixed, c->n,
-                       part0(c, P_SUM), vec_grid(c), part0(c, P_KL));
+void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r) {
+    hipLaunchKernelGGL(k_forces_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       vec_grid(c));
 }
 
-void launch_forces_t(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_forces_t, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, c->slot[0].w, c->fixed,
-                       c->slot[0].a, theta, c->n, c->t);
+void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r) {
+    hipLaunchKernelGGL(k_forces_t, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n);
 }
 
-void launch_forces_scalars(bioen_hip_ctx* c, double theta) {
-    hipLaunchKernelGGL(k_forces_scalars, dim3(1), dim3(kBlock), 0, c->stream, part0(c, P_CHI), combine_grid(c),
-                       part0(c, P_KL), vec_grid(c), theta, c->slot[0].scal);
+void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r) {
+    hipLaunchKernelGGL(k_forces_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, combine_grid(c), vec_grid(c));
 }
 
 // ---- L-BFGS vector kernels ----------------------------------------------------------------------

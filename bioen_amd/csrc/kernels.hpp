@@ -47,8 +47,8 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K);
 // add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
 void launch_rows_combine(bioen_hip_ctx* c, const Round& r);
 int combine_grid(const bioen_hip_ctx* c);
-// forces gradient (K = 1): gm = reduced centred sums
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c);
+// forces gradient: gm_c[row*K + a] = reduced centred sums
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K);
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
 void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);
 
@@ -63,12 +63,21 @@ void launch_logw_grad(bioen_hip_ctx* c, const Round& r);    // gradient epilogue
 void launch_finish_eval(bioen_hip_ctx* c, const Round& r);  // scal[S_DG], S_GG, S_XX
 void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal);   // scal[S_DGINIT] <- X_DGI
 
-// ---- forces N-vector kernels (single problem, slot 0) -------------------------------------
-void launch_max_vec(bioen_hip_ctx* c, const double* v, double* pmax);
-void launch_forces_exp(bioen_hip_ctx* c, const double* xj);
-void launch_forces_norm(bioen_hip_ctx* c);
-void launch_forces_t(bioen_hip_ctx* c, double theta);
-void launch_forces_scalars(bioen_hip_ctx* c, double theta);
+// ---- forces N-vector kernels (blockIdx.y = batch position) ---------------------------------
+struct ForcesRound {
+    int n;
+    double* a[kMaxBatch];      // xj = yTilde^T f, later b = yTilde^T r
+    double* w[kMaxBatch];
+    double* t[kMaxBatch];
+    double* scal[kMaxBatch];
+    double* part[kMaxBatch];
+    double theta[kMaxBatch];
+};
+void launch_forces_max(bioen_hip_ctx* c, const ForcesRound& r);
+void launch_forces_exp(bioen_hip_ctx* c, const ForcesRound& r);
+void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r);
+void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r);
+void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r);
 
 // ---- L-BFGS vector kernels (device-resident scalars) -------------------------------
 struct PairArgs {      // s = x - xp ; y = g - gp for the accepting problems

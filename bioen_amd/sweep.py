@@ -306,9 +306,16 @@ def sweep_log_weights_sharded(ctx, thetas, G, g_init, lbfgs_params, verbose=Fals
             for k, (th, i) in enumerate(zip(thetas, infos))]
 
 
-def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=False, verbose=False):
-    """Cold-started forces series (the ala5 notebook's protocol)."""
-    def solve(theta):
-        _, w, info = ctx.opt_lbfgs_forces(forces_init, w0, theta, lbfgs_params, verbose=verbose)
-        return w, info
-    return theta_sweep(ctx, thetas, solve, comm=comm, rccl=rccl)
+def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=False, verbose=False, max_batch=8):
+    """Cold-started forces series (the ala5 notebook's protocol); a rank's thetas run as one
+    lock-step batch sharing the four matrix passes of every evaluation."""
+    comm = comm or SingleComm()
+    thetas = [float(t) for t in thetas]
+    mine = shard_thetas(thetas, comm.rank, comm.world)
+    solved = {}
+    if mine:
+        _, w, infos = ctx.opt_lbfgs_forces_batch([thetas[i] for i in mine], forces_init, w0, lbfgs_params,
+                                                 max_batch=max_batch, verbose=verbose)
+        for k, i in enumerate(mine):
+            solved[i] = (w[k], infos[k])
+    return theta_sweep(ctx, thetas, None, comm=comm, rccl=rccl, presolved=solved)

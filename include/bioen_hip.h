@@ -181,6 +181,16 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* ctx, const double* forces0, const 
                                const bioen_visual_params* visual, double* result, double* w_opt,
                                bioen_opt_result* info);
 
+/* theta series of the forces method in one call (cf. bioen_hip_opt_lbfgs_logw_batch): the M
+ * variables of every problem stay on the host, the up to `max_batch` problems of a round share
+ * all four matrix passes of the evaluation.  forces0: shared (f0_stride = 0) or per theta
+ * (stride >= m); results[ntheta][m]; w_opt[ntheta][n] or NULL. */
+int bioen_hip_opt_lbfgs_forces_batch(bioen_hip_ctx* ctx, int ntheta, const double* thetas,
+                                     const double* forces0, size_t f0_stride, const double* w0,
+                                     const bioen_lbfgs_config* config, const bioen_visual_params* visual,
+                                     int max_batch, double* results, double* w_opt,
+                                     bioen_opt_result* infos);
+
 /* ---- shared pieces --------------------------------------------------------- */
 /* _bioen_chi_squared (c_bioen_common.c:70-108) / _getAve (c_bioen_kernels_forces.c:93-109):
  * yave[m] = yTilde . w ; *chi2 = 0.5 |yave - YTilde|^2.  Either output may be NULL. */

@@ -86,10 +86,26 @@ static void matvec(const double* yTilde, const double* v, double* out, size_t m,
     }
 }
 
+/* centred forward pass: out[i] = sum_j (yTilde[i,j] - ybar[i]) v[j]
+ * (c_bioen_kernels_forces.c:330-338 keeps the centring inside the sum) */
+static void matvec_centred(const double* yTilde, const double* ybar, const double* v, double* out, size_t m,
+                           size_t n) {
+#pragma omp parallel for schedule(static) if (m * n >= PAR_MIN)
+    for (size_t i = 0; i < m; ++i) {
+        const double* row = yTilde + i * n;
+        const double yb = ybar[i];
+        double acc = 0.0;
+        for (size_t j = 0; j < n; ++j) acc += (row[j] - yb) * v[j];
+        out[i] = acc;
+    }
+}
+
 /* adjoint pass: out[j] = sum_i yTilde[i,j] u[i], walking the row-major matrix
  * by rows (the reference walks a transposed copy instead,
  * c_bioen_kernels_logw.c:185-195; same sums, different order). */
-static void matvec_t(const double* yTilde, const double* u, double* out, size_t m, size_t n) {
+/* ybar == NULL: plain; else the centred sum  out[j] = sum_i u[i] (yTilde[i,j] - ybar[i])
+ * (c_bioen_kernels_logw.c:190) */
+static void matvec_t(const double* yTilde, const double* u, const double* ybar, double* out, size_t m, size_t n) {
 #pragma omp parallel if (m * n >= PAR_MIN)
     {
         const size_t chunk = 2048;
@@ -99,8 +115,9 @@ static void matvec_t(const double* yTilde, const double* u, double* out, size_t 
             for (size_t j = j0; j < j1; ++j) out[j] = 0.0;
             for (size_t i = 0; i < m; ++i) {
                 const double ui = u[i];
+                const double yb = ybar ? ybar[i] : 0.0;
                 const double* row = yTilde + i * n;
-                for (size_t j = j0; j < j1; ++j) out[j] += ui * row[j];
+                for (size_t j = j0; j < j1; ++j) out[j] += ui * (row[j] - yb);
             }
         }
     }
@@ -123,10 +140,9 @@ double oracle_chi_squared(const double* w, const double* yTilde, const double* Y
 /* A1 + A3 + A4 + A6 = interface_lbfgs_logw, c_bioen_kernels_logw.c:525-561.
  *
  *   L      = theta * ( sum_j w_j (g_j - G_j) - log s + log s0 ) + 0.5 |r|^2
- *   dL/dg_k = theta w_k [ (g_k - G_k) - P ] + w_k [ (yTilde^T r)_k - ybar.r ]
+ *   dL/dg_k = theta w_k [ (g_k - G_k) - P ] + w_k sum_i r_i (yTilde_ik - ybar_i)
  * with r = yTilde w - YTilde, ybar = yTilde w, P = sum_j w_j (g_j - G_j).
- * (c_bioen_kernels_logw.c:96-127 prior, :185-216 gradient; the centring
- * `(yTildeT[j*m+i] - tmp_m[i])` of :190 is the `- ybar.r` term.) */
+ * (c_bioen_kernels_logw.c:96-127 prior, :185-216 gradient, centred as in :190.) */
 double oracle_logw_fdf(int m_, int n_, const double* yTilde, const double* YTilde,
                        const double* g, const double* G, double theta,
                        double* grad, double* w_out) {
@@ -150,18 +166,17 @@ double oracle_logw_fdf(int m_, int n_, const double* yTilde, const double* YTild
     const double prior = theta * (P - logs + logs0);
 
     matvec(yTilde, w, ybar, m, n);
-    double chi = 0.0, c = 0.0;
+    double chi = 0.0;
     for (size_t i = 0; i < m; ++i) {
         r[i] = ybar[i] - YTilde[i];
         chi += r[i] * r[i];
-        c += ybar[i] * r[i];
     }
     const double f = prior + 0.5 * chi;
 
     if (grad) {
-        matvec_t(yTilde, r, grad, m, n);
+        matvec_t(yTilde, r, ybar, grad, m, n);
         for (size_t k = 0; k < n; ++k)
-            grad[k] = w[k] * (theta * ((g[k] - G[k]) - P) + (grad[k] - c));
+            grad[k] = w[k] * (theta * ((g[k] - G[k]) - P) + grad[k]);
     }
     free(ybar);
     free(r);
@@ -173,7 +188,7 @@ double oracle_logw_fdf(int m_, int n_, const double* yTilde, const double* YTild
 void oracle_forces_weights(int m_, int n_, const double* yTilde, const double* forces,
                            const double* w0, double* w) {
     const size_t m = (size_t)m_, n = (size_t)n_;
-    matvec_t(yTilde, forces, w, m, n);
+    matvec_t(yTilde, forces, NULL, w, m, n);
     double xmax = -DBL_MAX;
     for (size_t j = 0; j < n; ++j)
         if (w[j] > xmax) xmax = w[j];
@@ -213,16 +228,13 @@ double oracle_forces_fdf(int m_, int n_, const double* yTilde, const double* YTi
     const double f = theta * kl + 0.5 * chi;
 
     if (grad) {
-        matvec_t(yTilde, r, t, m, n);
-        double tsum = 0.0;
+        matvec_t(yTilde, r, NULL, t, m, n);
         for (size_t j = 0; j < n; ++j) {
             double d = 1.0;
             if (w[j] >= DBL_MIN && w0[j] >= DBL_MIN) d += log(w[j]) - log(w0[j]);
             t[j] = (d * theta + t[j]) * w[j];
-            tsum += t[j];
         }
-        matvec(yTilde, t, grad, m, n);
-        for (size_t i = 0; i < m; ++i) grad[i] -= ybar[i] * tsum;
+        matvec_centred(yTilde, ybar, t, grad, m, n);
     }
     free(ybar);
     free(r);

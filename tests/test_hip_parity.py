@@ -303,3 +303,59 @@ def test_gram_direction_matches_two_loop(hip, name):
     # and against the reference's own run
     if int(d["lbfgs_tight_code"]) in (0, 1, 2) and g_tight[2].lbfgs_code in (0, 1, 2):
         assert rel(g_tight[2].fmin, float(d["lbfgs_tight_fmin"])) < FMIN_RTOL
+
+
+# ---------------------------------------------------------------------------------------
+# forces method: theta series as one lock-step batch (BASELINE config 5 in miniature)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,max_batch", [("synth_forces_M30xN1000.npz", 8), ("synth_forces_M96xN3000.npz", 3),
+                                            ("ref_data_forces_M64xN64.npz", 5)])
+def test_batched_forces_series_equals_single_runs_bitwise(hip, name, max_batch):
+    d = load_golden(name)
+    thetas = [200.0, 0.5, 50.0, 7.0, 1.0, 20.0, 2.0, 100.0, 3.0, 10.0]
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        single = [ctx.opt_lbfgs_forces(d["forces_init"], d["w0"], th, LBFGS_DEFAULTS) for th in thetas]
+        res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, d["forces_init"], d["w0"], LBFGS_DEFAULTS,
+                                                   max_batch=max_batch)
+        starts = np.stack([d["forces_init"].ravel() + 1e-4 * i for i in range(len(thetas))])
+        res2, w2, infos2 = ctx.opt_lbfgs_forces_batch(thetas, starts, d["w0"], LBFGS_DEFAULTS, max_batch=max_batch)
+        single2 = [ctx.opt_lbfgs_forces(starts[i], d["w0"], th, LBFGS_DEFAULTS) for i, th in enumerate(thetas)]
+        bad = ctx.opt_lbfgs_forces_batch(thetas[:3], d["forces_init"], d["w0"], dict(LBFGS_DEFAULTS, delta=-1.0))
+    for i, (f1, w1, i1) in enumerate(single):
+        assert infos[i].lbfgs_code == i1.lbfgs_code and infos[i].iterations == i1.iterations
+        assert infos[i].evaluations == i1.evaluations
+        assert infos[i].fmin == i1.fmin and infos[i].chi2 == i1.chi2 and infos[i].kl == i1.kl
+        assert np.array_equal(res[i], f1) and np.array_equal(w[i], w1)
+        assert rel(infos[i].fmin, thetas[i] * infos[i].kl + infos[i].chi2) < 1e-12
+    for i, (f1, w1, i1) in enumerate(single2):
+        assert infos2[i].fmin == i1.fmin and np.array_equal(res2[i], f1) and np.array_equal(w2[i], w1)
+    assert all(i.lbfgs_code == -1015 and i.evaluations == 0 for i in bad[2])
+    # theta = 10 is the golden file's own theta for two of the three cases
+    if abs(d["theta"] - 10.0) < 1e-12:
+        k = thetas.index(10.0)
+        assert rel(infos[k].fmin, float(d["lbfgs_def_fmin"])) < 5e-6
+
+
+def test_large_forces_batch_vs_oracle(hip):
+    """N = 2e5 x M = 128 generated in HBM: one batched forces evaluation and a short series vs the oracle."""
+    from oracle import oracle_binding as O
+    M, N = 128, 200000
+    rng = np.random.default_rng(12345)
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp, sig_sim = 0.1 * YTrue, 0.5 * YTrue
+    YTilde = rng.normal(YTrue, sig_exp) / sig_exp
+    w0 = np.full(N, 1.0 / N)
+    with hip.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=7) as ctx:
+        y = ctx.read_ytilde()
+        f0 = 1e-4 * rng.standard_normal(M)
+        f, grad = ctx.forces_fdf(f0, w0, 10.0)
+        f_o, grad_o, w_o = O.forces_fdf(f0, w0, y, YTilde, 10.0)
+        assert rel(f, f_o) < 1e-12 and np.abs(grad - grad_o).max() <= 1e-9 * np.abs(grad_o).max()
+        thetas = [100.0, 10.0, 1.0]
+        res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, LBFGS_DEFAULTS)
+        for th, info, wi in zip(thetas, infos, w):
+            fo, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_forces(np.zeros(M), w0, y, YTilde, th)
+            # (-998: either side may end on an exhausted line search at the rounding floor)
+            assert info.lbfgs_code in (0, 1, -998) and code_o in (0, 1, -998)
+            assert rel(info.fmin, fmin_o) < 2e-5
+            assert abs(wi.sum() - 1.0) < 1e-12
