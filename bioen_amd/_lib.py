@@ -290,8 +290,8 @@ class Context(object):
                                              ptr(sc) if sc is not None else None))
 
     def set_direction_mode(self, mode):
-        """'auto' (two-loop on one GPU, Gram form when sharded), 'twoloop' or 'gram'
-        (see include/bioen_hip.h: bioen_hip_ctx_set_direction_mode)."""
+        """'auto' (= 'gram'), 'twoloop' (liblbfgs' literal order of operations on the vectors) or
+        'gram' (see include/bioen_hip.h: bioen_hip_ctx_set_direction_mode)."""
         code = {"auto": 0, "twoloop": 1, "gram": 2}[mode]
         check(lib().bioen_hip_ctx_set_direction_mode(self._h, code))
 

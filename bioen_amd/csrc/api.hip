@@ -393,7 +393,7 @@ struct LogwBatchEngine {
     // issued together.  A problem with a shorter history starts later, so that all of them
     // finish in the same launch (one X_DGI exchange for everybody).
     bool use_gram() const {
-        return c->direction_mode == 2 || (c->direction_mode == 0 && c->world > 1);
+        return c->direction_mode != 1;   // auto = Gram form
     }
 
     // Gram form (see kernels.hpp: GramArgs): 3 launches and one exchange for all accepting problems

@@ -165,7 +165,7 @@ struct bioen_hip_ctx {
     double* part = nullptr;          // kMaxBatch * P_COUNT * kMaxPartials
     double* scal = nullptr;          // kMaxBatch * kScalStride
     double* gram = nullptr;          // kMaxBatch * kGramStride
-    int direction_mode = 0;          // 0 auto (two-loop on one GPU, Gram form when sharded), 1 two-loop, 2 Gram
+    int direction_mode = 0;          // 0 auto (= Gram form), 1 two-loop on the vectors, 2 Gram form
     double* host_scal = nullptr;     // pinned mirror
 
     bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)

@@ -136,7 +136,8 @@ int bioen_hip_ctx_set_affine(bioen_hip_ctx* ctx, const double* row_offset, const
  *      inner products: one sweep commits (s, y) and yields all 39 new products, one sweep forms
  *      d -- half the vector traffic and ONE reduction stage instead of 14 (what matters when
  *      every stage is an all-gather between GPUs).  Mathematically identical; rounding differs;
- *   0  auto: 1 on a single GPU, 2 on a structure-sharded context (default). */
+ *   0  auto (default): 2.  Measured on one MI355X, same process: N = 1e6 x M = 1024 8-theta series
+ *      1.54 s vs 1.62-1.68 s; N = 1e5 x M = 256 single theta 176 vs 200 us per iteration. */
 int bioen_hip_ctx_set_direction_mode(bioen_hip_ctx* ctx, int mode);
 int bioen_hip_synchronize(bioen_hip_ctx* ctx);
 

@@ -278,8 +278,11 @@ def test_batched_series_with_failing_and_trivial_members(hip):
 def test_gram_direction_matches_two_loop(hip, name):
     d = load_golden(name)
     with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        ctx.set_direction_mode("twoloop")
         ref_def = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
         ref_tight = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_TIGHT)
+        tl_batch = ctx.opt_lbfgs_logw_batch([30.0, 3.0, 300.0], d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=8)
+        tl_single = [ctx.opt_lbfgs_logw(d["GInit"], d["G"], th, LBFGS_DEFAULTS) for th in (30.0, 3.0, 300.0)]
         ctx.set_direction_mode("gram")
         g_def = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
         g_tight = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_TIGHT)
@@ -288,6 +291,8 @@ def test_gram_direction_matches_two_loop(hip, name):
         batch = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=8)
         singles = [ctx.opt_lbfgs_logw(d["GInit"], d["G"], th, LBFGS_DEFAULTS) for th in thetas]
         ctx.set_direction_mode("auto")
+    for i, sgl in enumerate(tl_single):   # batched == single in the two-loop mode
+        assert tl_batch[2][i].fmin == sgl[2].fmin and np.array_equal(tl_batch[0][i], sgl[0])
     # deterministic, and batched == single also in this mode
     assert again[2].fmin == g_def[2].fmin and np.array_equal(again[0], g_def[0])
     for i, sgl in enumerate(singles):
