@@ -305,8 +305,7 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     launch_fwd_partial(c, r.n, w);         // A4: this rank's share of ybar_a = yTilde . w_a   [matrix pass 1]
     launch_fwd_rows_local(c, r.n);
     if ((rc = exchange(c, X_YBAR, (size_t)c->mp * r.n))) return rc;
-    launch_rows_combine(c, r);             //     ybar, r, chi^2, ybar . r (identical on every rank)
-    launch_logw_scalars(c, r);             // A5: f
+    launch_rows_combine(c, r, true);       //     ybar, r, chi^2, ybar . r, A5: f (identical on every rank)
     if (with_grad) {
         MVec8 out{};
         for (int a = 0; a < r.n; ++a) out.p[a] = r.a[a];
@@ -349,7 +348,7 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const R
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
     launch_fwd_partial(c, fr.n, v);           // F2: ybar                         [matrix pass 2]
     launch_fwd_rows_local(c, fr.n);
-    launch_rows_combine(c, r);
+    launch_rows_combine(c, r, false);
     launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
         MVec8 out{};
@@ -1389,7 +1388,7 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);
     launch_fwd_rows_local(c, 1);
-    launch_rows_combine(c, r);
+    launch_rows_combine(c, r, false);
     launch_forces_scalars(c, make_forces_round(c, one, 1, nullptr));   // S_CHI (the KL part is irrelevant here)
     if ((rc = check_launch())) return rc;
     if (yave)   // K = 1: the compact layout is the plain M-vector

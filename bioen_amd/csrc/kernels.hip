@@ -261,15 +261,19 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restr
 // keeps the RAW Y w, which is what the centred passes subtract: the offset cancels in
 // sum_i r_i (yTilde_eff_ik - ybar_eff_i) = sum_i (r_i sc_i) (Y_ik - (Y w)_i), so the adjoint's
 // operand r_c is stored pre-multiplied by sc_i.  (off, sc) = (0, 1): the plain model, same bits.
+// One block per problem (M is a few thousand rows at most in BioEn's use), so the block also
+// finishes the sums: LOGW: f = theta (P - log s + log s0) + 0.5 sum r^2  (c_bioen_kernels_logw.c:124-147)
+// lands in scal[S_F] without a further launch; forces: partial 0 feeds k_forces_scalars.
+template <bool LOGW>
 __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, const double* __restrict__ YT,
                                                          const double* __restrict__ row_offset,
                                                          const double* __restrict__ row_scale,
                                                          double* __restrict__ ybar_c, double* __restrict__ r_c,
-                                                         MVec8 part) {
+                                                         MVec8 part, Round rd) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     double chi = 0.0, cc = 0.0;
-    for (int row = blockIdx.x * kBlock + threadIdx.x; row < mp; row += gridDim.x * kBlock) {
+    for (int row = threadIdx.x; row < mp; row += kBlock) {
         double s = 0.0;
         for (int r = 0; r < xi.world; ++r) s += xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
         const double sc = row_scale[row];
@@ -283,9 +287,16 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
     chi = block_sum(chi, sh);
     cc = block_sum(cc, sh);
     if (threadIdx.x == 0) {
-        double* pa = part.p[a];
-        pa[(size_t)P_CHI * kMaxPartials + blockIdx.x] = chi;
-        pa[(size_t)P_C * kMaxPartials + blockIdx.x] = cc;
+        if (LOGW) {
+            double* sc = rd.scal[a];
+            sc[S_CHI] = chi;
+            sc[S_C] = cc;
+            sc[S_F] = rd.theta[a] * (sc[S_P] - sc[S_LOGS] + sc[S_LOGS0]) + 0.5 * chi;
+        } else {
+            double* pa = part.p[a];
+            pa[(size_t)P_CHI * kMaxPartials] = chi;
+            pa[(size_t)P_C * kMaxPartials] = cc;
+        }
     }
 }
 
@@ -492,21 +503,6 @@ __global__ __launch_bounds__(kBlock) void k_logsumexp1(const double* __restrict_
     if (threadIdx.x == 0) {
         const double v = mx + log(s);
         for (int a = 0; a < r.n; ++a) r.scal[a][S_LOGS0] = v;
-    }
-}
-
-// f = theta (P - log s + log s0) + 0.5 sum r^2       (c_bioen_kernels_logw.c:124-147)
-__global__ __launch_bounds__(kBlock) void k_logw_scalars(Round r, int np) {
-    __shared__ double sh[kWaves];
-    const int a = blockIdx.y;
-    const double* pa = r.part[a];
-    const double chi = sum_partials(pa + (size_t)P_CHI * kMaxPartials, np, sh);
-    const double c = sum_partials(pa + (size_t)P_C * kMaxPartials, np, sh);
-    if (threadIdx.x == 0) {
-        double* sc = r.scal[a];
-        sc[S_CHI] = chi;
-        sc[S_C] = c;
-        sc[S_F] = r.theta[a] * (sc[S_P] - sc[S_LOGS] + sc[S_LOGS0]) + 0.5 * chi;
     }
 }
 
@@ -821,53 +817,62 @@ __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
 
 // Per problem (one block): finish the 39 sums, update the Gram matrix, run the two-loop recursion
 // (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
+// The 39 sums are dealt to the 4 waves (a wave strides the [rank][block] list of its sum, then a
+// butterfly), the 13x13 matrix lives in LDS while one thread walks the two loops.
 __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
-    __shared__ double sh[kWaves];
     __shared__ double dots[kGramDots];
+    __shared__ double Gs[kBasis * kBasis];
+    __shared__ double coef[kBasis];
+    __shared__ double alpha[kHistory];
     const int a = blockIdx.y;
-    for (int c = 0; c < kGramDots; ++c) {
-        const double v = xsum<kGramDots>(xi, a, c, sh);
-        if (threadIdx.x == 0) dots[c] = v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* G = q.gram[a];
+    for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
+    for (int c = wave; c < kGramDots; c += kWaves) {
+        double s = 0.0;
+        for (int r = 0; r < xi.world; ++r) {
+            const double* p = xi.base + (size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl;
+            for (int k = lane; k < xi.npl; k += 64) s += p[k];
+        }
+        s = wave_sum(s);
+        if (lane == 0) dots[c] = s;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    double* G = q.gram[a];
     const int e = q.end[a], bound = q.bound[a];
     const int rs = e, ry = kHistory + e, rg = 2 * kHistory;
     for (int c = 0; c < kBasis; ++c) {
-        G[rs * kBasis + c] = G[c * kBasis + rs] = dots[c];
-        G[ry * kBasis + c] = G[c * kBasis + ry] = dots[kBasis + c];
+        Gs[rs * kBasis + c] = Gs[c * kBasis + rs] = dots[c];
+        Gs[ry * kBasis + c] = Gs[c * kBasis + ry] = dots[kBasis + c];
     }
-    for (int c = 0; c < kBasis; ++c) G[rg * kBasis + c] = G[c * kBasis + rg] = dots[2 * kBasis + c];
+    for (int c = 0; c < kBasis; ++c) Gs[rg * kBasis + c] = Gs[c * kBasis + rg] = dots[2 * kBasis + c];
+    for (int c = 0; c < kBasis; ++c) {        // the three rows/columns that changed go back to HBM
+        G[rs * kBasis + c] = G[c * kBasis + rs] = Gs[rs * kBasis + c];
+        G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
+        G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
+    }
     // q = -g as coefficients over {S, Y, g}
-    double coef[kBasis];
     for (int c = 0; c < kBasis; ++c) coef[c] = 0.0;
     coef[rg] = -1.0;
-    double alpha[kHistory];
-    int order[kHistory];
-    int j = (e + 1) % kHistory;
-    for (int b = 0; b < bound; ++b) {
-        j = (j + kHistory - 1) % kHistory;
-        order[b] = j;                         // newest -> oldest
-    }
-    for (int b = 0; b < bound; ++b) {         // first loop
-        const int i = order[b];
+    for (int b = 0; b < bound; ++b) {         // first loop, newest -> oldest
+        const int i = (e + kHistory - b) % kHistory;
         double sq = 0.0;
-        for (int c = 0; c < kBasis; ++c) sq = fma(coef[c], G[i * kBasis + c], sq);
-        alpha[i] = sq / G[(kHistory + i) * kBasis + i];
-        coef[kHistory + i] -= alpha[i];
+        for (int c = 0; c < kBasis; ++c) sq = fma(coef[c], Gs[i * kBasis + c], sq);
+        const double al = sq / Gs[(kHistory + i) * kBasis + i];
+        alpha[i] = al;
+        coef[kHistory + i] -= al;
     }
-    const double scale = G[ry * kBasis + rs] / G[ry * kBasis + ry];   // ys / yy of the newest pair
+    const double scale = Gs[ry * kBasis + rs] / Gs[ry * kBasis + ry];   // ys / yy of the newest pair
     for (int c = 0; c < kBasis; ++c) coef[c] *= scale;
-    for (int b = bound - 1; b >= 0; --b) {    // second loop
-        const int i = order[b];
+    for (int b = bound - 1; b >= 0; --b) {    // second loop, oldest -> newest
+        const int i = (e + kHistory - b) % kHistory;
         double yq = 0.0;
-        for (int c = 0; c < kBasis; ++c) yq = fma(coef[c], G[(kHistory + i) * kBasis + c], yq);
-        const double beta = yq / G[(kHistory + i) * kBasis + i];
+        for (int c = 0; c < kBasis; ++c) yq = fma(coef[c], Gs[(kHistory + i) * kBasis + c], yq);
+        const double beta = yq / Gs[(kHistory + i) * kBasis + i];
         coef[i] += alpha[i] - beta;
     }
     double dg = 0.0;
-    for (int c = 0; c < kBasis; ++c) dg = fma(coef[c], G[rg * kBasis + c], dg);
+    for (int c = 0; c < kBasis; ++c) dg = fma(coef[c], Gs[rg * kBasis + c], dg);
     for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = coef[c];
     q.scal[a][S_DGINIT] = dg;
 }
@@ -1032,17 +1037,19 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K) {
                        c->fwd_ctiles, c->mp, K, make_xch(c, X_YBAR, c->mp * K));
 }
 
-int combine_grid(const bioen_hip_ctx* c) {
-    int b = (c->mp + kBlock - 1) / kBlock;
-    return b > kMaxPartials ? kMaxPartials : b;
-}
+int combine_grid(const bioen_hip_ctx*) { return 1; }
 
-void launch_rows_combine(bioen_hip_ctx* c, const Round& r) {
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw) {
     MVec8 part;
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
-    hipLaunchKernelGGL(k_rows_combine, dim3(combine_grid(c), r.n), dim3(kBlock), 0, c->stream,
-                       make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale, c->ybar_c,
-                       c->r_c, part);
+    if (logw)
+        hipLaunchKernelGGL(k_rows_combine<true>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
+                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           c->ybar_c, c->r_c, part, r);
+    else
+        hipLaunchKernelGGL(k_rows_combine<false>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
+                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           c->ybar_c, c->r_c, part, r);
 }
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K) {
@@ -1104,10 +1111,6 @@ void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
 
 void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
     hipLaunchKernelGGL(k_logsumexp1, dim3(1), dim3(kBlock), 0, c->stream, c->fixed, c->n, r);
-}
-
-void launch_logw_scalars(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, combine_grid(c));
 }
 
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {

@@ -45,7 +45,7 @@ void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred = f
 // reduce the column tiles -> this rank's share of ybar in its X_YBAR segment   [exchange X_YBAR]
 void launch_fwd_rows_local(bioen_hip_ctx* c, int K);
 // add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
-void launch_rows_combine(bioen_hip_ctx* c, const Round& r);
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw);   // logw: also chi^2, c, f -> scal
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K);
@@ -58,7 +58,6 @@ void launch_max(bioen_hip_ctx* c, const Round& r);          // block maxima of x
 void launch_logw_exp(bioen_hip_ctx* c, const Round& r);     // e = exp(x - max) -> w ; partial sums
 void launch_logw_norm(bioen_hip_ctx* c, const Round& r);    // w /= S ; log s, P
 void launch_logw_logs0(bioen_hip_ctx* c, const Round& r);   // scal[S_LOGS0] = log sum exp(fixed)
-void launch_logw_scalars(bioen_hip_ctx* c, const Round& r); // chi^2, c, f
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r);    // gradient epilogue + g.d, g.g, x.x
 void launch_finish_eval(bioen_hip_ctx* c, const Round& r);  // scal[S_DG], S_GG, S_XX
 void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal);   // scal[S_DGINIT] <- X_DGI
