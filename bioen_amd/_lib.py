@@ -25,6 +25,12 @@ class LbfgsConfig(C.Structure):
                 ("max_linesearch", C.c_int)]
 
 
+class GslConfig(C.Structure):
+    # field order = reference gsl_config_params (c_bioen_common.h:62-67)
+    _fields_ = [("step_size", C.c_double), ("tol", C.c_double), ("max_iterations", C.c_int),
+                ("algorithm", C.c_int)]
+
+
 class VisualParams(C.Structure):
     # reference visual_params (c_bioen_common.h:89-92)
     _fields_ = [("debug", C.c_size_t), ("verbose", C.c_size_t)]
@@ -83,6 +89,12 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_gsl_strerror": (C.c_char_p, [C.c_int]),
+    "bioen_hip_opt_gsl_logw": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(GslConfig), C.POINTER(VisualParams),
+                                         dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_opt_gsl_forces": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(GslConfig), C.POINTER(VisualParams),
+                                           dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_selftest_multimin": (C.c_int, [C.c_int, C.c_int, dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_selftest_lbfgs": (C.c_int, [C.c_int, C.c_int, dp, C.POINTER(LbfgsConfig), dp, C.POINTER(OptResult)]),
     "bioen_hip_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
@@ -158,6 +170,29 @@ def selftest_lbfgs(kind, x0, params):
     out = np.empty_like(x0)
     info = OptResult()
     check(lib().bioen_hip_selftest_lbfgs(int(kind), x0.size, ptr(x0), C.byref(cfg), ptr(out), C.byref(info)))
+    return out, info
+
+
+GSL_ALGORITHMS = {"conjugate_fr": 0, "conjugate_pr": 1, "bfgs2": 2, "bfgs": 3, "steepest_descent": 4}
+
+
+def gsl_config(algorithm, params):
+    """algorithm: id 0..4 or one of GSL_ALGORITHMS; params: step_size, tol, max_iterations"""
+    c = GslConfig()
+    c.step_size, c.tol = float(params["step_size"]), float(params["tol"])
+    c.max_iterations = int(params["max_iterations"])
+    c.algorithm = GSL_ALGORITHMS[algorithm] if isinstance(algorithm, str) else int(algorithm)
+    return c
+
+
+def selftest_multimin(algorithm, kind, x0):
+    """GSL's multimin test programme on the library's minimizers (host vectors, no GPU).
+    -> (x, OptResult); OptResult.lbfgs_code = GSL status, .reserved = gradient evaluations"""
+    x0 = as_f64(x0).ravel()
+    out = np.empty_like(x0)
+    info = OptResult()
+    alg = GSL_ALGORITHMS[algorithm] if isinstance(algorithm, str) else int(algorithm)
+    check(lib().bioen_hip_selftest_multimin(alg, int(kind), ptr(x0), ptr(out), C.byref(info)))
     return out, info
 
 
@@ -325,6 +360,19 @@ class Context(object):
                                              ptr(res), ptr(w) if want_weights else None, C.byref(info)))
         return res, w, info
 
+    def opt_gsl_logw(self, g0, G, theta, algorithm, params, verbose=False, debug=False, want_weights=True):
+        """GSL-style minimizer (conjugate_fr/pr, bfgs2, bfgs, steepest_descent) with all vectors in HBM.
+        -> (gopt, w or None, OptResult with the GSL status in .lbfgs_code)"""
+        g0, G = self._nvec(g0, "g0"), self._nvec(G, "G")
+        cfg = gsl_config(algorithm, params)
+        vis = VisualParams(int(bool(debug)), int(bool(verbose)))
+        res = np.empty(self.n)
+        w = np.empty(self.n) if want_weights else None
+        info = OptResult()
+        check(lib().bioen_hip_opt_gsl_logw(self._h, ptr(g0), ptr(G), float(theta), C.byref(cfg), C.byref(vis),
+                                           ptr(res), ptr(w) if want_weights else None, C.byref(info)))
+        return res, w, info
+
     def opt_lbfgs_logw_batch(self, thetas, g0, G, params, max_batch=8, verbose=False, debug=False,
                              want_weights=True):
         """Solve a whole theta series; up to `max_batch` (<= 8) thetas share every pass over yTilde.
@@ -374,6 +422,17 @@ class Context(object):
         info = OptResult()
         check(lib().bioen_hip_opt_lbfgs_forces(self._h, ptr(f0), ptr(w0), float(theta), C.byref(cfg), C.byref(vis),
                                                ptr(res), ptr(w) if want_weights else None, C.byref(info)))
+        return res, w, info
+
+    def opt_gsl_forces(self, forces0, w0, theta, algorithm, params, verbose=False, debug=False, want_weights=True):
+        f0, w0 = self._mvec(forces0, "forces0"), self._nvec(w0, "w0")
+        cfg = gsl_config(algorithm, params)
+        vis = VisualParams(int(bool(debug)), int(bool(verbose)))
+        res = np.empty(self.m)
+        w = np.empty(self.n) if want_weights else None
+        info = OptResult()
+        check(lib().bioen_hip_opt_gsl_forces(self._h, ptr(f0), ptr(w0), float(theta), C.byref(cfg), C.byref(vis),
+                                             ptr(res), ptr(w) if want_weights else None, C.byref(info)))
         return res, w, info
 
     def opt_lbfgs_forces_batch(self, thetas, forces0, w0, params, max_batch=8, verbose=False, debug=False,

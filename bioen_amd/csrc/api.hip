@@ -14,6 +14,7 @@
 #include "ctx.hpp"
 #include "kernels.hpp"
 #include "lbfgs.hpp"
+#include "multimin.hpp"
 
 static_assert(bioen::kHistory == bioen::kLbfgsM, "history length");
 
@@ -294,6 +295,8 @@ static Round make_round(bioen_hip_ctx* c, const int* slots, int k, const double*
 
 // log-weights: r.x must hold the points and P_MAX their block maxima (launch_trial does both).
 // (the caller has produced this rank's block maxima in its X_MAX segment; they are not exchanged)
+static int enqueue_logw_adjoint(bioen_hip_ctx* c, const Round& r);
+
 static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     const size_t g = (size_t)vec_grid(c);
     int rc;
@@ -306,14 +309,19 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     launch_fwd_rows_local(c, r.n);
     if ((rc = exchange(c, X_YBAR, (size_t)c->mp * r.n))) return rc;
     launch_rows_combine(c, r, true);       //     ybar, r, chi^2, ybar . r, A5: f (identical on every rank)
-    if (with_grad) {
-        MVec8 out{};
-        for (int a = 0; a < r.n; ++a) out.p[a] = r.a[a];
-        launch_adj(c, r.n, c->r_c, out, true);   // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
-        launch_logw_grad(c, r);            //     gradient epilogue + g.d, g.g, x.x
-        if ((rc = exchange(c, X_GRAD, 3 * r.n * g))) return rc;
-        launch_finish_eval(c, r);
-    }
+    return with_grad ? enqueue_logw_adjoint(c, r) : 0;
+}
+
+// second half of an evaluation; needs w, scal[S_P] and the compact ybar_c / r_c of the SAME round
+// still in place (nothing else evaluated in between)
+static int enqueue_logw_adjoint(bioen_hip_ctx* c, const Round& r) {
+    int rc;
+    MVec8 out{};
+    for (int a = 0; a < r.n; ++a) out.p[a] = r.a[a];
+    launch_adj(c, r.n, c->r_c, out, true);       // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
+    launch_logw_grad(c, r);                //     gradient epilogue + g.d, g.g, x.x
+    if ((rc = exchange(c, X_GRAD, 3 * r.n * (size_t)vec_grid(c)))) return rc;
+    launch_finish_eval(c, r);
     return 0;
 }
 
@@ -1590,3 +1598,5 @@ int bioen_hip_comm_destroy(bioen_hip_ctx* c) {
 }
 
 }  // extern "C"
+
+#include "api_multimin.inl"

@@ -909,6 +909,89 @@ __global__ __launch_bounds__(kBlock) void k_combine(GramArgs q, int n) {
 }
 
 // ------------------------------------------------------------------------------
+// level-1 algebra on resident N-vectors for the host-driven GSL-style minimizers
+// (multimin.hpp).  Vectors may alias in the read-only positions, hence no __restrict__.
+// All loops run over pairs up to ld/2: the padding is zero in every operand and stays zero.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_vaxpy(double a, const double* x, double* y, int n2) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const d2 xv = *reinterpret_cast<const d2*>(x + 2 * p);
+        d2 yv = *reinterpret_cast<d2*>(y + 2 * p);
+        yv.x += a * xv.x;      // two roundings, as cblas_daxpy compiled without contraction
+        yv.y += a * xv.y;
+        *reinterpret_cast<d2*>(y + 2 * p) = yv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vscal(double a, double* x, int n2) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        d2 v = *reinterpret_cast<d2*>(x + 2 * p);
+        v.x *= a;
+        v.y *= a;
+        *reinterpret_cast<d2*>(x + 2 * p) = v;
+    }
+}
+
+// dx = coef p ; x1 = x + dx      (directional_minimize.c: take_step)
+__global__ __launch_bounds__(kBlock) void k_vstep(const double* x, const double* pv, double coef, double* x1,
+                                                  double* dx, int n2) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const d2 xv = *reinterpret_cast<const d2*>(x + 2 * p);
+        const d2 dv = *reinterpret_cast<const d2*>(pv + 2 * p);
+        const d2 s = {coef * dv.x, coef * dv.y};
+        *reinterpret_cast<d2*>(dx + 2 * p) = s;
+        const d2 o = {xv.x + s.x, xv.y + s.y};
+        *reinterpret_cast<d2*>(x1 + 2 * p) = o;
+    }
+}
+
+// up to 4 inner products in one pass; mode 1: [0] = #(x != y), [1] = max |x|
+__global__ __launch_bounds__(kBlock) void k_vdots(VDotArgs q, int n2, double* part) {
+    __shared__ double sh[kWaves];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < q.k) {
+                const d2 xv = *reinterpret_cast<const d2*>(q.x[k] + 2 * p);
+                const d2 yv = *reinterpret_cast<const d2*>(q.y[k] + 2 * p);
+                if (q.mode == 0) {
+                    acc[k] = fma(xv.x, yv.x, acc[k]);
+                    acc[k] = fma(xv.y, yv.y, acc[k]);
+                } else if (k == 0) {
+                    acc[0] += (xv.x != yv.x ? 1.0 : 0.0) + (xv.y != yv.y ? 1.0 : 0.0);
+                } else {
+                    acc[1] = fmax(acc[1], fmax(fabs(xv.x), fabs(xv.y)));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < q.k) {
+            const double v = (q.mode == 1 && k == 1) ? block_max(acc[k], sh) : block_sum(acc[k], sh);
+            if (threadIdx.x == 0) part[(size_t)k * kMaxPartials + blockIdx.x] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vdots_finish(const double* part, int np, int k, int mode, double* out) {
+    __shared__ double sh[kWaves];
+    for (int q = 0; q < k; ++q) {
+        const double* p = part + (size_t)q * kMaxPartials;
+        double v;
+        if (mode == 1 && q == 1) {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < np; i += kBlock) s = fmax(s, p[i]);
+            v = block_max(s, sh);
+        } else {
+            v = sum_partials(p, np, sh);
+        }
+        if (threadIdx.x == 0) out[q] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------
 // synthetic ensemble generated in HBM (bench): counter-based Box-Muller
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -1177,6 +1260,22 @@ void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
 
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {
     hipLaunchKernelGGL(k_combine, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+}
+
+// ---- level-1 algebra (multimin) -------------------------------------------------------------
+void launch_vaxpy(bioen_hip_ctx* c, double a, const double* x, double* y) {
+    hipLaunchKernelGGL(k_vaxpy, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, y, (int)(c->ld / 2));
+}
+void launch_vscal(bioen_hip_ctx* c, double a, double* x) {
+    hipLaunchKernelGGL(k_vscal, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, (int)(c->ld / 2));
+}
+void launch_vstep(bioen_hip_ctx* c, const double* x, const double* p, double coef, double* x1, double* dx) {
+    hipLaunchKernelGGL(k_vstep, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, x, p, coef, x1, dx, (int)(c->ld / 2));
+}
+void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out) {
+    const int g = vec_grid(c);
+    hipLaunchKernelGGL(k_vdots, dim3(g), dim3(kBlock), 0, c->stream, q, (int)(c->ld / 2), part);
+    hipLaunchKernelGGL(k_vdots_finish, dim3(1), dim3(kBlock), 0, c->stream, part, g, q.k, q.mode, out);
 }
 
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,

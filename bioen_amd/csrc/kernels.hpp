@@ -78,6 +78,18 @@ void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r);
 
+// ---- level-1 algebra on resident N-vectors (GSL-style minimizers, multimin.hpp) ----------
+struct VDotArgs {
+    int k;                 // number of (x, y) pairs, <= 4
+    int mode;              // 0: inner products ; 1: out[0] = #(x0 != y0), out[1] = max |x1|
+    const double* x[4];
+    const double* y[4];
+};
+void launch_vaxpy(bioen_hip_ctx* c, double a, const double* x, double* y);                  // y += a x
+void launch_vscal(bioen_hip_ctx* c, double a, double* x);
+void launch_vstep(bioen_hip_ctx* c, const double* x, const double* p, double coef, double* x1, double* dx);
+void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out);          // out: device, k doubles
+
 // ---- L-BFGS vector kernels (device-resident scalars) -------------------------------
 struct PairArgs {      // s = x - xp ; y = g - gp for the accepting problems
     int n;

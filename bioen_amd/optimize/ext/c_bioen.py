@@ -13,7 +13,11 @@ Differences from the reference, on purpose:
 * ``bioen_log_posterior_logw`` uses its ``G`` argument.  The reference passes the
   *initial* log-weights ``g`` in the ``G`` slot (c_bioen.pyx:279), which is
   invisible in its tests because every fixture has ``GInit == G``.
-* GSL is not part of this build (``library_gsl()`` is False).
+* GSL is not linked.  ``bioen_opt_bfgs_logw`` / ``bioen_opt_bfgs_forces`` run the library's own
+  restatement of the five GSL 2.5 multimin algorithms the reference selects from
+  (``bioen_amd/csrc/multimin.hpp``) on the device objective, so ``library_gsl()`` is True and
+  ``minimizer: gsl`` configurations keep working; iterates agree with a GSL build to rounding,
+  not bit for bit.
 """
 import os
 import weakref
@@ -29,7 +33,7 @@ gsl_enoprog = 27
 gsl_success = [gsl_continue, gsl_enoprog, 0]
 lbfgs_success = [0, 1, 2]
 
-_message_gsl_unavailable = "BioEN optimize was not compiled with GSL."   # c_bioen_error.h:7
+gsl_continue_msg = "Note: GSL might require more iterations, please check the parameters of the minimizer."
 
 
 # ------------------------------------------------------------------------------------
@@ -120,7 +124,8 @@ def get_gsl_method(algorithm):
 
 
 def library_gsl():
-    return False
+    """True: the five GSL minimizers are part of the device library (restated, GSL itself is not linked)."""
+    return True
 
 
 def library_lbfgs():
@@ -148,9 +153,30 @@ def grad_bioen_log_posterior_logw(gPrime, g, G, yTilde, YTilde, theta, caching=F
     return grad
 
 
+def _gsl_finish(func, info):
+    """c_bioen.pyx:432-438: {0, GSL_CONTINUE, GSL_ENOPROG} count as success"""
+    if info.lbfgs_code in gsl_success:
+        if info.lbfgs_code == gsl_continue:
+            print(gsl_continue_msg)
+        return
+    msg = _lib.lib().bioen_hip_gsl_strerror(int(info.lbfgs_code)).decode()
+    raise RuntimeError("{}, GSL return code: {}:{}".format(func, info.lbfgs_code, msg))
+
+
 def bioen_opt_bfgs_logw(g, G, yTilde, YTilde, theta, params):
-    get_gsl_method(params["algorithm"])      # same "unknown algorithm" error as the reference
-    raise RuntimeError("{}, GSL return code: {}:{}".format("bioen_opt_bfgs_logw", -1, _message_gsl_unavailable))
+    """-> (gopt[n], fmin) with params["algorithm"] in {conjugate_fr, conjugate_pr, bfgs2, bfgs,
+    steepest_descent} and params["params"] = {step_size, tol, max_iterations} (c_bioen.pyx:341-438)."""
+    global last_opt_info
+    alg = get_gsl_method(params["algorithm"])      # same "unknown algorithm" error as the reference
+    ctx, cached = _context_for(yTilde, YTilde)
+    try:
+        res, w, info = ctx.opt_gsl_logw(g, G, theta, alg, params["params"], verbose=params.get("verbose", False),
+                                        debug=params.get("debug", False), want_weights=False)
+    finally:
+        _release(ctx, cached)
+    last_opt_info = info
+    _gsl_finish("bioen_opt_bfgs_logw", info)
+    return res, info.fmin
 
 
 def _raise_lbfgs(func, code):
@@ -199,8 +225,19 @@ def grad_bioen_log_posterior_forces(forces, w0, yTilde, YTilde, theta, caching=F
 
 
 def bioen_opt_bfgs_forces(forces, w0, yTilde, YTilde, theta, params):
-    get_gsl_method(params["algorithm"])
-    raise RuntimeError("{}, GSL return code: {}:{}".format("bioen_opt_bfgs_forces", -1, _message_gsl_unavailable))
+    """-> (forces_opt[m], fmin); c_bioen.pyx:620-716"""
+    global last_opt_info
+    alg = get_gsl_method(params["algorithm"])
+    ctx, cached = _context_for(yTilde, YTilde)
+    try:
+        res, w, info = ctx.opt_gsl_forces(forces, w0, theta, alg, params["params"],
+                                          verbose=params.get("verbose", False), debug=params.get("debug", False),
+                                          want_weights=False)
+    finally:
+        _release(ctx, cached)
+    last_opt_info = info
+    _gsl_finish("bioen_opt_bfgs_forces", info)
+    return res, info.fmin
 
 
 def bioen_opt_lbfgs_forces(forces, w0, yTilde, YTilde, theta, params):

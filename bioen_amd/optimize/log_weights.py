@@ -213,7 +213,7 @@ def find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
     Returns (wopt (n,1), yopt (m,), gopt (n,), fmin_initial, fmin_final).
     cfg comes from ``minimize.Parameters``; minimizer "lbfgs"/"liblbfgs" runs the
     device-resident L-BFGS, "scipy" drives the device (or, with
-    use_c_functions False, the numpy) objective from the host; "gsl" is not built."""
+    use_c_functions False, the numpy) objective from the host; "gsl": the library's GSL-style minimizers with all vectors in HBM."""
     check_params_logweights(GInit, G, y, yTilde, YTilde)
 
     caching = cfg["cache_ytilde_transposed"]

@@ -51,6 +51,16 @@ typedef struct bioen_lbfgs_config {
     int max_linesearch;
 } bioen_lbfgs_config;
 
+/* Same fields, same order as the reference's gsl_config_params (c_bioen_common.h:62-67);
+ * algorithm ids of c_bioen_common.h:28-34: 0 conjugate_fr, 1 conjugate_pr, 2 vector_bfgs2,
+ * 3 vector_bfgs, 4 steepest_descent. */
+typedef struct bioen_gsl_config {
+    double step_size;
+    double tol;
+    int max_iterations;
+    int algorithm;
+} bioen_gsl_config;
+
 /* reference visual_params, c_bioen_common.h:89-92 */
 typedef struct bioen_visual_params {
     size_t debug;
@@ -63,7 +73,7 @@ typedef struct bioen_opt_result {
     double chi2;          /* 0.5 * |yTilde w - YTilde|^2 at the optimum          */
     double kl;            /* KL(w || w0) = -S at the optimum (S: utils.py:83-106) */
     double seconds;       /* wall time inside the minimiser (device-synchronised) */
-    int lbfgs_code;       /* liblbfgs status                                      */
+    int lbfgs_code;       /* liblbfgs status (GSL status for the opt_gsl_* entry points) */
     int iterations;       /* progress-callback count (accepted line searches)     */
     int evaluations;      /* objective+gradient evaluations                       */
     int reserved;
@@ -214,6 +224,30 @@ int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
  * (lbfgs.c:245-641, 645-734, 812-1296) without a device. */
 int bioen_hip_selftest_lbfgs(int kind, int n, const double* x0, const bioen_lbfgs_config* config,
                              double* x_out, bioen_opt_result* info);
+
+/* ---- GSL-style minimizers on the device objective -----------------------------------------
+ * Replace _opt_bfgs_logw (c_bioen_kernels_logw.c:366-509) and _opt_bfgs_forces
+ * (c_bioen_kernels_forces.c), i.e. gsl_multimin_fdfminimizer_{conjugate_fr, conjugate_pr,
+ * vector_bfgs2, vector_bfgs, steepest_descent} (GSL 2.5) driven by the reference's loop with its
+ * max-norm gradient test (c_bioen_common.c:112-138).  GSL is not linked: the five algorithms are
+ * restated in bioen_amd/csrc/multimin.hpp.  Log-weights: variables, gradient and all work vectors
+ * stay in HBM; forces: the M variables stay on the host.
+ * info->lbfgs_code carries the GSL status: 0 success, -2 GSL_CONTINUE (iteration budget used),
+ * 27 GSL_ENOPROG, 13 GSL_EBADTOL -- the reference treats {0, -2, 27} as success
+ * (c_bioen.pyx:109-116).  info->iterations = driver iterations, info->evaluations = f + gradient
+ * evaluations.  Unsharded contexts only. */
+const char* bioen_hip_gsl_strerror(int gsl_code);   /* replaces bioen_gsl_error(), c_bioen_error.c:14-20 */
+int bioen_hip_opt_gsl_logw(bioen_hip_ctx* ctx, const double* g0, const double* G, double theta,
+                           const bioen_gsl_config* config, const bioen_visual_params* visual,
+                           double* result, double* w_opt, bioen_opt_result* info);
+int bioen_hip_opt_gsl_forces(bioen_hip_ctx* ctx, const double* forces0, const double* w0, double theta,
+                             const bioen_gsl_config* config, const bioen_visual_params* visual,
+                             double* result, double* w_opt, bioen_opt_result* info);
+/* GSL's own multimin test programme (multimin/test.c:106-160, test_funcs.c) on the SAME minimizer
+ * code with host vectors, no GPU needed: kind 0 Roth, 1 Wood, 2 Rosenbrock, 3 SimpleAbs.
+ * info->lbfgs_code = last status, info->reserved = gradient evaluations. */
+int bioen_hip_selftest_multimin(int algorithm, int kind, const double* x0, double* x_out,
+                                bioen_opt_result* info);
 
 /* ---- theta-sweep gather over RCCL (multi-GPU; one process per GPU) ----------------- */
 /* rank 0 obtains the 128-byte ncclUniqueId; the host side ships it to the other ranks */

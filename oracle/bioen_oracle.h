@@ -78,6 +78,38 @@ int oracle_opt_lbfgs_forces(int m, int n, const double* yTilde, const double* YT
 int oracle_selftest_lbfgs(int kind, int n, const double* x0, const oracle_lbfgs_config* cfg,
                           double* x_out, double* fmin, oracle_lbfgs_stats* stats);
 
+/* ---- GSL multimin drivers (oracle/multimin_oracle.c) --------------------------------------
+ * same fields, same order as the reference's gsl_config_params (c_bioen_common.h:62-67);
+ * algorithm numbering of c_bioen_common.h:28-34 (0 conjugate_fr, 1 conjugate_pr, 2 vector_bfgs2,
+ * 3 vector_bfgs, 4 steepest_descent). */
+typedef struct oracle_gsl_config {
+    double step_size;
+    double tol;
+    int max_iterations;
+    int algorithm;
+} oracle_gsl_config;
+
+typedef struct oracle_gsl_stats {
+    int iterations;
+    int f_evaluations;
+    int g_evaluations;
+} oracle_gsl_stats;
+
+/* The reference's _opt_bfgs_logw / _opt_bfgs_forces (c_bioen_kernels_logw.c:366-509): return the
+ * GSL status (0 success, -2 GSL_CONTINUE = iteration budget used, 27 GSL_ENOPROG, 13 GSL_EBADTOL). */
+int oracle_opt_gsl_logw(int m, int n, const double* yTilde, const double* YTilde, const double* g0,
+                        const double* G, double theta, const oracle_gsl_config* cfg, double* result, double* fmin,
+                        oracle_gsl_stats* stats);
+int oracle_opt_gsl_forces(int m, int n, const double* yTilde, const double* YTilde, const double* forces0,
+                          const double* w0, double theta, const oracle_gsl_config* cfg, double* result,
+                          double* fmin, oracle_gsl_stats* stats);
+
+/* GSL's own multimin test programme (multimin/test.c, test_funcs.c): kind 0 Roth, 1 Wood,
+ * 2 Rosenbrock, 3 SimpleAbs, run exactly as test_fdf does. */
+int oracle_multimin_testfn_dim(int kind);
+int oracle_selftest_multimin(int algorithm, int kind, const double* x0, double* x_out, double* fmin,
+                             oracle_gsl_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

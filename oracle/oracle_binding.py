@@ -30,6 +30,18 @@ class lbfgs_stats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("evaluations", C.c_int)]
 
 
+class gsl_config(C.Structure):
+    _fields_ = [("step_size", C.c_double), ("tol", C.c_double), ("max_iterations", C.c_int),
+                ("algorithm", C.c_int)]
+
+
+class gsl_stats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("f_evaluations", C.c_int), ("g_evaluations", C.c_int)]
+
+
+GSL_ALGORITHMS = {"conjugate_fr": 0, "conjugate_pr": 1, "bfgs2": 2, "bfgs": 3, "steepest_descent": 4}
+GSL_DEFAULTS = dict(algorithm="bfgs2", step_size=0.01, tol=0.001, max_iterations=5000)   # bioen_optimize.yaml
+
 LBFGS_DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5,
                       gtol=0.9, wolfe=0.9, past=10, max_linesearch=100)
 
@@ -65,6 +77,15 @@ def lib():
         L.oracle_selftest_lbfgs.restype = C.c_int
         L.oracle_selftest_lbfgs.argtypes = [C.c_int, C.c_int, dp, C.POINTER(lbfgs_config), dp, dp,
                                             C.POINTER(lbfgs_stats)]
+        for name in ("oracle_opt_gsl_logw", "oracle_opt_gsl_forces"):
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, C.c_double, C.POINTER(gsl_config), dp, dp,
+                           C.POINTER(gsl_stats)]
+        L.oracle_multimin_testfn_dim.restype = C.c_int
+        L.oracle_multimin_testfn_dim.argtypes = [C.c_int]
+        L.oracle_selftest_multimin.restype = C.c_int
+        L.oracle_selftest_multimin.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.POINTER(gsl_stats)]
         _lib = L
     return _lib
 
@@ -158,3 +179,51 @@ def selftest_lbfgs(kind, x0, params=None):
     cfg = _cfg(params)
     code = lib().oracle_selftest_lbfgs(int(kind), x0.size, _p(x0), C.byref(cfg), _p(out), C.byref(fmin), C.byref(st))
     return out, fmin.value, code, st.iterations, st.evaluations
+
+
+def _gsl_cfg(params):
+    full = dict(GSL_DEFAULTS)
+    full.update(params or {})
+    alg = full["algorithm"]
+    c = gsl_config()
+    c.step_size, c.tol = float(full["step_size"]), float(full["tol"])
+    c.max_iterations = int(full["max_iterations"])
+    c.algorithm = GSL_ALGORITHMS[alg] if isinstance(alg, str) else int(alg)
+    return c
+
+
+def opt_gsl_logw(g0, G, yTilde, YTilde, theta, params=None):
+    """-> (gopt, fmin, gsl status, iterations, (f evaluations, gradient evaluations))"""
+    g0, G, yTilde, YTilde = _a(g0).ravel(), _a(G).ravel(), _a(yTilde), _a(YTilde).ravel()
+    m, n = yTilde.shape
+    res = np.empty(n); fmin = C.c_double(0.0); st = gsl_stats()
+    cfg = _gsl_cfg(params)
+    code = lib().oracle_opt_gsl_logw(m, n, _p(yTilde), _p(YTilde), _p(g0), _p(G), float(theta), C.byref(cfg),
+                                     _p(res), C.byref(fmin), C.byref(st))
+    return res, fmin.value, code, st.iterations, (st.f_evaluations, st.g_evaluations)
+
+
+def opt_gsl_forces(f0, w0, yTilde, YTilde, theta, params=None):
+    f0, w0, yTilde, YTilde = _a(f0).ravel(), _a(w0).ravel(), _a(yTilde), _a(YTilde).ravel()
+    m, n = yTilde.shape
+    res = np.empty(m); fmin = C.c_double(0.0); st = gsl_stats()
+    cfg = _gsl_cfg(params)
+    code = lib().oracle_opt_gsl_forces(m, n, _p(yTilde), _p(YTilde), _p(f0), _p(w0), float(theta), C.byref(cfg),
+                                       _p(res), C.byref(fmin), C.byref(st))
+    return res, fmin.value, code, st.iterations, (st.f_evaluations, st.g_evaluations)
+
+
+MULTIMIN_TESTS = {   # multimin/test_funcs.c start points
+    "Roth": (0, [4.5, 3.5]), "Wood": (1, [-3.0, -1.0, -3.0, -1.0]), "Rosenbrock": (2, [-1.2, 1.0]),
+    "Rosenbrock1": (2, [1.0, 1.0]), "SimpleAbs": (3, [1.0, 2.0]),
+}
+
+
+def selftest_multimin(algorithm, kind, x0):
+    """GSL's test_fdf protocol -> (x, f, status, iterations, (f evaluations, gradient evaluations))"""
+    x0 = _a(x0).ravel()
+    assert x0.size == lib().oracle_multimin_testfn_dim(int(kind))
+    out = np.empty_like(x0); fmin = C.c_double(0.0); st = gsl_stats()
+    alg = GSL_ALGORITHMS[algorithm] if isinstance(algorithm, str) else int(algorithm)
+    code = lib().oracle_selftest_multimin(alg, int(kind), _p(x0), _p(out), C.byref(fmin), C.byref(st))
+    return out, fmin.value, code, st.iterations, (st.f_evaluations, st.g_evaluations)

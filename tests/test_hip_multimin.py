@@ -1,0 +1,170 @@
+"""GPU tests of the GSL-style minimizers: the log-weights path with all vectors
+resident in HBM, the forces path with host vectors on the device objective, through the C ABI and
+through the bioen.optimize-compatible API (minimizer 'gsl'), against the oracle's restatement."""
+import numpy as np
+import pytest
+
+from conftest import LOGW_GOLDEN, FORCES_GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+ALGS = ["conjugate_fr", "conjugate_pr", "bfgs2", "bfgs", "steepest_descent"]
+P = dict(step_size=0.01, tol=0.001, max_iterations=5000)       # bioen_optimize.yaml, section gsl
+GSL_OK = (0, -2, 27)                                           # c_bioen.pyx:109-116
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def _both(d, alg, ctx, params=P):
+    from oracle import oracle_binding as O
+    if "forces_init" in d:
+        x, w, info = ctx.opt_gsl_forces(d["forces_init"], d["w0"], d["theta"], alg, params)
+        xo, fo, so, ito, evo = O.opt_gsl_forces(d["forces_init"], d["w0"], d["yTilde"], d["YTilde"], d["theta"],
+                                                dict(params, algorithm=alg))
+        wo = O.forces_weights(xo, d["w0"], d["yTilde"])
+    else:
+        x, w, info = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], alg, params)
+        xo, fo, so, ito, evo = O.opt_gsl_logw(d["GInit"], d["G"], d["yTilde"], d["YTilde"], d["theta"],
+                                              dict(params, algorithm=alg))
+        wo = O.logw_weights(xo)[0]
+    return (x, w, info), (xo, wo, fo, so, ito, sum(evo))
+
+
+@pytest.mark.parametrize("name", LOGW_GOLDEN + FORCES_GOLDEN)
+def test_bfgs2_takes_the_oracle_path(name):
+    """The reference's default GSL algorithm (bioen_optimize.yaml: vector_bfgs2): same status, same
+    iteration and evaluation counts as the CPU restatement, optimum equal to rounding."""
+    import bioen_amd
+    d = load_golden(name)
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+        (x, w, info), (xo, wo, fo, so, ito, evo) = _both(d, "bfgs2", ctx)
+    assert (info.lbfgs_code, info.iterations, info.evaluations) == (so, ito, evo)
+    assert rel(info.fmin, fo) < 1e-8
+    assert abs(w.sum() - 1.0) < 1e-12
+    assert np.abs(w - wo).max() <= 1e-5 * wo.max() or "deer_test_logw" in name   # flat valley, see below
+    if "deer_test_logw" in name:      # 10 structures, 808 observables: weights differ where f does not
+        assert np.abs(w - wo).max() <= 2e-3 * wo.max()
+
+
+@pytest.mark.parametrize("alg", [a for a in ALGS if a != "bfgs2"])
+@pytest.mark.parametrize("name", LOGW_GOLDEN + FORCES_GOLDEN)
+def test_other_gsl_algorithms_match_oracle(name, alg):
+    """Conjugate gradients, vector_bfgs and steepest descent run for hundreds of iterations on the
+    harder fixtures, where rounding differences between a GPU and a CPU objective move the path
+    (both stop on the same max|grad| < 1e-3 rule): short runs must agree exactly, long runs within
+    the width of that stopping rule and never below the converged optimum."""
+    import bioen_amd
+    d = load_golden(name)
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+        (x, w, info), (xo, wo, fo, so, ito, evo) = _both(d, alg, ctx)
+    assert info.lbfgs_code in GSL_OK and so in GSL_OK
+    if ito <= 30:
+        assert (info.lbfgs_code, info.iterations) == (so, ito)
+        assert rel(info.fmin, fo) < 1e-9
+    else:
+        assert rel(info.fmin, fo) < 5e-3
+    assert info.fmin <= float(d["f_init"])
+    assert abs(w.sum() - 1.0) < 1e-12
+
+
+def test_line_search_reuses_the_forward_pass():
+    """GSL's Fletcher search asks f(alpha) and then f'(alpha) at the same point; the device
+    backend answers the second call with the adjoint pass alone.  Visible as matrix passes:
+    fewer forward launches than f + gradient evaluations."""
+    import bioen_amd
+    d = load_golden("synth_logw_M64xN2000.npz")
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+        ctx.kernel_stats_enable(True)
+        ctx.kernel_stats_reset()
+        x, w, info = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "bfgs2", P)
+        st = ctx.kernel_stats()
+    assert info.lbfgs_code in GSL_OK
+    fwd, adj = st["forward"]["launches"], st["adjoint"]["launches"]
+    assert adj < fwd < info.evaluations + 2       # +1: the final pass that leaves w in place
+    assert fwd + adj < 2 * info.evaluations
+
+
+@pytest.fixture(scope="module")
+def optimize():
+    import bioen_amd
+    assert bioen_amd.device_count() >= 1
+    from bioen_amd import optimize
+    yield optimize
+    from bioen_amd.optimize.ext import c_bioen
+    c_bioen.clear_cache()
+
+
+REF_LOGW = ["ref_data_potra_part_2_logw_M205xN10.npz", "ref_data_16x15.npz", "ref_data_deer_test_logw_M808xN10.npz"]
+REF_FORCES = ["ref_data_deer_test_forces_M808xN10.npz", "ref_data_forces_M64xN64.npz"]
+tol = 5.e-14        # test_find_opt_analytical_grad_logw.py:9
+tol_min = 1.e-1     # :10
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("name", REF_LOGW)
+def test_find_optimum_logw_gsl(optimize, name, alg):
+    """test_find_opt_analytical_grad_logw.py:43-44,60-120 with exp['GSL']"""
+    assert optimize.util.library_gsl()
+    d = load_golden(name)
+    params = optimize.minimize.Parameters("gsl")
+    params["cache_ytilde_transposed"] = "False"
+    params["use_c_functions"] = True
+    params["algorithm"] = alg
+    params["verbose"] = False
+    YT = d["YTilde"].reshape(1, -1)
+    wopt, yopt, gopt, fmin_ini, fmin_fin = optimize.log_weights.find_optimum(d["GInit"], d["G"], d["y"], d["yTilde"],
+                                                                            YT, d["theta"], params)
+    assert optimize.util.compute_relative_difference_for_values(fmin_fin, float(d["ref_fmin_scipy_bfgs"])) < tol_min
+    re_fmin = optimize.log_weights.bioen_log_posterior(gopt, d["GInit"], d["G"], d["yTilde"], YT, d["theta"], use_c=True)
+    assert optimize.util.compute_relative_difference_for_values(fmin_fin, re_fmin) < tol
+    assert wopt.shape == (d["G"].shape[0], 1) and abs(wopt.sum() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("name", REF_FORCES)
+def test_find_optimum_forces_gsl(optimize, name, alg):
+    d = load_golden(name)
+    params = optimize.minimize.Parameters("gsl")
+    params.update(cache_ytilde_transposed="False", use_c_functions=True, algorithm=alg, verbose=False)
+    YT = d["YTilde"].reshape(1, -1)
+    out = optimize.forces.find_optimum(d["forces_init"], d["w0"], d["y"], d["yTilde"], YT, d["theta"], params)
+    wopt, yopt, forces_opt, fmin_ini, fmin_fin, chiSqr, S = out
+    assert rel(fmin_fin, float(d["ref_fmin_scipy_bfgs"])) < tol_min
+    re_fmin = optimize.forces.bioen_log_posterior(forces_opt, d["w0"], d["y"], d["yTilde"], YT, d["theta"], use_c=True)
+    assert rel(fmin_fin, re_fmin) < 1e-12
+
+
+def test_logw_reproducibility_gsl_bfgs2(optimize):
+    """test_logw_reproducibility.py:14-48 (minimizer gsl, algorithm bfgs2): repeated runs agree to 5e-14."""
+    d = load_golden("ref_data_deer_test_logw_M808xN10.npz")
+    params = optimize.minimize.Parameters("gsl")
+    params["cache_ytilde_transposed"] = True
+    params["use_c_functions"] = True
+    params["algorithm"] = "bfgs2"
+    params["verbose"] = False
+    YT = d["YTilde"].reshape(1, -1)
+    runs = [optimize.log_weights.find_optimum(d["GInit"], d["G"], d["y"], d["yTilde"], YT, d["theta"], params)
+            for _ in range(5)]
+    for r in runs[1:]:
+        assert r[4] == runs[0][4] and np.array_equal(r[2], runs[0][2])      # bitwise, not only 5e-14
+
+
+def test_gsl_error_and_budget_codes(optimize):
+    d = load_golden("ref_data_16x15.npz")
+    YT = d["YTilde"].reshape(1, -1)
+    params = optimize.minimize.Parameters("gsl")
+    params["verbose"] = False
+    params["algorithm"] = "conjugate_fr"
+    params["params"]["tol"] = -1.0
+    with pytest.raises(RuntimeError) as exc:          # GSL_EBADTOL from the stopping test
+        optimize.log_weights.find_optimum(d["GInit"], d["G"], d["y"], d["yTilde"], YT, d["theta"], params)
+    assert "GSL return code: 13" in str(exc.value) and "tolerance" in str(exc.value)
+    params = optimize.minimize.Parameters("gsl")
+    params["verbose"] = False
+    params["params"]["max_iterations"] = 2            # GSL_CONTINUE counts as success (c_bioen.pyx:432-435)
+    out = optimize.log_weights.find_optimum(d["GInit"], d["G"], d["y"], d["yTilde"], YT, d["theta"], params)
+    from bioen_amd.optimize.ext import c_bioen
+    assert c_bioen.last_opt_info.lbfgs_code == -2 and c_bioen.last_opt_info.iterations == 2
+    assert out[4] < out[3]

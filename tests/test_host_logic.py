@@ -44,7 +44,7 @@ def test_util_relative_differences():
     d, idx = util.compute_relative_difference_for_arrays(np.array([1.0, 2.2, 0.5]), np.array([1.0, 2.0, 0.0]))
     assert d == pytest.approx(0.1) and idx == 1
     assert util.compute_relative_difference_for_arrays(np.ones(3), np.zeros(3)) == (0.0, 0)
-    assert util.library_lbfgs() is True and util.library_gsl() is False
+    assert util.library_lbfgs() is True and util.library_gsl() is True
 
 
 def test_fast_openmp_flag_roundtrip():
@@ -90,6 +90,7 @@ def test_gsl_and_unknown_minimizer_errors():
     d = load_golden("ref_data_16x15.npz")
     cfg = minimize.Parameters("gsl")
     cfg["verbose"] = False
+    cfg["algorithm"] = "TEST_INVALID"               # rejected before anything touches the device
     with pytest.raises(RuntimeError) as e:
         c_bioen.bioen_opt_bfgs_logw(d["GInit"].ravel(), d["G"], d["yTilde"], d["YTilde"], d["theta"], cfg)
     assert "GSL return code" in str(e.value)
