@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -54,6 +55,7 @@ static int dalloc_zero(double** p, size_t count, hipStream_t s) {
 static void choose_fwd_tiling(bioen_hip_ctx* c) {
     const int total_steps = (int)(c->ld / 128);
     const int row_blocks = c->mp / kRowAlign;
+    // ~6144 blocks: 3072 and 2048 measured within noise (+-1.5 %) of it on N = 1e6 x M = 1024
     int want_tiles = (6144 + row_blocks - 1) / row_blocks;
     want_tiles = std::max(1, std::min(want_tiles, total_steps));
     int spt = (total_steps + want_tiles - 1) / want_tiles;

@@ -183,11 +183,46 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
     const double* ybp = ybar_c + (size_t)row0 * K;   // [r*K + k], wave-uniform
 
     size_t off = col;
-    for (; s + STEPS <= s_end; s += STEPS) {
-        d2 y[STEPS][R];
-        d2 vv[STEPS][K];
+    if constexpr (STEPS == 0) {
+        // software pipeline: the NEXT step's rows of Y are in flight while this step's K x R
+        // products are formed (two register sets, no moves)
+        d2 ya[R], yb2[R];
+        d2 vv[K];
+        auto loadY = [&](d2* y, int step) {
 #pragma unroll
-        for (int t = 0; t < STEPS; ++t) {
+            for (int r = 0; r < R; ++r) y[r] = ldg2<NT>(yp + (size_t)r * ld + (size_t)step * 128);
+        };
+        auto work = [&](const d2* y, int step) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) vv[k] = *reinterpret_cast<const d2*>(v.p[k] + off + (size_t)step * 128);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double yb = CENTER ? ybp[r * K + k] : 0.0;
+                    acc[k * R + r] = fma(y[r].x - yb, vv[k].x, acc[k * R + r]);
+                    acc[k * R + r] = fma(y[r].y - yb, vv[k].y, acc[k * R + r]);
+                }
+            }
+        };
+        const int nsteps = s_end - s;
+        int t = 0;
+        if (nsteps > 0) loadY(ya, 0);
+        for (; t + 1 < nsteps; t += 2) {
+            loadY(yb2, t + 1);
+            work(ya, t);
+            if (t + 2 < nsteps) loadY(ya, t + 2);
+            work(yb2, t + 1);
+        }
+        if (t < nsteps) work(ya, t);
+        s = s_end;
+    }
+    constexpr int ST = STEPS == 0 ? 1 : STEPS;
+    for (; s + ST <= s_end; s += ST) {
+        d2 y[ST][R];
+        d2 vv[ST][K];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) {
 #pragma unroll
             for (int r = 0; r < R; ++r) y[t][r] = ldg2<NT>(yp + (size_t)r * ld + t * 128);
 #pragma unroll
@@ -199,14 +234,14 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
             for (int r = 0; r < R; ++r) {
                 const double yb = CENTER ? ybp[r * K + k] : 0.0;
 #pragma unroll
-                for (int t = 0; t < STEPS; ++t) {
+                for (int t = 0; t < ST; ++t) {
                     acc[k * R + r] = fma(y[t][r].x - yb, vv[t][k].x, acc[k * R + r]);
                     acc[k * R + r] = fma(y[t][r].y - yb, vv[t][k].y, acc[k * R + r]);
                 }
             }
         }
-        yp += STEPS * 128;
-        off += STEPS * 128;
+        yp += ST * 128;
+        off += ST * 128;
     }
     for (; s < s_end; ++s) {   // tail (only when STEPS = 2 and the tile has an odd step count)
         d2 y[R];
@@ -1092,15 +1127,18 @@ static void fwd_launch(bioen_hip_ctx* c, const Vec8& v) {
                        c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
 }
 
+// STEPS = 0: software-pipelined (next step's Y rows in flight during the FMAs).  Measured on the
+// N = 1e6 x M = 1024 sweep (rocprofv3, r01): 0.6-1.7 % faster than the plain loop for K <= 6; at
+// K = 7, 8 the second register set drops the occupancy to one wave per SIMD and it loses 4-9 %.
 template <bool NT, bool CENTER>
 static void fwd_dispatch(bioen_hip_ctx* c, int K, const Vec8& v) {
     switch (K) {
-        case 1: fwd_launch<1, 2, NT, CENTER>(c, v); break;
-        case 2: fwd_launch<2, 2, NT, CENTER>(c, v); break;
-        case 3: fwd_launch<3, 1, NT, CENTER>(c, v); break;
-        case 4: fwd_launch<4, 1, NT, CENTER>(c, v); break;
-        case 5: fwd_launch<5, 1, NT, CENTER>(c, v); break;
-        case 6: fwd_launch<6, 1, NT, CENTER>(c, v); break;
+        case 1: fwd_launch<1, 0, NT, CENTER>(c, v); break;
+        case 2: fwd_launch<2, 0, NT, CENTER>(c, v); break;
+        case 3: fwd_launch<3, 0, NT, CENTER>(c, v); break;
+        case 4: fwd_launch<4, 0, NT, CENTER>(c, v); break;
+        case 5: fwd_launch<5, 0, NT, CENTER>(c, v); break;
+        case 6: fwd_launch<6, 0, NT, CENTER>(c, v); break;
         case 7: fwd_launch<7, 1, NT, CENTER>(c, v); break;
         default: fwd_launch<8, 1, NT, CENTER>(c, v); break;
     }
