@@ -1,0 +1,131 @@
+"""GPU tests at BASELINE.json's FULL sizes (config 3: N = 1e6 x M = 1024 log-weights, 8 thetas;
+config 5: N = 1e6 x M = 512 forces), where the oracle would need minutes per evaluation: the
+device results are checked through size-independent properties instead --
+
+  * sparse weights pick single columns: yTilde . w must equal the columns read back (forward pass,
+    every column index, exact to rounding);
+  * the gradient of sampled structures against the closed form built from those columns and the
+    device's own residual (adjoint pass);
+  * linearity of the ensemble average, normalisation, gauge invariance, directional derivatives;
+  * a batched theta series equals the single runs bit for bit, and the objective decreases.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LBFGS_DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9,
+                      past=10, max_linesearch=100)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def _targets(M, seed=12345):
+    rng = np.random.default_rng(seed)
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp, sig_sim = 0.1 * YTrue, 0.5 * YTrue
+    YTilde = rng.normal(YTrue, sig_exp) / sig_exp
+    return YTrue, sig_sim, sig_exp, YTilde
+
+
+def _columns(ctx, cols):
+    return np.hstack([ctx.read_ytilde(col0=int(j), cols=1) for j in cols])
+
+
+def test_logw_full_size_properties():
+    import bioen_amd
+    M, N = 1024, 1000000
+    YTrue, sig_sim, sig_exp, YTilde = _targets(M)
+    rng = np.random.default_rng(99)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        cols = np.array([0, 1, 127, 128, 65535, 500000, 999871, 999998, 999999])
+        Y = _columns(ctx, cols)                                   # (M, 9)
+        # forward pass: sparse weights
+        wts = rng.dirichlet(np.ones(cols.size))
+        w = np.zeros(N)
+        w[cols] = wts
+        chi2, yave = ctx.chi_squared(w)
+        expect = Y.dot(wts)
+        assert np.abs(yave - expect).max() <= 4e-16 * np.abs(expect).max() * cols.size
+        assert rel(chi2, 0.5 * np.sum((expect - YTilde) ** 2)) < 1e-13
+        # linearity of the ensemble average in w
+        w1, w2 = rng.dirichlet(np.ones(N)), rng.dirichlet(np.ones(N) * 0.3)
+        y1, y2 = ctx.chi_squared(w1)[1], ctx.chi_squared(w2)[1]
+        y12 = ctx.chi_squared(0.25 * w1 + 0.75 * w2)[1]
+        assert np.abs(y12 - (0.25 * y1 + 0.75 * y2)).max() <= 1e-13 * np.abs(y12).max()
+        # objective + gradient at a random point, non-uniform prior
+        theta = 10.0
+        G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+        g = G + 0.3 * rng.standard_normal(N)
+        f, grad = ctx.logw_fdf(g, G, theta)
+        wg, logs = ctx.logw_weights(g)
+        assert abs(wg.sum() - 1.0) < 1e-12 and rel(logs, np.log(np.exp(g - g.max()).sum()) + g.max()) < 1e-14
+        chi2g, ybar = ctx.chi_squared(wg)
+        P = float(np.dot(wg, g - G))
+        logs0 = np.log(np.exp(G - G.max()).sum()) + G.max()
+        assert rel(f, theta * (P - logs + logs0) + chi2g) < 1e-12          # c_bioen_kernels_logw.c:124-147
+        r = ybar - YTilde
+        a = (Y - ybar[:, None]).T.dot(r)                                   # centred adjoint of the sampled columns
+        expect_g = wg[cols] * (theta * ((g[cols] - G[cols]) - P) + a)      # :207-218
+        assert np.abs(grad[cols] - expect_g).max() <= 1e-11 * np.abs(expect_g).max()
+        assert abs(grad.sum()) < 1e-9 * np.abs(grad).sum()                 # gauge direction
+        dirn = rng.standard_normal(N)
+        h = 1e-4
+        fp = ctx.logw_fdf(g + h * dirn, G, theta, need_grad=False)[0]
+        fm = ctx.logw_fdf(g - h * dirn, G, theta, need_grad=False)[0]
+        assert abs((fp - fm) / (2 * h) - grad.dot(dirn)) < 1e-5 * max(1.0, abs(grad.dot(dirn)))
+        assert rel(ctx.logw_fdf(g + 3.7, G, theta, need_grad=False)[0], f) < 1e-12   # L(g + c) = L(g)
+
+        # optimiser at full size: batched == single bit for bit, objective decreases, budget code
+        G0 = np.zeros(N)
+        f0 = ctx.logw_fdf(G0, G0, 100.0, need_grad=False)[0]
+        short = dict(LBFGS_DEFAULTS, max_iterations=12)
+        thetas = [100.0, 3.0]
+        res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, G0, G0, short, max_batch=8)
+        for k, th in enumerate(thetas):
+            gs, ws, info = ctx.opt_lbfgs_logw(G0, G0, th, short)
+            assert info.lbfgs_code == -997 and infos[k].lbfgs_code == -997 and info.iterations == 12
+            assert infos[k].fmin == info.fmin and np.array_equal(res[k], gs) and np.array_equal(wopt[k], ws)
+            assert abs(ws.sum() - 1.0) < 1e-12
+            # fmin is the objective at the returned point
+            assert rel(ctx.logw_fdf(gs, G0, th, need_grad=False)[0], info.fmin) < 1e-13
+        assert infos[0].fmin < f0
+        assert rel(infos[0].fmin, thetas[0] * infos[0].kl + infos[0].chi2) < 1e-12
+
+
+def test_forces_full_size_properties():
+    import bioen_amd
+    M, N = 512, 1000000
+    YTrue, sig_sim, sig_exp, YTilde = _targets(M, seed=777)
+    rng = np.random.default_rng(5)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=777) as ctx:
+        cols = np.array([0, 129, 4097, 333333, 999999])
+        Y = _columns(ctx, cols)
+        w0 = rng.dirichlet(np.ones(N) * 2.0)
+        forces = 1e-3 * rng.standard_normal(M)
+        theta = 10.0
+        w = ctx.forces_weights(forces, w0)
+        assert abs(w.sum() - 1.0) < 1e-12
+        x = forces.dot(Y)                                                  # x_j = sum_i f_i yTilde_ij
+        ratio = (w[cols] / w0[cols]) / (w[cols[0]] / w0[cols[0]])          # w_j / w0_j  ~  exp(x_j)
+        assert np.abs(ratio - np.exp(x - x[0])).max() <= 1e-11 * ratio.max()
+        f, grad = ctx.forces_fdf(forces, w0, theta)
+        chi2, ybar = ctx.chi_squared(w)
+        kl = float(np.sum(w * np.log(w / w0)))
+        assert rel(f, theta * kl + chi2) < 1e-11                           # c_bioen_kernels_forces.c:226-270
+        dirn = rng.standard_normal(M)
+        h = 1e-6
+        fp = ctx.forces_fdf(forces + h * dirn, w0, theta, need_grad=False)[0]
+        fm = ctx.forces_fdf(forces - h * dirn, w0, theta, need_grad=False)[0]
+        assert abs((fp - fm) / (2 * h) - grad.dot(dirn)) < 2e-5 * max(1.0, abs(grad.dot(dirn)))
+        # theta series as one batch == single runs, bit for bit
+        short = dict(LBFGS_DEFAULTS, max_iterations=6)
+        thetas = [100.0, 10.0]
+        res, wopt, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, short)
+        for k, th in enumerate(thetas):
+            fs, ws, info = ctx.opt_lbfgs_forces(np.zeros(M), w0, th, short)
+            assert infos[k].lbfgs_code == info.lbfgs_code and infos[k].fmin == info.fmin
+            assert np.array_equal(res[k], fs) and np.array_equal(wopt[k], ws)
+            assert rel(info.fmin, th * info.kl + info.chi2) < 1e-11
