@@ -129,3 +129,53 @@ def test_forces_full_size_properties():
             assert infos[k].lbfgs_code == info.lbfgs_code and infos[k].fmin == info.fmin
             assert np.array_equal(res[k], fs) and np.array_equal(wopt[k], ws)
             assert rel(info.fmin, th * info.kl + info.chi2) < 1e-11
+
+
+def test_deer_nuisance_series_at_config4_scale():
+    """BASELINE config 4: DEER refinement with a modulation-depth nuisance parameter, N = 5e5
+    rotamers x M = 205 time points (SURVEY 8d).  The matrix F~ = (F - 1)/sigma is uploaded once;
+    every refit of m is one GEMV on the device plus a closed-form 1-D least-squares step.
+    Checked through properties: the data were generated with m_true, so the refits must move m
+    from the start value towards it; the affine model must equal an explicitly rebuilt matrix on a
+    column sample; the joint objective L(w, m) must not increase from one refit to the next
+    (alternating minimisation: the refit lowers chi^2 at fixed w, the optimiser lowers L at fixed m)."""
+    import bioen_amd
+    from bioen_amd import nuisance
+    N, M = 500000, 205
+    rng = np.random.default_rng(2024)
+    d = np.where(rng.random(N) < 0.6, rng.normal(3.2, 0.35, N), rng.normal(4.8, 0.5, N)).clip(2.0, 6.0)   # nm
+    t = np.linspace(0.0, 3.0, M)                                                                           # us
+    # dipolar modulation with an exponential background factor: any smooth F in (0, 1] serves the test
+    F = 0.5 * (1.0 + np.cos(2 * np.pi * 52.04 * t[:, None] / d[None, :] ** 3)) * np.exp(-0.15 * t[:, None])
+    sigma = 0.01
+    m_true = 0.23
+    w_true = rng.dirichlet(np.ones(N) * 0.5)
+    Y = 1.0 - m_true + m_true * F.dot(w_true) + sigma * rng.standard_normal(M)
+    Ft = (F - 1.0) / sigma
+    YT = Y / sigma
+    off = np.full(M, 1.0 / sigma)
+    G = np.zeros(N)
+    with bioen_amd.Context(Ft, YT) as ctx:
+        # affine model == explicit matrix, on the objective (value) and on sampled gradient entries
+        m0 = 0.15
+        ctx.set_affine(off, np.full(M, m0))
+        g = 0.2 * rng.standard_normal(N)
+        f, grad = ctx.logw_fdf(g, G, 50.0)
+        w, logs = ctx.logw_weights(g)
+        ybar_eff = off + m0 * Ft.dot(w)
+        chi2 = 0.5 * np.sum((ybar_eff - YT) ** 2)
+        P = float(np.dot(w, g - G))
+        assert rel(f, 50.0 * (P - logs + np.log(N)) + chi2) < 1e-11
+        cols = np.array([0, 77, 123456, 499999])
+        Yeff = off[:, None] + m0 * Ft[:, cols]
+        a = (Yeff - ybar_eff[:, None]).T.dot(ybar_eff - YT)
+        expect = w[cols] * (50.0 * ((g[cols] - G[cols]) - P) + a)
+        assert np.abs(grad[cols] - expect).max() <= 1e-10 * np.abs(expect).max()
+        # the series: 2 thetas x 4 refits, yaml-default L-BFGS
+        res = nuisance.series(ctx, [100.0, 10.0], G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=4)
+    for r in res:
+        fm = [s["fmin"] for s in r["trace"]]
+        assert all(b <= a * (1 + 2e-5) for a, b in zip(fm, fm[1:])), fm          # 2e-5: width of the delta stop
+        assert abs(r["w"].sum() - 1.0) < 1e-12
+    m_fit = res[-1]["scales"][0]
+    assert abs(m_fit - m_true) < abs(m0 - m_true) and abs(m_fit - m_true) < 0.03
