@@ -127,8 +127,8 @@ def main():
                     help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal "
                          "thetas; auto = structures when the measured all-gather latency makes it the faster one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cols", type=int, default=65536)
-    ap.add_argument("--cpu-iters", type=int, default=40)
+    ap.add_argument("--cpu-cols", type=int, default=524288, help="columns of the matrix the CPU baseline runs on")
+    ap.add_argument("--cpu-iters", type=int, default=120, help="L-BFGS iterations the CPU baseline is capped at")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

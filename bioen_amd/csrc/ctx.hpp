@@ -37,7 +37,9 @@ constexpr int kMaxBatch = 8;       // thetas sharing one matrix pass
 constexpr int kScalStride = 32;    // doubles per slot in `scal`
 constexpr int kBasis = 2 * kHistory + 1;   // S[6], Y[6], g
 constexpr int kGramDots = 3 * kBasis;      // new s, new y, new g against the basis
-constexpr int kGramStride = 256;           // doubles per slot: 13x13 Gram matrix + 13 coefficients
+constexpr int kGramStride = 256;           // doubles per slot: 13x13 Gram matrix + 13 coefficients + 39 sums
+constexpr int kGramSums = kBasis * kBasis + kBasis;   // offset of the finished sums
+static_assert(kGramSums + kGramDots <= kGramStride, "gram slot");
 
 // device-resident scalar slots (per problem slot)
 enum ScalarSlot : int {

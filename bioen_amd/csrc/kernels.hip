@@ -852,26 +852,25 @@ __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
 
 // Per problem (one block): finish the 39 sums, update the Gram matrix, run the two-loop recursion
 // (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
-// The 39 sums are dealt to the 4 waves (a wave strides the [rank][block] list of its sum, then a
-// butterfly), the 13x13 matrix lives in LDS while one thread walks the two loops.
-__global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
+// One block per (sum, problem) finishes the 39 sums (gram[kGramSums + c]); a single block doing
+// all of them walks 39 x npl partials as dependent L2 loads (66 us at N = 1e6, measured).
+__global__ __launch_bounds__(kBlock) void k_gram_reduce(GramArgs q, Xch xi) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    const double v = xsum<kGramDots>(xi, a, c, sh);
+    if (threadIdx.x == 0) q.gram[a][kGramSums + c] = v;
+}
+
+// The 13x13 matrix lives in LDS while one thread walks the two loops.
+__global__ __launch_bounds__(64) void k_gram_solve(GramArgs q) {
     __shared__ double dots[kGramDots];
     __shared__ double Gs[kBasis * kBasis];
     __shared__ double coef[kBasis];
     __shared__ double alpha[kHistory];
     const int a = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* G = q.gram[a];
-    for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
-    for (int c = wave; c < kGramDots; c += kWaves) {
-        double s = 0.0;
-        for (int r = 0; r < xi.world; ++r) {
-            const double* p = xi.base + (size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl;
-            for (int k = lane; k < xi.npl; k += 64) s += p[k];
-        }
-        s = wave_sum(s);
-        if (lane == 0) dots[c] = s;
-    }
+    for (int i = threadIdx.x; i < kBasis * kBasis; i += 64) Gs[i] = G[i];
+    for (int i = threadIdx.x; i < kGramDots; i += 64) dots[i] = G[kGramSums + i];
     __syncthreads();
     if (threadIdx.x != 0) return;
     const int e = q.end[a], bound = q.bound[a];
@@ -1292,8 +1291,9 @@ void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
 }
 
 void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
-    hipLaunchKernelGGL(k_gram_solve, dim3(1, a.n), dim3(kBlock), 0, c->stream, a,
+    hipLaunchKernelGGL(k_gram_reduce, dim3(kGramDots, a.n), dim3(kBlock), 0, c->stream, a,
                        make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
+    hipLaunchKernelGGL(k_gram_solve, dim3(1, a.n), dim3(64), 0, c->stream, a);
 }
 
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {

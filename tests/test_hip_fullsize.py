@@ -175,7 +175,10 @@ def test_deer_nuisance_series_at_config4_scale():
         res = nuisance.series(ctx, [100.0, 10.0], G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=4)
     for r in res:
         fm = [s["fmin"] for s in r["trace"]]
-        assert all(b <= a * (1 + 2e-5) for a, b in zip(fm, fm[1:])), fm          # 2e-5: width of the delta stop
+        # every optimisation restarts cold (procedure.py:46,66) and ends on the yaml-default plateau test
+        # (delta = 1e-6 over 10 iterations), whose end points scatter by ~1e-4 relative
+        assert all(b <= a * (1 + 3e-4) for a, b in zip(fm, fm[1:])), fm
+        assert fm[-1] <= fm[0]
         assert abs(r["w"].sum() - 1.0) < 1e-12
     m_fit = res[-1]["scales"][0]
     assert abs(m_fit - m_true) < abs(m0 - m_true) and abs(m_fit - m_true) < 0.03

@@ -23,7 +23,7 @@ def short(name):
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
-    out_dir = os.path.join(ROOT, "profiles")
+    out_dir = os.environ.get("PROFILES_OUT", os.path.join(ROOT, "profiles"))
     os.makedirs(out_dir, exist_ok=True)
     stats = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)
     lines = []
@@ -56,7 +56,7 @@ def main():
             fs, n = per[k].get("FETCH_SIZE", (0.0, 0))
             ws, _ = per[k].get("WRITE_SIZE", (0.0, 0))
             lines.append("| %s | %d | %.1f | %.4e | %.1f | %.4e |" % (k, n, fs, fs * 1024 * 2, ws, ws * 1024))
-            traffic[k] = fs * 1024 * 2 + ws * 1024
+            traffic[k] = (fs * 1024 * 2 + ws * 1024, n)
     with open(os.path.join(out_dir, "%s_rocprof_summary.md" % tag), "w") as fp:
         fp.write("\n".join(lines) + "\n")
     if "--key" in sys.argv and traffic:
@@ -64,10 +64,10 @@ def main():
         N, M = int(sys.argv[i + 1]), int(sys.argv[i + 2])
         tpath = os.path.join(out_dir, "traffic.json")
         tj = json.load(open(tpath)) if os.path.isfile(tpath) else {}
-        for k in traffic:
-            base = k.split("<")[0]
-            if base in ("k_fwd_partial", "k_adj"):
-                tj["%s_N%d_M%d" % (base, N, M)] = traffic[k]
+        for base in ("k_fwd_partial", "k_adj"):      # launch-weighted mean over the batch-width variants
+            sel = [v for k, v in traffic.items() if k.split("<")[0] == base]
+            if sel:
+                tj["%s_N%d_M%d" % (base, N, M)] = sum(b * n for b, n in sel) / max(sum(n for _, n in sel), 1)
         tj["_note"] = ("HBM bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 from separate rocprofv3 --pmc "
                        "passes (gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream), see *_rocprof_summary.md")
         json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
