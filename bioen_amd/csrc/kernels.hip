@@ -861,16 +861,33 @@ __global__ __launch_bounds__(kBlock) void k_gram_reduce(GramArgs q, Xch xi) {
     if (threadIdx.x == 0) q.gram[a][kGramSums + c] = v;
 }
 
-// The 13x13 matrix lives in LDS while one thread walks the two loops.
-__global__ __launch_bounds__(64) void k_gram_solve(GramArgs q) {
+// The 13x13 matrix lives in LDS while one thread walks the two loops.  FUSED: few partials per sum
+// (small or sharded problems) -- the block also finishes the 39 sums, dealt to its 4 waves, which
+// saves the k_gram_reduce launch.  The order of the additions differs between the two paths, so
+// the choice depends on (npl, world) alone: every rank and every batch width takes the same one.
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
     __shared__ double dots[kGramDots];
     __shared__ double Gs[kBasis * kBasis];
     __shared__ double coef[kBasis];
     __shared__ double alpha[kHistory];
     const int a = blockIdx.y;
     double* G = q.gram[a];
-    for (int i = threadIdx.x; i < kBasis * kBasis; i += 64) Gs[i] = G[i];
-    for (int i = threadIdx.x; i < kGramDots; i += 64) dots[i] = G[kGramSums + i];
+    for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
+    if (FUSED) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int c = wave; c < kGramDots; c += kWaves) {
+            double s = 0.0;
+            for (int r = 0; r < xi.world; ++r) {
+                const double* p = xi.base + (size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl;
+                for (int k = lane; k < xi.npl; k += 64) s += p[k];
+            }
+            s = wave_sum(s);
+            if (lane == 0) dots[c] = s;
+        }
+    } else {
+        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = G[kGramSums + i];
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
     const int e = q.end[a], bound = q.bound[a];
@@ -1291,9 +1308,13 @@ void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
 }
 
 void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3(kGramDots, a.n), dim3(kBlock), 0, c->stream, a,
-                       make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
-    hipLaunchKernelGGL(k_gram_solve, dim3(1, a.n), dim3(64), 0, c->stream, a);
+    const Xch xi = make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c));
+    if ((long long)vec_grid(c) * c->world <= 256) {      // <= 4 dependent loads per lane and sum
+        hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);
+    } else {
+        hipLaunchKernelGGL(k_gram_reduce, dim3(kGramDots, a.n), dim3(kBlock), 0, c->stream, a, xi);
+        hipLaunchKernelGGL(k_gram_solve<false>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);
+    }
 }
 
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {
