@@ -173,7 +173,7 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
         const size_t arrays[X_COUNT] = {1, 3, 0, 3, 2, 1, 1, 1, 0, kGramDots};
         for (int st = 0; st < X_COUNT; ++st) {
             size_t cap = arrays[st] * kMaxBatch * npl;
-            if (st == X_YBAR) cap = (size_t)c->mp * kMaxBatch;
+            if (st == X_YBAR) cap = (size_t)(c->mp + 3) * kMaxBatch;
             if (st == X_VEC) cap = world > 1 ? c->ld : 0;
             c->xcap[st] = cap;
             if (cap) TRY(dalloc_zero(&c->xbuf[st], cap * world, c->stream));
@@ -300,17 +300,14 @@ static Round make_round(bioen_hip_ctx* c, const int* slots, int k, const double*
 static int enqueue_logw_adjoint(bioen_hip_ctx* c, const Round& r);
 
 static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
-    const size_t g = (size_t)vec_grid(c);
     int rc;
-    launch_logw_exp(c, r);                 // A1 first half + prior partials (shift: this rank's own maximum)
-    if ((rc = exchange(c, X_EXP, 3 * r.n * g))) return rc;
-    launch_logw_norm(c, r);                // A1 second half -> w, log s, P
+    launch_logw_exp(c, r);                 // A1: e = exp(x - m_r) + prior partials (shift: this rank's own maximum)
     Vec8 w{};
     for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
-    launch_fwd_partial(c, r.n, w);         // A4: this rank's share of ybar_a = yTilde . w_a   [matrix pass 1]
-    launch_fwd_rows_local(c, r.n);
-    if ((rc = exchange(c, X_YBAR, (size_t)c->mp * r.n))) return rc;
-    launch_rows_combine(c, r, true);       //     ybar, r, chi^2, ybar . r, A5: f (identical on every rank)
+    launch_fwd_partial(c, r.n, w);         // A4: this rank's share of yTilde . e_a            [matrix pass 1]
+    launch_fwd_rows_local(c, r.n, true);   //     + this rank's {sum e, sum e (x - G), m_r}
+    if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, r.n, true)))) return rc;
+    launch_rows_combine(c, r, true);       //     normalisation, ybar, r, chi^2, A5: f (identical on every rank)
     return with_grad ? enqueue_logw_adjoint(c, r) : 0;
 }
 
@@ -357,7 +354,7 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const R
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
     launch_fwd_partial(c, fr.n, v);           // F2: ybar                         [matrix pass 2]
-    launch_fwd_rows_local(c, fr.n);
+    launch_fwd_rows_local(c, fr.n, false);
     launch_rows_combine(c, r, false);
     launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
@@ -617,7 +614,11 @@ struct LogwBatchEngine {
             info.chi2 = 0.5 * h[S_CHI];
             info.kl = h[S_P] - h[S_LOGS] + h[S_LOGS0];
             note(download_n(c, results + (size_t)p.id * c->n_global, res));
-            if (w_opt) note(download_n(c, w_opt + (size_t)p.id * c->n_global, sl.w));
+            if (w_opt) {
+                const int one[1] = {s};
+                launch_scale_w(c, make_round(c, one, 1, nullptr, &p.theta));   // e -> w, only now
+                note(download_n(c, w_opt + (size_t)p.id * c->n_global, sl.w));
+            }
             note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
             info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
             if (verbose) {
@@ -1397,7 +1398,7 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     Vec8 v{};
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);
-    launch_fwd_rows_local(c, 1);
+    launch_fwd_rows_local(c, 1, false);
     launch_rows_combine(c, r, false);
     launch_forces_scalars(c, make_forces_round(c, one, 1, nullptr));   // S_CHI (the KL part is irrelevant here)
     if ((rc = check_launch())) return rc;

@@ -101,6 +101,9 @@ public:
         if (rc) return rc;
         forward(x);
         fetch_f();
+        launch_scale_w(c, round_for(x, -1));   // e -> w
+        keep(check_launch());
+        fwd_vec = -1;                          // slot.w no longer holds e
         return rc;
     }
     long long saved_forward = 0, saved_none = 0;

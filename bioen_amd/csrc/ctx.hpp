@@ -61,7 +61,8 @@ enum ScalarSlot : int {
     S_SPARE1,
     S_YSH,                         // [kHistory] y.s per history slot
     S_ALPHA = S_YSH + kHistory,    // [kHistory]
-    S_COUNT = S_ALPHA + kHistory
+    S_INV = S_ALPHA + kHistory,    // w_j = e_j * S_INV on this rank (deferred softmax normalisation)
+    S_COUNT
 };
 static_assert(S_COUNT <= kScalStride, "scalar slots");
 
@@ -80,8 +81,10 @@ enum PartSlot : int {
 // communication.  world == 1: same code, no collective.
 enum XStage : int {
     X_MAX = 0,   // 1 array : block maxima of the trial point (consumed by the same rank: never exchanged)
-    X_EXP,       // 3 arrays: sum e, sum e (x - G), [0] = this rank's shift m_r
-    X_YBAR,      // mp values per problem: this rank's share of yTilde . w
+    X_EXP,       // 3 arrays: sum e, sum e (x - G), [0] = this rank's shift m_r (rank-local; its per-rank
+                 //           totals ride on X_YBAR -- exchanged only by bioen_hip_logw_weights)
+    X_YBAR,      // mp values per problem: this rank's share of yTilde . v ; log-weights rounds append
+                 //           {sum e, sum e (x - G), m_r} per problem (v = e, normalised by the consumer)
     X_GRAD,      // 3 arrays: g.d, g.g, x.x
     X_SY,        // 2 arrays: y.s, y.y
     X_REC0,      // 1 array : running dot of the two-loop recursion (ping)

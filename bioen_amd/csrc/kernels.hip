@@ -123,6 +123,15 @@ __device__ __forceinline__ double xsum(const Xch& x, int a, int q, double* sh) {
     return block_sum(s, sh);
 }
 
+// sum over the blocks of ONE rank's segment
+template <int A>
+__device__ __forceinline__ double xsum_rank(const Xch& x, int rk, int a, int q, double* sh) {
+    double s = 0.0;
+    const double* p = x.base + (size_t)rk * x.payload + (size_t)(a * A + q) * x.npl;
+    for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
+    return block_sum(s, sh);
+}
+
 template <int A>
 __device__ __forceinline__ double xmax(const Xch& x, int a, int q, double* sh) {
     double s = -DBL_MAX;
@@ -275,12 +284,27 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
 
 // reduce the column tiles of one (row, problem) per wave (fixed order): this rank's share of
 // ybar, written into its segment of the X_YBAR stage (compact layout [row*K + a])
+// WITH_EXP (log-weights rounds): block 0 of each problem also totals this rank's softmax partials
+// and appends {sum e, sum e (x - G), m_r} to the rank's segment, so the normalisation needs no
+// exchange of its own.
+template <bool WITH_EXP>
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restrict__ partial, int ctiles,
-                                                           int mp, int K, Xch xo) {
+                                                           int mp, int K, Xch xo, Xch xe) {
+    __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double* out = xo.base + (size_t)xo.rank * xo.payload;
+    if (WITH_EXP && blockIdx.x == 0) {
+        const double s = xsum_rank<3>(xe, xe.rank, a, 0, sh);
+        const double pp = xsum_rank<3>(xe, xe.rank, a, 1, sh);
+        if (threadIdx.x == 0) {
+            double* tail = out + (size_t)mp * K + 3 * a;
+            tail[0] = s;
+            tail[1] = pp;
+            tail[2] = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+        }
+    }
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
         const double* p = partial + ((size_t)row * K + a) * ctiles;
         double s = 0.0;
@@ -307,10 +331,39 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
                                                          MVec8 part, Round rd) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
+    // LOGW: the shares are yTilde . e_r with e_r = exp(x - m_r) unnormalised; global shift
+    // M = max_r m_r, S = sum_r e^{m_r - M} S_r, and rank r's share enters with e^{m_r - M} / S
+    // (exactly 1 / S on one GPU).  _get_weights' normalisation (c_bioen_kernels_logw.c:84-90) is
+    // thereby applied to the M sums instead of the N weights.
+    double gmax = 0.0, invS = 1.0;
+    if (LOGW) {
+        gmax = -DBL_MAX;
+        for (int r = 0; r < xi.world; ++r)
+            gmax = fmax(gmax, xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2]);
+        double S = 0.0, PP = 0.0;
+        for (int r = 0; r < xi.world; ++r) {
+            const double* tail = xi.base + (size_t)r * xi.payload + (size_t)mp * K + 3 * a;
+            const double fr = exp(tail[2] - gmax);
+            S = fma(fr, tail[0], S);
+            PP = fma(fr, tail[1], PP);
+        }
+        invS = 1.0 / S;
+        if (threadIdx.x == 0) {
+            double* sc = rd.scal[a];
+            const double mown = xi.base[(size_t)xi.rank * xi.payload + (size_t)mp * K + 3 * a + 2];
+            sc[S_LOGS] = gmax + log(S);
+            sc[S_P] = PP * invS;
+            sc[S_INV] = exp(mown - gmax) * invS;
+        }
+    }
     double chi = 0.0, cc = 0.0;
     for (int row = threadIdx.x; row < mp; row += kBlock) {
         double s = 0.0;
-        for (int r = 0; r < xi.world; ++r) s += xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
+        for (int r = 0; r < xi.world; ++r) {
+            const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
+            if (LOGW) s = fma(exp(xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2] - gmax) * invS, v, s);
+            else s += v;
+        }
         const double sc = row_scale[row];
         const double eff = fma(sc, s, row_offset[row]);
         const double res = eff - YT[row];
@@ -323,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
     cc = block_sum(cc, sh);
     if (threadIdx.x == 0) {
         if (LOGW) {
-            double* sc = rd.scal[a];
+            double* sc = rd.scal[a];            // S_P, S_LOGS: written above by this same thread
             sc[S_CHI] = chi;
             sc[S_C] = cc;
             sc[S_F] = rd.theta[a] * (sc[S_P] - sc[S_LOGS] + sc[S_LOGS0]) + 0.5 * chi;
@@ -480,15 +533,6 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
 }
 
 // second half: w = e / S ; scal[S_LOGS] = max + log S ; scal[S_P] = sum e (x-G) / S
-// sum over the blocks of ONE rank's segment
-template <int A>
-__device__ __forceinline__ double xsum_rank(const Xch& x, int rk, int a, int q, double* sh) {
-    double s = 0.0;
-    const double* p = x.base + (size_t)rk * x.payload + (size_t)(a * A + q) * x.npl;
-    for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
-    return block_sum(s, sh);
-}
-
 __global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
@@ -554,12 +598,15 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     double* __restrict__ g = r.g[a];
     const double theta = r.theta[a];
     const double P = r.scal[a][S_P];
+    const double inv = r.scal[a][S_INV];      // w = e * inv
     double dg = 0.0, gg = 0.0, xx = 0.0;
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
         const d2 xv = *reinterpret_cast<const d2*>(x + j);
-        const d2 wv = *reinterpret_cast<const d2*>(w + j);     // pad: w = 0  =>  g = 0
+        d2 wv = *reinterpret_cast<const d2*>(w + j);           // pad: e = 0  =>  g = 0
+        wv.x *= inv;
+        wv.y *= inv;
         const d2 Gv = *reinterpret_cast<const d2*>(G + j);
         const d2 aa = *reinterpret_cast<const d2*>(av + j);
         const d2 dv = *reinterpret_cast<const d2*>(d + j);
@@ -1169,9 +1216,34 @@ void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
     }
 }
 
-void launch_fwd_rows_local(bioen_hip_ctx* c, int K) {
-    hipLaunchKernelGGL(k_fwd_rows_local, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       c->fwd_ctiles, c->mp, K, make_xch(c, X_YBAR, c->mp * K));
+int ybar_payload(const bioen_hip_ctx* c, int K, bool logw) { return c->mp * K + (logw ? 3 * K : 0); }
+
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw) {
+    const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, K, logw));
+    const Xch xe = make_xch(c, X_EXP, 3 * K * vec_grid(c));
+    if (logw)
+        hipLaunchKernelGGL(k_fwd_rows_local<true>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                           c->fwd_ctiles, c->mp, K, xo, xe);
+    else
+        hipLaunchKernelGGL(k_fwd_rows_local<false>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, c->fwd_ctiles, c->mp, K, xo, xe);
+}
+
+// w = e * scal[S_INV]: the weights themselves are only needed when a result is handed out
+__global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n2) {
+    const int a = blockIdx.y;
+    const double inv = r.scal[a][S_INV];
+    double* __restrict__ w = r.w[a];
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        d2 v = *reinterpret_cast<d2*>(w + 2 * p);
+        v.x *= inv;
+        v.y *= inv;
+        *reinterpret_cast<d2*>(w + 2 * p) = v;
+    }
+}
+
+void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_scale_w, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, (int)(c->ld / 2));
 }
 
 int combine_grid(const bioen_hip_ctx*) { return 1; }
@@ -1181,7 +1253,7 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw) {
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
     if (logw)
         hipLaunchKernelGGL(k_rows_combine<true>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
-                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
                            c->ybar_c, c->r_c, part, r);
     else
         hipLaunchKernelGGL(k_rows_combine<false>, dim3(1, r.n), dim3(kBlock), 0, c->stream,

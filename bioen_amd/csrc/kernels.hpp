@@ -43,7 +43,9 @@ int rows_grid(const bioen_hip_ctx* c);
 // forward: fwd_partial[(row*K + a)*ctiles + tile] = sum_{j in tile} (Y[row][j] - [centred] ybar_c[row*K+a]) v_a[j]
 void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred = false);
 // reduce the column tiles -> this rank's share of ybar in its X_YBAR segment   [exchange X_YBAR]
-void launch_fwd_rows_local(bioen_hip_ctx* c, int K);
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw);   // logw: + {sum e, sum e (x-G), m_r} per problem
+int ybar_payload(const bioen_hip_ctx* c, int K, bool logw);        // doubles per rank in the X_YBAR stage
+void launch_scale_w(bioen_hip_ctx* c, const Round& r);              // w = e * scal[S_INV] (when a result is handed out)
 // add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
 void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw);   // logw: also chi^2, c, f -> scal
 int combine_grid(const bioen_hip_ctx* c);
