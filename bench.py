@@ -174,9 +174,9 @@ def main():
     nshard = world > 1 and args.shard in ("auto", "structures")
     ctx, gather, rccl = build(nshard)
     if world > 1 and args.shard == "auto":
-        # Splitting the structures pays when the per-pass saving beats the 4 small all-gathers a
-        # round then needs (softmax sums, ybar, gradient dots, Gram update) plus launch overhead:
-        # t_pass * (1 - 1/world)  vs  5 * t_exchange + 0.15 ms.
+        # Splitting the structures pays when the per-pass saving beats the 3 small all-gathers a
+        # round then needs (ybar + softmax totals, gradient dots, Gram update) plus launch
+        # overhead; decided with margin:  t_pass * (1 - 1/world)  vs  5 * t_exchange + 0.15 ms.
         t_ex = max(comm.allgather_object(ctx.exchange_probe(count=M * min(8, len(thetas)), reps=40)))
         t_pass_us = 2.0 * M * float(N) * 8 / 6.4e12 * 1e6
         gain_us = t_pass_us * (1.0 - 1.0 / world)
