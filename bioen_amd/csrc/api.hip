@@ -395,9 +395,6 @@ struct LogwBatchEngine {
     void note(int e) { if (e && !rc) rc = e; }
     void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
 
-    // d = -H gp for the problems in `list` (lbfgs.c:571-598): 1 + 2*bound fused launches each,
-    // issued together.  A problem with a shorter history starts later, so that all of them
-    // finish in the same launch (one X_DGI exchange for everybody).
     bool use_gram() const {
         return c->direction_mode != 1;   // auto = Gram form
     }
@@ -430,6 +427,10 @@ struct LogwBatchEngine {
         }
     }
 
+    // d = -H gp for the problems in `all` (lbfgs.c:571-598).  Gram mode: see directions_gram.
+    // Two-loop mode: 1 + 2*bound fused launches per problem, issued together; a problem with a
+    // shorter history starts later, so that all of them finish in the same launch (one X_DGI
+    // exchange for everybody).
     void directions(BatchProblem* slots, const std::vector<int>& all) {
         if (all.empty()) return;
         std::vector<int> list = all;
@@ -587,6 +588,12 @@ struct LogwBatchEngine {
                 note(upload_n(c, sl.xp, g0_host + (size_t)next * g0_stride));
             note(hipMemsetAsync(sl.d, 0, c->ld * sizeof(double), c->stream), "memset d");
             note(hipMemsetAsync(sl.gram, 0, kGramStride * sizeof(double), c->stream), "memset gram");
+            // the Gram sweep multiplies with every history buffer, live or not: leftovers of an earlier
+            // run in this slot (possibly non-finite after a diverged one) must not reach 0 * x
+            for (int i = 0; i < kHistory; ++i) {
+                note(hipMemsetAsync(sl.S[i], 0, c->ld * sizeof(double), c->stream), "memset S");
+                note(hipMemsetAsync(sl.Yh[i], 0, c->ld * sizeof(double), c->stream), "memset Y");
+            }
             occupied[s] = true;
             ++active;
             ++next;

@@ -168,3 +168,18 @@ def test_gsl_error_and_budget_codes(optimize):
     from bioen_amd.optimize.ext import c_bioen
     assert c_bioen.last_opt_info.lbfgs_code == -2 and c_bioen.last_opt_info.iterations == 2
     assert out[4] < out[3]
+
+
+def test_lbfgs_after_gsl_run_on_the_same_context_is_unaffected():
+    """The GSL-style minimizers borrow slot 0's L-BFGS history buffers as work vectors; a following
+    L-BFGS run on the same context must equal one on a fresh context bit for bit."""
+    import bioen_amd
+    from test_hip_fullsize import LBFGS_DEFAULTS
+    d = load_golden("synth_logw_M64xN2000.npz")
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+        fresh = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+        ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "conjugate_pr", P)
+        after = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
+    assert after[2].fmin == fresh[2].fmin and after[2].iterations == fresh[2].iterations
+    assert np.array_equal(after[0], fresh[0]) and np.array_equal(after[1], fresh[1])
