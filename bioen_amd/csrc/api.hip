@@ -164,7 +164,9 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     TRY(dalloc_zero(&c->gm, (size_t)c->mp * kMaxBatch, c->stream));
     TRY(dalloc_zero(&c->fixed, c->ld, c->stream));
     TRY(dalloc_zero(&c->t, c->ld, c->stream));
-    TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * c->fwd_ctiles, c->stream));
+    // per (row, problem) one partial per column tile of the forward pass, or per block of the fused
+    // forces pass (forces_fused_blocks)
+    TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * std::max(c->fwd_ctiles, kFusedBlocks), c->stream));
     TRY(dalloc_zero(&c->part, (size_t)kMaxBatch * P_COUNT * kMaxPartials, c->stream));
     TRY(dalloc_zero(&c->scal, (size_t)kMaxBatch * kScalStride, c->stream));
     TRY(dalloc_zero(&c->gram, (size_t)kMaxBatch * kGramStride, c->stream));
@@ -358,13 +360,23 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const R
     launch_rows_combine(c, r, false);
     launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
+        // measured at N = 1e6 x M = 512 (r01, one launch vs the two it replaces): K = 1 0.85 vs 1.22 ms,
+        // K = 4 1.03 vs 1.34, K = 6 1.40 vs 1.45, K = 8 1.74 vs 1.52 (11 registers spill).  Used for every
+        // K all the same: the two paths add in different orders, and a batched series must equal the
+        // single runs bit for bit; rounds with K >= 7 are the first dozen of a series.
+        const int nblk = forces_fused_blocks(c);
+        if (nblk > 0) {                       // F3 in one pass: b, t and the centred product per LDS strip
+            launch_forces_bt(c, fr, nblk);    //                                              [matrix pass 3]
+            launch_fwd_rows_forces_grad(c, fr.n, nblk);
+            return;
+        }
         MVec8 out{};
         for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
         launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
         launch_forces_t(c, fr);               //     t_j
         for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
         launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
-        launch_fwd_rows_forces_grad(c, fr.n);
+        launch_fwd_rows_forces_grad(c, fr.n, c->fwd_ctiles);
     }
 }
 

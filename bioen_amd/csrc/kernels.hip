@@ -718,6 +718,130 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(ForcesRound r, const double
     }
 }
 
+// ------------------------------------------------------------------------------
+// forces gradient in ONE matrix pass for M <= 512 (F3, c_bioen_kernels_forces.c:280-340):
+//     b_j = sum_i Y_ij r_i ;  t_j = (theta (1 + log w_j/w0_j) + b_j) w_j ;  grad_i = sum_j (Y_ij - ybar_i) t_j
+// b_j needs a whole column and grad_i a whole row, so a block keeps a STRIP of all mp rows x 16
+// columns (128-byte row segments, 68 KB at mp = 512) in LDS -- two blocks per CU -- and walks the
+// strips of its share of the columns:
+//   stash   : the strip prefetched into registers during the previous strip's work goes to LDS
+//   phase 1 : thread t owns rows t and t+256: products Y_ic r_i for 4 columns x K problems at a
+//             time, reduced over the wave by one transposing butterfly, over the 4 waves through LDS
+//   phase 2 : 16 x K threads turn the column sums into t_c
+//   phase 3 : the same two rows per thread: grad_i += sum_c (Y_ic - ybar_i) t_c, kept in registers
+// The reference spends two full passes on this (3 of its 5), the unfused device path two of four.
+// Output: partial[(row*K + a) * nblk + block], finished by k_fwd_rows_forces_grad.
+// ------------------------------------------------------------------------------
+constexpr int kStripCols = 16;
+constexpr int kStripRows = 512;
+
+template <int K, bool NT>
+// (min. 2 waves per SIMD: two blocks share a CU's LDS)
+__global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
+                                                      const double* __restrict__ r_c,
+                                                      const double* __restrict__ ybar_c, ForcesRound fr,
+                                                      const double* __restrict__ w0,
+                                                      double* __restrict__ partial, int nblk) {
+    constexpr int C = kStripCols;
+    constexpr int KP = next_pow2(K);
+    constexpr int CB = KP >= 8 ? 2 : 4;                         // columns per butterfly
+    constexpr int NV = CB * KP;                                 // values per butterfly (4 .. 16)
+    constexpr int SHIFT = (NV == 4) ? 4 : (NV == 8) ? 3 : 2;    // 6 - log2(NV)
+    constexpr int PIECES = kStripRows * (C / 2) / kBlock;       // 16-byte pieces per thread and strip: 16
+    __shared__ double tile[kStripRows][C + 1];                  // +1: rows 17 doubles apart, conflict-free columns
+    __shared__ double red[kWaves][C][K];
+    __shared__ double tv[C][K];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int row0 = t, row1 = t + kBlock;
+    const bool has0 = row0 < mp, has1 = row1 < mp;
+
+    double r0[K], r1[K], yb0[K], yb1[K], acc0[K], acc1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r0[k] = has0 ? r_c[(size_t)row0 * K + k] : 0.0;
+        r1[k] = has1 ? r_c[(size_t)row1 * K + k] : 0.0;
+        yb0[k] = has0 ? ybar_c[(size_t)row0 * K + k] : 0.0;
+        yb1[k] = has1 ? ybar_c[(size_t)row1 * K + k] : 0.0;
+        acc0[k] = 0.0;
+        acc1[k] = 0.0;
+    }
+    d2 pre[PIECES];
+    auto fetch = [&](int strip) {                               // global -> registers, 8 lanes per row segment
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            pre[i] = row < mp ? ldg2<NT>(Y + (size_t)row * ld + (size_t)strip * C + part * 2) : d2{0.0, 0.0};
+        }
+    };
+    auto stash = [&]() {                                        // registers -> LDS
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            tile[row][part * 2] = pre[i].x;
+            tile[row][part * 2 + 1] = pre[i].y;
+        }
+    };
+    int s = blockIdx.x;
+    if (s < nstrips) fetch(s);
+    for (; s < nstrips; s += gridDim.x) {
+        __syncthreads();                                        // phase 3 of the previous strip is done with the tile
+        stash();
+        __syncthreads();
+        // phase 2's operands first, THEN the prefetch: vmcnt retires in order, so waiting for a
+        // load issued after the prefetch would wait for the whole next strip as well
+        double wv = 0.0, w0v = 0.0;
+        if (t < C * K) {
+            const size_t col = (size_t)s * C + t / K;           // < ld; padded columns carry w = 0
+            wv = fr.w[t % K][col];
+            w0v = w0[col];
+        }
+        if (s + (int)gridDim.x < nstrips) fetch(s + gridDim.x); // in flight during the three phases
+        // ---- phase 1 ----
+#pragma unroll
+        for (int q = 0; q < C / CB; ++q) {
+            double v[NV];
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) {
+                const double y0 = tile[row0][CB * q + cc], y1 = tile[row1 & (kStripRows - 1)][CB * q + cc];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) v[cc * KP + k] = k < K ? fma(y1, r1[k < K ? k : 0], y0 * r0[k < K ? k : 0]) : 0.0;
+            }
+            wave_multi_reduce<NV>(v, lane);
+            if ((lane & ((1 << SHIFT) - 1)) == 0) {
+                const int idx = lane >> SHIFT, cc = idx / KP, k = idx % KP;
+                if (k < K) red[wave][CB * q + cc][k] = v[0];
+            }
+        }
+        __syncthreads();
+        // ---- phase 2 ----
+        if (t < C * K) {
+            const int c = t / K, k = t % K;
+            const double b = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+            double dd = 1.0;
+            if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += log(wv) - log(w0v);
+            tv[c][k] = (dd * fr.theta[k] + b) * wv;
+        }
+        __syncthreads();
+        // ---- phase 3 ----
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double y0 = tile[row0][c], y1 = tile[row1 & (kStripRows - 1)][c];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double tk = tv[c][k];
+                acc0[k] = fma(y0 - yb0[k], tk, acc0[k]);
+                acc1[k] = fma(y1 - yb1[k], tk, acc1[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (has0) partial[((size_t)row0 * K + k) * nblk + blockIdx.x] = acc0[k];
+        if (has1) partial[((size_t)row1 * K + k) * nblk + blockIdx.x] = acc1[k];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_forces_scalars(ForcesRound r, int npchi, int npkl) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
@@ -1261,9 +1385,41 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw) {
                            c->ybar_c, c->r_c, part, r);
 }
 
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K) {
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles) {
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       c->fwd_ctiles, c->mp, K, c->gm);
+                       ctiles, c->mp, K, c->gm);
+}
+
+// ---- fused forces gradient pass (M <= 512) ------------------------------------------------
+int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
+    if (c->mp > kStripRows || c->world != 1) return 0;
+    const int nstrips = (int)(c->ld / kStripCols);
+    return std::min(kFusedBlocks, nstrips);                     // two 70-KB blocks per CU
+}
+
+template <int K, bool NT>
+static void forces_bt_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    hipLaunchKernelGGL((k_forces_bt<K, NT>), dim3(nblk), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp,
+                       (int)(c->ld / kStripCols), c->r_c, c->ybar_c, fr, c->fixed, c->fwd_partial, nblk);
+}
+
+template <bool NT>
+static void forces_bt_dispatch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    switch (fr.n) {
+        case 1: forces_bt_launch<1, NT>(c, fr, nblk); break;
+        case 2: forces_bt_launch<2, NT>(c, fr, nblk); break;
+        case 3: forces_bt_launch<3, NT>(c, fr, nblk); break;
+        case 4: forces_bt_launch<4, NT>(c, fr, nblk); break;
+        case 5: forces_bt_launch<5, NT>(c, fr, nblk); break;
+        case 6: forces_bt_launch<6, NT>(c, fr, nblk); break;
+        case 7: forces_bt_launch<7, NT>(c, fr, nblk); break;
+        default: forces_bt_launch<8, NT>(c, fr, nblk); break;
+    }
+}
+
+void launch_forces_bt(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    TimedLaunch tl(c, 0, fr.n);
+    if (c->nontemporal) forces_bt_dispatch<true>(c, fr, nblk); else forces_bt_dispatch<false>(c, fr, nblk);
 }
 
 // ---- adjoint ---------------------------------------------------------------------------

@@ -50,7 +50,12 @@ void launch_scale_w(bioen_hip_ctx* c, const Round& r);              // w = e * s
 void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw);   // logw: also chi^2, c, f -> scal
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K);
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles);
+// forces gradient in one matrix pass (LDS-resident column strips, M <= 512, unsharded):
+// b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
+constexpr int kFusedBlocks = 512;
+int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
+void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
 void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);
 

@@ -15,7 +15,7 @@ YTilde = rng.normal(YTrue, sig_exp) / sig_exp
 thetas = np.logspace(3, -0.5, 8)
 w0 = np.full(N, 1.0 / N)
 with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
-    for batch in (8, 1):
+    for batch in (8,):
         ctx.opt_lbfgs_forces_batch(thetas[:2], np.zeros(M), w0, dict(P, max_iterations=3), max_batch=batch)  # warm
         ctx.kernel_stats_enable(True); ctx.kernel_stats_reset(); ctx.synchronize()
         t0 = time.perf_counter()
@@ -25,5 +25,7 @@ with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=123
         st = ctx.kernel_stats()
         its = sum(i.iterations for i in infos); evs = sum(i.evaluations for i in infos)
         print(json.dumps({"max_batch": batch, "wall_s": dt, "iterations": its, "evaluations": evs,
-                          "codes": [i.lbfgs_code for i in infos], "iterNM_per_s": its * float(N) * M / dt,
+                          "codes": [i.lbfgs_code for i in infos], "per_theta_iterations": [i.iterations for i in infos],
+                          "per_theta_evaluations": [i.evaluations for i in infos],
+                          "fmin": [i.fmin for i in infos], "iterNM_per_s": its * float(N) * M / dt,
                           "forward": st["forward"], "adjoint": st["adjoint"]}), flush=True)
