@@ -352,6 +352,23 @@ static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
 }
 
 static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
+    const int nblk = forces_fused_blocks(c);
+    if (nblk > 0) {
+        // M <= 512: two passes over LDS-resident column strips instead of four streaming ones.
+        // Measured at N = 1e6 x M = 512 (r01): pass 2 alone 0.85 ms at K = 1 against 1.22 ms for the
+        // two passes it replaces (K = 4: 1.03 / 1.34, K = 8: 1.74 / 1.52).  Used for every K: the
+        // paths add in different orders and a batched series must equal the single runs bit for bit.
+        launch_forces_xy(c, fr, nblk);        // F1 + F2: x, online softmax, ybar    [matrix pass 1]
+        launch_rows_combine(c, r, false);     //     r, chi^2
+        launch_forces_scalars_fused(c, fr);   //     f = theta KL + 0.5 chi^2
+        if (with_grad) {
+            launch_forces_bt(c, fr, nblk);    // F3: b, t, centred product            [matrix pass 2]
+            launch_fwd_rows_forces_grad(c, fr.n, nblk);
+        } else {
+            launch_forces_w_from_x(c, fr);    // f-only evaluations hand out the weights
+        }
+        return;
+    }
     enqueue_forces_weights(c, fr);
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
@@ -360,16 +377,6 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const R
     launch_rows_combine(c, r, false);
     launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
-        // measured at N = 1e6 x M = 512 (r01, one launch vs the two it replaces): K = 1 0.85 vs 1.22 ms,
-        // K = 4 1.03 vs 1.34, K = 6 1.40 vs 1.45, K = 8 1.74 vs 1.52 (11 registers spill).  Used for every
-        // K all the same: the two paths add in different orders, and a batched series must equal the
-        // single runs bit for bit; rounds with K >= 7 are the first dozen of a series.
-        const int nblk = forces_fused_blocks(c);
-        if (nblk > 0) {                       // F3 in one pass: b, t and the centred product per LDS strip
-            launch_forces_bt(c, fr, nblk);    //                                              [matrix pass 3]
-            launch_fwd_rows_forces_grad(c, fr.n, nblk);
-            return;
-        }
         MVec8 out{};
         for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
         launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]

@@ -737,6 +737,207 @@ constexpr int kStripRows = 512;
 
 template <int K, bool NT>
 // (min. 2 waves per SIMD: two blocks share a CU's LDS)
+__global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
+                                                         int n, const double* __restrict__ f_c, ForcesRound fr,
+                                                         const double* __restrict__ w0,
+                                                         double* __restrict__ partial, int nblk) {
+    constexpr int C = kStripCols;
+    constexpr int KP = next_pow2(K);
+    constexpr int CB = KP >= 8 ? 2 : 4;
+    constexpr int NV = CB * KP;
+    constexpr int SHIFT = (NV == 4) ? 4 : (NV == 8) ? 3 : 2;
+    constexpr int PIECES = kStripRows * (C / 2) / kBlock;
+    __shared__ double tile[kStripRows][C + 1];
+    __shared__ double red[kWaves][C][K];
+    __shared__ double xs[C][K];       // x of the strip, then e
+    __shared__ double scale[K];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int row0 = t, row1 = t + kBlock;
+    const bool has0 = row0 < mp, has1 = row1 < mp;
+
+    double f0[K], f1[K], acc0[K], acc1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        f0[k] = has0 ? f_c[(size_t)row0 * K + k] : 0.0;
+        f1[k] = has1 ? f_c[(size_t)row1 * K + k] : 0.0;
+        acc0[k] = 0.0;
+        acc1[k] = 0.0;
+    }
+    double m_run = -DBL_MAX, zacc = 0.0, pxacc = 0.0;           // live in the threads t < C*K
+    d2 pre[PIECES];
+    auto fetch = [&](int strip) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            pre[i] = row < mp ? ldg2<NT>(Y + (size_t)row * ld + (size_t)strip * C + part * 2) : d2{0.0, 0.0};
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            tile[row][part * 2] = pre[i].x;
+            tile[row][part * 2 + 1] = pre[i].y;
+        }
+    };
+    int s = blockIdx.x;
+    if (s < nstrips) fetch(s);
+    for (; s < nstrips; s += gridDim.x) {
+        __syncthreads();
+        stash();
+        __syncthreads();
+        double w0v = 0.0;                                       // before the prefetch (vmcnt retires in order)
+        const size_t col = (size_t)s * C + t / K;
+        if (t < C * K) w0v = w0[col];
+        if (s + (int)gridDim.x < nstrips) fetch(s + gridDim.x);
+        // ---- phase 1: x_c = sum_i Y_ic f_i ----
+#pragma unroll
+        for (int q = 0; q < C / CB; ++q) {
+            double v[NV];
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) {
+                const double y0 = tile[row0][CB * q + cc], y1 = tile[row1 & (kStripRows - 1)][CB * q + cc];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) v[cc * KP + k] = k < K ? fma(y1, f1[k < K ? k : 0], y0 * f0[k < K ? k : 0]) : 0.0;
+            }
+            wave_multi_reduce<NV>(v, lane);
+            if ((lane & ((1 << SHIFT) - 1)) == 0) {
+                const int idx = lane >> SHIFT, cc = idx / KP, k = idx % KP;
+                if (k < K) red[wave][CB * q + cc][k] = v[0];
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: x out; running maximum; e = w0 exp(x - m) ----
+        double x = 0.0;
+        bool valid = false;
+        if (t < C * K) {
+            const int c = t / K, k = t % K;
+            x = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+            valid = col < (size_t)n;
+            fr.a[k][col] = valid ? x : 0.0;
+            xs[c][k] = valid ? x : -DBL_MAX;
+        }
+        __syncthreads();
+        double e = 0.0;
+        if (t < C * K) {
+            const int c = t / K, k = t % K;
+            double smax = -DBL_MAX;
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) smax = fmax(smax, xs[cc][k]);
+            const double m_new = fmax(m_run, smax);
+            const double sc = exp(m_run - m_new);               // 1 when the maximum stands, 0 the first time
+            e = valid ? w0v * exp(x - m_new) : 0.0;
+            zacc = fma(zacc, sc, e);
+            pxacc = fma(pxacc, sc, valid ? e * x : 0.0);
+            m_run = m_new;
+            if (c == 0) scale[k] = sc;
+        }
+        __syncthreads();                                        // everyone has read xs
+        if (t < C * K) xs[t / K][t % K] = e;
+        __syncthreads();
+        // ---- phase 3: ybar_raw_i = ybar_raw_i * scale + sum_c Y_ic e_c ----
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double sc = scale[k];
+            acc0[k] *= sc;
+            acc1[k] *= sc;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double y0 = tile[row0][c], y1 = tile[row1 & (kStripRows - 1)][c];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double ek = xs[c][k];
+                acc0[k] = fma(y0, ek, acc0[k]);
+                acc1[k] = fma(y1, ek, acc1[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (has0) partial[((size_t)row0 * K + k) * nblk + blockIdx.x] = acc0[k];
+        if (has1) partial[((size_t)row1 * K + k) * nblk + blockIdx.x] = acc1[k];
+    }
+    // block statistics per problem: shift, sum e, sum e x  (the 16 column threads of a problem hold the same shift)
+    __syncthreads();
+    if (t < C * K) {
+        red[0][t / K][t % K] = zacc;
+        red[1][t / K][t % K] = pxacc;
+    }
+    __syncthreads();
+    if (t < K) {
+        double z = 0.0, px = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            z += red[0][c][t];
+            px += red[1][c][t];
+        }
+        double* pa = fr.part[t];
+        pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;   // thread t = (c 0, k t)
+        pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
+        pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = px;
+    }
+}
+
+// Merge the blocks of k_forces_xy (one block per problem): M = max_b m_b, Z = sum_b e^{m_b - M} Z_b.
+//   scal[S_LOGS] = M + log Z  (w_j = w0_j exp(x_j - S_LOGS)),  scal[S_P] = sum_j w_j x_j,
+//   KL = sum_j w_j log(w_j / w0_j) = S_P - S_LOGS   (c_bioen_kernels_forces.c:246-258, with
+//   log w_j - log w0_j = x_j - S_LOGS);  P_MAX[b] <- e^{m_b - M} / Z, the weight of block b's raw sums.
+__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int nblk) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    double* pa = fr.part[a];
+    double* pm = pa + (size_t)P_MAX * kMaxPartials;
+    const double M = max_partials(pm, nblk, sh);
+    double z = 0.0, px = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) {
+        const double fb = exp(pm[b] - M);
+        z = fma(fb, pa[(size_t)P_SUM * kMaxPartials + b], z);
+        px = fma(fb, pa[(size_t)P_PP * kMaxPartials + b], px);
+    }
+    z = block_sum(z, sh);
+    px = block_sum(px, sh);
+    const double invZ = 1.0 / z;
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblk; b += kBlock) pm[b] = exp(pm[b] - M) * invZ;
+    if (threadIdx.x == 0) {
+        double* sc = fr.scal[a];
+        const double logz = M + log(z);
+        sc[S_LOGS] = logz;
+        sc[S_P] = px * invZ;
+        pa[(size_t)P_KL * kMaxPartials] = px * invZ - logz;      // read by k_forces_scalars (npkl = 1)
+    }
+}
+
+// ybar_i = sum_b weight_b raw_i,b   (a wave per (row, problem), fixed order) -> X_YBAR segment
+__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted(const double* __restrict__ partial, int nblk, int mp,
+                                                                 int K, ForcesRound fr, Xch xo) {
+    const int a = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const double* __restrict__ wb = fr.part[a] + (size_t)P_MAX * kMaxPartials;
+    double* out = xo.base + (size_t)xo.rank * xo.payload;
+    for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
+        const double* p = partial + ((size_t)row * K + a) * nblk;
+        double s = 0.0;
+        for (int b = lane; b < nblk; b += 64) s = fma(wb[b], p[b], s);
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)row * K + a] = s;
+    }
+}
+
+// w_j = w0_j exp(x_j - S_LOGS): the weights themselves, when a result is handed out
+__global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, const double* __restrict__ w0, int n) {
+    const int a = blockIdx.y;
+    const double* __restrict__ x = fr.a[a];
+    double* __restrict__ w = fr.w[a];
+    const double logz = fr.scal[a][S_LOGS];
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] = w0[j] * exp(x[j] - logz);
+}
+
+template <int K, bool NT, bool FROMX>
+// (min. 2 waves per SIMD: two blocks share a CU's LDS)
 __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
                                                       const double* __restrict__ r_c,
                                                       const double* __restrict__ ybar_c, ForcesRound fr,
@@ -790,11 +991,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
         __syncthreads();
         // phase 2's operands first, THEN the prefetch: vmcnt retires in order, so waiting for a
         // load issued after the prefetch would wait for the whole next strip as well
-        double wv = 0.0, w0v = 0.0;
+        double wv = 0.0, w0v = 0.0, lr = 0.0;                   // lr = log(w / w0)
         if (t < C * K) {
-            const size_t col = (size_t)s * C + t / K;           // < ld; padded columns carry w = 0
-            wv = fr.w[t % K][col];
+            const size_t col = (size_t)s * C + t / K;           // < ld; padded columns carry w0 = w = 0
             w0v = w0[col];
+            if (FROMX) {                                        // weights from x (k_forces_xy): no log needed
+                lr = fr.a[t % K][col] - fr.scal[t % K][S_LOGS];
+                wv = w0v * exp(lr);
+            } else {
+                wv = fr.w[t % K][col];
+            }
         }
         if (s + (int)gridDim.x < nstrips) fetch(s + gridDim.x); // in flight during the three phases
         // ---- phase 1 ----
@@ -819,7 +1025,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
             const int c = t / K, k = t % K;
             const double b = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
             double dd = 1.0;
-            if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += log(wv) - log(w0v);
+            if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += FROMX ? lr : log(wv) - log(w0v);
             tv[c][k] = (dd * fr.theta[k] + b) * wv;
         }
         __syncthreads();
@@ -1398,28 +1604,53 @@ int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on t
 }
 
 template <int K, bool NT>
-static void forces_bt_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
-    hipLaunchKernelGGL((k_forces_bt<K, NT>), dim3(nblk), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp,
-                       (int)(c->ld / kStripCols), c->r_c, c->ybar_c, fr, c->fixed, c->fwd_partial, nblk);
+static void forces_strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
+    const int nstrips = (int)(c->ld / kStripCols);
+    if (pass == 1)
+        hipLaunchKernelGGL((k_forces_xy<K, NT>), dim3(nblk), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp, nstrips,
+                           c->n, c->um, fr, c->fixed, c->fwd_partial, nblk);
+    else
+        hipLaunchKernelGGL((k_forces_bt<K, NT, true>), dim3(nblk), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp,
+                           nstrips, c->r_c, c->ybar_c, fr, c->fixed, c->fwd_partial, nblk);
 }
 
 template <bool NT>
-static void forces_bt_dispatch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+static void forces_strip_dispatch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
     switch (fr.n) {
-        case 1: forces_bt_launch<1, NT>(c, fr, nblk); break;
-        case 2: forces_bt_launch<2, NT>(c, fr, nblk); break;
-        case 3: forces_bt_launch<3, NT>(c, fr, nblk); break;
-        case 4: forces_bt_launch<4, NT>(c, fr, nblk); break;
-        case 5: forces_bt_launch<5, NT>(c, fr, nblk); break;
-        case 6: forces_bt_launch<6, NT>(c, fr, nblk); break;
-        case 7: forces_bt_launch<7, NT>(c, fr, nblk); break;
-        default: forces_bt_launch<8, NT>(c, fr, nblk); break;
+        case 1: forces_strip_launch<1, NT>(c, fr, nblk, pass); break;
+        case 2: forces_strip_launch<2, NT>(c, fr, nblk, pass); break;
+        case 3: forces_strip_launch<3, NT>(c, fr, nblk, pass); break;
+        case 4: forces_strip_launch<4, NT>(c, fr, nblk, pass); break;
+        case 5: forces_strip_launch<5, NT>(c, fr, nblk, pass); break;
+        case 6: forces_strip_launch<6, NT>(c, fr, nblk, pass); break;
+        case 7: forces_strip_launch<7, NT>(c, fr, nblk, pass); break;
+        default: forces_strip_launch<8, NT>(c, fr, nblk, pass); break;
     }
 }
 
+// pass 1: x = yTilde^T f, online softmax, raw ybar per block; then the block merge and ybar -> X_YBAR
+void launch_forces_xy(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    {
+        TimedLaunch tl(c, 1, fr.n);
+        if (c->nontemporal) forces_strip_dispatch<true>(c, fr, nblk, 1); else forces_strip_dispatch<false>(c, fr, nblk, 1);
+    }
+    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk);
+    hipLaunchKernelGGL(k_forces_rows_weighted, dim3(rows_grid(c), fr.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       nblk, c->mp, fr.n, fr, make_xch(c, X_YBAR, ybar_payload(c, fr.n, false)));
+}
+
+// pass 2: b = yTilde^T r, t, centred yTilde . t
 void launch_forces_bt(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
     TimedLaunch tl(c, 0, fr.n);
-    if (c->nontemporal) forces_bt_dispatch<true>(c, fr, nblk); else forces_bt_dispatch<false>(c, fr, nblk);
+    if (c->nontemporal) forces_strip_dispatch<true>(c, fr, nblk, 2); else forces_strip_dispatch<false>(c, fr, nblk, 2);
+}
+
+void launch_forces_w_from_x(bioen_hip_ctx* c, const ForcesRound& fr) {
+    hipLaunchKernelGGL(k_forces_w_from_x, dim3(vec_grid(c), fr.n), dim3(kBlock), 0, c->stream, fr, c->fixed, c->n);
+}
+
+void launch_forces_scalars_fused(bioen_hip_ctx* c, const ForcesRound& r) {    // KL comes from k_forces_blockstats
+    hipLaunchKernelGGL(k_forces_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, combine_grid(c), 1);
 }
 
 // ---- adjoint ---------------------------------------------------------------------------

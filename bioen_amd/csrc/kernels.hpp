@@ -51,11 +51,15 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw);   // logw
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles);
-// forces gradient in one matrix pass (LDS-resident column strips, M <= 512, unsharded):
-// b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
+// forces evaluation in TWO matrix passes over LDS-resident column strips (M <= 512, unsharded):
+//   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
+//   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
 constexpr int kFusedBlocks = 512;
 int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
+void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
+void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
+void launch_forces_scalars_fused(bioen_hip_ctx* c, const struct ForcesRound& fr);
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
 void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);
 
