@@ -783,10 +783,17 @@ struct ForcesBatchEngine {
     const bioen_lbfgs_config& cfg;
     bool verbose;
     int rc = 0;
-    std::vector<double> um_h, gm_h;
+    double *um_h = nullptr, *gm_h = nullptr;     // pinned staging (pageable memory would make every copy a blocking one)
 
     ForcesBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
-        : c(ctx), cfg(config), verbose(verb), um_h((size_t)ctx->mp * kMaxBatch), gm_h((size_t)ctx->mp * kMaxBatch) {}
+        : c(ctx), cfg(config), verbose(verb) {
+        const size_t cnt = (size_t)c->mp * kMaxBatch;
+        if (!c->host_m)
+            note(hipHostMalloc(reinterpret_cast<void**>(&c->host_m), 2 * cnt * sizeof(double), hipHostMallocDefault),
+                 "hipHostMalloc");
+        um_h = c->host_m;
+        gm_h = c->host_m ? c->host_m + cnt : nullptr;
+    }
 
     void note(int e) { if (e && !rc) rc = e; }
     void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
@@ -794,16 +801,17 @@ struct ForcesBatchEngine {
     // evaluate the K points pts[a] (each m long); f -> host_scal, gradients -> gm_h (compact)
     void evaluate(const int* slots, int k, const double* const* pts, const double* thetas, bool with_grad) {
         const int m = c->m;
-        std::fill(um_h.begin(), um_h.begin() + (size_t)c->mp * k, 0.0);
+        if (rc) return;
+        std::fill(um_h, um_h + (size_t)c->mp * k, 0.0);
         for (int a = 0; a < k; ++a)
             for (int i = 0; i < m; ++i) um_h[(size_t)i * k + a] = pts[a][i];
-        note(hipMemcpyAsync(c->um, um_h.data(), (size_t)c->mp * k * sizeof(double), hipMemcpyHostToDevice, c->stream),
+        note(hipMemcpyAsync(c->um, um_h, (size_t)c->mp * k * sizeof(double), hipMemcpyHostToDevice, c->stream),
              "forces H2D");
         const ForcesRound fr = make_forces_round(c, slots, k, thetas);
         const Round r = make_round(c, slots, k, nullptr, thetas);
         enqueue_forces_eval(c, fr, r, with_grad);
         if (with_grad)
-            note(hipMemcpyAsync(gm_h.data(), c->gm, (size_t)c->mp * k * sizeof(double), hipMemcpyDeviceToHost, c->stream),
+            note(hipMemcpyAsync(gm_h, c->gm, (size_t)c->mp * k * sizeof(double), hipMemcpyDeviceToHost, c->stream),
                  "gradient D2H");
         note(read_scalars(c, kMaxBatch));
         note(check_launch());
@@ -1202,6 +1210,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         if (c->xbuf[st]) hipFree(c->xbuf[st]);
     if (c->exchange_host) hipHostFree(c->exchange_host);
     if (c->host_scal) hipHostFree(c->host_scal);
+    if (c->host_m) hipHostFree(c->host_m);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1379,7 +1388,7 @@ int bioen_hip_forces_fdf(bioen_hip_ctx* c, const double* forces, const double* w
     const double* pt[1] = {forces};
     eng.evaluate(one, 1, pt, &theta, grad != nullptr);
     if (eng.rc) return eng.rc;
-    if (grad) std::memcpy(grad, eng.gm_h.data(), (size_t)c->m * sizeof(double));
+    if (grad) std::memcpy(grad, eng.gm_h, (size_t)c->m * sizeof(double));
     if (f) *f = c->host_scal[S_F];
     return 0;
 }

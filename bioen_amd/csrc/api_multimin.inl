@@ -249,7 +249,7 @@ int bioen_hip_opt_gsl_forces(bioen_hip_ctx* c, const double* forces0, const doub
         const double* pt[1] = {x};
         eng.evaluate(one, 1, pt, &theta, grad != nullptr);
         if (eng.rc) return eng.rc;
-        if (grad) std::memcpy(grad, eng.gm_h.data(), (size_t)m * sizeof(double));
+        if (grad) std::memcpy(grad, eng.gm_h, (size_t)m * sizeof(double));
         *f = c->host_scal[S_F];
         return 0;
     });

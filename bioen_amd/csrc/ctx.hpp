@@ -172,6 +172,7 @@ struct bioen_hip_ctx {
     double* gram = nullptr;          // kMaxBatch * kGramStride
     int direction_mode = 0;          // 0 auto (= Gram form), 1 two-loop on the vectors, 2 Gram form
     double* host_scal = nullptr;     // pinned mirror
+    double* host_m = nullptr;        // pinned, 2 x mp*kMaxBatch: forces up / gradients down (lazy)
 
     bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)
     bioen::KernelTimer timer;
