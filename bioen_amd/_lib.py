@@ -89,6 +89,7 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_ctx_create_raw": (C.c_int, [C.c_int, C.c_longlong, C.c_int, dp, dp, dp, C.c_int, C.POINTER(ctx_p)]),
     "bioen_hip_gsl_strerror": (C.c_char_p, [C.c_int]),
     "bioen_hip_opt_gsl_logw": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(GslConfig), C.POINTER(VisualParams),
                                          dp, dp, C.POINTER(OptResult)]),
@@ -248,6 +249,23 @@ class Context(object):
                                                        C.c_ulonglong(seed), int(device), int(rank), int(world),
                                                        C.byref(h)))
         return cls(rank=rank, world=world, _handle=h, _shape=(int(m), int(n)))
+
+    @classmethod
+    def from_raw(cls, sim, exp, exp_err, structure_major=False, device=0):
+        """Context from RAW observables: yTilde = sim / exp_err and YTilde = exp / exp_err are formed on
+        the device.  sim: (M, N), or (N, M) with structure_major=True (one structure's observables
+        contiguous -- uploaded in chunks and transposed on the device)."""
+        sim = as_f64(sim)
+        if sim.ndim != 2:
+            raise ValueError("sim must be 2-D")
+        n, m = sim.shape if structure_major else sim.shape[::-1]
+        exp, err = as_f64(exp).ravel(), as_f64(exp_err).ravel()
+        if exp.size != m or err.size != m:
+            raise ValueError("exp / exp_err need one entry per observable")
+        h = ctx_p()
+        check(lib().bioen_hip_ctx_create_raw(int(m), int(n), 1 if structure_major else 0, ptr(sim), ptr(exp), ptr(err),
+                                             int(device), C.byref(h)))
+        return cls(_handle=h, _shape=(int(m), int(n)))
 
     def set_exchange(self, comm):
         """Complete cross-rank reductions through `comm.allgather_array` (host-staged; for ranks

@@ -1127,6 +1127,47 @@ int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTild
     return bioen_hip_ctx_create_sharded(m, n, yTilde, YTilde, device, 0, 1, ctx);
 }
 
+int bioen_hip_ctx_create_raw(int m, long long n, int structure_major, const double* sim, const double* exp_values,
+                             const double* exp_err, int device, bioen_hip_ctx** ctx) {
+    if (!sim || !exp_values || !exp_err) return fail(BIOEN_HIP_EINVAL, "sim / exp / exp_err is NULL");
+    for (int i = 0; i < m; ++i)
+        if (!(exp_err[i] > 0.0)) return fail(BIOEN_HIP_EINVAL, "experimental errors must be positive");
+    bioen_hip_ctx* c = nullptr;
+    int rc = ctx_alloc(m, n, device, 0, 1, &c);
+    if (rc) return rc;
+    std::vector<double> yt(m);
+    for (int i = 0; i < m; ++i) yt[i] = exp_values[i] / exp_err[i];
+    double* sigma = nullptr;     // device copy of the errors
+    double* stage = nullptr;     // structure-major chunks on their way through the transposer
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&sigma), (size_t)m * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(sigma, exp_err, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->YT, yt.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !structure_major) {
+        e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), sim, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                             (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) launch_rows_div(c, sigma);
+    } else if (e == hipSuccess) {
+        const long long chunk = std::max<long long>(1, std::min<long long>(n, (256ll << 20) / ((long long)m * 8)));
+        e = hipMalloc(reinterpret_cast<void**>(&stage), (size_t)chunk * m * sizeof(double));
+        for (long long j0 = 0; e == hipSuccess && j0 < n; j0 += chunk) {
+            const long long nc = std::min(chunk, n - j0);
+            e = hipMemcpyAsync(stage, sim + (size_t)j0 * m, (size_t)nc * m * sizeof(double), hipMemcpyHostToDevice,
+                               c->stream);
+            if (e == hipSuccess) launch_transpose_div(c, stage, (int)nc, (size_t)j0, sigma);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (sigma) hipFree(sigma);
+    if (stage) hipFree(stage);
+    if (e != hipSuccess) {
+        bioen_hip_ctx_destroy(c);
+        return hip_fail(e, "assembly of yTilde", __FILE__, __LINE__);
+    }
+    *ctx = c;
+    return 0;
+}
+
 int bioen_hip_ctx_create_synthetic_sharded(int m, long long n, const double* YTrue, const double* sig_sim,
                                            const double* sig_exp, const double* YTilde, unsigned long long seed,
                                            int device, int rank, int world, bioen_hip_ctx** ctx) {

@@ -1420,6 +1420,39 @@ __global__ __launch_bounds__(kBlock) void k_vdots_finish(const double* part, int
 }
 
 // ------------------------------------------------------------------------------
+// assembly of yTilde = sim / sigma from raw simulated observables (observables.py:123-143 does
+// this element by element in Python, then divides on the host)
+// ------------------------------------------------------------------------------
+// observables-major input already sits in Y: divide row i by sigma_i in place
+__global__ __launch_bounds__(kBlock) void k_rows_div(double* __restrict__ Y, size_t ld, int m, int n,
+                                                     const double* __restrict__ sigma) {
+    const size_t total = (size_t)m * ld;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t i = idx / ld, j = idx - i * ld;
+        if (j < (size_t)n) Y[idx] = Y[idx] / sigma[i];
+    }
+}
+
+// structure-major chunk src[jc][i] (jc < ncols, i < m: one structure's observables contiguous) ->
+// Y[i][col0 + jc] / sigma_i, through a 32 x 33 LDS tile so that both sides are coalesced
+__global__ __launch_bounds__(kBlock) void k_transpose_div(const double* __restrict__ src, int ncols, int m,
+                                                          double* __restrict__ Y, size_t ld, size_t col0,
+                                                          const double* __restrict__ sigma) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int jc = j0 + r, i = i0 + tx;
+        tile[r][tx] = (jc < ncols && i < m) ? src[(size_t)jc * m + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, jc = j0 + tx;
+        if (i < m && jc < ncols) Y[(size_t)i * ld + col0 + jc] = tile[tx][r] / sigma[i];
+    }
+}
+
+// ------------------------------------------------------------------------------
 // synthetic ensemble generated in HBM (bench): counter-based Box-Muller
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -1794,6 +1827,15 @@ void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out
     const int g = vec_grid(c);
     hipLaunchKernelGGL(k_vdots, dim3(g), dim3(kBlock), 0, c->stream, q, (int)(c->ld / 2), part);
     hipLaunchKernelGGL(k_vdots_finish, dim3(1), dim3(kBlock), 0, c->stream, part, g, q.k, q.mode, out);
+}
+
+void launch_rows_div(bioen_hip_ctx* c, const double* sigma) {
+    hipLaunchKernelGGL(k_rows_div, dim3(256 * 16), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->m, c->n, sigma);
+}
+
+void launch_transpose_div(bioen_hip_ctx* c, const double* src, int ncols, size_t col0, const double* sigma) {
+    dim3 grid((c->m + 31) / 32, (ncols + 31) / 32);
+    hipLaunchKernelGGL(k_transpose_div, grid, dim3(kBlock), 0, c->stream, src, ncols, c->m, c->Y, c->ld, col0, sigma);
 }
 
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,

@@ -89,6 +89,10 @@ void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r);
 
+// ---- assembly of yTilde = sim / sigma on the device ----------------------------------------
+void launch_rows_div(bioen_hip_ctx* c, const double* sigma);          // Y[i][:] /= sigma_i (device pointer)
+void launch_transpose_div(bioen_hip_ctx* c, const double* src, int ncols, size_t col0, const double* sigma);
+
 // ---- level-1 algebra on resident N-vectors (GSL-style minimizers, multimin.hpp) ----------
 struct VDotArgs {
     int k;                 // number of (x, y) pairs, <= 4

@@ -225,6 +225,17 @@ int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
 int bioen_hip_selftest_lbfgs(int kind, int n, const double* x0, const bioen_lbfgs_config* config,
                              double* x_out, bioen_opt_result* info);
 
+/* ---- yTilde assembled on the device from raw observables ---------------------------------
+ * Replaces the host loops of bioen/analyze/observables/observables.py:110-143 (sim / sigma built
+ * element by element, structure by structure) and the host division: yTilde_ij = sim_ij / err_i,
+ * YTilde_i = exp_i / err_i, divided on the device (true division: bitwise what numpy gives).
+ *   structure_major = 0: sim is [m][n] (observables-major, like yTilde);
+ *   structure_major = 1: sim is [n][m] -- each structure's (model's) M observables contiguous, the
+ *     order in which simulated data arrive; uploaded in chunks and transposed on the device. */
+int bioen_hip_ctx_create_raw(int m, long long n, int structure_major, const double* sim,
+                             const double* exp_values, const double* exp_err, int device,
+                             bioen_hip_ctx** ctx);
+
 /* ---- GSL-style minimizers on the device objective -----------------------------------------
  * Replace _opt_bfgs_logw (c_bioen_kernels_logw.c:366-509) and _opt_bfgs_forces
  * (c_bioen_kernels_forces.c), i.e. gsl_multimin_fdfminimizer_{conjugate_fr, conjugate_pr,

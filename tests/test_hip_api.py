@@ -314,3 +314,31 @@ def test_nuisance_series_matches_host_rebuild_loop(optimize):
         assert np.abs(res[k]["w"] - w).max() <= 5e-3 * w.max()
     # the refits recover the modulation depths the data were generated with
     assert np.allclose(res[-1]["scales"], m_true, atol=0.03)
+
+
+# ---------------------------------------------------------------------------------------
+# yTilde assembled on the device from raw observables
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N", [(1, 1), (7, 33), (37, 1000), (130, 4099)])
+def test_context_from_raw_observables_equals_host_division(M, N):
+    import bioen_amd
+    rng = np.random.default_rng(M * 7919 + N)
+    sim = rng.normal(5.0, 2.0, (M, N))
+    exp = rng.normal(5.0, 0.5, M)
+    err = rng.uniform(0.05, 2.0, M)
+    yTilde, YTilde = sim / err[:, None], exp / err
+    g = 0.3 * rng.standard_normal(N)
+    G = np.zeros(N)
+    with bioen_amd.Context(yTilde, YTilde) as ref:
+        f_ref, grad_ref = ref.logw_fdf(g, G, 3.0)
+    for structure_major in (False, True):
+        src = np.ascontiguousarray(sim.T) if structure_major else sim
+        with bioen_amd.Context.from_raw(src, exp, err, structure_major=structure_major) as ctx:
+            assert ctx.m == M and ctx.n == N
+            assert np.array_equal(ctx.read_ytilde(), yTilde)          # true division on the device: same bits
+            f, grad = ctx.logw_fdf(g, G, 3.0)
+        assert f == f_ref and np.array_equal(grad, grad_ref)
+    with pytest.raises(bioen_amd.BioenHipError):
+        bioen_amd.Context.from_raw(sim, exp, np.zeros(M))
+    with pytest.raises(ValueError):
+        bioen_amd.Context.from_raw(sim, exp[:-1] if M > 1 else np.zeros(2), err)
