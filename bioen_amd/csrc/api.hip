@@ -354,7 +354,7 @@ static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
 static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
     const int nblk = forces_fused_blocks(c);
     if (nblk > 0) {
-        // M <= 512: two passes over LDS-resident column strips instead of four streaming ones.
+        // M <= 1024: two passes over LDS-resident column strips instead of four streaming ones.
         // Measured at N = 1e6 x M = 512 (r01): pass 2 alone 0.85 ms at K = 1 against 1.22 ms for the
         // two passes it replaces (K = 4: 1.03 / 1.34, K = 8: 1.74 / 1.52).  Used for every K: the
         // paths add in different orders and a batched series must equal the single runs bit for bit.

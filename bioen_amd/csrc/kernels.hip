@@ -733,11 +733,17 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(ForcesRound r, const double
 // Output: partial[(row*K + a) * nblk + block], finished by k_fwd_rows_forces_grad.
 // ------------------------------------------------------------------------------
 constexpr int kStripCols = 16;
-constexpr int kStripRows = 512;
 
-template <int K, bool NT>
-// (min. 2 waves per SIMD: two blocks share a CU's LDS)
-__global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
+template <int WAVES, class F>
+__device__ __forceinline__ double sum_waves(F f) {          // fixed pairing, 4 or 8 waves
+    if constexpr (WAVES == 4) return (f(0) + f(1)) + (f(2) + f(3));
+    else return ((f(0) + f(1)) + (f(2) + f(3))) + ((f(4) + f(5)) + (f(6) + f(7)));
+}
+
+// THREADS = 256: up to 512 rows, two 70-KB blocks per CU; THREADS = 512: up to 1024 rows, one
+// 148-KB block per CU.  Either way a thread owns two rows, 2 waves per SIMD, 128 KB per CU in flight.
+template <int K, bool NT, int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
                                                          int n, const double* __restrict__ f_c, ForcesRound fr,
                                                          const double* __restrict__ w0,
                                                          double* __restrict__ partial, int nblk) {
@@ -746,14 +752,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restric
     constexpr int CB = KP >= 8 ? 2 : 4;
     constexpr int NV = CB * KP;
     constexpr int SHIFT = (NV == 4) ? 4 : (NV == 8) ? 3 : 2;
-    constexpr int PIECES = kStripRows * (C / 2) / kBlock;
-    __shared__ double tile[kStripRows][C + 1];
-    __shared__ double red[kWaves][C][K];
+    constexpr int ROWS = 2 * THREADS;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int PIECES = ROWS * (C / 2) / THREADS;
+    __shared__ double tile[ROWS][C + 1];
+    __shared__ double red[WAVES][C][K];
     __shared__ double xs[C][K];       // x of the strip, then e
     __shared__ double scale[K];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int row0 = t, row1 = t + kBlock;
+    const int row0 = t, row1 = t + THREADS;
     const bool has0 = row0 < mp, has1 = row1 < mp;
 
     double f0[K], f1[K], acc0[K], acc1[K];
@@ -769,14 +777,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restric
     auto fetch = [&](int strip) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            const int p = t + THREADS * i, row = p >> 3, part = p & 7;
             pre[i] = row < mp ? ldg2<NT>(Y + (size_t)row * ld + (size_t)strip * C + part * 2) : d2{0.0, 0.0};
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            const int p = t + THREADS * i, row = p >> 3, part = p & 7;
             tile[row][part * 2] = pre[i].x;
             tile[row][part * 2 + 1] = pre[i].y;
         }
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restric
             double v[NV];
 #pragma unroll
             for (int cc = 0; cc < CB; ++cc) {
-                const double y0 = tile[row0][CB * q + cc], y1 = tile[row1 & (kStripRows - 1)][CB * q + cc];
+                const double y0 = tile[row0][CB * q + cc], y1 = tile[row1 & (ROWS - 1)][CB * q + cc];
 #pragma unroll
                 for (int k = 0; k < KP; ++k) v[cc * KP + k] = k < K ? fma(y1, f1[k < K ? k : 0], y0 * f0[k < K ? k : 0]) : 0.0;
             }
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restric
         bool valid = false;
         if (t < C * K) {
             const int c = t / K, k = t % K;
-            x = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+            x = sum_waves<WAVES>([&](int wv_) { return red[wv_][c][k]; });
             valid = col < (size_t)n;
             fr.a[k][col] = valid ? x : 0.0;
             xs[c][k] = valid ? x : -DBL_MAX;
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_xy(const double* __restric
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double y0 = tile[row0][c], y1 = tile[row1 & (kStripRows - 1)][c];
+            const double y0 = tile[row0][c], y1 = tile[row1 & (ROWS - 1)][c];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const double ek = xs[c][k];
@@ -936,9 +944,8 @@ __global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, cons
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] = w0[j] * exp(x[j] - logz);
 }
 
-template <int K, bool NT, bool FROMX>
-// (min. 2 waves per SIMD: two blocks share a CU's LDS)
-__global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
+template <int K, bool NT, bool FROMX, int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void k_forces_bt(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
                                                       const double* __restrict__ r_c,
                                                       const double* __restrict__ ybar_c, ForcesRound fr,
                                                       const double* __restrict__ w0,
@@ -948,13 +955,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
     constexpr int CB = KP >= 8 ? 2 : 4;                         // columns per butterfly
     constexpr int NV = CB * KP;                                 // values per butterfly (4 .. 16)
     constexpr int SHIFT = (NV == 4) ? 4 : (NV == 8) ? 3 : 2;    // 6 - log2(NV)
-    constexpr int PIECES = kStripRows * (C / 2) / kBlock;       // 16-byte pieces per thread and strip: 16
-    __shared__ double tile[kStripRows][C + 1];                  // +1: rows 17 doubles apart, conflict-free columns
-    __shared__ double red[kWaves][C][K];
+    constexpr int ROWS = 2 * THREADS;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int PIECES = ROWS * (C / 2) / THREADS;       // 16-byte pieces per thread and strip: 16
+    __shared__ double tile[ROWS][C + 1];                  // +1: rows 17 doubles apart, conflict-free columns
+    __shared__ double red[WAVES][C][K];
     __shared__ double tv[C][K];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int row0 = t, row1 = t + kBlock;
+    const int row0 = t, row1 = t + THREADS;
     const bool has0 = row0 < mp, has1 = row1 < mp;
 
     double r0[K], r1[K], yb0[K], yb1[K], acc0[K], acc1[K];
@@ -971,14 +980,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
     auto fetch = [&](int strip) {                               // global -> registers, 8 lanes per row segment
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            const int p = t + THREADS * i, row = p >> 3, part = p & 7;
             pre[i] = row < mp ? ldg2<NT>(Y + (size_t)row * ld + (size_t)strip * C + part * 2) : d2{0.0, 0.0};
         }
     };
     auto stash = [&]() {                                        // registers -> LDS
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int p = t + kBlock * i, row = p >> 3, part = p & 7;
+            const int p = t + THREADS * i, row = p >> 3, part = p & 7;
             tile[row][part * 2] = pre[i].x;
             tile[row][part * 2 + 1] = pre[i].y;
         }
@@ -1009,7 +1018,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
             double v[NV];
 #pragma unroll
             for (int cc = 0; cc < CB; ++cc) {
-                const double y0 = tile[row0][CB * q + cc], y1 = tile[row1 & (kStripRows - 1)][CB * q + cc];
+                const double y0 = tile[row0][CB * q + cc], y1 = tile[row1 & (ROWS - 1)][CB * q + cc];
 #pragma unroll
                 for (int k = 0; k < KP; ++k) v[cc * KP + k] = k < K ? fma(y1, r1[k < K ? k : 0], y0 * r0[k < K ? k : 0]) : 0.0;
             }
@@ -1023,7 +1032,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
         // ---- phase 2 ----
         if (t < C * K) {
             const int c = t / K, k = t % K;
-            const double b = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+            const double b = sum_waves<WAVES>([&](int wv_) { return red[wv_][c][k]; });
             double dd = 1.0;
             if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += FROMX ? lr : log(wv) - log(w0v);
             tv[c][k] = (dd * fr.theta[k] + b) * wv;
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_forces_bt(const double* __restric
         // ---- phase 3 ----
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double y0 = tile[row0][c], y1 = tile[row1 & (kStripRows - 1)][c];
+            const double y0 = tile[row0][c], y1 = tile[row1 & (ROWS - 1)][c];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const double tk = tv[c][k];
@@ -1629,36 +1638,45 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles) {
                        ctiles, c->mp, K, c->gm);
 }
 
-// ---- fused forces gradient pass (M <= 512) ------------------------------------------------
+// ---- forces evaluation over LDS-resident column strips (M <= 1024) --------------------------
+static int strip_threads(const bioen_hip_ctx* c) { return c->mp <= 512 ? 256 : 512; }
+
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
-    if (c->mp > kStripRows || c->world != 1) return 0;
+    if (c->mp > 1024 || c->world != 1) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
-    return std::min(kFusedBlocks, nstrips);                     // two 70-KB blocks per CU
+    // 256 threads: two 70-KB blocks per CU; 512 threads: one 148-KB block per CU
+    return std::min(strip_threads(c) == 256 ? kFusedBlocks : kFusedBlocks / 2, nstrips);
 }
 
-template <int K, bool NT>
+template <int K, bool NT, int THREADS>
 static void forces_strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
     const int nstrips = (int)(c->ld / kStripCols);
     if (pass == 1)
-        hipLaunchKernelGGL((k_forces_xy<K, NT>), dim3(nblk), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp, nstrips,
-                           c->n, c->um, fr, c->fixed, c->fwd_partial, nblk);
+        hipLaunchKernelGGL((k_forces_xy<K, NT, THREADS>), dim3(nblk), dim3(THREADS), 0, c->stream, c->Y, c->ld, c->mp,
+                           nstrips, c->n, c->um, fr, c->fixed, c->fwd_partial, nblk);
     else
-        hipLaunchKernelGGL((k_forces_bt<K, NT, true>), dim3(nblk), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp,
-                           nstrips, c->r_c, c->ybar_c, fr, c->fixed, c->fwd_partial, nblk);
+        hipLaunchKernelGGL((k_forces_bt<K, NT, true, THREADS>), dim3(nblk), dim3(THREADS), 0, c->stream, c->Y, c->ld,
+                           c->mp, nstrips, c->r_c, c->ybar_c, fr, c->fixed, c->fwd_partial, nblk);
+}
+
+template <bool NT, int THREADS>
+static void forces_strip_dispatch_k(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
+    switch (fr.n) {
+        case 1: forces_strip_launch<1, NT, THREADS>(c, fr, nblk, pass); break;
+        case 2: forces_strip_launch<2, NT, THREADS>(c, fr, nblk, pass); break;
+        case 3: forces_strip_launch<3, NT, THREADS>(c, fr, nblk, pass); break;
+        case 4: forces_strip_launch<4, NT, THREADS>(c, fr, nblk, pass); break;
+        case 5: forces_strip_launch<5, NT, THREADS>(c, fr, nblk, pass); break;
+        case 6: forces_strip_launch<6, NT, THREADS>(c, fr, nblk, pass); break;
+        case 7: forces_strip_launch<7, NT, THREADS>(c, fr, nblk, pass); break;
+        default: forces_strip_launch<8, NT, THREADS>(c, fr, nblk, pass); break;
+    }
 }
 
 template <bool NT>
 static void forces_strip_dispatch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
-    switch (fr.n) {
-        case 1: forces_strip_launch<1, NT>(c, fr, nblk, pass); break;
-        case 2: forces_strip_launch<2, NT>(c, fr, nblk, pass); break;
-        case 3: forces_strip_launch<3, NT>(c, fr, nblk, pass); break;
-        case 4: forces_strip_launch<4, NT>(c, fr, nblk, pass); break;
-        case 5: forces_strip_launch<5, NT>(c, fr, nblk, pass); break;
-        case 6: forces_strip_launch<6, NT>(c, fr, nblk, pass); break;
-        case 7: forces_strip_launch<7, NT>(c, fr, nblk, pass); break;
-        default: forces_strip_launch<8, NT>(c, fr, nblk, pass); break;
-    }
+    if (strip_threads(c) == 256) forces_strip_dispatch_k<NT, 256>(c, fr, nblk, pass);
+    else forces_strip_dispatch_k<NT, 512>(c, fr, nblk, pass);
 }
 
 // pass 1: x = yTilde^T f, online softmax, raw ybar per block; then the block merge and ybar -> X_YBAR

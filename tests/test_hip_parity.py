@@ -180,10 +180,12 @@ def test_bitwise_reproducible(hip):
 # ---------------------------------------------------------------------------------------
 # edge shapes: ragged sizes around the 128-column / 32-row padding, tiny problems
 # ---------------------------------------------------------------------------------------
-# ... and around the 512-row limit of the fused forces gradient pass (k_forces_bt: rows 256..511 are
-# the second row of a thread, 513 rows fall back to the two-pass path)
+# ... and around the row limits of the forces strip passes (k_forces_xy / k_forces_bt: up to 512 rows
+# with 256-thread blocks, up to 1024 with 512-thread blocks, a thread's second row is t + THREADS;
+# beyond 1024 rows the four streaming passes take over)
 @pytest.mark.parametrize("M,N", [(1, 1), (1, 2), (3, 127), (31, 128), (32, 129), (33, 255), (65, 257), (7, 1000),
-                                 (255, 300), (257, 2049), (500, 1500), (512, 4100), (513, 700)])
+                                 (255, 300), (257, 2049), (500, 1500), (512, 4100), (513, 700), (1000, 900),
+                                 (1024, 1100), (1025, 300)])
 def test_ragged_shapes_vs_oracle(hip, M, N):
     from oracle import oracle_binding as O
     rng = np.random.default_rng(1000 * M + N)

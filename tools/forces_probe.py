@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bioen_amd
 
-N, M = 1000000, 512
+N, M = 1000000, int(os.environ.get("FORCES_M", "512"))
 P = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9, past=10,
          max_linesearch=100)
 rng = np.random.default_rng(12345)
