@@ -369,3 +369,24 @@ def test_large_forces_batch_vs_oracle(hip):
             assert info.lbfgs_code in (0, 1, -998) and code_o in (0, 1, -998)
             assert rel(info.fmin, fmin_o) < 2e-5
             assert abs(wi.sum() - 1.0) < 1e-12
+
+
+def test_forces_lbfgs_beyond_the_strip_limit_vs_oracle(hip):
+    """M > 1024 takes the four streaming passes (no LDS strips): a whole L-BFGS series through that
+    path, batched == single bit for bit and equal to the oracle within the stopping plateau."""
+    from oracle import oracle_binding as O
+    rng = np.random.default_rng(77)
+    M, N = 1030, 400
+    yTilde = rng.normal(5.0, 2.0, (M, N))
+    YTilde = rng.normal(5.0, 0.5, M)
+    w0 = rng.dirichlet(np.ones(N) * 3.0)
+    thetas = [1e4, 1e3]
+    with hip.Context(yTilde, YTilde) as ctx:
+        res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, LBFGS_DEFAULTS)
+        for k, th in enumerate(thetas):
+            fs, ws, info = ctx.opt_lbfgs_forces(np.zeros(M), w0, th, LBFGS_DEFAULTS)
+            assert infos[k].fmin == info.fmin and np.array_equal(res[k], fs) and np.array_equal(w[k], ws)
+            fo, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_forces(np.zeros(M), w0, yTilde, YTilde, th)
+            assert info.lbfgs_code in (0, 1, -998) and code_o in (0, 1, -998)
+            assert rel(info.fmin, fmin_o) < 2e-5
+            assert abs(ws.sum() - 1.0) < 1e-12
