@@ -351,24 +351,35 @@ static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
     launch_forces_norm(c, fr);                // w ; KL partials
 }
 
-static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
+static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
     const int nblk = forces_fused_blocks(c);
+    int rc;
     if (nblk > 0) {
         // M <= 1024: two passes over LDS-resident column strips instead of four streaming ones.
         // Measured at N = 1e6 x M = 512 (r01): pass 2 alone 0.85 ms at K = 1 against 1.22 ms for the
         // two passes it replaces (K = 4: 1.03 / 1.34, K = 8: 1.74 / 1.52).  Used for every K: the
         // paths add in different orders and a batched series must equal the single runs bit for bit.
-        launch_forces_xy(c, fr, nblk);        // F1 + F2: x, online softmax, ybar    [matrix pass 1]
-        launch_rows_combine(c, r, false);     //     r, chi^2
-        launch_forces_scalars_fused(c, fr);   //     f = theta KL + 0.5 chi^2
+        // Sharded contexts: every rank does this on its columns; the shares of ybar travel with the
+        // rank's softmax totals in ONE all-gather (the layout of the log-weights rounds, finished by
+        // the same k_rows_combine), the shares of the gradient in a second one.
+        launch_forces_xy(c, fr, nblk);        // F1 + F2: x, online softmax, this rank's ybar   [matrix pass 1]
+        if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
+        launch_rows_combine(c, r, true);      //     normalisation, ybar, r, chi^2, KL, f
         if (with_grad) {
             launch_forces_bt(c, fr, nblk);    // F3: b, t, centred product            [matrix pass 2]
-            launch_fwd_rows_forces_grad(c, fr.n, nblk);
+            if (c->world == 1) {
+                launch_fwd_rows_forces_grad(c, fr.n, nblk);
+            } else {
+                launch_fwd_rows_forces_grad_share(c, fr.n, nblk);
+                if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
+                launch_forces_grad_sum_ranks(c, fr.n);
+            }
         } else {
             launch_forces_w_from_x(c, fr);    // f-only evaluations hand out the weights
         }
-        return;
+        return 0;
     }
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "forces on a sharded context need M <= 1024 (strip passes)");
     enqueue_forces_weights(c, fr);
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
@@ -385,6 +396,7 @@ static void enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const R
         launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
         launch_fwd_rows_forces_grad(c, fr.n, c->fwd_ctiles);
     }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------
@@ -809,7 +821,7 @@ struct ForcesBatchEngine {
              "forces H2D");
         const ForcesRound fr = make_forces_round(c, slots, k, thetas);
         const Round r = make_round(c, slots, k, nullptr, thetas);
-        enqueue_forces_eval(c, fr, r, with_grad);
+        note(enqueue_forces_eval(c, fr, r, with_grad));
         if (with_grad)
             note(hipMemcpyAsync(gm_h, c->gm, (size_t)c->mp * k * sizeof(double), hipMemcpyDeviceToHost, c->stream),
                  "gradient D2H");
@@ -870,8 +882,7 @@ struct ForcesBatchEngine {
             info.chi2 = 0.5 * h[S_CHI];
             info.kl = h[S_KL];
             if (w_opt) {
-                note(hipMemcpyAsync(w_opt + (size_t)p.id * c->n, c->slot[s].w, (size_t)c->n * sizeof(double),
-                                    hipMemcpyDeviceToHost, c->stream), "weights D2H");
+                note(download_n(c, w_opt + (size_t)p.id * c->n_global, c->slot[s].w));   // gathers the ranks' blocks
                 note(hipStreamSynchronize(c->stream), "sync");
             }
             info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
@@ -1395,15 +1406,17 @@ int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* c, const double* g0, const double* G
 // ---- forces ---------------------------------------------------------------------------
 static bool is_affine(const bioen_hip_ctx* c) { return c->affine; }
 
-static int forces_guard(const bioen_hip_ctx* c) {
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
+static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
+    // sharded contexts run the forces method through the strip passes only (M <= 1024)
+    if (c->world != 1 && !(strip_path_ok && forces_fused_blocks(c) > 0))
+        return fail(BIOEN_HIP_ESTATE, "not available on this structure-sharded context");
     if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
     return 0;
 }
 
 int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const double* w0, double* w) {
     if (!c || !forces || !w0 || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    int rc = forces_guard(c);
+    int rc = forces_guard(c, false);          // streaming kernels: unsharded contexts only
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     if ((rc = upload_n(c, c->fixed, w0))) return rc;

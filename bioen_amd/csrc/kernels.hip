@@ -379,7 +379,8 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             double* sc = rd.scal[a];            // S_P, S_LOGS: written above by this same thread
             sc[S_CHI] = chi;
             sc[S_C] = cc;
-            sc[S_F] = rd.theta[a] * (sc[S_P] - sc[S_LOGS] + sc[S_LOGS0]) + 0.5 * chi;
+            sc[S_KL] = sc[S_P] - sc[S_LOGS] + sc[S_LOGS0];     // theta's factor: KL(w || w0) in both methods
+            sc[S_F] = rd.theta[a] * sc[S_KL] + 0.5 * chi;
         } else {
             double* pa = part.p[a];
             pa[(size_t)P_CHI * kMaxPartials] = chi;
@@ -888,37 +889,39 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
     }
 }
 
-// Merge the blocks of k_forces_xy (one block per problem): M = max_b m_b, Z = sum_b e^{m_b - M} Z_b.
+// Merge the blocks of k_forces_xy on THIS rank (one block per problem): m_r = max_b m_b,
+// Z_r = sum_b e^{m_b - m_r} Z_b, likewise sum e x; P_MAX[b] <- e^{m_b - m_r}, the weight of block
+// b's raw sums.  The rank totals {Z_r, sum e x, m_r} go to the tail of the rank's X_YBAR segment --
+// the layout of the log-weights rounds -- so k_rows_combine<true> finishes both methods alike:
 //   scal[S_LOGS] = M + log Z  (w_j = w0_j exp(x_j - S_LOGS)),  scal[S_P] = sum_j w_j x_j,
 //   KL = sum_j w_j log(w_j / w0_j) = S_P - S_LOGS   (c_bioen_kernels_forces.c:246-258, with
-//   log w_j - log w0_j = x_j - S_LOGS);  P_MAX[b] <- e^{m_b - M} / Z, the weight of block b's raw sums.
-__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int nblk) {
+//   log w_j - log w0_j = x_j - S_LOGS; the prior constant S_LOGS0 is zero for this method).
+__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int nblk, int mp, int K, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     double* pa = fr.part[a];
     double* pm = pa + (size_t)P_MAX * kMaxPartials;
-    const double M = max_partials(pm, nblk, sh);
+    const double mr = max_partials(pm, nblk, sh);
     double z = 0.0, px = 0.0;
     for (int b = threadIdx.x; b < nblk; b += kBlock) {
-        const double fb = exp(pm[b] - M);
+        const double fb = exp(pm[b] - mr);
         z = fma(fb, pa[(size_t)P_SUM * kMaxPartials + b], z);
         px = fma(fb, pa[(size_t)P_PP * kMaxPartials + b], px);
     }
     z = block_sum(z, sh);
     px = block_sum(px, sh);
-    const double invZ = 1.0 / z;
     __syncthreads();
-    for (int b = threadIdx.x; b < nblk; b += kBlock) pm[b] = exp(pm[b] - M) * invZ;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) pm[b] = exp(pm[b] - mr);
     if (threadIdx.x == 0) {
-        double* sc = fr.scal[a];
-        const double logz = M + log(z);
-        sc[S_LOGS] = logz;
-        sc[S_P] = px * invZ;
-        pa[(size_t)P_KL * kMaxPartials] = px * invZ - logz;      // read by k_forces_scalars (npkl = 1)
+        double* tail = xo.base + (size_t)xo.rank * xo.payload + (size_t)mp * K + 3 * a;
+        tail[0] = z;
+        tail[1] = px;
+        tail[2] = mr;
+        fr.scal[a][S_LOGS0] = 0.0;
     }
 }
 
-// ybar_i = sum_b weight_b raw_i,b   (a wave per (row, problem), fixed order) -> X_YBAR segment
+// this rank's share of ybar: sum_b weight_b raw_i,b   (a wave per (row, problem), fixed order)
 __global__ __launch_bounds__(kBlock) void k_forces_rows_weighted(const double* __restrict__ partial, int nblk, int mp,
                                                                  int K, ForcesRound fr, Xch xo) {
     const int a = blockIdx.y;
@@ -1638,11 +1641,33 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles) {
                        ctiles, c->mp, K, c->gm);
 }
 
+// sharded: this rank's share of the forces gradient -> its X_YBAR segment; after the exchange
+// k_sum_ranks adds the shares in rank order (identical on every rank) -> gm
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles) {
+    const Xch xo = make_xch(c, X_YBAR, c->mp * K);
+    hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_ranks(Xch xi, int count, double* __restrict__ out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int r = 0; r < xi.world; ++r) s += xi.base[(size_t)r * xi.payload + i];
+        out[i] = s;
+    }
+}
+
+void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K) {
+    const int count = c->mp * K;
+    hipLaunchKernelGGL(k_sum_ranks, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                       make_xch(c, X_YBAR, count), count, c->gm);
+}
+
 // ---- forces evaluation over LDS-resident column strips (M <= 1024) --------------------------
 static int strip_threads(const bioen_hip_ctx* c) { return c->mp <= 512 ? 256 : 512; }
 
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
-    if (c->mp > 1024 || c->world != 1) return 0;
+    if (c->mp > 1024) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
     // 256 threads: two 70-KB blocks per CU; 512 threads: one 148-KB block per CU
     return std::min(strip_threads(c) == 256 ? kFusedBlocks : kFusedBlocks / 2, nstrips);
@@ -1685,9 +1710,10 @@ void launch_forces_xy(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
         TimedLaunch tl(c, 1, fr.n);
         if (c->nontemporal) forces_strip_dispatch<true>(c, fr, nblk, 1); else forces_strip_dispatch<false>(c, fr, nblk, 1);
     }
-    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk);
+    const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, fr.n, true));
+    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk, c->mp, fr.n, xo);
     hipLaunchKernelGGL(k_forces_rows_weighted, dim3(rows_grid(c), fr.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       nblk, c->mp, fr.n, fr, make_xch(c, X_YBAR, ybar_payload(c, fr.n, false)));
+                       nblk, c->mp, fr.n, fr, xo);
 }
 
 // pass 2: b = yTilde^T r, t, centred yTilde . t
@@ -1700,9 +1726,7 @@ void launch_forces_w_from_x(bioen_hip_ctx* c, const ForcesRound& fr) {
     hipLaunchKernelGGL(k_forces_w_from_x, dim3(vec_grid(c), fr.n), dim3(kBlock), 0, c->stream, fr, c->fixed, c->n);
 }
 
-void launch_forces_scalars_fused(bioen_hip_ctx* c, const ForcesRound& r) {    // KL comes from k_forces_blockstats
-    hipLaunchKernelGGL(k_forces_scalars, dim3(1, r.n), dim3(kBlock), 0, c->stream, r, combine_grid(c), 1);
-}
+
 
 // ---- adjoint ---------------------------------------------------------------------------
 template <int K, bool NT, bool CENTER>

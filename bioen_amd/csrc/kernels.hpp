@@ -59,7 +59,8 @@ int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context doe
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
-void launch_forces_scalars_fused(bioen_hip_ctx* c, const struct ForcesRound& fr);
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles);   // sharded: -> X_YBAR segment
+void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K);                     //          shares -> gm
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
 void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);
 

@@ -308,7 +308,7 @@ def sweep_log_weights_sharded(ctx, thetas, G, g_init, lbfgs_params, verbose=Fals
 
 def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=False, verbose=False, max_batch=8):
     """Cold-started forces series (the ala5 notebook's protocol); a rank's thetas run as one
-    lock-step batch sharing the four matrix passes of every evaluation."""
+    lock-step batch sharing the matrix passes of every evaluation (two for M <= 1024, else four)."""
     comm = comm or SingleComm()
     thetas = [float(t) for t in thetas]
     mine = shard_thetas(thetas, comm.rank, comm.world)
@@ -319,3 +319,16 @@ def sweep_forces(ctx, thetas, w0, forces_init, lbfgs_params, comm=None, rccl=Fal
         for k, i in enumerate(mine):
             solved[i] = (w[k], infos[k])
     return theta_sweep(ctx, thetas, None, comm=comm, rccl=rccl, presolved=solved)
+
+
+def sweep_forces_sharded(ctx, thetas, w0, forces_init, lbfgs_params, verbose=False, max_batch=8):
+    """Forces series on a STRUCTURE-sharded context (BASELINE config 5's decomposition): every rank
+    keeps a column block of yTilde and of w0, all thetas stay batched on every rank, and an
+    evaluation needs two small all-gathers (the ranks' shares of ybar with their softmax totals, and
+    of the gradient); the M force variables and the L-BFGS state are replicated and, fed with
+    identical numbers, take identical decisions on every rank.  Needs M <= 1024 (strip passes)."""
+    thetas = [float(t) for t in thetas]
+    _, w, infos = ctx.opt_lbfgs_forces_batch(thetas, forces_init, w0, lbfgs_params, max_batch=max_batch, verbose=verbose)
+    return [{"theta": th, "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "iterations": i.iterations,
+             "evaluations": i.evaluations, "code": i.lbfgs_code, "seconds": i.seconds, "rank": -1, "w": w[k]}
+            for k, (th, i) in enumerate(zip(thetas, infos))]

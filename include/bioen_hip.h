@@ -225,6 +225,10 @@ int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
 int bioen_hip_selftest_lbfgs(int kind, int n, const double* x0, const bioen_lbfgs_config* config,
                              double* x_out, bioen_opt_result* info);
 
+/* Forces method on structure-sharded contexts: bioen_hip_forces_fdf and the forces optimizers work
+ * for M <= 1024 (two all-gathers per evaluation); bioen_hip_forces_weights and
+ * larger M return BIOEN_HIP_ESTATE there. */
+
 /* ---- yTilde assembled on the device from raw observables ---------------------------------
  * Replaces the host loops of bioen/analyze/observables/observables.py:110-143 (sim / sigma built
  * element by element, structure by structure) and the host division: yTilde_ij = sim_ij / err_i,

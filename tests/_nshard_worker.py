@@ -31,12 +31,25 @@ def main():
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
     ctx.close()
+
+    # forces method on a sharded context (strip passes: 2 all-gathers per evaluation)
+    fd = load_golden("synth_forces_M96xN3000.npz")
+    fctx = bioen_amd.Context(fd["yTilde"], fd["YTilde"], device=0, rank=comm.rank, world=comm.world)
+    fctx.set_exchange(comm)
+    f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
+    ff, fgrad = fctx.forces_fdf(f0, fd["w0"], 10.0)
+    fthetas = [100.0, 10.0, 1000.0]
+    fres, fw, finfos = fctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
+    fctx.close()
     comm.barrier()
     np.savez(out_path % comm.rank, w=w, logs=logs, f=f, grad=grad, res=res, wopt=wopt,
              fmin=np.array([i.fmin for i in infos]), iters=np.array([i.iterations for i in infos]),
              evals=np.array([i.evaluations for i in infos]), codes=np.array([i.lbfgs_code for i in infos]),
              chi2=np.array([i.chi2 for i in infos]), kl=np.array([i.kl for i in infos]),
-             block=block, col0=col0, n_local=n_local)
+             block=block, col0=col0, n_local=n_local,
+             ff=ff, fgrad=fgrad, fres=fres, fw=fw, ffmin=np.array([i.fmin for i in finfos]),
+             fiters=np.array([i.iterations for i in finfos]), fcodes=np.array([i.lbfgs_code for i in finfos]),
+             fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]))
     comm.close()
 
 

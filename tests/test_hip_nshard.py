@@ -40,9 +40,10 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
 
     # (a) every rank holds identical (gathered) results
     for r in range(1, world):
-        for key in ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl"):
+        for key in ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
+                    "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2"):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
-        assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"]
+        assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
 
     # the column blocks tile the matrix
     d = load_golden("synth_logw_M64xN2000.npz")
@@ -68,3 +69,18 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         assert abs(z[0]["fmin"][i] - info.fmin) <= 2e-5 * abs(info.fmin)
         assert abs(int(z[0]["iters"][i]) - info.iterations) <= max(5, info.iterations // 4)
         assert abs(z[0]["wopt"][i].sum() - 1.0) < 1e-12
+
+    # forces method: sharded strip passes against the single-GPU run
+    fd = load_golden("synth_forces_M96xN3000.npz")
+    f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
+    fthetas = [100.0, 10.0, 1000.0]
+    with bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as ctx:
+        ff1, fgrad1 = ctx.forces_fdf(f0, fd["w0"], 10.0)
+        fres1, fw1, finfos1 = ctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
+    assert abs(z[0]["ff"] - ff1) <= 1e-13 * abs(ff1)
+    assert np.abs(z[0]["fgrad"] - fgrad1).max() <= 1e-10 * np.abs(fgrad1).max()
+    for i, info in enumerate(finfos1):
+        assert z[0]["fcodes"][i] in (0, 1, -998) and info.lbfgs_code in (0, 1, -998)
+        assert abs(z[0]["ffmin"][i] - info.fmin) <= 2e-5 * abs(info.fmin)
+        assert abs(z[0]["fw"][i].sum() - 1.0) < 1e-12
+        assert abs(z[0]["ffmin"][i] - (fthetas[i] * z[0]["fkl"][i] + z[0]["fchi2"][i])) <= 1e-10 * abs(info.fmin)
