@@ -732,7 +732,7 @@ struct LogwBatchEngine {
 
 // ---------------------------------------------------------------------------------
 // forces method: the M variables of each problem live on the host (a few KB), the K problems of
-// a round share all four matrix passes of the evaluation.
+// a round share the matrix passes of the evaluation (two strip passes for M <= 1024, else four).
 // ---------------------------------------------------------------------------------
 struct ForcesProblem {
     int id = -1;

@@ -194,7 +194,7 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* ctx, const double* forces0, const 
 
 /* theta series of the forces method in one call (cf. bioen_hip_opt_lbfgs_logw_batch): the M
  * variables of every problem stay on the host, the up to `max_batch` problems of a round share
- * all four matrix passes of the evaluation.  forces0: shared (f0_stride = 0) or per theta
+ * all matrix passes of the evaluation (two for M <= 1024, else four).  forces0: shared (f0_stride = 0) or per theta
  * (stride >= m); results[ntheta][m]; w_opt[ntheta][n] or NULL. */
 int bioen_hip_opt_lbfgs_forces_batch(bioen_hip_ctx* ctx, int ntheta, const double* thetas,
                                      const double* forces0, size_t f0_stride, const double* w0,
