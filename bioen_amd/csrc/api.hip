@@ -399,640 +399,9 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
     return 0;
 }
 
-// ---------------------------------------------------------------------------------
-// lock-step batch engine for the log-weights method: up to kMaxBatch thetas advance one
-// evaluation per round and share both matrix passes of that round.
-// ---------------------------------------------------------------------------------
-struct BatchProblem {
-    int id = -1;                 // index into the caller's theta list
-    double theta = 0.0;
-    LbfgsMachine* machine = nullptr;
-    bool initial = true;         // next evaluation is the one at the start point
-    bool need_direction = false; // build d before the next trial
-    bool accept = false;         //   ... after committing the (s, y) pair
-    int end = 0, bound = 0;
-    std::chrono::steady_clock::time_point t0;
-};
-
-struct LogwBatchEngine {
-    bioen_hip_ctx* c;
-    const bioen_lbfgs_config& cfg;
-    bool verbose;
-    int rc = 0;
-
-    LogwBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
-        : c(ctx), cfg(config), verbose(verb) {}
-
-    void note(int e) { if (e && !rc) rc = e; }
-    void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
-
-    bool use_gram() const {
-        return c->direction_mode != 1;   // auto = Gram form
-    }
-
-    // Gram form (see kernels.hpp: GramArgs): 3 launches and one exchange for all accepting problems
-    void directions_gram(BatchProblem* slots, const std::vector<int>& list) {
-        GramArgs ga{};
-        ga.n = (int)list.size();
-        for (int a = 0; a < ga.n; ++a) {
-            BatchProblem& p = slots[list[a]];
-            ProblemSlot& sl = c->slot[list[a]];
-            std::swap(sl.x, sl.xp);           // the trial point becomes the accepted point
-            std::swap(sl.g, sl.gp);
-            ga.xnew[a] = sl.xp; ga.xold[a] = sl.x; ga.gnew[a] = sl.gp; ga.gold[a] = sl.g;
-            for (int i = 0; i < kHistory; ++i) {
-                ga.S[a][i] = sl.S[i];
-                ga.Y[a][i] = sl.Yh[i];
-            }
-            ga.d[a] = sl.d; ga.gram[a] = sl.gram; ga.scal[a] = sl.scal;
-            ga.end[a] = p.end;
-            ga.bound[a] = p.bound;
-        }
-        launch_gram(c, ga);
-        note(exchange(c, X_GRAM, (size_t)kGramDots * ga.n * vec_grid(c)));
-        launch_gram_solve(c, ga);
-        launch_combine(c, ga);
-        for (int s : list) {
-            slots[s].need_direction = false;
-            slots[s].accept = false;
-        }
-    }
-
-    // d = -H gp for the problems in `all` (lbfgs.c:571-598).  Gram mode: see directions_gram.
-    // Two-loop mode: 1 + 2*bound fused launches per problem, issued together; a problem with a
-    // shorter history starts later, so that all of them finish in the same launch (one X_DGI
-    // exchange for everybody).
-    void directions(BatchProblem* slots, const std::vector<int>& all) {
-        if (all.empty()) return;
-        std::vector<int> list = all;
-        if (use_gram()) {     // first directions (d = -g) keep the plain path; the rest go through the Gram form
-            std::vector<int> first, rest;
-            for (int s : all) (slots[s].accept ? rest : first).push_back(s);
-            if (!rest.empty()) directions_gram(slots, rest);
-            if (first.empty()) return;
-            list = first;
-        }
-        const int k = (int)list.size();
-        const size_t g = (size_t)vec_grid(c);
-        // commit the new pairs first
-        PairArgs pa{};
-        int np = 0;
-        for (int a = 0; a < k; ++a) {
-            const int s = list[a];
-            BatchProblem& p = slots[s];
-            if (!p.accept) continue;
-            ProblemSlot& sl = c->slot[s];
-            pa.x[np] = sl.x; pa.xp[np] = sl.xp; pa.g[np] = sl.g; pa.gp[np] = sl.gp;
-            pa.s[np] = sl.S[p.end]; pa.y[np] = sl.Yh[p.end]; pa.xpos[np] = a;
-            ++np;
-        }
-        if (np) {
-            pa.n = np;
-            launch_update_sy(c, pa, k);
-            note(exchange(c, X_SY, 2 * k * g));
-        }
-        int order[kMaxBatch][kHistory];
-        int maxb = 0;
-        for (int a = 0; a < k; ++a) {
-            BatchProblem& p = slots[list[a]];
-            ProblemSlot& sl = c->slot[list[a]];
-            if (p.accept) {   // the trial point becomes the accepted point
-                std::swap(sl.x, sl.xp);
-                std::swap(sl.g, sl.gp);
-            }
-            int j = (p.end + 1) % kHistory;
-            for (int b = 0; b < p.bound; ++b) {
-                j = (j + kHistory - 1) % kHistory;
-                order[a][b] = j;   // newest -> oldest
-            }
-            maxb = std::max(maxb, p.bound);
-        }
-        const int nlaunch = 1 + 2 * maxb;
-        for (int step = 0; step < nlaunch; ++step) {
-            RecurArgs q{};
-            q.n = k;
-            for (int a = 0; a < k; ++a) {
-                BatchProblem& p = slots[list[a]];
-                ProblemSlot& sl = c->slot[list[a]];
-                const int bound = p.bound;
-                const int my = step - 2 * (maxb - bound);   // this problem's own step index
-                q.d[a] = sl.d; q.gp[a] = sl.gp; q.scal[a] = sl.scal;
-                q.mode[a] = -1;
-                if (my < 0) continue;
-                const double* vdot = nullptr;
-                bool to_dginit = false;
-                if (my == 0) {
-                    q.mode[a] = 0;
-                    q.hist[a] = p.end;
-                    q.finalize_sy[a] = p.accept ? 1 : 0;
-                    if (bound == 0) { vdot = sl.gp; to_dginit = true; }
-                    else vdot = sl.S[order[a][0]];
-                } else if (my <= bound) {            // first loop, newest -> oldest
-                    const int b = my - 1;
-                    const bool last = (b == bound - 1);
-                    q.mode[a] = 1;
-                    q.hist[a] = order[a][b];
-                    q.vaxpy[a] = sl.Yh[order[a][b]];
-                    q.scale[a] = last ? 1 : 0;
-                    vdot = last ? sl.Yh[order[a][b]] : sl.S[order[a][b + 1]];
-                } else {                             // second loop, oldest -> newest
-                    const int b = bound - 1 - (my - 1 - bound);
-                    const bool last = (b == 0);
-                    q.mode[a] = 2;
-                    q.hist[a] = order[a][b];
-                    q.vaxpy[a] = sl.S[order[a][b]];
-                    if (last) { vdot = sl.gp; to_dginit = true; }
-                    else vdot = sl.Yh[order[a][b - 1]];
-                }
-                q.vdot[a] = vdot;
-                q.to_dginit[a] = to_dginit ? 1 : 0;
-            }
-            launch_recur(c, q, step);
-            if (step + 1 < nlaunch) note(exchange(c, (step & 1) ? X_REC1 : X_REC0, k * g));
-            else note(exchange(c, X_DGI, k * g));
-        }
-        MVec8 sc{};
-        for (int a = 0; a < k; ++a) sc.p[a] = c->slot[list[a]].scal;
-        launch_store_dginit(c, k, sc);
-        for (int s : list) {
-            slots[s].need_direction = false;
-            slots[s].accept = false;
-        }
-    }
-
-    int run(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride, const double* G_host,
-            int max_batch, double* results, double* w_opt, bioen_opt_result* infos) {
-        for (int i = 0; i < ntheta; ++i) std::memset(&infos[i], 0, sizeof(bioen_opt_result));
-        LbfgsMachine probe((int)std::min<long long>(c->n_global, 0x7fffffff), cfg);
-        const int bad = probe.validate();
-        if (bad != 0) {   // liblbfgs rejects the parameters before touching x (lbfgs.c:285-331)
-            for (int i = 0; i < ntheta; ++i) {
-                infos[i].lbfgs_code = bad;
-                std::memcpy(results + (size_t)i * c->n_global, g0_host + (size_t)i * g0_stride,
-                            (size_t)c->n_global * sizeof(double));
-            }
-            return 0;
-        }
-        int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
-        for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, true));
-        if (rc) return rc;
-        note(upload_n(c, c->fixed, G_host));
-        const bool shared_start = (g0_stride == 0) || ntheta == 1;
-        if (shared_start) {
-            if (!c->g0) note(dalloc_zero(&c->g0, c->ld, c->stream));
-            if (rc) return rc;
-            note(upload_n(c, c->g0, g0_host));
-        }
-        {   // log sum exp(G) once, written into every slot of the batch
-            int all[kMaxBatch];
-            for (int s = 0; s < kb; ++s) all[s] = s;
-            const Round r = make_round(c, all, kb, nullptr, nullptr);
-            if (c->world == 1) {
-                launch_logw_logs0(c, r);
-            } else {   // G is sharded on the device but whole on the host: same value on every rank
-                const double v = host_logsumexp(G_host, c->n_global);
-                for (int s = 0; s < kb; ++s)
-                    note(hipMemcpyAsync(c->slot[s].scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream),
-                         "logs0");
-                note(hipStreamSynchronize(c->stream), "sync");
-            }
-        }
-
-        BatchProblem slots[kMaxBatch];
-        std::vector<LbfgsMachine> machines;
-        machines.reserve(ntheta);
-        for (int i = 0; i < ntheta; ++i) machines.emplace_back((int)std::min<long long>(c->n_global, 0x7fffffff), cfg);
-        int next = 0, active = 0;
-        bool occupied[kMaxBatch] = {};
-
-        auto start_problem = [&](int s) {
-            BatchProblem& p = slots[s];
-            p = BatchProblem();
-            p.id = next;
-            p.theta = thetas[next];
-            p.machine = &machines[next];
-            p.t0 = std::chrono::steady_clock::now();
-            ProblemSlot& sl = c->slot[s];
-            if (shared_start)
-                note(hipMemcpyAsync(sl.xp, c->g0, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "copy g0");
-            else
-                note(upload_n(c, sl.xp, g0_host + (size_t)next * g0_stride));
-            note(hipMemsetAsync(sl.d, 0, c->ld * sizeof(double), c->stream), "memset d");
-            note(hipMemsetAsync(sl.gram, 0, kGramStride * sizeof(double), c->stream), "memset gram");
-            // the Gram sweep multiplies with every history buffer, live or not: leftovers of an earlier
-            // run in this slot (possibly non-finite after a diverged one) must not reach 0 * x
-            for (int i = 0; i < kHistory; ++i) {
-                note(hipMemsetAsync(sl.S[i], 0, c->ld * sizeof(double), c->stream), "memset S");
-                note(hipMemsetAsync(sl.Yh[i], 0, c->ld * sizeof(double), c->stream), "memset Y");
-            }
-            occupied[s] = true;
-            ++active;
-            ++next;
-        };
-        auto finish_problem = [&](int s, int code, bool keep_trial) {
-            BatchProblem& p = slots[s];
-            ProblemSlot& sl = c->slot[s];
-            bioen_opt_result& info = infos[p.id];
-            info.lbfgs_code = code;
-            info.iterations = p.machine->iterations();
-            info.evaluations = p.machine->evaluations();
-            info.fmin = p.machine->fx();
-            const double* res = keep_trial ? sl.x : sl.xp;
-            if (!keep_trial && !p.initial) {
-                // line search failed: liblbfgs returns the previous point; re-establish w, chi^2, KL there
-                note(hipMemcpyAsync(sl.x, sl.xp, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "revert");
-                const int one[1] = {s};
-                const Round r = make_round(c, one, 1, nullptr, &p.theta);
-                launch_max(c, r);
-                note(enqueue_logw_eval(c, r, false));
-                note(read_scalars(c, kMaxBatch));
-                res = sl.x;
-            }
-            const double* h = c->host_scal + (size_t)s * kScalStride;
-            info.chi2 = 0.5 * h[S_CHI];
-            info.kl = h[S_P] - h[S_LOGS] + h[S_LOGS0];
-            note(download_n(c, results + (size_t)p.id * c->n_global, res));
-            if (w_opt) {
-                const int one[1] = {s};
-                launch_scale_w(c, make_round(c, one, 1, nullptr, &p.theta));   // e -> w, only now
-                note(download_n(c, w_opt + (size_t)p.id * c->n_global, sl.w));
-            }
-            note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
-            info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
-            if (verbose) {
-                std::printf("\ttheta = %g\n", p.theta);
-                print_summary(c, info);
-            }
-            occupied[s] = false;
-            --active;
-        };
-
-        for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
-
-        while (active > 0 && !rc) {
-            // ---- one round: every active problem evaluates its next point -------------------------
-            int list[kMaxBatch];
-            double stp[kMaxBatch], th[kMaxBatch];
-            int k = 0;
-            for (int s = 0; s < kb; ++s) {
-                if (!occupied[s]) continue;
-                list[k] = s;
-                stp[k] = slots[s].initial ? 0.0 : slots[s].machine->trial_step();
-                th[k] = slots[s].theta;
-                ++k;
-            }
-            const Round r = make_round(c, list, k, stp, th);
-            launch_trial(c, r);
-            note(enqueue_logw_eval(c, r, true));
-            note(read_scalars(c, kMaxBatch));
-            note(check_launch());
-            if (rc) break;
-
-            std::vector<int> dir_list;
-            for (int a = 0; a < k; ++a) {
-                const int s = list[a];
-                BatchProblem& p = slots[s];
-                ProblemSlot& sl = c->slot[s];
-                const double* h = c->host_scal + (size_t)s * kScalStride;
-                LbfgsMachine::Action act;
-                if (p.initial) {
-                    act = p.machine->on_initial(h[S_F], h[S_GG], h[S_XX]);
-                    if (act.kind != LbfgsMachine::DONE) {
-                        std::swap(sl.g, sl.gp);      // gradient at the accepted (= start) point
-                        p.initial = false;
-                        p.need_direction = true;
-                        p.accept = false;
-                        p.end = 0;
-                        p.bound = 0;
-                        dir_list.push_back(s);
-                    }
-                } else {
-                    TrialResult t{h[S_F], h[S_DG], h[S_GG], h[S_XX], h[S_DGINIT]};
-                    act = p.machine->on_trial(t);
-                    if (act.kind == LbfgsMachine::ACCEPT) {
-                        p.need_direction = true;
-                        p.accept = true;
-                        p.end = act.end;
-                        p.bound = act.bound;
-                        dir_list.push_back(s);
-                    }
-                }
-                if (act.kind == LbfgsMachine::DONE) {
-                    finish_problem(s, act.code, act.keep_trial);
-                    if (next < ntheta && !rc) start_problem(s);
-                }
-            }
-            directions(slots, dir_list);
-        }
-        note(hipStreamSynchronize(c->stream), "sync");
-        note(check_launch());
-        return rc;
-    }
-};
-
-// ---------------------------------------------------------------------------------
-// forces method: the M variables of each problem live on the host (a few KB), the K problems of
-// a round share the matrix passes of the evaluation (two strip passes for M <= 1024, else four).
-// ---------------------------------------------------------------------------------
-struct ForcesProblem {
-    int id = -1;
-    double theta = 0.0;
-    LbfgsMachine* machine = nullptr;
-    bool initial = true;
-    std::vector<double> x, xp, g, gp, d;
-    std::vector<double> S[kHistory], Y[kHistory];
-    double ys[kHistory] = {}, alpha[kHistory] = {};
-    std::chrono::steady_clock::time_point t0;
-
-    static double dot(const std::vector<double>& a, const std::vector<double>& b) {
-        double s = 0.0;
-        for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
-        return s;
-    }
-    void start(int m, const double* x0) {
-        x.assign(m, 0.0);
-        xp.assign(x0, x0 + m);
-        g.assign(m, 0.0);
-        gp.assign(m, 0.0);
-        d.assign(m, 0.0);
-        for (int i = 0; i < kHistory; ++i) {
-            S[i].assign(m, 0.0);
-            Y[i].assign(m, 0.0);
-        }
-        initial = true;
-    }
-    // lbfgs.c:543-598 on host vectors
-    void accept(int end, int bound) {
-        const int m = (int)x.size();
-        for (int i = 0; i < m; ++i) {
-            S[end][i] = x[i] - xp[i];
-            Y[end][i] = g[i] - gp[i];
-        }
-        const double ys_new = dot(Y[end], S[end]), yy = dot(Y[end], Y[end]);
-        ys[end] = ys_new;
-        x.swap(xp);
-        g.swap(gp);
-        for (int i = 0; i < m; ++i) d[i] = -gp[i];
-        int j = (end + 1) % kHistory;
-        for (int b = 0; b < bound; ++b) {
-            j = (j + kHistory - 1) % kHistory;
-            alpha[j] = dot(S[j], d) / ys[j];
-            for (int i = 0; i < m; ++i) d[i] -= alpha[j] * Y[j][i];
-        }
-        const double sc = ys_new / yy;
-        for (int i = 0; i < m; ++i) d[i] *= sc;
-        for (int b = 0; b < bound; ++b) {
-            const double beta = dot(Y[j], d) / ys[j];
-            const double coef = alpha[j] - beta;
-            for (int i = 0; i < m; ++i) d[i] += coef * S[j][i];
-            j = (j + 1) % kHistory;
-        }
-    }
-};
-
-struct ForcesBatchEngine {
-    bioen_hip_ctx* c;
-    const bioen_lbfgs_config& cfg;
-    bool verbose;
-    int rc = 0;
-    double *um_h = nullptr, *gm_h = nullptr;     // pinned staging (pageable memory would make every copy a blocking one)
-
-    ForcesBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
-        : c(ctx), cfg(config), verbose(verb) {
-        const size_t cnt = (size_t)c->mp * kMaxBatch;
-        if (!c->host_m)
-            note(hipHostMalloc(reinterpret_cast<void**>(&c->host_m), 2 * cnt * sizeof(double), hipHostMallocDefault),
-                 "hipHostMalloc");
-        um_h = c->host_m;
-        gm_h = c->host_m ? c->host_m + cnt : nullptr;
-    }
-
-    void note(int e) { if (e && !rc) rc = e; }
-    void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
-
-    // evaluate the K points pts[a] (each m long); f -> host_scal, gradients -> gm_h (compact)
-    void evaluate(const int* slots, int k, const double* const* pts, const double* thetas, bool with_grad) {
-        const int m = c->m;
-        if (rc) return;
-        std::fill(um_h, um_h + (size_t)c->mp * k, 0.0);
-        for (int a = 0; a < k; ++a)
-            for (int i = 0; i < m; ++i) um_h[(size_t)i * k + a] = pts[a][i];
-        note(hipMemcpyAsync(c->um, um_h, (size_t)c->mp * k * sizeof(double), hipMemcpyHostToDevice, c->stream),
-             "forces H2D");
-        const ForcesRound fr = make_forces_round(c, slots, k, thetas);
-        const Round r = make_round(c, slots, k, nullptr, thetas);
-        note(enqueue_forces_eval(c, fr, r, with_grad));
-        if (with_grad)
-            note(hipMemcpyAsync(gm_h, c->gm, (size_t)c->mp * k * sizeof(double), hipMemcpyDeviceToHost, c->stream),
-                 "gradient D2H");
-        note(read_scalars(c, kMaxBatch));
-        note(check_launch());
-    }
-
-    int run(int ntheta, const double* thetas, const double* f0, size_t f0_stride, const double* w0_host, int max_batch,
-            double* results, double* w_opt, bioen_opt_result* infos) {
-        const int m = c->m;
-        for (int i = 0; i < ntheta; ++i) std::memset(&infos[i], 0, sizeof(bioen_opt_result));
-        LbfgsMachine probe(m, cfg);
-        const int bad = probe.validate();
-        if (bad != 0) {
-            for (int i = 0; i < ntheta; ++i) {
-                infos[i].lbfgs_code = bad;
-                std::memcpy(results + (size_t)i * m, f0 + (size_t)i * f0_stride, (size_t)m * sizeof(double));
-            }
-            return 0;
-        }
-        const int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
-        for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, false));
-        if (rc) return rc;
-        note(upload_n(c, c->fixed, w0_host));
-
-        std::vector<LbfgsMachine> machines;
-        machines.reserve(ntheta);
-        for (int i = 0; i < ntheta; ++i) machines.emplace_back(m, cfg);
-        std::vector<ForcesProblem> probs(kb);
-        bool occupied[kMaxBatch] = {};
-        int next = 0, active = 0;
-
-        auto start_problem = [&](int s) {
-            ForcesProblem& p = probs[s];
-            p.id = next;
-            p.theta = thetas[next];
-            p.machine = &machines[next];
-            p.start(m, f0 + (size_t)next * f0_stride);
-            p.t0 = std::chrono::steady_clock::now();
-            occupied[s] = true;
-            ++active;
-            ++next;
-        };
-        auto finish_problem = [&](int s, int code, bool keep_trial) {
-            ForcesProblem& p = probs[s];
-            bioen_opt_result& info = infos[p.id];
-            info.lbfgs_code = code;
-            info.iterations = p.machine->iterations();
-            info.evaluations = p.machine->evaluations();
-            info.fmin = p.machine->fx();
-            const std::vector<double>& res = keep_trial ? p.x : p.xp;
-            std::memcpy(results + (size_t)p.id * m, res.data(), (size_t)m * sizeof(double));
-            // weights, chi^2 and KL at the returned forces (forces.py:535-548 recomputes them too)
-            const int one[1] = {s};
-            const double* pt[1] = {res.data()};
-            evaluate(one, 1, pt, &p.theta, false);
-            const double* h = c->host_scal + (size_t)s * kScalStride;
-            info.chi2 = 0.5 * h[S_CHI];
-            info.kl = h[S_KL];
-            if (w_opt) {
-                note(download_n(c, w_opt + (size_t)p.id * c->n_global, c->slot[s].w));   // gathers the ranks' blocks
-                note(hipStreamSynchronize(c->stream), "sync");
-            }
-            info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
-            if (verbose) {
-                std::printf("\ttheta = %g\n", p.theta);
-                print_summary(c, info);
-            }
-            occupied[s] = false;
-            --active;
-        };
-
-        for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
-        while (active > 0 && !rc) {
-            int list[kMaxBatch];
-            double th[kMaxBatch];
-            const double* pts[kMaxBatch];
-            int k = 0;
-            for (int s = 0; s < kb; ++s) {
-                if (!occupied[s]) continue;
-                ForcesProblem& p = probs[s];
-                if (p.initial) {
-                    pts[k] = p.xp.data();
-                } else {
-                    const double stp = p.machine->trial_step();
-                    for (int i = 0; i < m; ++i) p.x[i] = p.xp[i] + stp * p.d[i];
-                    pts[k] = p.x.data();
-                }
-                list[k] = s;
-                th[k] = p.theta;
-                ++k;
-            }
-            evaluate(list, k, pts, th, true);
-            if (rc) break;
-            for (int a = 0; a < k; ++a) {
-                const int s = list[a];
-                ForcesProblem& p = probs[s];
-                const double f = c->host_scal[(size_t)s * kScalStride + S_F];
-                std::vector<double>& grad = p.initial ? p.gp : p.g;
-                for (int i = 0; i < m; ++i) grad[i] = gm_h[(size_t)i * k + a];
-                LbfgsMachine::Action act;
-                if (p.initial) {
-                    act = p.machine->on_initial(f, ForcesProblem::dot(p.gp, p.gp), ForcesProblem::dot(p.xp, p.xp));
-                    if (act.kind != LbfgsMachine::DONE) {
-                        for (int i = 0; i < m; ++i) p.d[i] = -p.gp[i];
-                        p.initial = false;
-                    }
-                } else {
-                    TrialResult t{f, ForcesProblem::dot(p.g, p.d), ForcesProblem::dot(p.g, p.g),
-                                  ForcesProblem::dot(p.x, p.x), ForcesProblem::dot(p.gp, p.d)};
-                    act = p.machine->on_trial(t);
-                    if (act.kind == LbfgsMachine::ACCEPT) p.accept(act.end, act.bound);
-                }
-                if (act.kind == LbfgsMachine::DONE) {
-                    finish_problem(s, act.code, act.keep_trial && !p.initial);
-                    if (next < ntheta && !rc) start_problem(s);
-                }
-            }
-        }
-        note(hipStreamSynchronize(c->stream), "sync");
-        return rc;
-    }
-};
-
-// analytic objectives of bioen_hip_selftest_lbfgs (host only, test hook)
-static double selftest_objective(int kind, int n, const double* x, double* g) {
-    double f = 0.0;
-    for (int i = 0; i < n; ++i) g[i] = 0.0;
-    if (kind == 0) {   // extended Rosenbrock over consecutive pairs
-        for (int i = 0; i + 1 < n; i += 2) {
-            const double t1 = 1.0 - x[i];
-            const double t2 = 10.0 * (x[i + 1] - x[i] * x[i]);
-            g[i + 1] = 20.0 * t2;
-            g[i] = -2.0 * (x[i] * g[i + 1] + t1);
-            f += t1 * t1 + t2 * t2;
-        }
-        if (n & 1) {
-            f += x[n - 1] * x[n - 1];
-            g[n - 1] = 2.0 * x[n - 1];
-        }
-    } else {           // sum_i c_i (x_i - 1)^2 + 0.01 (x_i - 1)^4, c_i spread over 4 decades
-        for (int i = 0; i < n; ++i) {
-            const double c = std::pow(10.0, 4.0 * i / (n > 1 ? n - 1 : 1) - 2.0);
-            const double d = x[i] - 1.0;
-            f += c * d * d + 0.01 * d * d * d * d;
-            g[i] = 2.0 * c * d + 0.04 * d * d * d;
-        }
-    }
-    return f;
-}
-
-struct HostSelftestBackend {
-    int kind, n;
-    std::vector<double> x, xp, g, gp, d;
-    std::vector<double> S[kHistory], Y[kHistory];
-    double ys[kHistory] = {}, alpha[kHistory] = {};
-    bool result_is_trial = false;
-
-    HostSelftestBackend(int k, int nn, const double* x0) : kind(k), n(nn), x(nn), xp(x0, x0 + nn), g(nn), gp(nn), d(nn) {
-        for (int i = 0; i < kHistory; ++i) {
-            S[i].assign(nn, 0.0);
-            Y[i].assign(nn, 0.0);
-        }
-    }
-    static double dot(const std::vector<double>& a, const std::vector<double>& b) {
-        double s = 0.0;
-        for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
-        return s;
-    }
-    void initial(double* f, double* gg, double* xx) {
-        *f = selftest_objective(kind, n, xp.data(), gp.data());
-        *gg = dot(gp, gp);
-        *xx = dot(xp, xp);
-        for (int i = 0; i < n; ++i) d[i] = -gp[i];
-    }
-    void trial(double stp, TrialResult* t) {
-        for (int i = 0; i < n; ++i) x[i] = xp[i] + stp * d[i];
-        t->f = selftest_objective(kind, n, x.data(), g.data());
-        t->dg = dot(g, d);
-        t->gg = dot(g, g);
-        t->xx = dot(x, x);
-        t->dginit = dot(gp, d);
-    }
-    void accept(int end, int bound) {
-        for (int i = 0; i < n; ++i) {
-            S[end][i] = x[i] - xp[i];
-            Y[end][i] = g[i] - gp[i];
-        }
-        const double ys_new = dot(Y[end], S[end]), yy = dot(Y[end], Y[end]);
-        ys[end] = ys_new;
-        x.swap(xp);
-        g.swap(gp);
-        for (int i = 0; i < n; ++i) d[i] = -gp[i];
-        int j = (end + 1) % kHistory;
-        for (int b = 0; b < bound; ++b) {
-            j = (j + kHistory - 1) % kHistory;
-            alpha[j] = dot(S[j], d) / ys[j];
-            for (int i = 0; i < n; ++i) d[i] -= alpha[j] * Y[j][i];
-        }
-        const double sc = ys_new / yy;
-        for (int i = 0; i < n; ++i) d[i] *= sc;
-        for (int b = 0; b < bound; ++b) {
-            const double beta = dot(Y[j], d) / ys[j];
-            const double coef = alpha[j] - beta;
-            for (int i = 0; i < n; ++i) d[i] += coef * S[j][i];
-            j = (j + 1) % kHistory;
-        }
-    }
-    void revert() { result_is_trial = false; }
-    void keep_trial() { result_is_trial = true; }
-};
+#include "engine_logw.inl"
+#include "engine_forces.inl"
+#include "selftest_lbfgs.inl"
 
 static void print_config(const bioen_lbfgs_config& p) {
     // same table the reference prints when verbose (c_bioen_kernels_logw.c:620-634)
