@@ -177,12 +177,17 @@ def main():
         # Splitting the structures pays when the per-pass saving beats the 3 small all-gathers a
         # round then needs (ybar + softmax totals, gradient dots, Gram update) plus launch
         # overhead; decided with margin:  t_pass * (1 - 1/world)  vs  5 * t_exchange + 0.15 ms.
-        t_ex = max(comm.allgather_object(ctx.exchange_probe(count=M * min(8, len(thetas)), reps=40)))
+        try:
+            t_mine, probe_error = ctx.exchange_probe(count=M * min(8, len(thetas)), reps=40), None
+        except bioen_amd.BioenHipError as e:      # an exchange that does not work anywhere: deal thetas everywhere
+            t_mine, probe_error = float("inf"), str(e)
+        t_ex = max(comm.allgather_object(t_mine))
         t_pass_us = 2.0 * M * float(N) * 8 / 6.4e12 * 1e6
         gain_us = t_pass_us * (1.0 - 1.0 / world)
         cost_us = 5.0 * t_ex + 150.0
-        decision = {"exchange_us": t_ex, "pass_saving_us": gain_us, "exchange_cost_us": cost_us,
-                    "chosen": "structures" if gain_us > cost_us else "thetas"}
+        decision = {"exchange_us": t_ex if np.isfinite(t_ex) else None, "pass_saving_us": gain_us,
+                    "exchange_cost_us": cost_us if np.isfinite(cost_us) else None,
+                    "chosen": "structures" if gain_us > cost_us else "thetas", "probe_error": probe_error}
         if gain_us <= cost_us:
             ctx.close()
             nshard = False
