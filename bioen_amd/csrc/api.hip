@@ -172,10 +172,11 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     TRY(dalloc_zero(&c->gram, (size_t)kMaxBatch * kGramStride, c->stream));
     {   // exchange stages: [world][capacity]
         const size_t npl = (size_t)vec_grid(c);
-        const size_t arrays[X_COUNT] = {1, 3, 0, 3, 2, 1, 1, 1, 0, kGramDots};
+        const size_t arrays[X_COUNT] = {1, 3, 0, 3, 2, 1, 1, 1, 0, kGramDots, 0};
         for (int st = 0; st < X_COUNT; ++st) {
             size_t cap = arrays[st] * kMaxBatch * npl;
             if (st == X_YBAR) cap = (size_t)(c->mp + 3) * kMaxBatch;
+            if (st == X_GRAMR) cap = world > 1 ? (size_t)kGramDots * kMaxBatch : 0;
             if (st == X_VEC) cap = world > 1 ? c->ld : 0;
             c->xcap[st] = cap;
             if (cap) TRY(dalloc_zero(&c->xbuf[st], cap * world, c->stream));

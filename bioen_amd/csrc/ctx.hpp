@@ -91,7 +91,8 @@ enum XStage : int {
     X_REC1,      //                                                  (pong)
     X_DGI,       // 1 array : gp . d
     X_VEC,       // ld values per problem: result vectors at the end
-    X_GRAM,      // kGramDots arrays: inner products of (s, y, g) with the 13 basis vectors
+    X_GRAM,      // kGramDots arrays: inner products of (s, y, g) with the 13 basis vectors (block partials)
+    X_GRAMR,     // kGramDots values per problem: the rank's totals of X_GRAM -- what sharded contexts exchange
     X_COUNT
 };
 

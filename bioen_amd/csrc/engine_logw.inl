@@ -50,7 +50,10 @@ struct LogwBatchEngine {
             ga.bound[a] = p.bound;
         }
         launch_gram(c, ga);
-        note(exchange(c, X_GRAM, (size_t)kGramDots * ga.n * vec_grid(c)));
+        if (c->world > 1) {                       // ship 39 totals per problem, not 39 x blocks partials
+            launch_gram_rank_reduce(c, ga.n);
+            note(exchange(c, X_GRAMR, (size_t)kGramDots * ga.n));
+        }
         launch_gram_solve(c, ga);
         launch_combine(c, ga);
         for (int s : list) {

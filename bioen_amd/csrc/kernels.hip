@@ -1241,6 +1241,15 @@ __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
 
 // Per problem (one block): finish the 39 sums, update the Gram matrix, run the two-loop recursion
 // (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
+// Sharded contexts: one block per (sum, problem) totals THIS rank's block partials into the compact
+// X_GRAMR stage, so that the all-gather ships 39 doubles per problem and rank instead of 39 x npl.
+__global__ __launch_bounds__(kBlock) void k_gram_rank_reduce(Xch xi, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    const double v = xsum_rank<kGramDots>(xi, xi.rank, a, c, sh);
+    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kGramDots + c] = v;
+}
+
 // One block per (sum, problem) finishes the 39 sums (gram[kGramSums + c]); a single block doing
 // all of them walks 39 x npl partials as dependent L2 loads (66 us at N = 1e6, measured).
 __global__ __launch_bounds__(kBlock) void k_gram_reduce(GramArgs q, Xch xi) {
@@ -1841,7 +1850,22 @@ void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
                        make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
 }
 
+static Xch gram_rank_view(const bioen_hip_ctx* c, int k) {      // X_GRAMR: one value per (rank, problem, sum)
+    Xch x = make_xch(c, X_GRAMR, kGramDots * k);
+    x.npl = 1;
+    return x;
+}
+
+void launch_gram_rank_reduce(bioen_hip_ctx* c, int k) {
+    hipLaunchKernelGGL(k_gram_rank_reduce, dim3(kGramDots, k), dim3(kBlock), 0, c->stream,
+                       make_xch(c, X_GRAM, kGramDots * k * vec_grid(c)), gram_rank_view(c, k));
+}
+
 void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
+    if (c->world > 1) {                                  // the ranks' totals (after the X_GRAMR exchange)
+        hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, gram_rank_view(c, a.n));
+        return;
+    }
     const Xch xi = make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c));
     if ((long long)vec_grid(c) * c->world <= 256) {      // <= 4 dependent loads per lane and sum
         hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);

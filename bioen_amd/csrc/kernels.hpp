@@ -154,6 +154,7 @@ struct GramArgs {
     int bound[kMaxBatch];            // pairs in use (including the new one)
 };
 void launch_gram(bioen_hip_ctx* c, const GramArgs& a);          // [exchange X_GRAM]
+void launch_gram_rank_reduce(bioen_hip_ctx* c, int k);   // sharded: X_GRAM block partials -> X_GRAMR rank totals
 void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a);
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a);
 
