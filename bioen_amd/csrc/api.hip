@@ -1,5 +1,5 @@
 // extern "C" entry points of libbioen_hip.so (declared in include/bioen_hip.h) and the
-// two L-BFGS backends that sit on the kernels of kernels.hip.
+// two L-BFGS backends that sit on the kernels of kernels_*.hip.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 

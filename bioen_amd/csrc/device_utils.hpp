@@ -1,0 +1,174 @@
+// Device-side building blocks shared by the kernel files: wave / block reductions with fixed
+// shapes, accessors of the exchange stages (ctx.hpp: XStage), 16-byte loads, launch timing.
+#pragma once
+
+#include "kernels.hpp"
+
+#include <cfloat>
+
+namespace bioen {
+
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+// ------------------------------------------------------------------------------
+// reductions (fixed order => deterministic)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;   // every lane holds the sum
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Butterfly-reduce NV (power of two, <= 64) per-lane values at once: at every stage the two
+// lanes of a pair split the remaining values between them, so the whole thing costs NV-1
+// shuffles instead of 6*NV.  Each value's sum is formed in the same pair order
+// (32,16,8,4,2,1) as wave_sum, hence bitwise equal to it.  On return v[0] of lane l is the
+// total of value number  l >> (6 - log2 NV).
+template <int CNT, int O, int NV>
+__device__ __forceinline__ void multi_stage(double (&v)[NV], int lane) {
+    if constexpr (O >= 1) {
+        if constexpr (CNT > 1) {
+            const bool upper = (lane & O) != 0;
+            constexpr int half = CNT / 2;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const double send = upper ? v[i] : v[i + half];
+                const double keep = upper ? v[i + half] : v[i];
+                v[i] = keep + __shfl_xor(send, O, 64);
+            }
+            multi_stage<half, O / 2, NV>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], O, 64);
+            multi_stage<1, O / 2, NV>(v, lane);
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void wave_multi_reduce(double (&v)[NV], int lane) {
+    multi_stage<NV, 32, NV>(v, lane);
+}
+
+// sum over the 256 threads of a block; result in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh /* [kWaves] */) {
+    v = wave_sum(v);
+    __syncthreads();   // protect sh against the previous use
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// Sum an array of per-block partials written by the PREVIOUS kernel.  Every block of the
+// consumer kernel does this redundantly in its prologue (<= 8 KiB, L2 resident), which
+// replaces a separate 1-block "finalise" launch.
+__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int np, double* sh) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < np; k += kBlock) s += p[k];
+    return block_sum(s, sh);
+}
+
+__device__ __forceinline__ double max_partials(const double* __restrict__ p, int np, double* sh) {
+    double s = -DBL_MAX;
+    for (int k = threadIdx.x; k < np; k += kBlock) s = fmax(s, p[k]);
+    return block_max(s, sh);
+}
+
+// ---- exchange-stage accessors (ctx.hpp: XStage).  Layout [rank][problem a][array q][block].
+// put: this rank's block partial.  sum/max: over all ranks and blocks in a fixed order
+// (rank-major), identical on every rank.
+template <int A>
+__device__ __forceinline__ void xput(const Xch& x, int a, int q, double v) {
+    x.base[(size_t)x.rank * x.payload + (size_t)(a * A + q) * x.npl + blockIdx.x] = v;
+}
+
+template <int A>
+__device__ __forceinline__ double xsum(const Xch& x, int a, int q, double* sh) {
+    double s = 0.0;
+    for (int r = 0; r < x.world; ++r) {
+        const double* p = x.base + (size_t)r * x.payload + (size_t)(a * A + q) * x.npl;
+        for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
+    }
+    return block_sum(s, sh);
+}
+
+// sum over the blocks of ONE rank's segment
+template <int A>
+__device__ __forceinline__ double xsum_rank(const Xch& x, int rk, int a, int q, double* sh) {
+    double s = 0.0;
+    const double* p = x.base + (size_t)rk * x.payload + (size_t)(a * A + q) * x.npl;
+    for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
+    return block_sum(s, sh);
+}
+
+template <int A>
+__device__ __forceinline__ double xmax(const Xch& x, int a, int q, double* sh) {
+    double s = -DBL_MAX;
+    for (int r = 0; r < x.world; ++r) {
+        const double* p = x.base + (size_t)r * x.payload + (size_t)(a * A + q) * x.npl;
+        for (int k = threadIdx.x; k < x.npl; k += kBlock) s = fmax(s, p[k]);
+    }
+    return block_max(s, sh);
+}
+
+// maximum over THIS rank's segment only (no exchange needed before it)
+template <int A>
+__device__ __forceinline__ double xmax_local(const Xch& x, int a, int q, double* sh) {
+    double s = -DBL_MAX;
+    const double* p = x.base + (size_t)x.rank * x.payload + (size_t)(a * A + q) * x.npl;
+    for (int k = threadIdx.x; k < x.npl; k += kBlock) s = fmax(s, p[k]);
+    return block_max(s, sh);
+}
+
+template <bool NT>
+__device__ __forceinline__ d2 ldg2(const double* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    return *reinterpret_cast<const d2*>(p);
+}
+
+constexpr int next_pow2(int v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : 8)); }
+
+
+struct TimedLaunch {
+    bioen_hip_ctx* c;
+    KernelTimer::Pair pr;
+    bool on;
+    TimedLaunch(bioen_hip_ctx* ctx, int which, int k) : c(ctx), on(ctx->timer.enabled) {
+        if (!on) return;
+        KernelTimer& t = c->timer;
+        if (!t.pool.empty()) {
+            pr = t.pool.back();
+            t.pool.pop_back();
+        } else {
+            (void)hipEventCreate(&pr.a);
+            (void)hipEventCreate(&pr.b);
+        }
+        pr.which = which;
+        pr.k = k;
+        (void)hipEventRecord(pr.a, c->stream);
+    }
+    ~TimedLaunch() {
+        if (!on) return;
+        (void)hipEventRecord(pr.b, c->stream);
+        c->timer.pending.push_back(pr);
+    }
+};
+
+}  // namespace bioen

@@ -1,4 +1,5 @@
-// Host-side launch API of the gfx950 kernels (definitions: kernels.hip).
+// Host-side launch API of the gfx950 kernels (definitions: kernels_matrix.hip, kernels_logw.hip,
+// kernels_forces.hip, kernels_misc.hip; shared device helpers: device_utils.hpp).
 // Every function enqueues on ctx->stream and returns without synchronising.
 //
 // All kernels are batched: a launch serves the K (<= kMaxBatch) problems listed in a
@@ -119,7 +120,7 @@ struct PairArgs {      // s = x - xp ; y = g - gp for the accepting problems
 };
 void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a, int kdir);
 
-// One fused step of the two-loop recursion per problem (see kernels.hip: k_recur).
+// One fused step of the two-loop recursion per problem (see kernels_logw.hip: k_recur).
 struct RecurArgs {
     int n;
     int mode[kMaxBatch];          // -1 idle, 0 init (d = -gp), 1 first loop, 2 second loop
@@ -135,7 +136,7 @@ struct RecurArgs {
 };
 void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step);
 
-// Direction from inner products (kernels.hip: k_gram / k_gram_solve / k_combine): the same
+// Direction from inner products (kernels_logw.hip: k_gram / k_gram_solve / k_combine): the same
 // two-loop recursion carried out on coefficients over the basis {S_0..5, Y_0..5, g}.  One sweep
 // commits the new (s, y) pair and produces every inner product the recursion needs, so a direction
 // costs 3 launches and ONE stage exchange instead of 14 + 14.

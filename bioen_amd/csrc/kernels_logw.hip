@@ -1,0 +1,574 @@
+// N-vector kernels of the log-weights evaluation and of the L-BFGS direction (gfx950).
+#include "device_utils.hpp"
+
+namespace bioen {
+
+// ------------------------------------------------------------------------------
+// log-weights N-vector kernels (blockIdx.y = position a in the round's batch)
+// ------------------------------------------------------------------------------
+// x = xp + stp * d ; block maxima of x
+__global__ __launch_bounds__(kBlock) void k_trial(Round r, int n, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    double* __restrict__ x = r.x[a];
+    const double* __restrict__ xp = r.xp[a];
+    const double* __restrict__ d = r.d[a];
+    const double stp = r.stp[a];
+    double mx = -DBL_MAX;
+    const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 dv = *reinterpret_cast<const d2*>(d + j);
+        const d2 pv = *reinterpret_cast<const d2*>(xp + j);
+        d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
+        *reinterpret_cast<d2*>(x + j) = v;
+        mx = fmax(mx, v.x);
+        if (j + 1 < n) mx = fmax(mx, v.y);
+    }
+    mx = block_max(mx, sh);
+    if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
+}
+
+__global__ __launch_bounds__(kBlock) void k_max(Round r, int n, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = r.x[a];
+    double mx = -DBL_MAX;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, x[j]);
+    mx = block_max(mx, sh);
+    if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
+}
+
+// _get_weights (c_bioen_kernels_logw.c:55-94) with a max shift, first half:
+//   e_j = exp(x_j - m_r) ; partials of sum e and sum e (x - G)   (prior, :96-127)
+// m_r is the maximum over THIS rank's structures (its own block maxima need no exchange); it
+// travels with the sums (third array, entry 0) and k_logw_norm rescales by exp(m_r - max_r m_r),
+// which is exactly 1 on a single GPU.
+__global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, Xch xmx,
+                                                     Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = r.x[a];
+    double* __restrict__ e = r.w[a];
+    const double gmax = xmax_local<1>(xmx, a, 0, sh);
+    double s = 0.0, pp = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 xv = *reinterpret_cast<const d2*>(x + j);
+        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        d2 ev;
+        ev.x = exp(xv.x - gmax);
+        ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
+        *reinterpret_cast<d2*>(e + j) = ev;
+        s += ev.x;
+        pp = fma(ev.x, xv.x - Gv.x, pp);
+        s += ev.y;
+        pp = fma(ev.y, xv.y - Gv.y, pp);
+    }
+    s = block_sum(s, sh);
+    pp = block_sum(pp, sh);
+    if (threadIdx.x == 0) {
+        xput<3>(xo, a, 0, s);
+        xput<3>(xo, a, 1, pp);
+        if (blockIdx.x == 0) xput<3>(xo, a, 2, gmax);
+    }
+}
+
+// second half: w = e / S ; scal[S_LOGS] = max + log S ; scal[S_P] = sum e (x-G) / S
+__global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    double* __restrict__ w = r.w[a];
+    // global shift M = max_r m_r ; S = sum_r e^{m_r - M} S_r   (rank order; e^0 = 1 on one GPU)
+    double gmax = -DBL_MAX;
+    for (int rk = 0; rk < xe.world; ++rk)
+        gmax = fmax(gmax, xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl]);
+    double S = 0.0;
+    for (int rk = 0; rk < xe.world; ++rk) {
+        const double mr = xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+        S = fma(exp(mr - gmax), xsum_rank<3>(xe, rk, a, 0, sh), S);
+    }
+    const double mown = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+    const double inv = exp(mown - gmax) / S;
+    if (blockIdx.x == 0) {
+        double PP = 0.0;
+        for (int rk = 0; rk < xe.world; ++rk) {
+            const double mr = xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+            PP = fma(exp(mr - gmax), xsum_rank<3>(xe, rk, a, 1, sh), PP);
+        }
+        if (threadIdx.x == 0) {
+            r.scal[a][S_LOGS] = gmax + log(S);
+            r.scal[a][S_P] = PP * (1.0 / S);
+        }
+    }
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        d2 v = *reinterpret_cast<const d2*>(w + 2 * p);
+        v.x *= inv;
+        v.y *= inv;
+        *reinterpret_cast<d2*>(w + 2 * p) = v;
+    }
+}
+
+// log s0 = log sum exp(G): constant per problem, computed once (the reference recomputes it
+// at every evaluation, c_bioen_kernels_logw.c:122).  One block; every problem of the round
+// gets the value.
+__global__ __launch_bounds__(kBlock) void k_logsumexp1(const double* __restrict__ G, int n, Round r) {
+    __shared__ double sh[kWaves];
+    double mx = -DBL_MAX;
+    for (int j = threadIdx.x; j < n; j += kBlock) mx = fmax(mx, G[j]);
+    mx = block_max(mx, sh);
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n; j += kBlock) s += exp(G[j] - mx);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        const double v = mx + log(s);
+        for (int a = 0; a < r.n; ++a) r.scal[a][S_LOGS0] = v;
+    }
+}
+
+// gradient epilogue (c_bioen_kernels_logw.c:207-218):
+//   g_k = w_k [ theta (x_k - G_k - P) + a_k ],  a_k = sum_i r_i (yTilde_ik - ybar_i)  (centred adjoint)
+// plus the three dot products the line search / convergence test needs.
+__global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __restrict__ G, int n, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = r.x[a];
+    const double* __restrict__ w = r.w[a];
+    const double* __restrict__ av = r.a[a];
+    const double* __restrict__ d = r.d[a];
+    double* __restrict__ g = r.g[a];
+    const double theta = r.theta[a];
+    const double P = r.scal[a][S_P];
+    const double inv = r.scal[a][S_INV];      // w = e * inv
+    double dg = 0.0, gg = 0.0, xx = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 xv = *reinterpret_cast<const d2*>(x + j);
+        d2 wv = *reinterpret_cast<const d2*>(w + j);           // pad: e = 0  =>  g = 0
+        wv.x *= inv;
+        wv.y *= inv;
+        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        const d2 aa = *reinterpret_cast<const d2*>(av + j);
+        const d2 dv = *reinterpret_cast<const d2*>(d + j);
+        d2 gv;
+        gv.x = wv.x * (theta * ((xv.x - Gv.x) - P) + aa.x);
+        gv.y = wv.y * (theta * ((xv.y - Gv.y) - P) + aa.y);
+        *reinterpret_cast<d2*>(g + j) = gv;
+        dg = fma(gv.x, dv.x, dg);
+        gg = fma(gv.x, gv.x, gg);
+        xx = fma(xv.x, xv.x, xx);
+        dg = fma(gv.y, dv.y, dg);
+        gg = fma(gv.y, gv.y, gg);
+        xx = fma(xv.y, xv.y, xx);
+    }
+    dg = block_sum(dg, sh);
+    gg = block_sum(gg, sh);
+    xx = block_sum(xx, sh);
+    if (threadIdx.x == 0) {
+        xput<3>(xo, a, 0, dg);
+        xput<3>(xo, a, 1, gg);
+        xput<3>(xo, a, 2, xx);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double dg = xsum<3>(xg, a, 0, sh);
+    const double gg = xsum<3>(xg, a, 1, sh);
+    const double xx = xsum<3>(xg, a, 2, sh);
+    if (threadIdx.x == 0) {
+        double* sc = r.scal[a];
+        sc[S_DG] = dg;
+        sc[S_GG] = gg;
+        sc[S_XX] = xx;
+    }
+}
+
+// gp . d of the freshly built direction -> scal[S_DGINIT] (the next line search's initial slope)
+__global__ __launch_bounds__(kBlock) void k_store_dginit(MVec8 scal, Xch xd) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double di = xsum<1>(xd, a, 0, sh);
+    if (threadIdx.x == 0) scal.p[a][S_DGINIT] = di;
+}
+
+
+// ------------------------------------------------------------------------------
+// L-BFGS vector kernels (liblbfgs lbfgs.c:543-615 with every scalar device-resident)
+// ------------------------------------------------------------------------------
+// s = x - xp, y = g - gp (lbfgs.c:549-551); partials of y.s and y.y (:559-561)
+__global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const double* __restrict__ x = p.x[a];
+    const double* __restrict__ xp = p.xp[a];
+    const double* __restrict__ g = p.g[a];
+    const double* __restrict__ gp = p.gp[a];
+    double* __restrict__ s = p.s[a];
+    double* __restrict__ y = p.y[a];
+    double ys = 0.0, yy = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < n2; q += gridDim.x * kBlock) {
+        const int j = 2 * q;
+        const d2 xa = *reinterpret_cast<const d2*>(x + j), xb = *reinterpret_cast<const d2*>(xp + j);
+        const d2 ga = *reinterpret_cast<const d2*>(g + j), gb = *reinterpret_cast<const d2*>(gp + j);
+        const d2 sv = {xa.x - xb.x, xa.y - xb.y};
+        const d2 yv = {ga.x - gb.x, ga.y - gb.y};
+        *reinterpret_cast<d2*>(s + j) = sv;
+        *reinterpret_cast<d2*>(y + j) = yv;
+        ys = fma(yv.x, sv.x, ys);
+        yy = fma(yv.x, yv.x, yy);
+        ys = fma(yv.y, sv.y, ys);
+        yy = fma(yv.y, yv.y, yy);
+    }
+    ys = block_sum(ys, sh);
+    yy = block_sum(yy, sh);
+    if (threadIdx.x == 0) {
+        xput<2>(xo, p.xpos[a], 0, ys);
+        xput<2>(xo, p.xpos[a], 1, yy);
+    }
+}
+
+// One fused step of the two-loop recursion (lbfgs.c:571-598).  The dot product a step needs
+// was left as per-block partials by the previous step; every block re-reduces them (fixed
+// order) in its prologue, so a step is ONE launch:
+//   mode 0: d = -gp                                   [+ finalise y.s, y.y of slot `hist`]
+//   mode 1: alpha_h = (S_h . d) / ys_h ; d -= alpha_h Y_h        (first loop)
+//   mode 2: beta = (Y_h . d) / ys_h ; d += (alpha_h - beta) S_h  (second loop)
+//   scale : d *= ys / yy   after the update (last step of the first loop)
+// and in the same sweep  out_partials = vdot . d  for the next step (or gp . d, the next
+// line search's initial slope).  mode -1: this problem has no step in this launch.
+__global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int n, Xch xin, Xch xsy, Xch xrec, Xch xdgi) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const int mode = q.mode[a];
+    if (mode < 0) return;
+    const int hist = q.hist[a];
+    const int scale = q.scale[a];
+    double* __restrict__ d = q.d[a];
+    const double* __restrict__ gp = q.gp[a];
+    const double* __restrict__ vaxpy = q.vaxpy[a];
+    const double* __restrict__ vdot = q.vdot[a];
+    double* scal = q.scal[a];
+    double coef = 0.0, sc = 1.0;
+    if (mode == 0) {
+        if (q.finalize_sy[a] && blockIdx.x == 0) {
+            const double ys = xsum<2>(xsy, a, 0, sh);
+            const double yy = xsum<2>(xsy, a, 1, sh);
+            if (threadIdx.x == 0) {
+                scal[S_YSH + hist] = ys;
+                scal[S_YS] = ys;
+                scal[S_YY] = yy;
+            }
+        }
+    } else {
+        const double dot = xsum<1>(xin, a, 0, sh);
+        const double ysh = scal[S_YSH + hist];
+        if (mode == 1) {
+            const double alpha = dot / ysh;
+            coef = -alpha;
+            if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_ALPHA + hist] = alpha;
+        } else {
+            coef = scal[S_ALPHA + hist] - dot / ysh;
+        }
+        if (scale) sc = scal[S_YS] / scal[S_YY];
+    }
+    double acc = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        d2 dv;
+        if (mode == 0) {
+            const d2 gv = *reinterpret_cast<const d2*>(gp + j);
+            dv.x = -gv.x;
+            dv.y = -gv.y;
+        } else {
+            const d2 av = *reinterpret_cast<const d2*>(vaxpy + j);
+            const d2 old = *reinterpret_cast<const d2*>(d + j);
+            dv.x = fma(coef, av.x, old.x);
+            dv.y = fma(coef, av.y, old.y);
+            if (scale) {
+                dv.x *= sc;
+                dv.y *= sc;
+            }
+        }
+        *reinterpret_cast<d2*>(d + j) = dv;
+        if (vdot) {
+            const d2 vv = *reinterpret_cast<const d2*>(vdot + j);
+            acc = fma(vv.x, dv.x, acc);
+            acc = fma(vv.y, dv.y, acc);
+        }
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) {
+        if (q.to_dginit[a]) xput<1>(xdgi, a, 0, acc);
+        else if (vdot) xput<1>(xrec, a, 0, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// direction from inner products ("compact" two-loop recursion)
+// ------------------------------------------------------------------------------
+// One sweep: s = xnew - xold, y = gnew - gold -> history slot `end`; and the 39 inner products
+// of (s, y, gnew) with the basis B = {S_0..5, Y_0..5, gnew} (S_end = s, Y_end = y).
+__global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
+    __shared__ double sh[kWaves][64];
+    const int a = blockIdx.y;
+    const int e = q.end[a];
+    const double* __restrict__ xn = q.xnew[a];
+    const double* __restrict__ xo_ = q.xold[a];
+    const double* __restrict__ gn = q.gnew[a];
+    const double* __restrict__ go = q.gold[a];
+    double acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 a0 = *reinterpret_cast<const d2*>(xn + j), a1 = *reinterpret_cast<const d2*>(xo_ + j);
+        const d2 gv = *reinterpret_cast<const d2*>(gn + j), g1 = *reinterpret_cast<const d2*>(go + j);
+        const d2 sv = {a0.x - a1.x, a0.y - a1.y};
+        const d2 yv = {gv.x - g1.x, gv.y - g1.y};
+        d2 B[kBasis];
+#pragma unroll
+        for (int k = 0; k < kHistory; ++k) {
+            B[k] = (k == e) ? sv : *reinterpret_cast<const d2*>(q.S[a][k] + j);
+            B[kHistory + k] = (k == e) ? yv : *reinterpret_cast<const d2*>(q.Y[a][k] + j);
+        }
+        B[2 * kHistory] = gv;
+        *reinterpret_cast<d2*>(q.S[a][e] + j) = sv;
+        *reinterpret_cast<d2*>(q.Y[a][e] + j) = yv;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) {
+            acc[c] = fma(sv.x, B[c].x, acc[c]);
+            acc[c] = fma(sv.y, B[c].y, acc[c]);
+            acc[kBasis + c] = fma(yv.x, B[c].x, acc[kBasis + c]);
+            acc[kBasis + c] = fma(yv.y, B[c].y, acc[kBasis + c]);
+            acc[2 * kBasis + c] = fma(gv.x, B[c].x, acc[2 * kBasis + c]);
+            acc[2 * kBasis + c] = fma(gv.y, B[c].y, acc[2 * kBasis + c]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_multi_reduce<64>(acc, lane);          // lane l now holds the wave total of value l
+    sh[wave][lane] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < kGramDots) {
+        const double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        xo.base[(size_t)xo.rank * xo.payload + (size_t)(a * kGramDots + threadIdx.x) * xo.npl + blockIdx.x] = v;
+    }
+}
+
+// Per problem (one block): finish the 39 sums, update the Gram matrix, run the two-loop recursion
+// (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
+// Sharded contexts: one block per (sum, problem) totals THIS rank's block partials into the compact
+// X_GRAMR stage, so that the all-gather ships 39 doubles per problem and rank instead of 39 x npl.
+__global__ __launch_bounds__(kBlock) void k_gram_rank_reduce(Xch xi, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    const double v = xsum_rank<kGramDots>(xi, xi.rank, a, c, sh);
+    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kGramDots + c] = v;
+}
+
+// One block per (sum, problem) finishes the 39 sums (gram[kGramSums + c]); a single block doing
+// all of them walks 39 x npl partials as dependent L2 loads (66 us at N = 1e6, measured).
+__global__ __launch_bounds__(kBlock) void k_gram_reduce(GramArgs q, Xch xi) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    const double v = xsum<kGramDots>(xi, a, c, sh);
+    if (threadIdx.x == 0) q.gram[a][kGramSums + c] = v;
+}
+
+// The 13x13 matrix lives in LDS while one thread walks the two loops.  FUSED: few partials per sum
+// (small or sharded problems) -- the block also finishes the 39 sums, dealt to its 4 waves, which
+// saves the k_gram_reduce launch.  The order of the additions differs between the two paths, so
+// the choice depends on (npl, world) alone: every rank and every batch width takes the same one.
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
+    __shared__ double dots[kGramDots];
+    __shared__ double Gs[kBasis * kBasis];
+    __shared__ double coef[kBasis];
+    __shared__ double alpha[kHistory];
+    const int a = blockIdx.y;
+    double* G = q.gram[a];
+    for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
+    if (FUSED) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int c = wave; c < kGramDots; c += kWaves) {
+            double s = 0.0;
+            for (int r = 0; r < xi.world; ++r) {
+                const double* p = xi.base + (size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl;
+                for (int k = lane; k < xi.npl; k += 64) s += p[k];
+            }
+            s = wave_sum(s);
+            if (lane == 0) dots[c] = s;
+        }
+    } else {
+        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = G[kGramSums + i];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int e = q.end[a], bound = q.bound[a];
+    const int rs = e, ry = kHistory + e, rg = 2 * kHistory;
+    for (int c = 0; c < kBasis; ++c) {
+        Gs[rs * kBasis + c] = Gs[c * kBasis + rs] = dots[c];
+        Gs[ry * kBasis + c] = Gs[c * kBasis + ry] = dots[kBasis + c];
+    }
+    for (int c = 0; c < kBasis; ++c) Gs[rg * kBasis + c] = Gs[c * kBasis + rg] = dots[2 * kBasis + c];
+    for (int c = 0; c < kBasis; ++c) {        // the three rows/columns that changed go back to HBM
+        G[rs * kBasis + c] = G[c * kBasis + rs] = Gs[rs * kBasis + c];
+        G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
+        G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
+    }
+    // q = -g as coefficients over {S, Y, g}
+    for (int c = 0; c < kBasis; ++c) coef[c] = 0.0;
+    coef[rg] = -1.0;
+    for (int b = 0; b < bound; ++b) {         // first loop, newest -> oldest
+        const int i = (e + kHistory - b) % kHistory;
+        double sq = 0.0;
+        for (int c = 0; c < kBasis; ++c) sq = fma(coef[c], Gs[i * kBasis + c], sq);
+        const double al = sq / Gs[(kHistory + i) * kBasis + i];
+        alpha[i] = al;
+        coef[kHistory + i] -= al;
+    }
+    const double scale = Gs[ry * kBasis + rs] / Gs[ry * kBasis + ry];   // ys / yy of the newest pair
+    for (int c = 0; c < kBasis; ++c) coef[c] *= scale;
+    for (int b = bound - 1; b >= 0; --b) {    // second loop, oldest -> newest
+        const int i = (e + kHistory - b) % kHistory;
+        double yq = 0.0;
+        for (int c = 0; c < kBasis; ++c) yq = fma(coef[c], Gs[(kHistory + i) * kBasis + c], yq);
+        const double beta = yq / Gs[(kHistory + i) * kBasis + i];
+        coef[i] += alpha[i] - beta;
+    }
+    double dg = 0.0;
+    for (int c = 0; c < kBasis; ++c) dg = fma(coef[c], Gs[rg * kBasis + c], dg);
+    for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = coef[c];
+    q.scal[a][S_DGINIT] = dg;
+}
+
+// d = sum_c coef_c B_c
+__global__ __launch_bounds__(kBlock) void k_combine(GramArgs q, int n) {
+    const int a = blockIdx.y;
+    const double* coef = q.gram[a] + kBasis * kBasis;
+    double cf[kBasis];
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] = coef[c];
+    double* __restrict__ d = q.d[a];
+    const double* __restrict__ gn = q.gnew[a];
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 gv = *reinterpret_cast<const d2*>(gn + j);
+        d2 dv = {cf[2 * kHistory] * gv.x, cf[2 * kHistory] * gv.y};
+#pragma unroll
+        for (int k = 0; k < kHistory; ++k) {
+            if (cf[k] != 0.0) {               // unused history slots may hold another problem's leftovers
+                const d2 v = *reinterpret_cast<const d2*>(q.S[a][k] + j);
+                dv.x = fma(cf[k], v.x, dv.x);
+                dv.y = fma(cf[k], v.y, dv.y);
+            }
+            if (cf[kHistory + k] != 0.0) {
+                const d2 v = *reinterpret_cast<const d2*>(q.Y[a][k] + j);
+                dv.x = fma(cf[kHistory + k], v.x, dv.x);
+                dv.y = fma(cf[kHistory + k], v.y, dv.y);
+            }
+        }
+        *reinterpret_cast<d2*>(d + j) = dv;
+    }
+}
+
+
+// ---- log-weights vector kernels -----------------------------------------------------------
+void launch_trial(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_trial, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+}
+
+void launch_max(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_max, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+}
+
+void launch_logw_exp(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+}
+
+void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+}
+
+void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logsumexp1, dim3(1), dim3(kBlock), 0, c->stream, c->fixed, c->n, r);
+}
+
+void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logw_grad, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
+}
+
+void launch_finish_eval(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_finish_eval, dim3(1, r.n), dim3(kBlock), 0, c->stream, r,
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
+}
+
+void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal) {
+    hipLaunchKernelGGL(k_store_dginit, dim3(1, k), dim3(kBlock), 0, c->stream, scal,
+                       make_xch(c, X_DGI, k * vec_grid(c)));
+}
+
+
+// ---- L-BFGS vector kernels ----------------------------------------------------------------------
+void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a, int kdir) {
+    hipLaunchKernelGGL(k_update_sy, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+                       make_xch(c, X_SY, 2 * kdir * vec_grid(c)));
+}
+
+void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step) {
+    const int k = a.n, g = vec_grid(c);
+    // step s reads the running dot its predecessor left in REC[(s-1)&1] and writes REC[s&1]
+    hipLaunchKernelGGL(k_recur, dim3(g, k), dim3(kBlock), 0, c->stream, a, c->n,
+                       make_xch(c, ((step - 1) & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_SY, 2 * k * g),
+                       make_xch(c, (step & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_DGI, k * g));
+}
+
+void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
+    hipLaunchKernelGGL(k_gram, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+                       make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
+}
+
+static Xch gram_rank_view(const bioen_hip_ctx* c, int k) {      // X_GRAMR: one value per (rank, problem, sum)
+    Xch x = make_xch(c, X_GRAMR, kGramDots * k);
+    x.npl = 1;
+    return x;
+}
+
+void launch_gram_rank_reduce(bioen_hip_ctx* c, int k) {
+    hipLaunchKernelGGL(k_gram_rank_reduce, dim3(kGramDots, k), dim3(kBlock), 0, c->stream,
+                       make_xch(c, X_GRAM, kGramDots * k * vec_grid(c)), gram_rank_view(c, k));
+}
+
+void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
+    if (c->world > 1) {                                  // the ranks' totals (after the X_GRAMR exchange)
+        hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, gram_rank_view(c, a.n));
+        return;
+    }
+    const Xch xi = make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c));
+    if ((long long)vec_grid(c) * c->world <= 256) {      // <= 4 dependent loads per lane and sum
+        hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);
+    } else {
+        hipLaunchKernelGGL(k_gram_reduce, dim3(kGramDots, a.n), dim3(kBlock), 0, c->stream, a, xi);
+        hipLaunchKernelGGL(k_gram_solve<false>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);
+    }
+}
+
+void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {
+    hipLaunchKernelGGL(k_combine, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+}
+
+
+}  // namespace bioen

@@ -1,0 +1,497 @@
+// gfx950 (CDNA4, wave64) kernels of the BioEn log-weights / forces hot path.
+//
+// Two kernels touch the M x N matrix and carry >99 % of the bytes:
+//   k_fwd_partial : ybar_a = yTilde . v_a    (replaces _bioen_chi_squared's GEMV,
+//                                             c_bioen_common.c:76-86, and _getAve,
+//                                             c_bioen_kernels_forces.c:93-109)
+//   k_adj         : out_a  = yTilde^T . u_a  (replaces the transposed-cache walks of
+//                                             c_bioen_kernels_logw.c:185-205 and
+//                                             c_bioen_kernels_forces.c:127-150,300-320)
+// for a = 0..K-1: up to K = 8 optimisation problems (thetas of a series) share one pass,
+// so the matrix bytes per problem drop by K while the arithmetic per problem -- and its
+// order -- is exactly that of a K = 1 launch (batched runs are bitwise equal to single
+// runs).  Both kernels stream the row-major matrix once with 16-byte-per-lane loads (one
+// aligned KiB per wave instruction) straight into registers: the operand is read once and
+// not shared across waves, so an LDS round trip would be pure overhead.  FP64 FMA issue
+// stays far below the HBM-bound budget up to K = 8 (2K flop per 8 bytes), which is why the
+// batch runs on the vector ALU rather than on v_mfma_f64 (whose 16x16x4 shape would also
+// force 64-byte row fragments instead of KiB-wide coalesced loads).
+// Every reduction has a fixed shape => results are bitwise reproducible run to run.
+#include "device_utils.hpp"
+
+namespace bioen {
+
+// ------------------------------------------------------------------------------
+// forward pass: partial[(row*K + a)*ctiles + tile] = sum_{j in tile} Y[row][j] v_a[j]
+//   block = 4 waves stacked over rows, R rows per wave; a wave walks its column tile in
+//   128-column (1 KiB) steps, STEPS steps in flight, K x R accumulators.
+//   CENTER: sum_j (Y[row][j] - ybar_a[row]) v_a[j] -- the centred form the reference uses for the
+//   forces gradient (c_bioen_kernels_forces.c:330-338); ybar_a[row] is wave-uniform and read
+//   through the scalar cache (compact layout [row*K + a]).
+// ------------------------------------------------------------------------------
+template <int R, int K, int STEPS, bool NT, bool CENTER>
+__global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict__ Y, size_t ld, Vec8 v,
+                                                        const double* __restrict__ ybar_c,
+                                                        double* __restrict__ partial, int ctiles,
+                                                        int steps_per_tile, int total_steps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // blockIdx.x = row block (fast index): consecutive blocks share the column tile, so the
+    // tile's slice of v_a is fetched from HBM once per XCD and then served by L2
+    const int tile = blockIdx.y;
+    const int row0 = (blockIdx.x * kWaves + wave) * R;
+    int s = tile * steps_per_tile;
+    int s_end = s + steps_per_tile;
+    if (s_end > total_steps) s_end = total_steps;
+
+    const size_t col = (size_t)s * 128 + lane * 2;
+    const double* yp = Y + (size_t)row0 * ld + col;
+
+    constexpr int KP = next_pow2(K);
+    double acc[KP * R];
+#pragma unroll
+    for (int i = 0; i < KP * R; ++i) acc[i] = 0.0;
+    const double* ybp = ybar_c + (size_t)row0 * K;   // [r*K + k], wave-uniform
+
+    size_t off = col;
+    if constexpr (STEPS == 0) {
+        // software pipeline: the NEXT step's rows of Y are in flight while this step's K x R
+        // products are formed (two register sets, no moves)
+        d2 ya[R], yb2[R];
+        d2 vv[K];
+        auto loadY = [&](d2* y, int step) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) y[r] = ldg2<NT>(yp + (size_t)r * ld + (size_t)step * 128);
+        };
+        auto work = [&](const d2* y, int step) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) vv[k] = *reinterpret_cast<const d2*>(v.p[k] + off + (size_t)step * 128);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double yb = CENTER ? ybp[r * K + k] : 0.0;
+                    acc[k * R + r] = fma(y[r].x - yb, vv[k].x, acc[k * R + r]);
+                    acc[k * R + r] = fma(y[r].y - yb, vv[k].y, acc[k * R + r]);
+                }
+            }
+        };
+        const int nsteps = s_end - s;
+        int t = 0;
+        if (nsteps > 0) loadY(ya, 0);
+        for (; t + 1 < nsteps; t += 2) {
+            loadY(yb2, t + 1);
+            work(ya, t);
+            if (t + 2 < nsteps) loadY(ya, t + 2);
+            work(yb2, t + 1);
+        }
+        if (t < nsteps) work(ya, t);
+        s = s_end;
+    }
+    constexpr int ST = STEPS == 0 ? 1 : STEPS;
+    for (; s + ST <= s_end; s += ST) {
+        d2 y[ST][R];
+        d2 vv[ST][K];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) y[t][r] = ldg2<NT>(yp + (size_t)r * ld + t * 128);
+#pragma unroll
+            for (int k = 0; k < K; ++k) vv[t][k] = *reinterpret_cast<const d2*>(v.p[k] + off + t * 128);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double yb = CENTER ? ybp[r * K + k] : 0.0;
+#pragma unroll
+                for (int t = 0; t < ST; ++t) {
+                    acc[k * R + r] = fma(y[t][r].x - yb, vv[t][k].x, acc[k * R + r]);
+                    acc[k * R + r] = fma(y[t][r].y - yb, vv[t][k].y, acc[k * R + r]);
+                }
+            }
+        }
+        yp += ST * 128;
+        off += ST * 128;
+    }
+    for (; s < s_end; ++s) {   // tail (only when STEPS = 2 and the tile has an odd step count)
+        d2 y[R];
+        d2 vv[K];
+#pragma unroll
+        for (int r = 0; r < R; ++r) y[r] = ldg2<NT>(yp + (size_t)r * ld);
+#pragma unroll
+        for (int k = 0; k < K; ++k) vv[k] = *reinterpret_cast<const d2*>(v.p[k] + off);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double yb = CENTER ? ybp[r * K + k] : 0.0;
+                acc[k * R + r] = fma(y[r].x - yb, vv[k].x, acc[k * R + r]);
+                acc[k * R + r] = fma(y[r].y - yb, vv[k].y, acc[k * R + r]);
+            }
+        }
+        yp += 128;
+        off += 128;
+    }
+
+    constexpr int NV = KP * R;
+    wave_multi_reduce<NV>(acc, lane);
+    constexpr int SHIFT = (NV == 8) ? 3 : (NV == 16) ? 2 : (NV == 32) ? 1 : 0;   // 6 - log2(NV)
+    if ((lane & ((1 << SHIFT) - 1)) == 0) {
+        const int idx = lane >> SHIFT;
+        const int k = idx / R, r = idx % R;
+        if (k < K) partial[((size_t)(row0 + r) * K + k) * ctiles + tile] = acc[0];
+    }
+}
+
+// reduce the column tiles of one (row, problem) per wave (fixed order): this rank's share of
+// ybar, written into its segment of the X_YBAR stage (compact layout [row*K + a])
+// WITH_EXP (log-weights rounds): block 0 of each problem also totals this rank's softmax partials
+// and appends {sum e, sum e (x - G), m_r} to the rank's segment, so the normalisation needs no
+// exchange of its own.
+template <bool WITH_EXP>
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restrict__ partial, int ctiles,
+                                                           int mp, int K, Xch xo, Xch xe) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double* out = xo.base + (size_t)xo.rank * xo.payload;
+    if (WITH_EXP && blockIdx.x == 0) {
+        const double s = xsum_rank<3>(xe, xe.rank, a, 0, sh);
+        const double pp = xsum_rank<3>(xe, xe.rank, a, 1, sh);
+        if (threadIdx.x == 0) {
+            double* tail = out + (size_t)mp * K + 3 * a;
+            tail[0] = s;
+            tail[1] = pp;
+            tail[2] = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+        }
+    }
+    for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
+        const double* p = partial + ((size_t)row * K + a) * ctiles;
+        double s = 0.0;
+        for (int k = lane; k < ctiles; k += 64) s += p[k];
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)row * K + a] = s;
+    }
+}
+
+// add the ranks' shares (rank order) -> ybar, r = ybar - YT (compact) ; per-block partials of
+// sum r^2 and sum ybar r.  Every rank computes the same numbers.
+// Affine observable model (ctx.hpp): ybar_eff_i = off_i + sc_i (Y w)_i  (sum w = 1), while ybar_c
+// keeps the RAW Y w, which is what the centred passes subtract: the offset cancels in
+// sum_i r_i (yTilde_eff_ik - ybar_eff_i) = sum_i (r_i sc_i) (Y_ik - (Y w)_i), so the adjoint's
+// operand r_c is stored pre-multiplied by sc_i.  (off, sc) = (0, 1): the plain model, same bits.
+// One block per problem (M is a few thousand rows at most in BioEn's use), so the block also
+// finishes the sums: LOGW: f = theta (P - log s + log s0) + 0.5 sum r^2  (c_bioen_kernels_logw.c:124-147)
+// lands in scal[S_F] without a further launch; forces: partial 0 feeds k_forces_scalars.
+template <bool LOGW>
+__global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, const double* __restrict__ YT,
+                                                         const double* __restrict__ row_offset,
+                                                         const double* __restrict__ row_scale,
+                                                         double* __restrict__ ybar_c, double* __restrict__ r_c,
+                                                         MVec8 part, Round rd) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    // LOGW: the shares are yTilde . e_r with e_r = exp(x - m_r) unnormalised; global shift
+    // M = max_r m_r, S = sum_r e^{m_r - M} S_r, and rank r's share enters with e^{m_r - M} / S
+    // (exactly 1 / S on one GPU).  _get_weights' normalisation (c_bioen_kernels_logw.c:84-90) is
+    // thereby applied to the M sums instead of the N weights.
+    double gmax = 0.0, invS = 1.0;
+    if (LOGW) {
+        gmax = -DBL_MAX;
+        for (int r = 0; r < xi.world; ++r)
+            gmax = fmax(gmax, xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2]);
+        double S = 0.0, PP = 0.0;
+        for (int r = 0; r < xi.world; ++r) {
+            const double* tail = xi.base + (size_t)r * xi.payload + (size_t)mp * K + 3 * a;
+            const double fr = exp(tail[2] - gmax);
+            S = fma(fr, tail[0], S);
+            PP = fma(fr, tail[1], PP);
+        }
+        invS = 1.0 / S;
+        if (threadIdx.x == 0) {
+            double* sc = rd.scal[a];
+            const double mown = xi.base[(size_t)xi.rank * xi.payload + (size_t)mp * K + 3 * a + 2];
+            sc[S_LOGS] = gmax + log(S);
+            sc[S_P] = PP * invS;
+            sc[S_INV] = exp(mown - gmax) * invS;
+        }
+    }
+    double chi = 0.0, cc = 0.0;
+    for (int row = threadIdx.x; row < mp; row += kBlock) {
+        double s = 0.0;
+        for (int r = 0; r < xi.world; ++r) {
+            const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
+            if (LOGW) s = fma(exp(xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2] - gmax) * invS, v, s);
+            else s += v;
+        }
+        const double sc = row_scale[row];
+        const double eff = fma(sc, s, row_offset[row]);
+        const double res = eff - YT[row];
+        ybar_c[(size_t)row * K + a] = s;
+        r_c[(size_t)row * K + a] = res * sc;
+        chi = fma(res, res, chi);
+        cc = fma(eff, res, cc);
+    }
+    chi = block_sum(chi, sh);
+    cc = block_sum(cc, sh);
+    if (threadIdx.x == 0) {
+        if (LOGW) {
+            double* sc = rd.scal[a];            // S_P, S_LOGS: written above by this same thread
+            sc[S_CHI] = chi;
+            sc[S_C] = cc;
+            sc[S_KL] = sc[S_P] - sc[S_LOGS] + sc[S_LOGS0];     // theta's factor: KL(w || w0) in both methods
+            sc[S_F] = rd.theta[a] * sc[S_KL] + 0.5 * chi;
+        } else {
+            double* pa = part.p[a];
+            pa[(size_t)P_CHI * kMaxPartials] = chi;
+            pa[(size_t)P_C * kMaxPartials] = cc;
+        }
+    }
+}
+
+// forces gradient (c_bioen_kernels_forces.c:330-338): the partials already hold the centred
+// sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* __restrict__ partial, int ctiles,
+                                                                 int mp, int K, double* __restrict__ gm_c) {
+    const int a = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
+        const double* p = partial + ((size_t)row * K + a) * ctiles;
+        double s = 0.0;
+        for (int k = lane; k < ctiles; k += 64) s += p[k];
+        s = wave_sum(s);
+        if (lane == 0) gm_c[(size_t)row * K + a] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// adjoint pass: out_a[j] = sum_i Y[i][j] u_a[i]      (u, ybar compact: [i*K + a])
+//   block = one 128-column strip (a lane owns 2 adjacent columns = 16 B), the 4 waves split
+//   the rows; U rows (U KiB) in flight per wave; the K operands of a row are wave-uniform
+//   and come through the scalar cache with one load.
+//   CENTER: out_a[j] = sum_i u_a[i] (Y[i][j] - ybar_a[i]) -- the reference's centred gradient
+//   sum (c_bioen_kernels_logw.c:185-195); padded columns then hold -u.ybar, which nobody reads.
+// ------------------------------------------------------------------------------
+template <int U, int K, bool NT, bool CENTER>
+__global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, size_t ld, int rows_per_wave,
+                                                const double* __restrict__ u_c,
+                                                const double* __restrict__ ybar_c, MVec8 out) {
+    __shared__ d2 red[kWaves][K][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t col = (size_t)blockIdx.x * 128 + lane * 2;
+    const int r0 = wave * rows_per_wave;
+    const double* yp = Y + (size_t)r0 * ld + col;
+    const double* up = u_c + (size_t)r0 * K;
+    const double* bp = ybar_c + (size_t)r0 * K;
+
+    d2 acc0[K], acc1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        acc0[k] = d2{0.0, 0.0};
+        acc1[k] = d2{0.0, 0.0};
+    }
+    for (int i = 0; i < rows_per_wave; i += U) {
+        d2 y[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) y[q] = ldg2<NT>(yp + (size_t)q * ld);
+#pragma unroll
+        for (int q = 0; q < U; q += 2) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double u0 = up[(size_t)(i + q) * K + k], u1 = up[(size_t)(i + q + 1) * K + k];
+                const double b0 = CENTER ? bp[(size_t)(i + q) * K + k] : 0.0;
+                const double b1 = CENTER ? bp[(size_t)(i + q + 1) * K + k] : 0.0;
+                acc0[k].x = fma(y[q].x - b0, u0, acc0[k].x);
+                acc0[k].y = fma(y[q].y - b0, u0, acc0[k].y);
+                acc1[k].x = fma(y[q + 1].x - b1, u1, acc1[k].x);
+                acc1[k].y = fma(y[q + 1].y - b1, u1, acc1[k].y);
+            }
+        }
+        yp += (size_t)U * ld;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave][k][lane] = d2{acc0[k].x + acc1[k].x, acc0[k].y + acc1[k].y};
+    __syncthreads();
+    for (int k = wave; k < K; k += kWaves) {
+        const d2 a0 = red[0][k][lane], a1 = red[1][k][lane], a2 = red[2][k][lane], a3 = red[3][k][lane];
+        d2 o = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
+        *reinterpret_cast<d2*>(out.p[k] + col) = o;
+    }
+}
+
+
+// ==============================================================================
+// host-side launchers
+// ==============================================================================
+
+int vec_grid(const bioen_hip_ctx* c) {
+    // from ld (identical on every rank of a sharded context), 2 pairs (4 elements) per thread
+    long long b = ((long long)c->ld + 4 * kBlock - 1) / (4 * kBlock);
+    const long long cap = kMaxPartials / c->world;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+Xch make_xch(const bioen_hip_ctx* c, int stage, int payload) {
+    Xch x;
+    x.base = c->xbuf[stage];
+    x.payload = payload;
+    x.world = c->world;
+    x.rank = c->rank;
+    x.npl = vec_grid(c);
+    return x;
+}
+
+int rows_grid(const bioen_hip_ctx* c) {
+    int b = c->mp / kWaves;
+    if (b > kMaxPartials) b = kMaxPartials;
+    return b;
+}
+
+
+
+// ---- forward ---------------------------------------------------------------------------
+template <int K, int STEPS, bool NT, bool CENTER>
+static void fwd_launch(bioen_hip_ctx* c, const Vec8& v) {
+    const int total_steps = (int)(c->ld / 128);
+    dim3 grid(c->mp / kRowAlign, c->fwd_ctiles);
+    hipLaunchKernelGGL((k_fwd_partial<8, K, STEPS, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v,
+                       c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
+}
+
+// STEPS = 0: software-pipelined (next step's Y rows in flight during the FMAs).  Measured on the
+// N = 1e6 x M = 1024 sweep (rocprofv3, r01): 0.6-1.7 % faster than the plain loop for K <= 6; at
+// K = 7, 8 the second register set drops the occupancy to one wave per SIMD and it loses 4-9 %.
+template <bool NT, bool CENTER>
+static void fwd_dispatch(bioen_hip_ctx* c, int K, const Vec8& v) {
+    switch (K) {
+        case 1: fwd_launch<1, 0, NT, CENTER>(c, v); break;
+        case 2: fwd_launch<2, 0, NT, CENTER>(c, v); break;
+        case 3: fwd_launch<3, 0, NT, CENTER>(c, v); break;
+        case 4: fwd_launch<4, 0, NT, CENTER>(c, v); break;
+        case 5: fwd_launch<5, 0, NT, CENTER>(c, v); break;
+        case 6: fwd_launch<6, 0, NT, CENTER>(c, v); break;
+        case 7: fwd_launch<7, 1, NT, CENTER>(c, v); break;
+        default: fwd_launch<8, 1, NT, CENTER>(c, v); break;
+    }
+}
+
+void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
+    TimedLaunch tl(c, 0, K);
+    if (c->nontemporal) {
+        if (centred) fwd_dispatch<true, true>(c, K, v); else fwd_dispatch<true, false>(c, K, v);
+    } else {
+        if (centred) fwd_dispatch<false, true>(c, K, v); else fwd_dispatch<false, false>(c, K, v);
+    }
+}
+
+int ybar_payload(const bioen_hip_ctx* c, int K, bool logw) { return c->mp * K + (logw ? 3 * K : 0); }
+
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw) {
+    const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, K, logw));
+    const Xch xe = make_xch(c, X_EXP, 3 * K * vec_grid(c));
+    if (logw)
+        hipLaunchKernelGGL(k_fwd_rows_local<true>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                           c->fwd_ctiles, c->mp, K, xo, xe);
+    else
+        hipLaunchKernelGGL(k_fwd_rows_local<false>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, c->fwd_ctiles, c->mp, K, xo, xe);
+}
+
+// w = e * scal[S_INV]: the weights themselves are only needed when a result is handed out
+__global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n2) {
+    const int a = blockIdx.y;
+    const double inv = r.scal[a][S_INV];
+    double* __restrict__ w = r.w[a];
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        d2 v = *reinterpret_cast<d2*>(w + 2 * p);
+        v.x *= inv;
+        v.y *= inv;
+        *reinterpret_cast<d2*>(w + 2 * p) = v;
+    }
+}
+
+void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_scale_w, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, (int)(c->ld / 2));
+}
+
+int combine_grid(const bioen_hip_ctx*) { return 1; }
+
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw) {
+    MVec8 part;
+    for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
+    if (logw)
+        hipLaunchKernelGGL(k_rows_combine<true>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
+                           make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           c->ybar_c, c->r_c, part, r);
+    else
+        hipLaunchKernelGGL(k_rows_combine<false>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
+                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           c->ybar_c, c->r_c, part, r);
+}
+
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles) {
+    hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       ctiles, c->mp, K, c->gm);
+}
+
+// sharded: this rank's share of the forces gradient -> its X_YBAR segment; after the exchange
+// k_sum_ranks adds the shares in rank order (identical on every rank) -> gm
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles) {
+    const Xch xo = make_xch(c, X_YBAR, c->mp * K);
+    hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_ranks(Xch xi, int count, double* __restrict__ out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int r = 0; r < xi.world; ++r) s += xi.base[(size_t)r * xi.payload + i];
+        out[i] = s;
+    }
+}
+
+void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K) {
+    const int count = c->mp * K;
+    hipLaunchKernelGGL(k_sum_ranks, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                       make_xch(c, X_YBAR, count), count, c->gm);
+}
+
+// ---- adjoint ---------------------------------------------------------------------------
+template <int K, bool NT, bool CENTER>
+static void adj_launch(bioen_hip_ctx* c, const double* u_c, const MVec8& out) {
+    dim3 grid((unsigned)(c->ld / 128));
+    hipLaunchKernelGGL((k_adj<8, K, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp / kWaves,
+                       u_c, c->ybar_c, out);
+}
+
+template <bool NT, bool CENTER>
+static void adj_dispatch(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out) {
+    switch (K) {
+        case 1: adj_launch<1, NT, CENTER>(c, u_c, out); break;
+        case 2: adj_launch<2, NT, CENTER>(c, u_c, out); break;
+        case 3: adj_launch<3, NT, CENTER>(c, u_c, out); break;
+        case 4: adj_launch<4, NT, CENTER>(c, u_c, out); break;
+        case 5: adj_launch<5, NT, CENTER>(c, u_c, out); break;
+        case 6: adj_launch<6, NT, CENTER>(c, u_c, out); break;
+        case 7: adj_launch<7, NT, CENTER>(c, u_c, out); break;
+        default: adj_launch<8, NT, CENTER>(c, u_c, out); break;
+    }
+}
+
+void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred) {
+    TimedLaunch tl(c, 1, K);
+    if (c->nontemporal) {
+        if (centred) adj_dispatch<true, true>(c, K, u_c, out); else adj_dispatch<true, false>(c, K, u_c, out);
+    } else {
+        if (centred) adj_dispatch<false, true>(c, K, u_c, out); else adj_dispatch<false, false>(c, K, u_c, out);
+    }
+}
+
+
+}  // namespace bioen

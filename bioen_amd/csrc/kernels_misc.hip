@@ -1,0 +1,194 @@
+// Level-1 algebra for the GSL-style minimizers, yTilde assembly, synthetic generator (gfx950).
+#include "device_utils.hpp"
+
+namespace bioen {
+
+// ------------------------------------------------------------------------------
+// level-1 algebra on resident N-vectors for the host-driven GSL-style minimizers
+// (multimin.hpp).  Vectors may alias in the read-only positions, hence no __restrict__.
+// All loops run over pairs up to ld/2: the padding is zero in every operand and stays zero.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_vaxpy(double a, const double* x, double* y, int n2) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const d2 xv = *reinterpret_cast<const d2*>(x + 2 * p);
+        d2 yv = *reinterpret_cast<d2*>(y + 2 * p);
+        yv.x += a * xv.x;      // two roundings, as cblas_daxpy compiled without contraction
+        yv.y += a * xv.y;
+        *reinterpret_cast<d2*>(y + 2 * p) = yv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vscal(double a, double* x, int n2) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        d2 v = *reinterpret_cast<d2*>(x + 2 * p);
+        v.x *= a;
+        v.y *= a;
+        *reinterpret_cast<d2*>(x + 2 * p) = v;
+    }
+}
+
+// dx = coef p ; x1 = x + dx      (directional_minimize.c: take_step)
+__global__ __launch_bounds__(kBlock) void k_vstep(const double* x, const double* pv, double coef, double* x1,
+                                                  double* dx, int n2) {
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const d2 xv = *reinterpret_cast<const d2*>(x + 2 * p);
+        const d2 dv = *reinterpret_cast<const d2*>(pv + 2 * p);
+        const d2 s = {coef * dv.x, coef * dv.y};
+        *reinterpret_cast<d2*>(dx + 2 * p) = s;
+        const d2 o = {xv.x + s.x, xv.y + s.y};
+        *reinterpret_cast<d2*>(x1 + 2 * p) = o;
+    }
+}
+
+// up to 4 inner products in one pass; mode 1: [0] = #(x != y), [1] = max |x|
+__global__ __launch_bounds__(kBlock) void k_vdots(VDotArgs q, int n2, double* part) {
+    __shared__ double sh[kWaves];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < q.k) {
+                const d2 xv = *reinterpret_cast<const d2*>(q.x[k] + 2 * p);
+                const d2 yv = *reinterpret_cast<const d2*>(q.y[k] + 2 * p);
+                if (q.mode == 0) {
+                    acc[k] = fma(xv.x, yv.x, acc[k]);
+                    acc[k] = fma(xv.y, yv.y, acc[k]);
+                } else if (k == 0) {
+                    acc[0] += (xv.x != yv.x ? 1.0 : 0.0) + (xv.y != yv.y ? 1.0 : 0.0);
+                } else {
+                    acc[1] = fmax(acc[1], fmax(fabs(xv.x), fabs(xv.y)));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < q.k) {
+            const double v = (q.mode == 1 && k == 1) ? block_max(acc[k], sh) : block_sum(acc[k], sh);
+            if (threadIdx.x == 0) part[(size_t)k * kMaxPartials + blockIdx.x] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vdots_finish(const double* part, int np, int k, int mode, double* out) {
+    __shared__ double sh[kWaves];
+    for (int q = 0; q < k; ++q) {
+        const double* p = part + (size_t)q * kMaxPartials;
+        double v;
+        if (mode == 1 && q == 1) {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < np; i += kBlock) s = fmax(s, p[i]);
+            v = block_max(s, sh);
+        } else {
+            v = sum_partials(p, np, sh);
+        }
+        if (threadIdx.x == 0) out[q] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// assembly of yTilde = sim / sigma from raw simulated observables (observables.py:123-143 does
+// this element by element in Python, then divides on the host)
+// ------------------------------------------------------------------------------
+// observables-major input already sits in Y: divide row i by sigma_i in place
+__global__ __launch_bounds__(kBlock) void k_rows_div(double* __restrict__ Y, size_t ld, int m, int n,
+                                                     const double* __restrict__ sigma) {
+    const size_t total = (size_t)m * ld;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const size_t i = idx / ld, j = idx - i * ld;
+        if (j < (size_t)n) Y[idx] = Y[idx] / sigma[i];
+    }
+}
+
+// structure-major chunk src[jc][i] (jc < ncols, i < m: one structure's observables contiguous) ->
+// Y[i][col0 + jc] / sigma_i, through a 32 x 33 LDS tile so that both sides are coalesced
+__global__ __launch_bounds__(kBlock) void k_transpose_div(const double* __restrict__ src, int ncols, int m,
+                                                          double* __restrict__ Y, size_t ld, size_t col0,
+                                                          const double* __restrict__ sigma) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int jc = j0 + r, i = i0 + tx;
+        tile[r][tx] = (jc < ncols && i < m) ? src[(size_t)jc * m + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, jc = j0 + tx;
+        if (i < m && jc < ncols) Y[(size_t)i * ld + col0 + jc] = tile[tx][r] / sigma[i];
+    }
+}
+
+// ------------------------------------------------------------------------------
+// synthetic ensemble generated in HBM (bench): counter-based Box-Muller
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate(double* __restrict__ Y, size_t ld, int m, int n, int mp,
+                                                     unsigned long long col0, unsigned long long n_global,
+                                                     const double* __restrict__ YTrue,
+                                                     const double* __restrict__ sig_sim,
+                                                     const double* __restrict__ sig_exp, unsigned long long seed) {
+    const size_t half = ld / 2;
+    const size_t total = (size_t)mp * half;
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kBlock) {
+        const int i = (int)(idx / half);
+        const size_t jp = idx - (size_t)i * half;
+        const size_t j = jp * 2;
+        d2 out = {0.0, 0.0};
+        if (i < m && j < (size_t)n) {
+            // counter = position of the column PAIR in the global (unsharded) matrix
+            const unsigned long long ctr = (unsigned long long)i * ((n_global + 1) / 2) + (col0 / 2 + jp);
+            const unsigned long long h1 = mix64(seed + 0x9E3779B97F4A7C15ULL * (2 * ctr + 1));
+            const unsigned long long h2 = mix64(seed + 0x9E3779B97F4A7C15ULL * (2 * ctr + 2));
+            const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            const double u2 = ((double)(h2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            const double rad = sqrt(-2.0 * log(u1));
+            double sn, cs;
+            sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+            const double mu = YTrue[i], ss = sig_sim[i], inv = 1.0 / sig_exp[i];
+            out.x = (mu + ss * rad * cs) * inv;
+            if (j + 1 < (size_t)n) out.y = (mu + ss * rad * sn) * inv;
+        }
+        *reinterpret_cast<d2*>(Y + (size_t)i * ld + j) = out;
+    }
+}
+
+
+// ---- level-1 algebra (multimin) -------------------------------------------------------------
+void launch_vaxpy(bioen_hip_ctx* c, double a, const double* x, double* y) {
+    hipLaunchKernelGGL(k_vaxpy, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, y, (int)(c->ld / 2));
+}
+void launch_vscal(bioen_hip_ctx* c, double a, double* x) {
+    hipLaunchKernelGGL(k_vscal, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, (int)(c->ld / 2));
+}
+void launch_vstep(bioen_hip_ctx* c, const double* x, const double* p, double coef, double* x1, double* dx) {
+    hipLaunchKernelGGL(k_vstep, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, x, p, coef, x1, dx, (int)(c->ld / 2));
+}
+void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out) {
+    const int g = vec_grid(c);
+    hipLaunchKernelGGL(k_vdots, dim3(g), dim3(kBlock), 0, c->stream, q, (int)(c->ld / 2), part);
+    hipLaunchKernelGGL(k_vdots_finish, dim3(1), dim3(kBlock), 0, c->stream, part, g, q.k, q.mode, out);
+}
+
+void launch_rows_div(bioen_hip_ctx* c, const double* sigma) {
+    hipLaunchKernelGGL(k_rows_div, dim3(256 * 16), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->m, c->n, sigma);
+}
+
+void launch_transpose_div(bioen_hip_ctx* c, const double* src, int ncols, size_t col0, const double* sigma) {
+    dim3 grid((c->m + 31) / 32, (ncols + 31) / 32);
+    hipLaunchKernelGGL(k_transpose_div, grid, dim3(kBlock), 0, c->stream, src, ncols, c->m, c->Y, c->ld, col0, sigma);
+}
+
+void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,
+                     unsigned long long seed) {
+    hipLaunchKernelGGL(k_generate, dim3(256 * 16), dim3(kBlock), 0, c->stream, c->Y, c->ld, c->m, c->n, c->mp,
+                       (unsigned long long)c->col0, (unsigned long long)c->n_global, YTrue, sig_sim, sig_exp, seed);
+}
+
+
+}  // namespace bioen
