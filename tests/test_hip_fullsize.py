@@ -94,10 +94,19 @@ def test_logw_full_size_properties():
         assert infos[0].fmin < f0
         assert rel(infos[0].fmin, thetas[0] * infos[0].kl + infos[0].chi2) < 1e-12
 
+        # GSL-style minimizers with all vectors resident: a few bfgs2 / conjugate_pr iterations at full size
+        for alg in ("bfgs2", "conjugate_pr"):
+            gg, wg2, ginfo = ctx.opt_gsl_logw(G0, G0, 100.0, alg, dict(step_size=0.01, tol=0.001, max_iterations=4))
+            assert ginfo.lbfgs_code in (0, -2, 27) and ginfo.iterations <= 4
+            assert ginfo.fmin < f0 and abs(wg2.sum() - 1.0) < 1e-12
+            assert rel(ctx.logw_fdf(gg, G0, 100.0, need_grad=False)[0], ginfo.fmin) < 1e-13
+            assert rel(ginfo.fmin, 100.0 * ginfo.kl + ginfo.chi2) < 1e-12
 
-def test_forces_full_size_properties():
+
+@pytest.mark.parametrize("M", [512, 1024, 1056])      # 256-thread strips, 512-thread strips, streaming passes
+def test_forces_full_size_properties(M):
     import bioen_amd
-    M, N = 512, 1000000
+    N = 1000000
     YTrue, sig_sim, sig_exp, YTilde = _targets(M, seed=777)
     rng = np.random.default_rng(5)
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=777) as ctx:
