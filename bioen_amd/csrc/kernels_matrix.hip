@@ -275,7 +275,12 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* _
 //   CENTER: out_a[j] = sum_i u_a[i] (Y[i][j] - ybar_a[i]) -- the reference's centred gradient
 //   sum (c_bioen_kernels_logw.c:185-195); padded columns then hold -u.ybar, which nobody reads.
 // ------------------------------------------------------------------------------
-template <int U, int K, bool NT, bool CENTER>
+//   LDSOPS (K = 4..7; at K = 8 it measured 3 % slower than the scalar path): 16 K doubles of row operands per 8-row step exceed what the scalar cache path
+//   can keep in SGPRs (a diagnostic build with constant operands runs K = 8 at the K = 1 time), so a
+//   wave stages the {u, ybar} pairs of its next 32 rows in LDS -- inside its own slice of the final
+//   reduction buffer, which it does not need before its loop ends -- and reads them back as
+//   same-address (broadcast) 16-byte loads.  Same operands, same order: bitwise the scalar path.
+template <int U, int K, bool NT, bool CENTER, bool LDSOPS>
 __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, size_t ld, int rows_per_wave,
                                                 const double* __restrict__ u_c,
                                                 const double* __restrict__ ybar_c, MVec8 out) {
@@ -294,7 +299,22 @@ __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, si
         acc0[k] = d2{0.0, 0.0};
         acc1[k] = d2{0.0, 0.0};
     }
+    d2* const ops = &red[wave][0][0];          // 64 K entries; 32 K used as [row of the chunk][k] = {u, ybar}
     for (int i = 0; i < rows_per_wave; i += U) {
+        if (LDSOPS && (i & 31) == 0) {    // before this step's matrix loads: vmcnt retires in order
+            int cnt = rows_per_wave - i;
+            cnt = (cnt < 32 ? cnt : 32) * K;
+            for (int e = lane; e < cnt; e += 64) {
+                d2 o;
+                o.x = up[(size_t)i * K + e];
+                o.y = CENTER ? bp[(size_t)i * K + e] : 0.0;
+                ops[e] = o;
+            }
+            // wave-private LDS: the wave's own program order is the synchronisation; fences for the compiler
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         d2 y[U];
 #pragma unroll
         for (int q = 0; q < U; ++q) y[q] = ldg2<NT>(yp + (size_t)q * ld);
@@ -302,9 +322,16 @@ __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, si
         for (int q = 0; q < U; q += 2) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double u0 = up[(size_t)(i + q) * K + k], u1 = up[(size_t)(i + q + 1) * K + k];
-                const double b0 = CENTER ? bp[(size_t)(i + q) * K + k] : 0.0;
-                const double b1 = CENTER ? bp[(size_t)(i + q + 1) * K + k] : 0.0;
+                double u0, u1, b0, b1;
+                if (LDSOPS) {
+                    const d2 o0 = ops[((i & 31) + q) * K + k], o1 = ops[((i & 31) + q + 1) * K + k];
+                    u0 = o0.x; b0 = o0.y; u1 = o1.x; b1 = o1.y;
+                } else {
+                    u0 = up[(size_t)(i + q) * K + k];
+                    u1 = up[(size_t)(i + q + 1) * K + k];
+                    b0 = CENTER ? bp[(size_t)(i + q) * K + k] : 0.0;
+                    b1 = CENTER ? bp[(size_t)(i + q + 1) * K + k] : 0.0;
+                }
                 acc0[k].x = fma(y[q].x - b0, u0, acc0[k].x);
                 acc0[k].y = fma(y[q].y - b0, u0, acc0[k].y);
                 acc1[k].x = fma(y[q + 1].x - b1, u1, acc1[k].x);
@@ -466,8 +493,8 @@ void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K) {
 template <int K, bool NT, bool CENTER>
 static void adj_launch(bioen_hip_ctx* c, const double* u_c, const MVec8& out) {
     dim3 grid((unsigned)(c->ld / 128));
-    hipLaunchKernelGGL((k_adj<8, K, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, c->mp / kWaves,
-                       u_c, c->ybar_c, out);
+    hipLaunchKernelGGL((k_adj<8, K, NT, CENTER, (K >= 4 && K <= 7)>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld,
+                       c->mp / kWaves, u_c, c->ybar_c, out);
 }
 
 template <bool NT, bool CENTER>
