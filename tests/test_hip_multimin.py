@@ -174,7 +174,7 @@ def test_lbfgs_after_gsl_run_on_the_same_context_is_unaffected():
     """The GSL-style minimizers borrow slot 0's L-BFGS history buffers as work vectors; a following
     L-BFGS run on the same context must equal one on a fresh context bit for bit."""
     import bioen_amd
-    from test_hip_fullsize import LBFGS_DEFAULTS
+    from conftest import LBFGS_DEFAULTS
     d = load_golden("synth_logw_M64xN2000.npz")
     with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
         fresh = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
