@@ -55,8 +55,12 @@ static int dalloc_zero(double** p, size_t count, hipStream_t s) {
 static void choose_fwd_tiling(bioen_hip_ctx* c) {
     const int total_steps = (int)(c->ld / 128);
     const int row_blocks = c->mp / kRowAlign;
-    // ~6144 blocks: 3072 and 2048 measured within noise (+-1.5 %) of it on N = 1e6 x M = 1024
-    int want_tiles = (6144 + row_blocks - 1) / row_blocks;
+    // Tiles of >= 42 steps (a block ends with a 63-shuffle reduction and K x 32 scattered stores),
+    // between 512 and ~6144 blocks.  N = 1e6 x M = 1024: 5952 blocks (3072 and 2048 measured within
+    // +-1.5 % of it); N = 1.25e5 (one rank of an 8-way sharded run): 736 blocks, 165 us per launch
+    // against 179 us with 6-step tiles.
+    const int min_tiles = (512 + row_blocks - 1) / row_blocks, max_tiles = (6144 + row_blocks - 1) / row_blocks;
+    int want_tiles = std::max(min_tiles, std::min(max_tiles, total_steps / 42));
     want_tiles = std::max(1, std::min(want_tiles, total_steps));
     int spt = (total_steps + want_tiles - 1) / want_tiles;
     if (spt & 1) ++spt;   // two 1-KiB steps in flight per row
