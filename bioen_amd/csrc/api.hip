@@ -851,17 +851,17 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
 // ---- shared ---------------------------------------------------------------------------
 int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, double* chi2) {
     if (!c || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "not available on a structure-sharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     ProblemSlot& s0 = c->slot[0];
     int rc;
-    if ((rc = upload_n(c, s0.w, w))) return rc;
+    if ((rc = upload_n(c, s0.w, w))) return rc;       // sharded: this rank's block of the (global) w
     const int one[1] = {0};
     const Round r = make_round(c, one, 1, nullptr, nullptr);
     Vec8 v{};
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);
     launch_fwd_rows_local(c, 1, false);
+    if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, 1, false)))) return rc;   // the ranks' shares of yTilde . w
     launch_rows_combine(c, r, false);
     launch_forces_scalars(c, make_forces_round(c, one, 1, nullptr));   // S_CHI (the KL part is irrelevant here)
     if ((rc = check_launch())) return rc;

@@ -28,6 +28,7 @@ def main():
     w, logs = ctx.logw_weights(g)
     f, grad = ctx.logw_fdf(g, d["G"], d["theta"])
     res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    chi2, yave = ctx.chi_squared(w)
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
     ctx.close()
@@ -46,7 +47,7 @@ def main():
              fmin=np.array([i.fmin for i in infos]), iters=np.array([i.iterations for i in infos]),
              evals=np.array([i.evaluations for i in infos]), codes=np.array([i.lbfgs_code for i in infos]),
              chi2=np.array([i.chi2 for i in infos]), kl=np.array([i.kl for i in infos]),
-             block=block, col0=col0, n_local=n_local,
+             block=block, col0=col0, n_local=n_local, chi2w=chi2, yave=yave,
              ff=ff, fgrad=fgrad, fres=fres, fw=fw, ffmin=np.array([i.fmin for i in finfos]),
              fiters=np.array([i.iterations for i in finfos]), fcodes=np.array([i.lbfgs_code for i in finfos]),
              fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]))

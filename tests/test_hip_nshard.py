@@ -60,6 +60,10 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         f1, grad1 = ctx.logw_fdf(g, d["G"], d["theta"])
         res1, wopt1, infos1 = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
     assert np.abs(z[0]["w"] - w1).max() <= 1e-13 * w1.max() and abs(z[0]["logs"] - logs1) < 1e-12
+    yave1 = d["yTilde"].dot(z[0]["w"])
+    for r in range(world):
+        assert np.abs(z[r]["yave"] - yave1).max() <= 1e-13 * np.abs(yave1).max()
+        assert abs(z[r]["chi2w"] - 0.5 * np.sum((yave1 - d["YTilde"].ravel()) ** 2)) <= 1e-12 * z[r]["chi2w"]
     assert abs(z[0]["f"] - f1) <= 1e-13 * abs(f1)
     assert np.abs(z[0]["grad"] - grad1).max() <= 1e-11 * np.abs(grad1).max()
     for i, info in enumerate(infos1):
