@@ -203,6 +203,24 @@ def bioen_opt_lbfgs_logw(g, G, yTilde, YTilde, theta, params):
     return res, info.fmin
 
 
+def bioen_opt_lbfgs_logw_series(g, G, yTilde, YTilde, thetas, params):
+    """Not in the reference: a cold-started theta series (the loop of bioen/analyze/procedure.py:62-67)
+    as ONE call -- up to 8 thetas share every pass over the resident matrix, each result bitwise what
+    bioen_opt_lbfgs_logw returns for that theta.  -> ([gopt[n]] * ntheta, [fmin] * ntheta)"""
+    global last_opt_info
+    ctx, cached = _context_for(yTilde, YTilde)
+    try:
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, g, G, params["params"], verbose=params.get("verbose", False),
+                                                 debug=params.get("debug", False), want_weights=False)
+    finally:
+        _release(ctx, cached)
+    last_opt_info = infos
+    for info in infos:
+        if info.lbfgs_code not in lbfgs_success:
+            _raise_lbfgs("bioen_opt_lbfgs_logw_series", info.lbfgs_code)
+    return [res[k] for k in range(len(infos))], [info.fmin for info in infos]
+
+
 # ------------------------------------------------------------------------------------
 # forces  (c_bioen.pyx:523-792)
 # ------------------------------------------------------------------------------------

@@ -274,3 +274,23 @@ def find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
         print("fmin_final    = ", fmin_final)
         print("========================")
     return wopt, yopt, gopt, fmin_initial, fmin_final
+
+
+def find_optimum_series(GInit, G, y, yTilde, YTilde, thetas, cfg):
+    """Not in the reference: ``find_optimum`` for a whole cold-started theta series in one device call
+    (what bioen/analyze/procedure.py:62-67 does one theta at a time).  Minimizer "lbfgs"/"liblbfgs"
+    only; every entry of the returned list is the 5-tuple ``find_optimum`` returns for that theta --
+    the optimisation itself bit for bit, since a batched run equals the single runs."""
+    check_params_logweights(GInit, G, y, yTilde, YTilde)
+    if cfg["minimizer"].upper() not in ('LIBLBFGS', 'LBFGS'):
+        raise RuntimeError("find_optimum_series needs the lbfgs minimizer, got " + str(cfg["minimizer"]))
+    g = GInit.copy()
+    gPrime = np.asarray(g[:].T)[0]
+    fmin_initial = [c_bioen.bioen_log_posterior_logw(gPrime, g, G, yTilde, YTilde, float(t)) for t in thetas]
+    gopts, fmins = c_bioen.bioen_opt_lbfgs_logw_series(gPrime, G, yTilde, YTilde, [float(t) for t in thetas], cfg)
+    out = []
+    for k in range(len(fmins)):
+        wopt = getWOpt(G, gopts[k])
+        yopt = c_bioen.get_ave(wopt, yTilde, YTilde) if y is yTilde else common.getAve(wopt, y)
+        out.append((wopt, yopt, gopts[k], fmin_initial[k], fmins[k]))
+    return out

@@ -342,3 +342,19 @@ def test_context_from_raw_observables_equals_host_division(M, N):
         bioen_amd.Context.from_raw(sim, exp, np.zeros(M))
     with pytest.raises(ValueError):
         bioen_amd.Context.from_raw(sim, exp[:-1] if M > 1 else np.zeros(2), err)
+
+
+def test_find_optimum_series_equals_find_optimum_per_theta(optimize):
+    d = load_golden("synth_logw_M64xN2000.npz")
+    YT = d["YTilde"].reshape(1, -1)
+    params = optimize.minimize.Parameters("lbfgs")
+    params["verbose"] = False
+    thetas = [100.0, 10.0, 1.0]
+    series = optimize.log_weights.find_optimum_series(d["GInit"], d["G"], d["y"], d["yTilde"], YT, thetas, params)
+    for theta, got in zip(thetas, series):
+        ref = optimize.log_weights.find_optimum(d["GInit"], d["G"], d["y"], d["yTilde"], YT, theta, params)
+        assert got[4] == ref[4] and got[3] == ref[3]
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    with pytest.raises(RuntimeError):
+        optimize.log_weights.find_optimum_series(d["GInit"], d["G"], d["y"], d["yTilde"], YT, thetas,
+                                                 optimize.minimize.Parameters("scipy"))
