@@ -204,7 +204,22 @@ def main():
                                        max_batch=args.max_batch)
 
     results = None
-    for _ in range(args.warmup):
+    warm_done = 0
+    if nshard:
+        # one untimed sharded sweep first: if the collectives fail on any rank, every rank falls back to
+        # dealing thetas (no communication inside the loop) instead of losing the measurement
+        try:
+            results, ok, why = step(), True, None
+        except bioen_amd.BioenHipError as e:
+            ok, why = False, str(e)
+        if all(comm.allgather_object(ok)):
+            warm_done = 1
+        else:
+            ctx.close()
+            nshard = False
+            ctx, gather, rccl = build(False)
+            decision = dict(decision or {}, chosen="thetas", fallback="structure-sharded sweep failed: %s" % why)
+    for _ in range(max(args.warmup - warm_done, 0)):
         results = step()
 
     ctx.kernel_stats_enable(True)
