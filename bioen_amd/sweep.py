@@ -21,6 +21,8 @@ import time
 
 import numpy as np
 
+from ._lib import BioenHipError
+
 HEADER = 8   # doubles in front of w[N]: theta, fmin, chi2, kl, iterations, evaluations, code, seconds
 
 
@@ -219,8 +221,15 @@ def init_rccl(ctx, comm):
     ncclUniqueId, the control plane ships its 128 bytes."""
     if comm.world == 1:
         return False
-    uid = ctx.comm_unique_id() if comm.rank == 0 else None
-    uid = comm.allgather_object(uid)[0]
+    uid, err = None, None
+    if comm.rank == 0:
+        try:
+            uid = ctx.comm_unique_id()
+        except BioenHipError as e:        # e.g. librccl not loadable: every rank must learn it, none may wait
+            err = str(e)
+    uid, err = comm.allgather_object((uid, err))[0]
+    if uid is None:
+        raise BioenHipError("RCCL unavailable on rank 0: %s" % err)
     ctx.comm_init(uid, comm.rank, comm.world)
     return True
 
