@@ -96,6 +96,8 @@ _SIGNATURES = {
     "bioen_hip_opt_gsl_forces": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(GslConfig), C.POINTER(VisualParams),
                                            dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_selftest_multimin": (C.c_int, [C.c_int, C.c_int, dp, dp, C.POINTER(OptResult)]),
+    "bioen_hip_multimin_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, dp, C.POINTER(GslConfig), dp,
+                                          C.POINTER(OptResult)]),
     "bioen_hip_selftest_lbfgs": (C.c_int, [C.c_int, C.c_int, dp, C.POINTER(LbfgsConfig), dp, C.POINTER(OptResult)]),
     "bioen_hip_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
@@ -194,6 +196,41 @@ def selftest_multimin(algorithm, kind, x0):
     info = OptResult()
     alg = GSL_ALGORITHMS[algorithm] if isinstance(algorithm, str) else int(algorithm)
     check(lib().bioen_hip_selftest_multimin(alg, int(kind), ptr(x0), ptr(out), C.byref(info)))
+    return out, info
+
+
+HOST_OBJECTIVE = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, dp)
+
+
+def multimin_host(objective, user, x0, algorithm, params):
+    """The library's GSL-style minimizers on a host objective (no GPU).  `objective`: address of a C
+    function ``int(void* user, const double* x, double* f, double* grad_or_NULL)`` (an int / c_void_p /
+    ctypes function pointer) or a Python callable ``(x ndarray) -> f`` / ``(x, grad_out) -> f``
+    wrapped here.  -> (x, OptResult); .lbfgs_code = GSL status, .reserved = gradient evaluations"""
+    x0 = as_f64(x0).ravel()
+    n = x0.size
+    keep = None
+    if callable(objective) and not isinstance(objective, C._CFuncPtr):
+        pyfn = objective
+
+        def _cb(_user, xp, fp, gp):
+            try:
+                x = np.ctypeslib.as_array(xp, shape=(n,))
+                g = np.ctypeslib.as_array(gp, shape=(n,)) if gp else None
+                fp[0] = float(pyfn(x, g))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        keep = HOST_OBJECTIVE(_cb)
+        fn_addr = C.cast(keep, C.c_void_p)
+    else:
+        fn_addr = C.cast(objective, C.c_void_p) if not isinstance(objective, int) else C.c_void_p(objective)
+    out = np.empty_like(x0)
+    info = OptResult()
+    cfg = gsl_config(algorithm, params)
+    check(lib().bioen_hip_multimin_host(n, fn_addr, user, ptr(x0), C.byref(cfg), ptr(out), C.byref(info)))
     return out, info
 
 

@@ -298,4 +298,25 @@ int bioen_hip_selftest_multimin(int algorithm, int kind, const double* x0, doubl
     return 0;
 }
 
+int bioen_hip_multimin_host(int n, bioen_host_objective objective, void* user, const double* x0,
+                            const bioen_gsl_config* config, double* x_out, bioen_opt_result* info) {
+    if (n <= 0 || !objective || !x0 || !config || !x_out || !info) return fail(BIOEN_HIP_EINVAL, "bad argument");
+    if (config->algorithm < 0 || config->algorithm > 4) return fail(BIOEN_HIP_EINVAL, "unknown GSL algorithm id");
+    std::memset(info, 0, sizeof *info);
+    const auto t0 = std::chrono::steady_clock::now();
+    multimin::HostVectors B(n, [&](const double* x, double* f, double* grad) -> int { return objective(user, x, f, grad); });
+    std::memcpy(B.data(multimin::V_X), x0, (size_t)n * sizeof(double));
+    const multimin::Config cfg{config->step_size, config->tol, config->max_iterations, config->algorithm};
+    const multimin::Outcome out = multimin::run(B, cfg);
+    if (B.failed()) return fail(BIOEN_HIP_ESTATE, "the caller's objective reported an error");
+    std::memcpy(x_out, B.data(multimin::V_X), (size_t)n * sizeof(double));
+    info->fmin = out.fmin;
+    info->lbfgs_code = out.status;
+    info->iterations = out.iterations;
+    info->evaluations = out.f_evaluations + out.g_evaluations;
+    info->reserved = out.g_evaluations;
+    info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
 }  // extern "C"

@@ -264,6 +264,15 @@ int bioen_hip_opt_gsl_forces(bioen_hip_ctx* ctx, const double* forces0, const do
 int bioen_hip_selftest_multimin(int algorithm, int kind, const double* x0, double* x_out,
                                 bioen_opt_result* info);
 
+/* The same minimizer code on a host objective the CALLER supplies (host vectors, no GPU): run under the
+ * reference's driver loop (c_bioen_kernels_logw.c:434-464) exactly as bioen_hip_opt_gsl_* are.
+ * objective(user, x, &f, grad): grad == NULL asks for f alone (GSL's `f` callback), otherwise f and
+ * the gradient (`df` / `fdf`); a non-zero return aborts the run.  The tests drive this with the
+ * reference's own C objective to pin the minimizers against real GSL runs bit for bit. */
+typedef int (*bioen_host_objective)(void* user, const double* x, double* f, double* grad);
+int bioen_hip_multimin_host(int n, bioen_host_objective objective, void* user, const double* x0,
+                            const bioen_gsl_config* config, double* x_out, bioen_opt_result* info);
+
 /* ---- theta-sweep gather over RCCL (multi-GPU; one process per GPU) ----------------- */
 /* rank 0 obtains the 128-byte ncclUniqueId; the host side ships it to the other ranks */
 int bioen_hip_comm_unique_id(unsigned char id[128]);

@@ -104,6 +104,33 @@ int oracle_opt_gsl_forces(int m, int n, const double* yTilde, const double* YTil
                           const double* w0, double theta, const oracle_gsl_config* cfg, double* result,
                           double* fmin, oracle_gsl_stats* stats);
 
+/* The restated minimizers driven by the REFERENCE's own kernels (addresses taken from a build of the
+ * reference; prototypes of c_bioen_kernels_logw.h:8-50, c_bioen_kernels_forces.h:10-56).  forces = 0:
+ * x0 = log-weights (n), fixed = G; forces = 1: x0 = forces (m), fixed = w0.  yTildeT = NULL switches
+ * the reference's transposed cache off. */
+typedef struct oracle_ref_kernels {
+    double (*get_weights)(double* g, double* w, size_t n);
+    double (*logw_f)(double* g, double* G, double* yTilde, double* YTilde, double* w, double* t1, double theta,
+                     int caching, double* yTildeT, double* tmp_n, double* tmp_m, int m, int n, double weights_sum);
+    void (*logw_df)(double* g, double* G, double* yTilde, double* YTilde, double* w, double* gradient, double theta,
+                    int caching, double* yTildeT, double* tmp_n, double* tmp_m, int m, int n, double weights_sum);
+    void (*forces_weights)(double* w0, double* yTilde, double* forces, double* w, int caching, double* yTildeT,
+                           double* tmp_n, size_t m, size_t n);
+    double (*forces_f)(double* w0, double* yTilde, double* YTilde, double* w, double* t1, double theta, int caching,
+                       double* yTildeT, double* tmp_n, double* tmp_m, int m, int n);
+    void (*forces_df)(double* w0, double* yTilde, double* YTilde, double* w, double* gradient, double theta,
+                      int caching, double* yTildeT, double* tmp_n, double* tmp_m, int m, int n);
+} oracle_ref_kernels;
+int oracle_opt_gsl_refobj(const oracle_ref_kernels* k, int forces, int m, int n, const double* yTilde,
+                          const double* yTildeT, const double* YTilde, const double* x0, const double* fixed,
+                          double theta, const oracle_gsl_config* cfg, double* result, double* fmin,
+                          oracle_gsl_stats* stats);
+
+void* oracle_refobj_create(const oracle_ref_kernels* k, int forces, int m, int n, const double* yTilde,
+                           const double* yTildeT, const double* YTilde, const double* fixed, double theta);
+void oracle_refobj_destroy(void* handle);
+int oracle_refobj_eval(void* handle, const double* x, double* f, double* grad);   /* grad == NULL: f alone */
+
 /* GSL's own multimin test programme (multimin/test.c, test_funcs.c): kind 0 Roth, 1 Wood,
  * 2 Rosenbrock, 3 SimpleAbs, run exactly as test_fdf does. */
 int oracle_multimin_testfn_dim(int kind);

@@ -651,6 +651,112 @@ int oracle_opt_gsl_forces(int m, int n, const double* yTilde, const double* YTil
     return bioen_driver(cfg->algorithm, &F, forces0, cfg, result, fmin, stats);
 }
 
+/* ---- the restated minimizers on the REFERENCE's own objective functions ------------------------
+ * The caller hands in the addresses of the reference's C kernels (taken from a build of the
+ * reference: oracle/_ref/libbioen_ref.so, or the Cython extension of a full reference build) and
+ * the glue below calls them exactly as the reference's GSL callbacks do
+ * (c_bioen_kernels_logw.c:274-362: f = _get_weights + _bioen_log_posterior_logw, df = _get_weights +
+ * _grad_bioen_log_posterior_logw, fdf = all three; c_bioen_kernels_forces.c:343-428 likewise).
+ * With the objective identical to the last bit, any difference to a real GSL run is a difference
+ * of the minimizer restatement itself -- this is how tests/golden/make_golden_gsl.py pins it. */
+typedef struct {
+    const oracle_ref_kernels* k;
+    int m, n, caching;
+    double *yTilde, *yTildeT, *YTilde, *fixed, *w, *tmp_n, *tmp_m;
+    double theta;
+} ref_args;
+
+static double rlogw_f(const double* x, void* p) {
+    ref_args* a = (ref_args*)p;
+    const double s = a->k->get_weights((double*)x, a->w, (size_t)a->n);
+    return a->k->logw_f((double*)x, a->fixed, a->yTilde, a->YTilde, a->w, NULL, a->theta, -1, NULL, a->tmp_n, a->tmp_m,
+                        a->m, a->n, s);
+}
+static void rlogw_df(const double* x, void* p, double* g) {
+    ref_args* a = (ref_args*)p;
+    a->k->get_weights((double*)x, a->w, (size_t)a->n);
+    a->k->logw_df((double*)x, a->fixed, a->yTilde, a->YTilde, a->w, g, a->theta, a->caching, a->yTildeT, a->tmp_n,
+                  a->tmp_m, a->m, a->n, -1.0);
+}
+static void rlogw_fdf(const double* x, void* p, double* f, double* g) {
+    ref_args* a = (ref_args*)p;
+    const double s = a->k->get_weights((double*)x, a->w, (size_t)a->n);
+    *f = a->k->logw_f((double*)x, a->fixed, a->yTilde, a->YTilde, a->w, NULL, a->theta, a->caching, a->yTildeT, a->tmp_n,
+                      a->tmp_m, a->m, a->n, s);
+    a->k->logw_df((double*)x, a->fixed, a->yTilde, a->YTilde, a->w, g, a->theta, a->caching, a->yTildeT, a->tmp_n,
+                  a->tmp_m, a->m, a->n, -1.0);
+}
+static double rforces_f(const double* x, void* p) {
+    ref_args* a = (ref_args*)p;
+    a->k->forces_weights(a->fixed, a->yTilde, (double*)x, a->w, a->caching, a->yTildeT, a->tmp_n, (size_t)a->m, (size_t)a->n);
+    return a->k->forces_f(a->fixed, a->yTilde, a->YTilde, a->w, NULL, a->theta, a->caching, a->yTildeT, a->tmp_n,
+                          a->tmp_m, a->m, a->n);
+}
+static void rforces_df(const double* x, void* p, double* g) {
+    ref_args* a = (ref_args*)p;
+    a->k->forces_weights(a->fixed, a->yTilde, (double*)x, a->w, a->caching, a->yTildeT, a->tmp_n, (size_t)a->m, (size_t)a->n);
+    a->k->forces_df(a->fixed, a->yTilde, a->YTilde, a->w, g, a->theta, a->caching, a->yTildeT, a->tmp_n, a->tmp_m,
+                    a->m, a->n);
+}
+static void rforces_fdf(const double* x, void* p, double* f, double* g) {
+    *f = rforces_f(x, p);
+    ref_args* a = (ref_args*)p;
+    a->k->forces_df(a->fixed, a->yTilde, a->YTilde, a->w, g, a->theta, a->caching, a->yTildeT, a->tmp_n, a->tmp_m,
+                    a->m, a->n);
+}
+
+/* The same glue as a free-standing objective `int fn(void* handle, const double* x, double* f, double* grad)`
+ * (grad == NULL: f alone) so that OTHER minimizer implementations -- the product's, through
+ * bioen_hip_multimin_host -- can be driven by the reference's objective too. */
+void* oracle_refobj_create(const oracle_ref_kernels* k, int forces, int m, int n, const double* yTilde,
+                           const double* yTildeT, const double* YTilde, const double* fixed, double theta) {
+    ref_args* a = (ref_args*)malloc(sizeof(ref_args) + sizeof(oracle_ref_kernels) + sizeof(int));
+    if (!a) return NULL;
+    oracle_ref_kernels* kc = (oracle_ref_kernels*)(a + 1);
+    *kc = *k;
+    *(int*)(kc + 1) = forces;
+    a->k = kc; a->m = m; a->n = n; a->caching = yTildeT != NULL;
+    a->yTilde = (double*)yTilde; a->yTildeT = (double*)yTildeT; a->YTilde = (double*)YTilde; a->fixed = (double*)fixed;
+    a->theta = theta;
+    a->w = (double*)malloc(sizeof(double) * (size_t)(2 * n + m));
+    if (!a->w) { free(a); return NULL; }
+    a->tmp_n = a->w + n; a->tmp_m = a->tmp_n + n;
+    return a;
+}
+void oracle_refobj_destroy(void* h) {
+    if (!h) return;
+    free(((ref_args*)h)->w);
+    free(h);
+}
+int oracle_refobj_eval(void* h, const double* x, double* f, double* grad) {
+    ref_args* a = (ref_args*)h;
+    const int forces = *(const int*)((const oracle_ref_kernels*)(a + 1) + 1);
+    if (forces) {
+        if (grad) rforces_fdf(x, a, f, grad); else *f = rforces_f(x, a);
+    } else {
+        if (grad) rlogw_fdf(x, a, f, grad); else *f = rlogw_f(x, a);
+    }
+    return 0;
+}
+
+int oracle_opt_gsl_refobj(const oracle_ref_kernels* k, int forces, int m, int n, const double* yTilde,
+                          const double* yTildeT, const double* YTilde, const double* x0, const double* fixed,
+                          double theta, const oracle_gsl_config* cfg, double* result, double* fmin,
+                          oracle_gsl_stats* stats) {
+    ref_args a;
+    a.k = k; a.m = m; a.n = n; a.caching = yTildeT != NULL;
+    a.yTilde = (double*)yTilde; a.yTildeT = (double*)yTildeT; a.YTilde = (double*)YTilde; a.fixed = (double*)fixed;
+    a.theta = theta;
+    a.w = (double*)malloc(sizeof(double) * (size_t)(2 * n + m));
+    if (!a.w) return -1;
+    a.tmp_n = a.w + n; a.tmp_m = a.tmp_n + n;
+    mm_fn F = {forces ? m : n, forces ? rforces_f : rlogw_f, forces ? rforces_df : rlogw_df,
+               forces ? rforces_fdf : rlogw_fdf, &a, 0, 0};
+    const int status = bioen_driver(cfg->algorithm, &F, x0, cfg, result, fmin, stats);
+    free(a.w);
+    return status;
+}
+
 /* ---- GSL's own test functions (multimin/test_funcs.c) ------------------------------------------ */
 static double sgn1(double v) { return v >= 0.0 ? 1.0 : -1.0; }   /* GSL_SIGN */
 

@@ -213,6 +213,69 @@ def opt_gsl_forces(f0, w0, yTilde, YTilde, theta, params=None):
     return res, fmin.value, code, st.iterations, (st.f_evaluations, st.g_evaluations)
 
 
+class ref_kernels(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("get_weights", "logw_f", "logw_df", "forces_weights", "forces_f", "forces_df")]
+
+
+_REF_SYMBOLS = ("_get_weights", "_bioen_log_posterior_logw", "_grad_bioen_log_posterior_logw",
+                "_get_weights_from_forces", "_bioen_log_posterior_forces", "_grad_bioen_log_posterior_forces")
+
+
+def opt_gsl_refobj(ref_cdll, kind, x0, fixed, yTilde, YTilde, theta, params=None, caching=True):
+    """The restated GSL minimizers on the REFERENCE's own objective: `ref_cdll` is a ctypes.CDLL of a
+    build of the reference (oracle/_ref/libbioen_ref.so, or the Cython extension of a full build);
+    the C glue calls its kernels the way the reference's GSL callbacks do.
+    kind 'logw': x0 = GInit, fixed = G; 'forces': x0 = forces_init, fixed = w0.
+    -> (x, fmin, gsl status, iterations, (f evaluations, gradient evaluations))"""
+    x0, fixed, yTilde, YTilde = _a(x0).ravel(), _a(fixed).ravel(), _a(yTilde), _a(YTilde).ravel()
+    m, n = yTilde.shape
+    k = ref_kernels(*[C.cast(getattr(ref_cdll, name), C.c_void_p) for name in _REF_SYMBOLS])
+    yT = np.ascontiguousarray(yTilde.T) if caching else None
+    forces = 1 if kind == "forces" else 0
+    res = np.empty(m if forces else n); fmin = C.c_double(0.0); st = gsl_stats()
+    cfg = _gsl_cfg(params)
+    fn = lib().oracle_opt_gsl_refobj
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(ref_kernels), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_double,
+                   C.POINTER(gsl_config), dp, C.POINTER(C.c_double), C.POINTER(gsl_stats)]
+    code = fn(C.byref(k), forces, m, n, _p(yTilde), _p(yT) if caching else None, _p(YTilde), _p(x0), _p(fixed),
+              float(theta), C.byref(cfg), _p(res), C.byref(fmin), C.byref(st))
+    return res, fmin.value, code, st.iterations, (st.f_evaluations, st.g_evaluations)
+
+
+class RefObjective(object):
+    """The reference's objective as a plain C callback: `.fn` (address of oracle_refobj_eval) and
+    `.handle` (its `user` argument) can be handed to any minimizer that takes
+    ``int fn(void* user, const double* x, double* f, double* grad_or_NULL)``."""
+
+    def __init__(self, ref_cdll, kind, fixed, yTilde, YTilde, theta, caching=True):
+        self._keep = [_a(fixed).ravel(), _a(yTilde), _a(YTilde).ravel()]
+        fixed, yTilde, YTilde = self._keep
+        m, n = yTilde.shape
+        yT = np.ascontiguousarray(yTilde.T) if caching else None
+        self._keep.append(yT)
+        k = ref_kernels(*[C.cast(getattr(ref_cdll, name), C.c_void_p) for name in _REF_SYMBOLS])
+        L = lib()
+        L.oracle_refobj_create.restype = C.c_void_p
+        L.oracle_refobj_create.argtypes = [C.POINTER(ref_kernels), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.c_double]
+        L.oracle_refobj_destroy.argtypes = [C.c_void_p]
+        self.handle = C.c_void_p(L.oracle_refobj_create(C.byref(k), 1 if kind == "forces" else 0, m, n, _p(yTilde),
+                                                        _p(yT) if caching else None, _p(YTilde), _p(fixed), float(theta)))
+        assert self.handle.value
+        self.fn = C.cast(L.oracle_refobj_eval, C.c_void_p)
+
+    def close(self):
+        if self.handle is not None:
+            lib().oracle_refobj_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 MULTIMIN_TESTS = {   # multimin/test_funcs.c start points
     "Roth": (0, [4.5, 3.5]), "Wood": (1, [-3.0, -1.0, -3.0, -1.0]), "Rosenbrock": (2, [-1.2, 1.0]),
     "Rosenbrock1": (2, [1.0, 1.0]), "SimpleAbs": (3, [1.0, 2.0]),

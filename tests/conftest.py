@@ -31,7 +31,7 @@ def golden_files(kind):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
         b = os.path.basename(p)
-        if b == "error_codes.npz":
+        if b == "error_codes.npz" or b.startswith("gsl_") or b.startswith("bench_"):
             continue
         z = np.load(p, allow_pickle=False)
         if z["kind"].item() == kind:
@@ -45,6 +45,11 @@ FORCES_GOLDEN = golden_files("forces")
 LBFGS_DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9,
                       wolfe=0.9, past=10, max_linesearch=100)
 LBFGS_TIGHT = dict(LBFGS_DEFAULTS, epsilon=1e-7, delta=1e-11)
+# converged: no plateau test, gradient test at 1e-9 -- a run ends AT the optimum (epsilon test, or an
+# exhausted line search at the rounding floor); make_golden.py stores the reference's runs as
+# lbfgs_conv_* (backtracking-Wolfe) and lbfgs_convmt_* (More-Thuente)
+LBFGS_CONV = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
+LBFGS_CONVMT = dict(LBFGS_CONV, linesearch=0)
 
 
 @pytest.fixture(scope="session")

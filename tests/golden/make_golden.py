@@ -35,6 +35,12 @@ DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, fto
 TIGHT = dict(DEFAULTS, epsilon=1e-7, delta=1e-11)                 # converged-optimum parity runs
 MORETHUENTE = dict(DEFAULTS, linesearch=0)
 STRONG = dict(DEFAULTS, linesearch=3)
+# "conv": the stopping rules that let an implementation stop early are switched off (no plateau
+# test, gradient test at 1e-9), so every run ends AT the optimum -- on the epsilon test or, where
+# the objective is flat to the last bit first, on an exhausted line search (-998 / -1001) at the
+# rounding floor.  These runs are what north_star's 1e-6 (L) / 1e-5 (weights) are asserted on.
+CONV = dict(DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
+CONVMT = dict(CONV, linesearch=0)
 
 
 def arr(x):
@@ -58,7 +64,8 @@ def logw_case(GInit, G, y, yTilde, YTilde, theta, ref_value=None):
     out["g_pert"] = gp
     out["f_pert"] = R.logw_f(gp, G, yTilde, YTilde, theta)
     out["grad_pert"] = R.logw_df(gp, G, yTilde, YTilde, theta, caching=True)
-    for tag, cfg in (("def", DEFAULTS), ("tight", TIGHT), ("mt", MORETHUENTE), ("strong", STRONG)):
+    for tag, cfg in (("def", DEFAULTS), ("tight", TIGHT), ("mt", MORETHUENTE), ("strong", STRONG),
+                     ("conv", CONV), ("convmt", CONVMT)):
         gopt, fmin, code = R.opt_lbfgs_logw(GInit, G, yTilde, YTilde, theta, cfg)
         out["lbfgs_%s_fmin" % tag] = fmin
         out["lbfgs_%s_code" % tag] = code
@@ -91,7 +98,7 @@ def forces_case(forces_init, w0, y, yTilde, YTilde, theta, ref_value=None):
     out["w_pert"] = R.forces_weights(fp, w0, yTilde)
     out["f_pert"] = R.forces_f(fp, w0, yTilde, YTilde, theta)
     out["grad_pert"] = R.forces_df(fp, w0, yTilde, YTilde, theta)
-    for tag, cfg in (("def", DEFAULTS), ("tight", TIGHT), ("mt", MORETHUENTE)):
+    for tag, cfg in (("def", DEFAULTS), ("tight", TIGHT), ("mt", MORETHUENTE), ("conv", CONV), ("convmt", CONVMT)):
         fopt, fmin, code = R.opt_lbfgs_forces(forces_init, w0, yTilde, YTilde, theta, cfg)
         out["lbfgs_%s_fmin" % tag] = fmin
         out["lbfgs_%s_code" % tag] = code

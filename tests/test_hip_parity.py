@@ -9,7 +9,8 @@ unit tests use 5e-14 / 5e-12 between its C and Python paths, test_func_gradient_
 import numpy as np
 import pytest
 
-from conftest import LOGW_GOLDEN, FORCES_GOLDEN, LBFGS_DEFAULTS, LBFGS_TIGHT, load_golden
+from conftest import (LOGW_GOLDEN, FORCES_GOLDEN, LBFGS_DEFAULTS, LBFGS_TIGHT, LBFGS_CONV, LBFGS_CONVMT,
+                      load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -126,6 +127,116 @@ def test_forces_lbfgs_vs_reference(hip, name):
         assert rel(f_again, info.fmin) < 5e-14
         if "ref_fmin_scipy_bfgs" in d:
             assert rel(info.fmin, float(d["ref_fmin_scipy_bfgs"])) < 1e-1
+
+
+# ---------------------------------------------------------------------------------------
+# north_star's numbers, un-widened: converged runs against the REFERENCE's converged runs
+# ---------------------------------------------------------------------------------------
+# Two fixtures are left out of the strict comparison, as the reference's own optimiser tests leave them out
+# (test_find_opt_analytical_grad_logw.py:15-27: "(*) require specific tuning of parameters"; GSL conjugate_pr /
+# bfgs end in NaN on the second, which tests/golden/gsl_*.npz reproduce): theta = 1e-3 resp. 808 observables on
+# 100 structures make L(g) a staircase of plateaus (dL/dg_k ~ w_k vanishes wherever a weight has died), and
+# the reference's liblbfgs gives up on one of them -- -998 / -1001 at 4386.96 resp. 4350.19 / 4427.69 while
+# GSL bfgs2 reaches 4042.79 resp. 4159.16 and scipy's BFGS (the stored *.ref) 4313.60 resp. 4350.19.  A
+# plateau is not an optimum, so there is no reference point to be within 1e-5 of; what is held there is the
+# reference's own regression tolerance (1e-1 on fmin against *.ref, :134-147) and "no worse than the start".
+REFERENCE_EXCLUDES = {"ref_data_potra_part_1_logw_M808xN80.npz", "ref_data_potra_part_2_logw_M808xN10.npz"}
+
+
+def _converged_checks(name, tag, d, info, w, wref, theta):
+    code_ref, fmin_ref = int(d["lbfgs_%s_code" % tag]), float(d["lbfgs_%s_fmin" % tag])
+    # the reference ends on the epsilon test (0) or on an exhausted line search at the rounding floor
+    # (-998 backtracking / -1001 More-Thuente: no representable decrease is left); both are "at the optimum"
+    assert code_ref in (0, -998, -1001)
+    assert info.lbfgs_code in (0, -998, -1001), (name, tag, info.lbfgs_code)
+    if name in REFERENCE_EXCLUDES:
+        assert rel(info.fmin, float(d["ref_fmin_scipy_bfgs"])) < 1e-1 and info.fmin < float(d["f_init"])
+        return
+    assert rel(info.fmin, fmin_ref) < FMIN_RTOL, (name, tag, info.fmin, fmin_ref)
+    # theta = 0 (the two deer_test fixtures): no prior, 808 observables on 10 structures -- L is pinned,
+    # the weights are not (a flat direction); everywhere else north_star's 1e-5 holds as is
+    if theta > 0:
+        assert np.abs(w - wref).max() <= W_RTOL * wref.max(), (name, tag, np.abs(w - wref).max() / wref.max())
+    # secondary: RELATIVE agreement of the entries above 1e-3 max(w).  A weight's own relative
+    # error is the absolute error of its log-weight, which an epsilon = 1e-9 gradient test pins only to
+    # ~epsilon |x| / (w_k x curvature): the reference and its restatement already differ by 1.7e-4 on
+    # synth_logw_M64xN2000 and 1.4e-5 on synth_logw_M37xN500 by this measure (2e-6 / 1e-7 by the one above)
+    big = wref > 1e-3 * wref.max()
+    if theta > 0:
+        assert np.abs(w[big] / wref[big] - 1.0).max() <= 1e-3, (name, tag)
+
+
+@pytest.mark.parametrize("name", LOGW_GOLDEN)
+@pytest.mark.parametrize("tag,params", [("conv", LBFGS_CONV), ("convmt", LBFGS_CONVMT)])
+def test_logw_converged_vs_reference(hip, name, tag, params):
+    """max|w - w_ref| <= 1e-5 max(w_ref) and |fmin - fmin_ref| <= 1e-6 |fmin_ref| against the reference's own
+    liblbfgs run, no conditioning term: epsilon = 1e-9, delta = 0, past = 0 leave no early exit."""
+    d = load_golden(name)
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        gopt, w, info = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], params)
+        f_again, _ = ctx.logw_fdf(gopt, d["G"], d["theta"], need_grad=False)
+    _converged_checks(name, tag, d, info, w, d["lbfgs_%s_wopt" % tag], d["theta"])
+    if info.lbfgs_code == 0:
+        assert rel(f_again, info.fmin) < 5e-14
+    else:       # after a failed search liblbfgs restores x but reports the last trial's f (lbfgs.c:470-479)
+        assert rel(f_again, info.fmin) < 1e-9
+    assert abs(w.sum() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("name", FORCES_GOLDEN)
+@pytest.mark.parametrize("tag,params", [("conv", LBFGS_CONV), ("convmt", LBFGS_CONVMT)])
+def test_forces_converged_vs_reference(hip, name, tag, params):
+    d = load_golden(name)
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        fopt, w, info = ctx.opt_lbfgs_forces(d["forces_init"], d["w0"], d["theta"], params)
+    if name == "ref_data_deer_test_forces_M808xN10.npz" and tag == "convmt":
+        # theta = 0 and the reference's More-Thuente run stops 0.35 % above its backtracking run
+        # (25538.77 vs 25449.08, -1001 after 14 iterations): hold to "no worse than the reference"
+        assert info.lbfgs_code in (0, -998, -1001)
+        assert info.fmin <= float(d["lbfgs_convmt_fmin"]) * (1 + 1e-9)
+        assert info.fmin >= float(d["lbfgs_conv_fmin"]) * (1 - FMIN_RTOL)
+        return
+    _converged_checks(name, tag, d, info, w, d["lbfgs_%s_wopt" % tag], d["theta"])
+    assert abs(w.sum() - 1.0) < 1e-12
+
+
+# ... and the reference's runs under the other line searches / settings that make_golden.py stores
+@pytest.mark.parametrize("name", LOGW_GOLDEN)
+@pytest.mark.parametrize("tag,ls", [("mt", 0), ("strong", 3)])
+def test_logw_other_linesearch_goldens_vs_reference(hip, name, tag, ls):
+    """liblbfgs More-Thuente (linesearch 0) and backtracking strong-Wolfe (3) at the yaml defaults, against
+    the reference's runs (lbfgs_mt_*, lbfgs_strong_*).  Default settings stop on the 1e-6 plateau, so
+    fmin is pinned to the width of that plateau and the weights to the recorded conditioning of the
+    stopping point; the converged tests above carry the un-widened claim."""
+    d = load_golden(name)
+    code_ref = int(d["lbfgs_%s_code" % tag])
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        gopt, w, info = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], dict(LBFGS_DEFAULTS, linesearch=ls))
+    if code_ref not in (0, 1, 2):
+        assert info.lbfgs_code < 0 or info.lbfgs_code in (0, 1)
+        return
+    assert info.lbfgs_code in (0, 1, 2), (name, tag, info.lbfgs_code)
+    assert rel(info.fmin, float(d["lbfgs_%s_fmin" % tag])) < 2e-5, (name, tag, info.fmin)
+    wref = d["lbfgs_%s_wopt" % tag]
+    wtol = max(W_RTOL, 3.0 * float(d["lbfgs_%s_wspread" % tag]))
+    assert np.abs(w - wref).max() <= wtol * wref.max(), (name, tag)
+
+
+@pytest.mark.parametrize("name", FORCES_GOLDEN)
+@pytest.mark.parametrize("tag,params", [("tight", LBFGS_TIGHT), ("mt", dict(LBFGS_DEFAULTS, linesearch=0))])
+def test_forces_other_goldens_vs_reference(hip, name, tag, params):
+    d = load_golden(name)
+    code_ref = int(d["lbfgs_%s_code" % tag])
+    with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+        fopt, w, info = ctx.opt_lbfgs_forces(d["forces_init"], d["w0"], d["theta"], params)
+    if code_ref not in (0, 1, 2):
+        assert info.lbfgs_code < 0 or info.lbfgs_code in (0, 1)
+        return
+    assert info.lbfgs_code in (0, 1, 2), (name, tag, info.lbfgs_code)
+    assert rel(info.fmin, float(d["lbfgs_%s_fmin" % tag])) < (FMIN_RTOL if tag == "tight" else 5e-6), (name, tag)
+    wref = d["lbfgs_%s_wopt" % tag]
+    wtol = max(W_RTOL, 3.0 * float(d["lbfgs_%s_wspread" % tag]))
+    assert np.abs(w - wref).max() <= wtol * wref.max(), (name, tag)
 
 
 @pytest.mark.parametrize("linesearch", [0, 1, 3])
