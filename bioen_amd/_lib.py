@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbioen_hip.so")
+# BIOEN_HIP_LIBRARY: another build of the same library (diagnostic / A-B builds of tools/); never a fallback
+LIB_PATH = os.environ.get("BIOEN_HIP_LIBRARY") or os.path.join(_HERE, "libbioen_hip.so")
 
 dp = C.POINTER(C.c_double)
 ctx_p = C.c_void_p
@@ -80,6 +81,7 @@ _SIGNATURES = {
                                                  C.POINTER(VisualParams), C.c_int, dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_forces_weights": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_forces_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
+    "bioen_hip_forces_fdf_batch": (C.c_int, [ctx_p, C.c_int, dp, dp, dp, dp, dp]),
     "bioen_hip_opt_lbfgs_forces": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(LbfgsConfig),
                                              C.POINTER(VisualParams), dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_opt_lbfgs_forces_batch": (C.c_int, [ctx_p, C.c_int, dp, dp, C.c_size_t, dp, C.POINTER(LbfgsConfig),
@@ -89,6 +91,7 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_debug_strip_stamps": (C.c_int, [ctx_p, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
     "bioen_hip_ctx_create_raw": (C.c_int, [C.c_int, C.c_longlong, C.c_int, dp, dp, dp, C.c_int, C.POINTER(ctx_p)]),
     "bioen_hip_gsl_strerror": (C.c_char_p, [C.c_int]),
     "bioen_hip_opt_gsl_logw": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(GslConfig), C.POINTER(VisualParams),
@@ -467,6 +470,18 @@ class Context(object):
         check(lib().bioen_hip_forces_fdf(self._h, ptr(fo), ptr(w0), float(theta), C.byref(f),
                                          ptr(grad) if need_grad else None))
         return (f.value if need_f else None), grad
+
+    def forces_fdf_batch(self, forces, w0, thetas, need_grad=True):
+        """K <= 8 evaluations sharing every matrix pass.  forces: (K, m), thetas: (K,) -> (f[K], grad[K, m] or None)"""
+        thetas = as_f64(thetas).ravel()
+        k = thetas.size
+        fo = as_f64(forces).reshape(k, self.m)
+        w0 = self._nvec(w0, "w0")
+        f = np.empty(k)
+        grad = np.empty((k, self.m)) if need_grad else None
+        check(lib().bioen_hip_forces_fdf_batch(self._h, k, ptr(fo), ptr(w0), ptr(thetas), ptr(f),
+                                               ptr(grad) if need_grad else None))
+        return f, grad
 
     def opt_lbfgs_forces(self, forces0, w0, theta, params, verbose=False, debug=False, want_weights=True):
         f0, w0 = self._mvec(forces0, "forces0"), self._nvec(w0, "w0")

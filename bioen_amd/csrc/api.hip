@@ -140,6 +140,10 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     choose_fwd_tiling(c);
     // stream yTilde with non-temporal loads once it no longer fits the 256 MiB Infinity Cache
     c->nontemporal = (size_t)c->mp * c->ld * sizeof(double) > (size_t)192 * 1024 * 1024;
+    {
+        const char* e = std::getenv("BIOEN_HIP_STRIP_OLD");
+        c->strip_old = (e && e[0] == '1') ? 1 : 0;
+    }
 
     int rc = 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -357,8 +361,27 @@ static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
 }
 
 static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
-    const int nblk = forces_fused_blocks(c);
+    int nblk = forces_fused_blocks(c);
     int rc;
+    if ((nblk > 0 && c->strip_old) || (nblk == 0 && forces_fused_blocks_old(c) > 0)) {        // r01 kernels on the row-major matrix, kept for A/B measurements
+        nblk = forces_fused_blocks_old(c);
+        launch_forces_xy_old(c, fr, nblk);
+        if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
+        launch_rows_combine(c, r, true);
+        if (with_grad) {
+            launch_forces_bt_old(c, fr, nblk);
+            if (c->world == 1) {
+                launch_fwd_rows_forces_grad(c, fr.n, nblk);
+            } else {
+                launch_fwd_rows_forces_grad_share(c, fr.n, nblk);
+                if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
+                launch_forces_grad_sum_ranks(c, fr.n);
+            }
+        } else {
+            launch_forces_w_from_x(c, fr);
+        }
+        return 0;
+    }
     if (nblk > 0) {
         // M <= 1024: two passes over LDS-resident column strips instead of four streaming ones.
         // Measured at N = 1e6 x M = 512 (r01): pass 2 alone 0.85 ms at K = 1 against 1.22 ms for the
@@ -367,15 +390,18 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         // Sharded contexts: every rank does this on its columns; the shares of ybar travel with the
         // rank's softmax totals in ONE all-gather (the layout of the log-weights rounds, finished by
         // the same k_rows_combine), the shares of the gradient in a second one.
+        // Both passes read the strip-major copy centred on the targets (kernels_strip.hip); ybar_c then holds
+        // ybar - center, the row offset of k_rows_combine puts the centre back for r, chi^2 and f.
+        if ((rc = ensure_strip_copy(c))) return rc;
         launch_forces_xy(c, fr, nblk);        // F1 + F2: x, online softmax, this rank's ybar   [matrix pass 1]
         if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
-        launch_rows_combine(c, r, true);      //     normalisation, ybar, r, chi^2, KL, f
+        launch_rows_combine(c, r, true, c->strip_center);   //     normalisation, ybar, r, chi^2, KL, f
         if (with_grad) {
-            launch_forces_bt(c, fr, nblk);    // F3: b, t, centred product            [matrix pass 2]
+            launch_forces_bt(c, fr, nblk);    // F3: b, t, product with t            [matrix pass 2]
             if (c->world == 1) {
-                launch_fwd_rows_forces_grad(c, fr.n, nblk);
+                launch_fwd_rows_forces_grad(c, fr.n, nblk, &fr);
             } else {
-                launch_fwd_rows_forces_grad_share(c, fr.n, nblk);
+                launch_fwd_rows_forces_grad_share(c, fr.n, nblk, &fr);
                 if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
                 launch_forces_grad_sum_ranks(c, fr.n);
             }
@@ -618,8 +644,8 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    double* bufs[] = {c->Y, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed, c->t, c->g0, c->fwd_partial,
-                      c->part, c->scal};
+    double* bufs[] = {c->Y, c->Ys, c->strip_center, c->strip_stamps, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed,
+                      c->t, c->g0, c->fwd_partial, c->part, c->scal};
     for (double* p : bufs)
         if (p) hipFree(p);
     for (int s = 0; s < kMaxBatch; ++s) {
@@ -782,7 +808,7 @@ static bool is_affine(const bioen_hip_ctx* c) { return c->affine; }
 
 static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
     // sharded contexts run the forces method through the strip passes only (M <= 1024)
-    if (c->world != 1 && !(strip_path_ok && forces_fused_blocks(c) > 0))
+    if (c->world != 1 && !(strip_path_ok && (forces_fused_blocks(c) > 0 || forces_fused_blocks_old(c) > 0)))
         return fail(BIOEN_HIP_ESTATE, "not available on this structure-sharded context");
     if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
     return 0;
@@ -818,6 +844,49 @@ int bioen_hip_forces_fdf(bioen_hip_ctx* c, const double* forces, const double* w
     if (eng.rc) return eng.rc;
     if (grad) std::memcpy(grad, eng.gm_h, (size_t)c->m * sizeof(double));
     if (f) *f = c->host_scal[S_F];
+    return 0;
+}
+
+// diagnostic builds (-DSTRIP_DIAG=4): phase-cycle sums of the last forces strip launch, [blocks][16][8]
+int bioen_hip_debug_strip_stamps(bioen_hip_ctx* c, int enable, long long* out, int nblocks) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    const size_t cnt = (size_t)kFusedBlocks * 16 * 8;
+    if (enable && !c->strip_stamps) {
+        int rc = dalloc_zero(&c->strip_stamps, cnt, c->stream);
+        if (rc) return rc;
+    }
+    if (out && c->strip_stamps) {
+        BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+        BIOEN_HIP_CHECK(hipMemcpy(out, c->strip_stamps, (size_t)nblocks * 16 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int bioen_hip_forces_fdf_batch(bioen_hip_ctx* c, int k, const double* forces, const double* w0, const double* thetas,
+                               double* f, double* grad) {
+    if (!c || !forces || !w0 || !thetas) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (k < 1 || k > kMaxBatch) return fail(BIOEN_HIP_EINVAL, "k must be in [1, 8]");
+    int rc = forces_guard(c);
+    if (rc) return rc;
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    for (int s = 0; s < k; ++s)
+        if ((rc = alloc_slot(c, s, false))) return rc;
+    if ((rc = upload_n(c, c->fixed, w0))) return rc;
+    bioen_lbfgs_config dummy{};
+    ForcesBatchEngine eng(c, dummy, false);
+    int slots[kMaxBatch];
+    const double* pt[kMaxBatch];
+    for (int a = 0; a < k; ++a) {
+        slots[a] = a;
+        pt[a] = forces + (size_t)a * c->m;
+    }
+    eng.evaluate(slots, k, pt, thetas, grad != nullptr);
+    if (eng.rc) return eng.rc;
+    for (int a = 0; a < k; ++a) {
+        if (grad)
+            for (int i = 0; i < c->m; ++i) grad[(size_t)a * c->m + i] = eng.gm_h[(size_t)i * k + a];
+        if (f) f[a] = c->host_scal[(size_t)a * kScalStride + S_F];
+    }
     return 0;
 }
 

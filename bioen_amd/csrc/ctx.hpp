@@ -62,6 +62,7 @@ enum ScalarSlot : int {
     S_YSH,                         // [kHistory] y.s per history slot
     S_ALPHA = S_YSH + kHistory,    // [kHistory]
     S_INV = S_ALPHA + kHistory,    // w_j = e_j * S_INV on this rank (deferred softmax normalisation)
+    S_B0,                          // sum_i row_offset_i r_i  (forces strip passes: the adjoint's constant)
     S_COUNT
 };
 static_assert(S_COUNT <= kScalStride, "scalar slots");
@@ -148,6 +149,11 @@ struct bioen_hip_ctx {
     hipStream_t stream = nullptr;
 
     double* Y = nullptr;       // mp x ld
+    // forces method, M <= 1024 (kernels_strip.hip): strip-major copy centred on the targets, built on first use
+    double* Ys = nullptr;            // [ld / 16][strip rows][16]
+    double* strip_center = nullptr;  // mp: YTilde at the time of the copy
+    double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
+    int strip_old = 0;               // BIOEN_HIP_STRIP_OLD=1: the r01 strip kernels on the row-major matrix (A/B)
     double* YT = nullptr;      // mp   experimental targets (YTilde)
     // affine observable model: yTilde_eff[i][j] = row_offset[i] + row_scale[i] * Y[i][j]
     // (default 0, 1).  DEER / SAXS nuisance parameters enter exactly like this, so a refit never

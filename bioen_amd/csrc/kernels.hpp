@@ -48,19 +48,26 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw);   // logw: + {su
 int ybar_payload(const bioen_hip_ctx* c, int K, bool logw);        // doubles per rank in the X_YBAR stage
 void launch_scale_w(bioen_hip_ctx* c, const Round& r);              // w = e * scal[S_INV] (when a result is handed out)
 // add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
-void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw);   // logw: also chi^2, c, f -> scal
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw,   // logw: also chi^2, c, f -> scal
+                         const double* row_offset = nullptr);            // != NULL: instead of the context's affine offset
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles);
+// tsum = true (strip passes on the centred copy): gm = sum of partials - ybar_c * T, T = sum of the blocks' P_KL shares
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr);
 // forces evaluation in TWO matrix passes over LDS-resident column strips (M <= 512, unsharded):
 //   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
-constexpr int kFusedBlocks = 512;
+constexpr int kFusedBlocks = 1024;
 int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
-void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles);   // sharded: -> X_YBAR segment
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr);   // sharded: -> X_YBAR segment
+int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
+void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
+int forces_fused_blocks_old(const bioen_hip_ctx* c);   // r01 strip kernels (A/B only)
+void launch_forces_xy_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
+void launch_forces_bt_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K);                     //          shares -> gm
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
 void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);

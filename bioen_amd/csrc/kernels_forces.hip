@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(ForcesRound r, const double
 // The reference spends two full passes on this (3 of its 5), the unfused device path two of four.
 // Output: partial[(row*K + a) * nblk + block], finished by k_fwd_rows_forces_grad.
 // ------------------------------------------------------------------------------
-constexpr int kStripCols = 16;
+constexpr int kOldStripCols = 16;
 
 template <int WAVES, class F>
 __device__ __forceinline__ double sum_waves(F f) {          // fixed pairing, 4 or 8 waves
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
                                                          int n, const double* __restrict__ f_c, ForcesRound fr,
                                                          const double* __restrict__ w0,
                                                          double* __restrict__ partial, int nblk) {
-    constexpr int C = kStripCols;
+    constexpr int C = kOldStripCols;
     constexpr int KP = next_pow2(K);
     constexpr int CB = KP >= 8 ? 2 : 4;
     constexpr int NV = CB * KP;
@@ -238,71 +238,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
     }
 }
 
-// Merge the blocks of k_forces_xy on THIS rank (one block per problem): m_r = max_b m_b,
-// Z_r = sum_b e^{m_b - m_r} Z_b, likewise sum e x; P_MAX[b] <- e^{m_b - m_r}, the weight of block
-// b's raw sums.  The rank totals {Z_r, sum e x, m_r} go to the tail of the rank's X_YBAR segment --
-// the layout of the log-weights rounds -- so k_rows_combine<true> finishes both methods alike:
-//   scal[S_LOGS] = M + log Z  (w_j = w0_j exp(x_j - S_LOGS)),  scal[S_P] = sum_j w_j x_j,
-//   KL = sum_j w_j log(w_j / w0_j) = S_P - S_LOGS   (c_bioen_kernels_forces.c:246-258, with
-//   log w_j - log w0_j = x_j - S_LOGS; the prior constant S_LOGS0 is zero for this method).
-__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int nblk, int mp, int K, Xch xo) {
-    __shared__ double sh[kWaves];
-    const int a = blockIdx.y;
-    double* pa = fr.part[a];
-    double* pm = pa + (size_t)P_MAX * kMaxPartials;
-    const double mr = max_partials(pm, nblk, sh);
-    double z = 0.0, px = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += kBlock) {
-        const double fb = exp(pm[b] - mr);
-        z = fma(fb, pa[(size_t)P_SUM * kMaxPartials + b], z);
-        px = fma(fb, pa[(size_t)P_PP * kMaxPartials + b], px);
-    }
-    z = block_sum(z, sh);
-    px = block_sum(px, sh);
-    __syncthreads();
-    for (int b = threadIdx.x; b < nblk; b += kBlock) pm[b] = exp(pm[b] - mr);
-    if (threadIdx.x == 0) {
-        double* tail = xo.base + (size_t)xo.rank * xo.payload + (size_t)mp * K + 3 * a;
-        tail[0] = z;
-        tail[1] = px;
-        tail[2] = mr;
-        fr.scal[a][S_LOGS0] = 0.0;
-    }
-}
-
-// this rank's share of ybar: sum_b weight_b raw_i,b   (a wave per (row, problem), fixed order)
-__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted(const double* __restrict__ partial, int nblk, int mp,
-                                                                 int K, ForcesRound fr, Xch xo) {
-    const int a = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const double* __restrict__ wb = fr.part[a] + (size_t)P_MAX * kMaxPartials;
-    double* out = xo.base + (size_t)xo.rank * xo.payload;
-    for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
-        const double* p = partial + ((size_t)row * K + a) * nblk;
-        double s = 0.0;
-        for (int b = lane; b < nblk; b += 64) s = fma(wb[b], p[b], s);
-        s = wave_sum(s);
-        if (lane == 0) out[(size_t)row * K + a] = s;
-    }
-}
-
-// w_j = w0_j exp(x_j - S_LOGS): the weights themselves, when a result is handed out
-__global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, const double* __restrict__ w0, int n) {
-    const int a = blockIdx.y;
-    const double* __restrict__ x = fr.a[a];
-    double* __restrict__ w = fr.w[a];
-    const double logz = fr.scal[a][S_LOGS];
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] = w0[j] * exp(x[j] - logz);
-}
-
 template <int K, bool NT, bool FROMX, int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void k_forces_bt(const double* __restrict__ Y, size_t ld, int mp, int nstrips,
                                                       const double* __restrict__ r_c,
                                                       const double* __restrict__ ybar_c, ForcesRound fr,
                                                       const double* __restrict__ w0,
                                                       double* __restrict__ partial, int nblk) {
-    constexpr int C = kStripCols;
+    constexpr int C = kOldStripCols;
     constexpr int KP = next_pow2(K);
     constexpr int CB = KP >= 8 ? 2 : 4;                         // columns per butterfly
     constexpr int NV = CB * KP;                                 // values per butterfly (4 .. 16)
@@ -425,18 +367,18 @@ __global__ __launch_bounds__(kBlock) void k_forces_scalars(ForcesRound r, int np
 
 
 // ---- forces evaluation over LDS-resident column strips (M <= 1024) --------------------------
-static int strip_threads(const bioen_hip_ctx* c) { return c->mp <= 512 ? 256 : 512; }
+static int old_strip_threads(const bioen_hip_ctx* c) { return c->mp <= 512 ? 256 : 512; }
 
-int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
+int forces_fused_blocks_old(const bioen_hip_ctx* c) {
     if (c->mp > 1024) return 0;
-    const int nstrips = (int)(c->ld / kStripCols);
+    const int nstrips = (int)(c->ld / kOldStripCols);
     // 256 threads: two 70-KB blocks per CU; 512 threads: one 148-KB block per CU
-    return std::min(strip_threads(c) == 256 ? kFusedBlocks : kFusedBlocks / 2, nstrips);
+    return std::min(old_strip_threads(c) == 256 ? 512 : 256, nstrips);
 }
 
 template <int K, bool NT, int THREADS>
 static void forces_strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
-    const int nstrips = (int)(c->ld / kStripCols);
+    const int nstrips = (int)(c->ld / kOldStripCols);
     if (pass == 1)
         hipLaunchKernelGGL((k_forces_xy<K, NT, THREADS>), dim3(nblk), dim3(THREADS), 0, c->stream, c->Y, c->ld, c->mp,
                            nstrips, c->n, c->um, fr, c->fixed, c->fwd_partial, nblk);
@@ -461,34 +403,24 @@ static void forces_strip_dispatch_k(bioen_hip_ctx* c, const ForcesRound& fr, int
 
 template <bool NT>
 static void forces_strip_dispatch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
-    if (strip_threads(c) == 256) forces_strip_dispatch_k<NT, 256>(c, fr, nblk, pass);
+    if (old_strip_threads(c) == 256) forces_strip_dispatch_k<NT, 256>(c, fr, nblk, pass);
     else forces_strip_dispatch_k<NT, 512>(c, fr, nblk, pass);
 }
 
 // pass 1: x = yTilde^T f, online softmax, raw ybar per block; then the block merge and ybar -> X_YBAR
-void launch_forces_xy(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+void launch_forces_xy_old(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
     {
         TimedLaunch tl(c, 1, fr.n);
         if (c->nontemporal) forces_strip_dispatch<true>(c, fr, nblk, 1); else forces_strip_dispatch<false>(c, fr, nblk, 1);
     }
-    const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, fr.n, true));
-    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk, c->mp, fr.n, xo);
-    hipLaunchKernelGGL(k_forces_rows_weighted, dim3(rows_grid(c), fr.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       nblk, c->mp, fr.n, fr, xo);
+    launch_forces_blockmerge(c, fr, nblk);
 }
 
 // pass 2: b = yTilde^T r, t, centred yTilde . t
-void launch_forces_bt(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+void launch_forces_bt_old(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
     TimedLaunch tl(c, 0, fr.n);
     if (c->nontemporal) forces_strip_dispatch<true>(c, fr, nblk, 2); else forces_strip_dispatch<false>(c, fr, nblk, 2);
 }
-
-void launch_forces_w_from_x(bioen_hip_ctx* c, const ForcesRound& fr) {
-    hipLaunchKernelGGL(k_forces_w_from_x, dim3(vec_grid(c), fr.n), dim3(kBlock), 0, c->stream, fr, c->fixed, c->n);
-}
-
-
-
 
 // ---- forces ------------------------------------------------------------------------------------
 void launch_forces_max(bioen_hip_ctx* c, const ForcesRound& r) {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             sc[S_INV] = exp(mown - gmax) * invS;
         }
     }
-    double chi = 0.0, cc = 0.0;
+    double chi = 0.0, cc = 0.0, b0 = 0.0;
     for (int row = threadIdx.x; row < mp; row += kBlock) {
         double s = 0.0;
         for (int r = 0; r < xi.world; ++r) {
@@ -233,14 +233,17 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
         r_c[(size_t)row * K + a] = res * sc;
         chi = fma(res, res, chi);
         cc = fma(eff, res, cc);
+        b0 = fma(row_offset[row], res * sc, b0);
     }
     chi = block_sum(chi, sh);
     cc = block_sum(cc, sh);
+    b0 = block_sum(b0, sh);
     if (threadIdx.x == 0) {
         if (LOGW) {
             double* sc = rd.scal[a];            // S_P, S_LOGS: written above by this same thread
             sc[S_CHI] = chi;
             sc[S_C] = cc;
+            sc[S_B0] = b0;
             sc[S_KL] = sc[S_P] - sc[S_LOGS] + sc[S_LOGS0];     // theta's factor: KL(w || w0) in both methods
             sc[S_F] = rd.theta[a] * sc[S_KL] + 0.5 * chi;
         } else {
@@ -251,19 +254,26 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
     }
 }
 
-// forces gradient (c_bioen_kernels_forces.c:330-338): the partials already hold the centred
-// sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.
+// forces gradient (c_bioen_kernels_forces.c:330-338).  Streaming path: the partials already hold the centred
+// sums  sum_j (Y_ij - ybar_i) t_j ; only the column tiles remain to be added up.  Strip passes on the
+// centred copy (kernels_strip.hip): the partials hold sum_j Y'_ij t_j and  ybar'_i sum_j t_j  is taken off
+// here, T = the blocks' shares of sum_j t_j in the problem's P_KL partials (every block re-sums them in the
+// same fixed order).
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* __restrict__ partial, int ctiles,
-                                                                 int mp, int K, double* __restrict__ gm_c) {
+                                                                 int mp, int K, double* __restrict__ gm_c,
+                                                                 const double* __restrict__ ybar_c, MVec8 tpart) {
+    __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    double T = 0.0;
+    if (ybar_c) T = sum_partials(tpart.p[a] + (size_t)P_KL * kMaxPartials, ctiles, sh);
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
         const double* p = partial + ((size_t)row * K + a) * ctiles;
         double s = 0.0;
         for (int k = lane; k < ctiles; k += 64) s += p[k];
         s = wave_sum(s);
-        if (lane == 0) gm_c[(size_t)row * K + a] = s;
+        if (lane == 0) gm_c[(size_t)row * K + a] = ybar_c ? fma(-ybar_c[(size_t)row * K + a], T, s) : s;
     }
 }
 
@@ -449,30 +459,39 @@ void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
 
 int combine_grid(const bioen_hip_ctx*) { return 1; }
 
-void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw) {
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw, const double* row_offset) {
     MVec8 part;
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
+    const double* off = row_offset ? row_offset : c->row_offset;
     if (logw)
         hipLaunchKernelGGL(k_rows_combine<true>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
-                           make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, off, c->row_scale,
                            c->ybar_c, c->r_c, part, r);
     else
         hipLaunchKernelGGL(k_rows_combine<false>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
-                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, off, c->row_scale,
                            c->ybar_c, c->r_c, part, r);
 }
 
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles) {
+static MVec8 tsum_parts(const ForcesRound* fr) {
+    MVec8 t{};
+    if (fr)
+        for (int a = 0; a < fr->n; ++a) t.p[a] = fr->part[a];
+    return t;
+}
+
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum) {
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       ctiles, c->mp, K, c->gm);
+                       ctiles, c->mp, K, c->gm, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
 }
 
 // sharded: this rank's share of the forces gradient -> its X_YBAR segment; after the exchange
 // k_sum_ranks adds the shares in rank order (identical on every rank) -> gm
-void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles) {
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum) {
     const Xch xo = make_xch(c, X_YBAR, c->mp * K);
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload);
+                       ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, tsum ? c->ybar_c : nullptr,
+                       tsum_parts(tsum));
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_ranks(Xch xi, int count, double* __restrict__ out) {

@@ -1,0 +1,525 @@
+// Forces method, M <= 512: the whole evaluation in TWO passes over a strip-major copy of yTilde, with both
+// products of each pass on the FP64 matrix cores (v_mfma_f64_4x4x4_4b_f64).
+//
+// Reference: _get_weights_from_forces (c_bioen_kernels_forces.c:111-224), _bioen_log_posterior_forces
+// (:227-277), _grad_bioen_log_posterior_forces (:280-340) -- five passes over the matrix there.
+//
+// Layout.  The row-major matrix serves the log-weights kernels (whole rows / 128-column strips of rows
+// stream at 6.8 TB/s).  The forces evaluation needs whole COLUMNS (x_j = sum_i Y_ij f_i) and whole ROWS
+// (ybar_i = sum_j Y_ij e_j) of the same data in one pass, i.e. a block must hold all rows of a few
+// columns: 128-byte row segments 8 MB apart in the row-major matrix, which reach 4.9 TB/s at best (r01).
+// So the forces method gets its own copy, built on first use:
+//     Ys[strip s][row][c ^ swz(row)] = Y[row][16 s + c] - center[row]
+// * strip-major: the 16 columns x all rows a block works on are ONE contiguous chunk (64 KB at
+//   M = 512) -- every wave-load is a contiguous KiB, as in the streaming kernels;
+// * centred on center = YTilde (the targets, identical on every rank of a sharded context).  The
+//   softmax is invariant under x_j -> x_j + const, ybar_i = center_i + sum_j Y'_ij w_j, the adjoint picks
+//   up the constant B0 = sum_i center_i r_i, and the reference's centred gradient sum becomes
+//       sum_j (Y_ij - ybar_i) t_j  =  sum_j Y'_ij t_j  -  (ybar_i - center_i) sum_j t_j
+//   with BOTH terms at the scale of the data's spread instead of its offset: the plain matrix product
+//   the matrix cores compute loses nothing to cancellation, and no per-problem centring is needed
+//   inside the product;
+// * the XOR swizzle (columns permuted by bits 1..4 of the row) makes the LDS image of a strip -- a plain
+//   copy, 16 doubles per row, no padding -- conflict-free for both operand fetch patterns below.
+//
+// Kernel (K = batch width as a template parameter, both passes from one template):
+//   a wave owns 64 rows of the strip: it prefetches them two strips ahead (2 x 8 KiB in registers: 128 KB
+//   in flight per CU), copies them to its slice of the LDS tile and is the only reader of that slice (no
+//   block barrier around the tile);
+//   P1  column sums  D1[c][k] = sum_i Y'[i][c] u[i][k]:  16 x ceil(K/4) matrix instructions per wave; A = 4 rows
+//       x 16 columns from the tile, B = 4 rows x 4 problems of u = forces | residuals from an LDS table;
+//       the waves' partial D1 meet in LDS                                                        -> barrier
+//   P2  16 K threads (a problem's 16 columns in one 16-lane group): xy: x_j out, online softmax (running
+//       maximum per block), e_j;   bt: t_j = (theta (1 + log w_j/w0_j) + b_j) w_j                 -> barrier
+//   P3  row sums  D3[i][k] += sum_c Y'[i][c] v[c][k]:  16 x ceil(K/4) matrix instructions per wave into
+//       persistent accumulators; A = 16 rows x 4 columns from the tile (fetched BEFORE the barriers: it does
+//       not depend on P2), B = v (e | t) from LDS.
+//   The 4x4x4 four-block form computes exactly the K <= 4 (or 8) problems -- the 16x16x4 form pads them to 16
+//   at the same 32 FLOP/clk/SIMD, which is also the vector ALU's FP64 rate -- and delivers the cross-lane sums
+//   of P1 without a single shuffle; all operand fetches of a phase are issued before its first instruction.
+//   Measured (r02, N = 1e6 x M = 512, 4.1 GB per pass): 0.60 / 0.62 ms per pass at K = 1 (6.7 TB/s), 0.68 /
+//   0.78 ms at K = 8, against 0.81 / 0.85 ms and 2.28 / 1.61 ms for the r01 kernels on the row-major matrix.
+#include "device_utils.hpp"
+
+#ifndef STRIP_WAVES_PER_SIMD
+#define STRIP_WAVES_PER_SIMD 2
+#endif
+#ifndef STRIP_DEPTH
+#define STRIP_DEPTH 2      // strips in flight per wave (register sets)
+#endif
+#ifndef STRIP_DIAG
+#define STRIP_DIAG 0      // diagnostic builds: 1 = no MFMAs, 2 = no matrix loads
+#endif
+
+namespace bioen {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int kStripCols = 16;
+constexpr int kWaveRows = 64;
+
+// physical column of logical column c in row r:  c ^ strip_swz(r)
+__device__ __forceinline__ int strip_swz(int row) { return (((row >> 1) & 7) << 1) ^ ((row >> 4) & 1); }
+
+// ---- one-time construction of the strip-major copy -------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__ Y, size_t ld, int mp, int mps, int n,
+                                                      const double* __restrict__ center, double* __restrict__ Ys,
+                                                      int nstrips) {
+    for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
+        double* dst = Ys + (size_t)s * mps * kStripCols;
+        for (int p = threadIdx.x; p < mps * 8; p += 256) {
+            const int row = p >> 3, part = p & 7;
+            d2 v{0.0, 0.0};
+            if (row < mp) {
+                const size_t col = (size_t)s * kStripCols + part * 2;
+                v = *reinterpret_cast<const d2*>(Y + (size_t)row * ld + col);
+                const double cen = center[row];
+                v.x = col < (size_t)n ? v.x - cen : 0.0;
+                v.y = col + 1 < (size_t)n ? v.y - cen : 0.0;
+            }
+            const int sw = strip_swz(row);      // bit 0 swaps the two columns inside their aligned pair
+            if (sw & 1) v = d2{v.y, v.x};
+            *reinterpret_cast<d2*>(dst + (size_t)row * kStripCols + ((part * 2) ^ (sw & ~1))) = v;
+        }
+    }
+}
+
+struct StripArgs {
+    const double* Ys;       // strip-major centred copy
+    int mps;                // rows of a strip (multiple of 128)
+    int mp;                 // rows of the operands u_c / outputs
+    int nstrips;
+    int n;                  // valid columns
+    int K;
+    int nblk;
+    const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
+    const double* w0;
+    double* partial;        // [(row * K + k) * nblk + block]
+    long long* stamps;      // diagnostic builds (STRIP_DIAG & 4): per wave 8 phase-cycle sums
+};
+
+// dynamic LDS: tile[mps * 16] | ul[mps * 8] | red[waves][8][16] | v[8][16] | scale[8]
+//
+// v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction, 16 cycles; maps measured with
+// one-hot operands, tools/mfma_f64_4x4_probe.hip): lane l = 16 kk + 4 blk + r holds A_blk[i = r][kk],
+// B_blk[kk][j = r]; the result lane 16 i + 4 blk + j holds D_blk[i][j].  Unlike the 16x16x4 form nothing is
+// padded: K <= 4 problems take one instruction per operand fetch, K <= 8 two, at 32 FLOP/clk/SIMD either way.
+template <int K, bool NT, bool XY>
+__global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
+    constexpr int NK = (K + 3) / 4;                 // problem quads
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwaves = blockDim.x >> 6;
+    double* tile = lds;
+    double* ul = tile + (size_t)q.mps * kStripCols;  // u[row][8]: forces | residuals, zero beyond K and mp
+    double* red = ul + (size_t)q.mps * 8;           // [wave][problem 8][column 16]: the waves' partial column sums
+    double* tv = red + nwaves * 128;                // v[problem 8][column 16]: e | t of the strip
+    double* scale = tv + 128;
+    const int rbase = wave * kWaveRows;
+    const bool owner = rbase < q.mps;               // a block has at least two waves; the second may own no rows
+    const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
+
+    for (int i = t; i < q.mps * 8; i += blockDim.x) {
+        const int row = i >> 3, k = i & 7;
+        ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
+    }
+    for (int i = t; i < 128; i += blockDim.x) tv[i] = 0.0;         // problems k >= K of a quad stay zero
+    if (t < 8) scale[t] = 1.0;
+
+    // P3 accumulators: row block h (16 rows), problem quad kq: lane 16 i + 4 blk + j holds
+    // row rbase + 16 h + 4 blk + i, problem 4 kq + j
+    double acc[kWaveRows / 16][NK];
+#pragma unroll
+    for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) acc[h][kq] = 0.0;
+
+    // P2 state (threads t < 16 K: problem k = t / 16, column c = t % 16 -- a problem's 16 columns sit in one
+    // 16-lane group, so the strip's maximum needs no LDS and no barrier)
+    const bool p2 = t < kStripCols * K;
+    const int pk = p2 ? t >> 4 : 0, pc = t & 15;
+    double m_run = -DBL_MAX, zacc = 0.0, pxacc = 0.0;             // xy: running maximum, sum e, sum e x | bt: zacc = sum t
+    double logs = 0.0, theta = 0.0, b0 = 0.0;
+    if (!XY && p2) {
+        logs = fr.scal[pk][S_LOGS];
+        b0 = fr.scal[pk][S_B0];
+        theta = fr.theta[pk];
+    }
+
+    // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
+    d2 preA[kWaveRows / 8];
+#if STRIP_DEPTH == 2
+    d2 preB[kWaveRows / 8];
+#endif
+    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
+    auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
+#if !(STRIP_DIAG & 2)
+        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+#pragma unroll
+        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
+#endif
+    };
+    const int G = gridDim.x;
+#if STRIP_DIAG & 4
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define STAMP(i)
+#endif
+    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
+        if (owner) {
+            double* dst = tile + wave_off;
+#pragma unroll
+            for (int i = 0; i < kWaveRows / 8; ++i) *reinterpret_cast<d2*>(dst + i * 128) = pre[i];
+        }
+        // wave-private slice of the tile: the wave's own program order is the synchronisation
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(0)    // waited for the strip, copied it to LDS
+        // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
+        // prefetch would wait for the whole strip after next
+        const size_t col = (size_t)s * kStripCols + pc;
+        double w0v = 0.0, xv = 0.0;
+        if (p2) {
+            w0v = q.w0[col];
+            if (!XY) xv = fr.a[pk][col];
+        }
+        if (owner && s + STRIP_DEPTH * G < q.nstrips) fetch(s + STRIP_DEPTH * G, pre);
+        // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
+        // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
+        if (owner) {
+            double d[4][NK];                        // four chains over the row groups: the result latency is 3 issues
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) d[ch][kq] = 0.0;
+            // row rbase + 4 g + lq: its swizzle has period 8 in g (rbase is a multiple of 64): compile-time
+            // offsets on four per-lane bases address all of P1
+            const double* p1 = tile + (size_t)(rbase + lq) * kStripCols;
+            const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
+#if !(STRIP_DIAG & 1)
+            // all operand fetches first (one LDS round trip instead of sixteen), then the matrix instructions
+            double a1[kWaveRows / 4], b1[kWaveRows / 4][NK];
+#pragma unroll
+            for (int g = 0; g < kWaveRows / 4; ++g) {
+                a1[g] = p1[g * 64 + (lr ^ (((((lq >> 1) + 2 * g) & 7) << 1) ^ ((g >> 2) & 1)))];
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) b1[g][kq] = pu[g * 32 + 4 * kq];
+            }
+#pragma unroll
+            for (int g = 0; g < kWaveRows / 4; ++g)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq)
+                    d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[g][kq], d[g & 3][kq], 0, 0, 0);
+#else
+            d[0][0] = p1[lr] * pu[0];
+#endif
+            // result lane 16 i + 4 blk + j: column c = 4 blk + i, problem 4 kq + j
+            const int c = 4 * ((lane >> 2) & 3) + lq;
+            double* redw = red;
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq)
+                redw[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
+        }
+        // P3's matrix operands do not depend on P2: fetched here, they arrive behind the two barriers
+        // row rbase + 16 h + lr: only bit 0 of its swizzle depends on h
+        double a3[4][kWaveRows / 16];
+        if (owner) {
+            const double* p3 = tile + (size_t)(rbase + lr) * kStripCols;
+            const int sw3 = strip_swz(lr);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int h = 0; h < kWaveRows / 16; ++h) a3[qq][h] = p3[h * 256 + (((4 * qq + lq) ^ sw3) ^ (h & 1))];
+        }
+        STAMP(1)    // issued the prefetch, P1
+        __syncthreads();
+        STAMP(2)    // first barrier
+        // ---- P2 ----
+        if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
+            double colsum = 0.0;
+            if (p2) {
+                const int nown = q.mps / kWaveRows;
+                for (int wv = 0; wv < nown; ++wv) colsum += red[wv * 128 + pk * 16 + pc];
+            }
+            if (XY) {
+                const bool valid = p2 && col < (size_t)q.n;
+                if (p2) fr.a[pk][col] = valid ? colsum : 0.0;
+                double smax = valid ? colsum : -DBL_MAX;          // the strip's maximum: over the 16 lanes of the problem
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
+                const double m_new = fmax(m_run, smax);
+                // the running maximum rarely moves after the first strips: exp(0) = 1 exactly, skip it wave-wide
+                double sc = 1.0;
+                if (__any(m_new != m_run)) sc = exp(m_run - m_new);   // 0 the first time
+                const double e = valid ? w0v * exp(colsum - m_new) : 0.0;
+                zacc = fma(zacc, sc, e);
+                pxacc = fma(pxacc, sc, valid ? e * colsum : 0.0);
+                m_run = m_new;
+                if (p2) {
+                    if (pc == 0) scale[pk] = sc;
+                    tv[pk * 16 + pc] = e;
+                }
+            } else if (p2) {
+                const double lrat = xv - logs;                    // log(w / w0)
+                const double wv = w0v * exp(lrat);
+                double dd = 1.0;
+                if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += lrat;  // c_bioen_kernels_forces.c:320-328
+                const double tval = (dd * theta + (colsum + b0)) * wv;
+                tv[pk * 16 + pc] = tval;
+                zacc += tval;
+            }
+        }
+        STAMP(3)    // P2
+        __syncthreads();
+        STAMP(4)    // second barrier
+        // ---- P3: acc[row][k] (+)= sum_c Y'[row][c] v[c][k] ----
+        // A: lane (kk = lq, blk, i) = Y'[r0 + 4 blk + i = r0 + lr][c = 4 qq + lq]; B: lane (kk, blk, j) = v[4 qq + lq][4 kq + j]
+        if (owner) {
+            if (XY) {
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) {
+                    const double sc = scale[4 * kq + lj];
+#pragma unroll
+                    for (int h = 0; h < kWaveRows / 16; ++h) acc[h][kq] *= sc;
+                }
+            }
+#if !(STRIP_DIAG & 1)
+            double bv[4][NK];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tv[(4 * kq + lj) * 16 + 4 * qq + lq];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+                    for (int kq = 0; kq < NK; ++kq)
+                        acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3[qq][h], bv[qq][kq], acc[h][kq], 0, 0, 0);
+#else
+            acc[0][0] += a3[0][0] * tv[lj * 16];
+#endif
+        }
+        STAMP(5)    // P3
+        // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
+        // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
+    };
+    int s = blockIdx.x;
+    if (owner && s < q.nstrips) fetch(s, preA);
+#if STRIP_DEPTH == 2
+    if (owner && s + G < q.nstrips) fetch(s + G, preB);
+    __syncthreads();                                              // ul / tv / scale initialised
+    for (; s < q.nstrips; s += 2 * G) {
+        one_strip(s, preA, 0);
+        if (s + G < q.nstrips) one_strip(s + G, preB, 1);
+    }
+#else
+    __syncthreads();
+    for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
+#endif
+#if STRIP_DIAG & 4
+    if (q.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) q.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + i] = tacc[i];
+#endif
+    if (owner) {
+        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
+        const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
+#pragma unroll
+        for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const int row = rr + 16 * h, k = 4 * kq + lj;
+                if (row < q.mp && k < K) q.partial[((size_t)row * K + k) * q.nblk + blockIdx.x] = acc[h][kq];
+            }
+    }
+    // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
+    {
+        double z = zacc, px = pxacc;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            z += __shfl_xor(z, o, 64);
+            px += __shfl_xor(px, o, 64);
+        }
+        if (p2 && pc == 0) {
+            double* pa = fr.part[pk];
+            if (XY) {
+                pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;
+                pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
+                pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = px;
+            } else {
+                pa[(size_t)P_KL * kMaxPartials + blockIdx.x] = z;        // this block's share of sum_j t_j
+            }
+        }
+    }
+}
+
+// ---- geometry ------------------------------------------------------------------------------------
+static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->mp, kWaveRows); }
+static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_rows(c) / kWaveRows); }
+static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
+    return ((size_t)strip_rows(c) * (kStripCols + 8) + (size_t)(strip_threads(c) / 64) * 128 + 128 + 16) * sizeof(double);
+}
+
+int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
+    if (c->mp > 512) return 0;
+    const int nstrips = (int)(c->ld / kStripCols);
+    // blocks per CU: LDS (160 KiB) and the waves per SIMD the kernel's register budget admits
+    const int by_lds = (int)((size_t)160 * 1024 / strip_lds_bytes(c));
+    const int by_waves = 4 * STRIP_WAVES_PER_SIMD / (strip_threads(c) / 64);
+    const int per_cu = std::max(1, std::min(by_lds, by_waves));
+    return std::min(std::min(256 * per_cu, kFusedBlocks), nstrips);
+}
+
+int ensure_strip_copy(bioen_hip_ctx* c) {
+    if (c->Ys) return 0;
+    const int mps = strip_rows(c);
+    const int nstrips = (int)(c->ld / kStripCols);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->Ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
+    if (e != hipSuccess) {
+        c->Ys = nullptr;
+        return hip_fail(e, "hipMalloc (strip-major copy of yTilde for the forces method)", __FILE__, __LINE__);
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&c->strip_center), (size_t)c->mp * sizeof(double));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    e = hipMemcpyAsync(c->strip_center, c->YT, (size_t)c->mp * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+    hipLaunchKernelGGL(k_build_strips, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
+                       c->n, c->strip_center, c->Ys, nstrips);
+    return 0;
+}
+
+template <int K, bool NT, bool XY>
+static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+    static bool attr_done = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip<K, NT, XY>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_strip<K, NT, XY>), dim3(q.nblk), block, lds, c->stream, q, fr);
+}
+
+template <bool NT, bool XY>
+static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+    switch (fr.n) {
+        case 1: strip_launch_k<1, NT, XY>(c, q, fr, block, lds); break;
+        case 2: strip_launch_k<2, NT, XY>(c, q, fr, block, lds); break;
+        case 3: strip_launch_k<3, NT, XY>(c, q, fr, block, lds); break;
+        case 4: strip_launch_k<4, NT, XY>(c, q, fr, block, lds); break;
+        case 5: strip_launch_k<5, NT, XY>(c, q, fr, block, lds); break;
+        case 6: strip_launch_k<6, NT, XY>(c, q, fr, block, lds); break;
+        case 7: strip_launch_k<7, NT, XY>(c, q, fr, block, lds); break;
+        default: strip_launch_k<8, NT, XY>(c, q, fr, block, lds); break;
+    }
+}
+
+template <bool XY>
+static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, const double* u_c) {
+    StripArgs q{};
+    q.Ys = c->Ys;
+    q.mps = strip_rows(c);
+    q.mp = c->mp;
+    q.nstrips = (int)(c->ld / kStripCols);
+    q.n = c->n;
+    q.K = fr.n;
+    q.nblk = nblk;
+    q.u_c = u_c;
+    q.w0 = c->fixed;
+    q.partial = c->fwd_partial;
+    q.stamps = reinterpret_cast<long long*>(c->strip_stamps);
+    const dim3 block(strip_threads(c));
+    const size_t lds = strip_lds_bytes(c);
+    if (c->nontemporal) strip_launch_nt<true, XY>(c, q, fr, block, lds);
+    else strip_launch_nt<false, XY>(c, q, fr, block, lds);
+}
+
+// Merge the blocks of the xy pass on THIS rank (one block per problem): m_r = max_b m_b,
+// Z_r = sum_b e^{m_b - m_r} Z_b, likewise sum e x; P_MAX[b] <- e^{m_b - m_r}, the weight of block
+// b's raw sums.  The rank totals {Z_r, sum e x, m_r} go to the tail of the rank's X_YBAR segment --
+// the layout of the log-weights rounds -- so k_rows_combine<true> finishes both methods alike:
+//   scal[S_LOGS] = M + log Z  (w_j = w0_j exp(x_j - S_LOGS)),  scal[S_P] = sum_j w_j x_j,
+//   KL = sum_j w_j log(w_j / w0_j) = S_P - S_LOGS   (c_bioen_kernels_forces.c:246-258, with
+//   log w_j - log w0_j = x_j - S_LOGS; the prior constant S_LOGS0 is zero for this method).
+__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int nblk, int mp, int K, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    double* pa = fr.part[a];
+    double* pm = pa + (size_t)P_MAX * kMaxPartials;
+    const double mr = max_partials(pm, nblk, sh);
+    double z = 0.0, px = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) {
+        const double fb = exp(pm[b] - mr);
+        z = fma(fb, pa[(size_t)P_SUM * kMaxPartials + b], z);
+        px = fma(fb, pa[(size_t)P_PP * kMaxPartials + b], px);
+    }
+    z = block_sum(z, sh);
+    px = block_sum(px, sh);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblk; b += kBlock) pm[b] = exp(pm[b] - mr);
+    if (threadIdx.x == 0) {
+        double* tail = xo.base + (size_t)xo.rank * xo.payload + (size_t)mp * K + 3 * a;
+        tail[0] = z;
+        tail[1] = px;
+        tail[2] = mr;
+        fr.scal[a][S_LOGS0] = 0.0;
+    }
+}
+
+// this rank's share of ybar' : sum_b weight_b raw_i,b   (a wave per (row, problem), fixed order)
+__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted(const double* __restrict__ partial, int nblk, int mp,
+                                                                 int K, ForcesRound fr, Xch xo) {
+    const int a = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const double* __restrict__ wb = fr.part[a] + (size_t)P_MAX * kMaxPartials;
+    double* out = xo.base + (size_t)xo.rank * xo.payload;
+    for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
+        const double* p = partial + ((size_t)row * K + a) * nblk;
+        double s = 0.0;
+        for (int b = lane; b < nblk; b += 64) s = fma(wb[b], p[b], s);
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)row * K + a] = s;
+    }
+}
+
+// w_j = w0_j exp(x_j - S_LOGS): the weights themselves, when a result is handed out
+__global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, const double* __restrict__ w0, int n) {
+    const int a = blockIdx.y;
+    const double* __restrict__ x = fr.a[a];
+    double* __restrict__ w = fr.w[a];
+    const double logz = fr.scal[a][S_LOGS];
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] = w0[j] * exp(x[j] - logz);
+}
+
+void launch_forces_blockmerge(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, fr.n, true));
+    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk, c->mp, fr.n, xo);
+    hipLaunchKernelGGL(k_forces_rows_weighted, dim3(rows_grid(c), fr.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                       nblk, c->mp, fr.n, fr, xo);
+}
+
+// pass 1: x' = Y'^T f, online softmax, raw ybar' per block; then the block merge and ybar' -> X_YBAR
+void launch_forces_xy(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    {
+        TimedLaunch tl(c, 1, fr.n);
+        strip_launch<true>(c, fr, nblk, c->um);
+    }
+    launch_forces_blockmerge(c, fr, nblk);
+}
+
+// pass 2: b' = Y'^T r, t, Y' . t
+void launch_forces_bt(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+    TimedLaunch tl(c, 0, fr.n);
+    strip_launch<false>(c, fr, nblk, c->r_c);
+}
+
+void launch_forces_w_from_x(bioen_hip_ctx* c, const ForcesRound& fr) {
+    hipLaunchKernelGGL(k_forces_w_from_x, dim3(vec_grid(c), fr.n), dim3(kBlock), 0, c->stream, fr, c->fixed, c->n);
+}
+
+}  // namespace bioen

@@ -186,6 +186,10 @@ int bioen_hip_forces_weights(bioen_hip_ctx* ctx, const double* forces, const dou
 /* interface_lbfgs_forces, c_bioen_kernels_forces.c:43-76 (= F1 + :227-277 + :280-340) */
 int bioen_hip_forces_fdf(bioen_hip_ctx* ctx, const double* forces, const double* w0, double theta,
                          double* f, double* grad);
+/* The same evaluation for K <= 8 force vectors at once (forces[K][m], thetas[K]; f[K], grad[K][m] or NULL):
+ * the K problems share every pass over yTilde, each result equal to the last bit to the single call. */
+int bioen_hip_forces_fdf_batch(bioen_hip_ctx* ctx, int k, const double* forces, const double* w0,
+                               const double* thetas, double* f, double* grad);
 /* _opt_lbfgs_forces, c_bioen_kernels_forces.c:574-662.  result[m] = optimal forces. */
 int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* ctx, const double* forces0, const double* w0,
                                double theta, const bioen_lbfgs_config* config,
@@ -216,6 +220,10 @@ int bioen_hip_kernel_stats_ex(bioen_hip_ctx* ctx, int which, double* total_ms, l
                               long long* problem_passes);
 int bioen_hip_kernel_stats_reset(bioen_hip_ctx* ctx);
 int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
+
+/* Diagnostic builds only (-DSTRIP_DIAG=4, tools/strip_probe.py): per-phase cycle sums of the last forces strip
+ * launch, out[nblocks][16 waves][8 phases]; a normal build leaves the buffer untouched. */
+int bioen_hip_debug_strip_stamps(bioen_hip_ctx* ctx, int enable, long long* out, int nblocks);
 
 /* ---- host self-test of the L-BFGS driver (no GPU needed) ------------------------------
  * Runs the SAME driver + line-search code as the optimizers above on a built-in analytic
