@@ -34,6 +34,20 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 G
 SEED = 12345
 
 
+def kernel_source_sha():
+    """Identifies the kernel sources a measurement belongs to (the GPU box has no .git): sha256 over
+    bioen_amd/csrc/*.  profiles/traffic.json records it; a mismatch means the PMC pass is stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bioen_amd", "csrc", "*"))):
+        if os.path.isfile(f) and not f.endswith((".so", ".o")):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fp:
+                h.update(fp.read())
+    return h.hexdigest()[:16]
+
+
 def synthetic_targets(M, seed=SEED):
     """Per-observable vectors of the SURVEY 8(d) recipe (after forces.py:19-68)."""
     rng = np.random.default_rng(seed)
@@ -99,6 +113,111 @@ def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
     }
 
 
+def _ref_lbfgs_logw(R, yT, yTT, YT, G, theta, params):
+    """the reference's own _opt_lbfgs_logw on host arrays (transposed cache given) -> (gopt, fmin, code, seconds)"""
+    import ctypes as C
+    M, cols = yT.shape
+    g0 = G.copy()
+    w = np.empty(cols); tmp_n = np.empty(cols); tmp_m = np.empty(M); result = np.empty(cols)
+    p = R.params_t()
+    p.g, p.G, p.yTilde, p.YTilde, p.w, p.result = R._p(g0), R._p(G), R._p(yT), R._p(YT), R._p(w), R._p(result)
+    p.theta, p.yTildeT, p.caching = float(theta), R._p(yTT), 1
+    p.tmp_n, p.tmp_m, p.m, p.n = R._p(tmp_n), R._p(tmp_m), M, cols
+    err = C.c_int(0)
+    t0 = time.perf_counter()
+    fmin = R.lib()._opt_lbfgs_logw(p, R._lbfgs_cfg(params), R.visual_params(0, 0), C.byref(err))
+    return result, fmin, err.value, time.perf_counter() - t0
+
+
+def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
+    """BASELINE configs[1] (N = 1e5 x M = 256) end to end on BOTH sides, same inputs, same settings:
+    the whole theta series through the reference's C + liblbfgs path on all granted cores (serially over
+    theta, as procedure.py:62 does) next to the device's lock-step batch, with per-theta agreement of the
+    minima; plus the 1-thread figure BASELINE.md 3.3 asks for (theta = 10, capped)."""
+    from oracle import ref_binding as R
+    from oracle import cpus
+    if not R.available():
+        return None
+    N, M = 100000, 256
+    YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M, seed)
+    cores = cpus.usable_cpus()
+    out = {"workload": "log-weights theta series, N=%d x M=%d, %d thetas, cold starts, yaml-default liblbfgs" % (N, M, len(thetas)),
+           "cores": cores}
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=seed) as ctx:
+        from bioen_amd import sweep
+        G = np.zeros(N)
+        sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)                       # warm-up
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
+        ctx.synchronize()
+        out["gpu_sweep_s"] = time.perf_counter() - t0
+        out["gpu_iterations"] = int(sum(r["iterations"] for r in res))
+        yT = np.ascontiguousarray(ctx.read_ytilde())
+    yTT = np.ascontiguousarray(yT.T)
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cores)
+    R.logw_f(G, G, yT, YTilde, 10.0)                                                     # thread pool up
+    cpu_s, rel, codes = 0.0, [], []
+    for th, r in zip(thetas, res):
+        gopt, fmin, code, dt = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, th, LBFGS_DEFAULTS)
+        cpu_s += dt
+        codes.append(code)
+        rel.append(abs(r["fmin"] - fmin) / abs(fmin))
+    out.update({"cpu_sweep_s": cpu_s, "cpu_codes": codes, "speedup": cpu_s / out["gpu_sweep_s"],
+                "fmin_rel_diff_per_theta": rel, "fmin_rel_diff_max": max(rel)})
+    # 1 thread: theta = 10 capped at budget_iters_1t iterations (-997 = cap reached)
+    R.omp_set_num_threads(1)
+    capped = dict(LBFGS_DEFAULTS, max_iterations=budget_iters_1t)
+    _, _, code, dt = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, 10.0, capped)
+    if code == -997:
+        out["single_thread"] = {"value": budget_iters_1t * float(N) * M / dt, "unit": "iter*N*M/s", "cores": 1,
+                                "ms_per_iteration": 1e3 * dt / budget_iters_1t,
+                                "sample": "theta=10, %d iterations in %.2f s" % (budget_iters_1t, dt)}
+    R.omp_set_num_threads(cores)
+    return out
+
+
+def forces_record(bioen_amd, thetas, seed, max_batch):
+    """BASELINE configs[4] on one GPU: forces method, N = 1e6 x M = 512, the theta series as ONE lock-step
+    batch (cold starts, yaml-default liblbfgs).  Not part of `value`; reported beside it."""
+    N, M = 1000000, 512
+    YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M, seed)
+    w0 = np.full(N, 1.0 / N)
+    f0 = np.zeros(M)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=seed) as ctx:
+        ctx.opt_lbfgs_forces_batch(thetas[:2], f0, w0, dict(LBFGS_DEFAULTS, max_iterations=3), max_batch=max_batch)   # builds the strip copy
+        ctx.kernel_stats_enable(True)
+        ctx.kernel_stats_reset()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, LBFGS_DEFAULTS, max_batch=max_batch)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.kernel_stats()
+    its = int(sum(i.iterations for i in infos))
+    kern = {}
+    for name, which in (("xy", "adjoint"), ("bt", "forward")):       # timer slots of launch_forces_xy / _bt
+        s_ = st[which]
+        launches = max(s_["launches"], 1)
+        avg_ms = s_["total_ms"] / launches
+        avg_k = s_["problem_passes"] / launches
+        alg = float(M) * N * 8 + avg_k * (8.0 * N + 8.0 * M)         # the matrix once + per theta an N- and an M-vector
+        kern[name] = {"kernel": "k_strip<K, nt, %s>" % ("true" if name == "xy" else "false"), "launches": s_["launches"],
+                      "avg_ms": avg_ms, "avg_batch_width": avg_k, "algorithmic_bytes": alg,
+                      "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
+    dom = max(kern, key=lambda k: kern[k]["avg_ms"])
+    return {"workload": "forces theta series, N=%d x M=%d, %d thetas, cold starts, yaml-default liblbfgs, one lock-step batch"
+                        % (N, M, len(thetas)),
+            "value": its * float(N) * M / dt, "unit": "iter*N*M/s", "ms_per_step": 1e3 * dt, "iterations": its,
+            "evaluations": int(sum(i.evaluations for i in infos)),
+            "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                         "traffic": None, "kernels": kern},
+            "per_theta": [{"theta": float(t), "iterations": i.iterations, "evaluations": i.evaluations, "code": i.lbfgs_code,
+                           "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "seconds": i.seconds} for t, i in zip(thetas, infos)]}
+
+
 class stdout_to_stderr(object):
     """librccl prints a version banner on stdout when a communicator is created; keep this
     process' stdout for the ONE JSON line."""
@@ -127,6 +246,8 @@ def main():
                     help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal "
                          "thetas; auto = structures when the measured all-gather latency makes it the faster one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forces", action="store_true", help="skip the forces-method record (configs[4])")
+    ap.add_argument("--no-matched", action="store_true", help="skip the matched CPU/GPU sweep at configs[1] size")
     ap.add_argument("--cpu-cols", type=int, default=524288, help="columns of the matrix the CPU baseline runs on")
     ap.add_argument("--cpu-iters", type=int, default=120, help="L-BFGS iterations the CPU baseline is capped at")
     args = ap.parse_args()
@@ -265,7 +386,8 @@ def main():
                 with open(tpath) as fp:
                     tj = json.load(fp)
                 key = "%s_N%d_M%d" % (kern[dom]["kernel"], n_rank, M)
-                traffic = tj.get(key)
+                # only a PMC pass of THESE kernel sources counts; a stale file yields null
+                traffic = tj.get(key) if tj.get("_source_sha") == kernel_source_sha() else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
@@ -278,6 +400,27 @@ def main():
                 cpu = cpu_baseline(ctx, M, N, YTilde, 10.0, args.cpu_cols, args.cpu_iters)
             except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
                 cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
+
+        forces = None
+        if world == 1 and not args.no_forces:
+            ctx.close()              # 8 GB back before the second workload (closed again below: idempotent)
+            try:
+                forces = forces_record(bioen_amd, thetas, SEED, args.max_batch)
+                tj_f = None
+                if os.path.isfile(tpath):
+                    with open(tpath) as fp:
+                        tj_f = json.load(fp)
+                if tj_f and tj_f.get("_source_sha") == kernel_source_sha():
+                    forces["roofline"]["traffic"] = tj_f.get("k_strip_N1000000_M512")
+            except Exception as e:
+                forces = {"error": repr(e)}
+        if cpu is not None and world == 1 and not args.no_matched and not args.no_cpu_baseline:
+            try:
+                cpu["matched_sweep"] = cpu_matched(bioen_amd, thetas, SEED)
+                if cpu["matched_sweep"] and "single_thread" in cpu["matched_sweep"]:
+                    cpu["single_thread"] = cpu["matched_sweep"].pop("single_thread")
+            except Exception as e:
+                cpu["matched_sweep"] = {"error": repr(e)}
 
         line = {
             "metric": "L-BFGS iterations/sec x (N structures * M observables), log-weights theta sweep",
@@ -297,9 +440,14 @@ def main():
                        "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
                        "sharding": ("structures (columns) split over %d rank(s), all thetas batched on every rank" % world)
                        if nshard else ("theta round-robin over %d rank(s)" % world), "gather": gather,
-                       "max_batch": args.max_batch, "shard_decision": decision},
+                       "max_batch": args.max_batch, "shard_decision": decision,
+                       "rccl_ranks": world if rccl else (0 if world > 1 else None),
+                       "exchange_us": (decision or {}).get("exchange_us"),
+                       "decomposition": ("structures" if nshard else "thetas") if world > 1 else "single GPU",
+                       "sharding_fallback": bool(world > 1 and ((decision or {}).get("fallback") or not rccl))},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "forces": forces,
             "sweep_wall_s": dt / max(args.steps, 1),
             "iterations_per_sweep": iters_per_sweep,
             "evaluations_per_sweep": evals_per_sweep,

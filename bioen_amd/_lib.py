@@ -87,6 +87,7 @@ _SIGNATURES = {
     "bioen_hip_opt_lbfgs_forces_batch": (C.c_int, [ctx_p, C.c_int, dp, dp, C.c_size_t, dp, C.POINTER(LbfgsConfig),
                                                    C.POINTER(VisualParams), C.c_int, dp, dp, C.POINTER(OptResult)]),
     "bioen_hip_chi_squared": (C.c_int, [ctx_p, dp, dp, dp]),
+    "bioen_hip_last_average": (C.c_int, [ctx_p, dp, dp]),
     "bioen_hip_kernel_stats": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
@@ -530,7 +531,18 @@ class Context(object):
         return res, w, list(infos)
 
     # -- shared -------------------------------------------------------------------
+    def last_average(self):
+        """(yraw, yeff) of the most recent single-problem call on this context: yraw = yTilde . w of the
+        resident matrix at the point that call ended on, yeff = row_offset + row_scale * yraw.  Only
+        2 m doubles cross PCIe (no weights)."""
+        yraw, yeff = np.empty(self.m), np.empty(self.m)
+        check(lib().bioen_hip_last_average(self._h, ptr(yraw), ptr(yeff)))
+        return yraw, yeff
+
     def chi_squared(self, w):
+        """-> (0.5 |y_eff - YTilde|^2, yave).  With an affine row model set (set_affine) chi^2 is that of the
+        effective observables off + sc * (yTilde . w), while yave is the RAW product yTilde . w of the
+        resident matrix (what a nuisance refit needs); last_average() returns both."""
         w = self._nvec(w, "w")
         yave = np.empty(self.m)
         chi2 = C.c_double(0.0)

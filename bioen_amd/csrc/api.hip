@@ -115,8 +115,11 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     long long col0 = 0, n_local = n_global, per = 0;
     if (world > 1) {
         shard_columns(n_global, rank, world, &col0, &n_local, &per);
-        if (n_global < (long long)world * kColAlign || n_local <= 0)
-            return fail(BIOEN_HIP_EINVAL, "too few structures to shard: need n >= 128 * world");
+        // rank-independent test (every rank must fail together, else the others hang in the first collective):
+        // the LAST rank still has to own at least one column of its 128-aligned block
+        if ((long long)(world - 1) * per >= n_global)
+            return fail(BIOEN_HIP_EINVAL, "too few structures to shard: with 128-column blocks of ceil(n / world) the "
+                                          "last rank would be empty (need (world - 1) * round_up(ceil(n / world), 128) < n)");
     }
     if (n_local > 0x7fffffff) return fail(BIOEN_HIP_EINVAL, "n per GPU exceeds 2^31-1");
     const int n = (int)n_local;
@@ -938,6 +941,21 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
         BIOEN_HIP_CHECK(hipMemcpyAsync(yave, c->ybar_c, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if ((rc = read_scalars(c))) return rc;
     if (chi2) *chi2 = 0.5 * c->host_scal[S_CHI];
+    return 0;
+}
+
+int bioen_hip_last_average(bioen_hip_ctx* c, double* yraw, double* yeff) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> raw((size_t)c->m), off((size_t)c->m), sc((size_t)c->m);
+    BIOEN_HIP_CHECK(hipMemcpyAsync(raw.data(), c->ybar_c, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BIOEN_HIP_CHECK(hipMemcpyAsync(off.data(), c->row_offset, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BIOEN_HIP_CHECK(hipMemcpyAsync(sc.data(), c->row_scale, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->m; ++i) {
+        if (yraw) yraw[i] = raw[i];
+        if (yeff) yeff[i] = off[i] + sc[i] * raw[i];
+    }
     return 0;
 }
 

@@ -216,6 +216,8 @@ int bioen_hip_opt_gsl_logw(bioen_hip_ctx* c, const double* g0, const double* G, 
     if ((rc = B.finalize(multimin::V_X))) return rc;        // w, chi^2, S at the result
     if ((rc = download_n(c, result, B.data(multimin::V_X)))) return rc;
     if (w_opt && (rc = download_n(c, w_opt, c->slot[0].w))) return rc;
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));      // pageable destinations, work queued by finalize()
+    if ((rc = check_launch())) return rc;
     const double* h = c->host_scal;
     info->fmin = out.fmin;
     info->chi2 = 0.5 * h[S_CHI];
@@ -264,6 +266,8 @@ int bioen_hip_opt_gsl_forces(bioen_hip_ctx* c, const double* forces0, const doub
     }
     std::memcpy(result, B.data(multimin::V_X), (size_t)m * sizeof(double));
     if (w_opt && (rc = download_n(c, w_opt, c->slot[0].w))) return rc;
+    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));      // pageable destination
+    if ((rc = check_launch())) return rc;
     const double* h = c->host_scal;
     info->fmin = out.fmin;
     info->chi2 = 0.5 * h[S_CHI];

@@ -59,7 +59,7 @@ def series(ctx, thetas, G, g_init, lbfgs_params, YTilde, groups=None, row_offset
             g, w, info = ctx.opt_lbfgs_logw(g_init, G, float(theta), lbfgs_params, verbose=verbose)
             if info.lbfgs_code not in (0, 1, 2):
                 raise RuntimeError("nuisance.series, liblbfgs return code: %d" % info.lbfgs_code)
-            _, yraw = ctx.chi_squared(w)             # raw Y . w from the resident matrix
+            yraw, _ = ctx.last_average()             # raw Y . w at the optimum: already on the device, 8 m bytes back
             trace.append({"scales": list(scales), "fmin": info.fmin, "chi2": info.chi2,
                           "iterations": info.iterations})
             scales = refit_scales(yraw, YTilde, row_offset, groups)

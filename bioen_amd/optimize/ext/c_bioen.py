@@ -43,39 +43,50 @@ _CACHE = OrderedDict()
 _CACHE_MAX = int(os.environ.get("BIOEN_HIP_CACHE", "2"))
 
 
+_FULL_CHECK_BYTES = int(os.environ.get("BIOEN_HIP_CACHE_FULLCHECK_MB", "256")) << 20
+
+
 def _fingerprint(a):
-    """Cheap content check of a (possibly huge) matrix: shape + a strided sample."""
-    m, n = a.shape
-    ri = np.unique(np.linspace(0, m - 1, min(m, 61)).astype(np.int64))
-    ci = np.unique(np.linspace(0, n - 1, min(n, 67)).astype(np.int64))
-    sample = a[np.ix_(ri, ci)]
-    return (m, n, float(sample.sum()), float(np.abs(sample).sum()), float(a[0, 0]), float(a[-1, -1]))
+    """Content check of the host matrix.  Up to BIOEN_HIP_CACHE_FULLCHECK_MB (default 256 MB) EVERY element
+    enters (sum and sum of squares over the whole buffer: two BLAS-speed passes, far cheaper than the
+    upload they save); beyond that a strided sample of ~4 M elements spread over all rows and columns."""
+    flat = a.reshape(-1)
+    if flat.nbytes > _FULL_CHECK_BYTES:
+        stride = max(1, flat.size // (1 << 22)) | 1          # odd: walks through every column residue
+        flat = flat[::stride]
+    return (a.shape, float(flat.sum()), float(np.dot(flat, flat)), float(a[0, 0]), float(a[-1, -1]))
 
 
 def _context_for(yTilde, YTilde):
     """Return a device context holding yTilde, creating/uploading it if needed.
 
-    The key is the host buffer's address plus a content fingerprint; an in-place edit
-    that misses the sampled entries would go unnoticed, so callers that rewrite a
-    matrix in place should call ``clear_cache()`` (or set BIOEN_HIP_CACHE=0)."""
+    A cached context is reused only for the VERY SAME live host object (identity through a weak
+    reference -- a new array that happens to land on a freed address never matches) whose content check
+    still agrees (`_fingerprint`: complete up to 256 MB, so in-place edits such as finite-difference
+    perturbations are seen; sampled beyond).  Anything else is a miss and uploads afresh, which is what the
+    reference does on every call.  BIOEN_HIP_CACHE=0 switches the cache off."""
     yT = _lib.as_f64(yTilde)
     if yT.ndim != 2:
         raise ValueError("yTilde must be a 2-D (M x N) array")
     YT = _lib.as_f64(YTilde).ravel()
-    if _CACHE_MAX <= 0:
+    weakable = isinstance(yTilde, np.ndarray)              # np.matrix included; lists etc. are never cached
+    if _CACHE_MAX <= 0 or not weakable:
         return _lib.Context(yT, YT), False
-    key = (yT.ctypes.data,) + _fingerprint(yT)
+    key = id(yTilde)
+    fp = _fingerprint(yT)
     ctx = _CACHE.get(key)
     if ctx is not None:
-        _CACHE.move_to_end(key)
-        if not np.array_equal(ctx._YT_host, YT):
-            ctx.set_target(YT)
-            ctx._YT_host = YT.copy()
-        return ctx, True
+        if ctx._host_ref() is yTilde and ctx._fingerprint == fp:
+            _CACHE.move_to_end(key)
+            if not np.array_equal(ctx._YT_host, YT):
+                ctx.set_target(YT)
+                ctx._YT_host = YT.copy()
+            return ctx, True
+        _CACHE.pop(key).close()                            # same id, other object or other content: stale
     ctx = _lib.Context(yT, YT)
     ctx._YT_host = YT.copy()
-    # keep the host array alive while cached only if it is the caller's own object
-    ctx._host_ref = weakref.ref(yTilde) if isinstance(yTilde, np.ndarray) and yT is yTilde else None
+    ctx._fingerprint = fp
+    ctx._host_ref = weakref.ref(yTilde)
     _CACHE[key] = ctx
     while len(_CACHE) > _CACHE_MAX:
         _, old = _CACHE.popitem(last=False)

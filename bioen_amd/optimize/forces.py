@@ -193,7 +193,9 @@ def find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg):
     if cfg["verbose"]:
         print('time elapsed ', (end - start))
 
-    forces_opt = np.asarray(res[0]).T
+    # the reference's c_bioen / scipy drivers hand back a 1-D (m,) vector whose `.T` is itself (forces.py:532-535),
+    # and bioen/analyze/procedure.py:77 relies on it: np.matrix(out_min[2]).T must be the (m, 1) start of the next theta
+    forces_opt = np.asarray(res[0], dtype=np.float64).reshape(-1)
     fmin_final = res[1]
 
     if use_device:

@@ -13,9 +13,12 @@ Control plane (rendezvous, barrier, max-over-ranks): ``SocketComm`` (pure-Python
 TCP, no torch -- the GPU processes stay torch-free) or ``TorchComm`` (any
 ``torch.distributed`` process group, e.g. gloo in the tests).
 """
+import hmac
+import json
 import os
-import pickle
+import secrets
 import socket
+import stat
 import struct
 import time
 
@@ -95,14 +98,57 @@ class TorchComm(object):
         pass
 
 
+def _enc(obj):
+    """Small control objects only (None, bool, numbers, str, bytes, lists / tuples of those): JSON, no pickle."""
+    def conv(o):
+        if isinstance(o, (bytes, bytearray)):
+            return {"__bytes__": bytes(o).hex()}
+        if isinstance(o, (list, tuple)):
+            return [conv(x) for x in o]
+        if isinstance(o, (np.floating, np.integer, np.bool_)):
+            return o.item()
+        if o is None or isinstance(o, (bool, int, float, str)):
+            return o
+        raise TypeError("SocketComm.allgather_object: unsupported type %r" % type(o))
+    return json.dumps(conv(obj)).encode("utf-8")
+
+
+def _dec(payload):
+    def conv(o):
+        if isinstance(o, dict):
+            if set(o) != {"__bytes__"}:
+                raise ValueError("SocketComm: malformed control message")
+            return bytes.fromhex(o["__bytes__"])
+        if isinstance(o, list):
+            return [conv(x) for x in o]
+        return o
+    return conv(json.loads(payload.decode("utf-8")))
+
+
 class SocketComm(object):
     """Star-topology TCP communicator for the ranks of ONE node, driven by the
-    torchrun environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT).
+    torchrun environment (RANK, WORLD_SIZE, MASTER_PORT).
 
-    Rank 0 listens on an ephemeral port and publishes it in a rendezvous file under
-    /tmp keyed by MASTER_PORT (torchrun's own store owns MASTER_PORT itself)."""
+    Rank 0 listens on an ephemeral LOOPBACK port and publishes port + a random 32-byte token in a
+    rendezvous file inside a directory only this user can enter (mode 0700, ownership checked, file
+    created with O_EXCL | O_NOFOLLOW).  A peer is accepted only after presenting the token; messages
+    are length-prefixed raw float64 buffers or JSON for the small control objects -- nothing that
+    arrives from the network is ever unpickled."""
 
     MAGIC = b"BIOENAMD"
+    MAX_MSG = 1 << 34
+
+    @staticmethod
+    def _private_dir():
+        d = os.path.join("/tmp", "bioen_amd_%d" % os.getuid())
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(d)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError("SocketComm: %s is not a private directory of this user" % d)
+        return d
 
     def __init__(self, rank=None, world=None, timeout=300.0):
         self.rank = int(os.environ.get("RANK", 0) if rank is None else rank)
@@ -111,50 +157,63 @@ class SocketComm(object):
         self._sock = None
         if self.world == 1:
             return
-        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = os.environ.get("MASTER_PORT", "29500")
         run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-        path = os.path.join("/tmp", "bioen_amd_rdzv_%s_%s_%d" % (port, run_id, os.getuid()))
+        safe = "".join(ch if ch.isalnum() else "_" for ch in "%s_%s" % (port, run_id))
+        path = os.path.join(self._private_dir(), "rdzv_" + safe)
         deadline = time.time() + timeout
         if self.rank == 0:
+            token = secrets.token_bytes(32)
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", 0))
+            srv.bind(("127.0.0.1", 0))
             srv.listen(self.world)
-            tmp = path + ".tmp%d" % os.getpid()
-            with open(tmp, "w") as fp:
-                fp.write("%d %d\n" % (srv.getsockname()[1], os.getpid()))
-            os.replace(tmp, path)
+            try:
+                os.unlink(path)                   # a stale file of an earlier run of ours (the directory is private)
+            except FileNotFoundError:
+                pass
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, "w") as fp:
+                fp.write("%d %s\n" % (srv.getsockname()[1], token.hex()))
             self._path = path
             peers = {}
             srv.settimeout(timeout)
             while len(peers) < self.world - 1:
                 conn, _ = srv.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                hello = self._recv_exact(conn, len(self.MAGIC) + 4)
-                if hello[:len(self.MAGIC)] != self.MAGIC:
+                conn.settimeout(timeout)
+                try:
+                    hello = self._recv_exact(conn, len(self.MAGIC) + 4 + 32)
+                except (RuntimeError, OSError):
                     conn.close()
                     continue
-                r = struct.unpack("<i", hello[len(self.MAGIC):])[0]
+                r = struct.unpack("<i", hello[len(self.MAGIC):len(self.MAGIC) + 4])[0]
+                if (hello[:len(self.MAGIC)] != self.MAGIC or not hmac.compare_digest(hello[len(self.MAGIC) + 4:], token)
+                        or not 0 < r < self.world or r in peers):
+                    conn.close()
+                    continue
                 conn.sendall(self.MAGIC)
                 peers[r] = conn
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
-            host = addr if addr not in ("localhost",) else "127.0.0.1"
             while True:
                 try:
-                    with open(path) as fp:
-                        p = int(fp.read().split()[0])
-                    s = socket.create_connection((host, p), timeout=5.0)
+                    fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+                    with os.fdopen(fd) as fp:
+                        if os.fstat(fp.fileno()).st_uid != os.getuid():
+                            raise ValueError("foreign rendezvous file")
+                        fields = fp.read().split()
+                    p, token = int(fields[0]), bytes.fromhex(fields[1])
+                    s = socket.create_connection(("127.0.0.1", p), timeout=5.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    s.sendall(self.MAGIC + struct.pack("<i", self.rank))
+                    s.sendall(self.MAGIC + struct.pack("<i", self.rank) + token)
                     s.settimeout(timeout)
                     if self._recv_exact(s, len(self.MAGIC)) == self.MAGIC:
                         self._sock = s
                         break
                     s.close()
-                except (OSError, ValueError, IndexError):
+                except (OSError, ValueError, IndexError, RuntimeError):
                     pass
                 if time.time() > deadline:
                     raise RuntimeError("SocketComm: rendezvous with rank 0 timed out (%s)" % path)
@@ -175,19 +234,34 @@ class SocketComm(object):
 
     def _recv_msg(self, s):
         n = struct.unpack("<q", self._recv_exact(s, 8))[0]
+        if n < 0 or n > self.MAX_MSG:
+            raise RuntimeError("SocketComm: bad message length")
         return self._recv_exact(s, n)
 
     def _allgather_bytes(self, payload):
+        """-> [payload of rank 0, ..., payload of rank world-1]; framing: count, lengths, concatenated bytes"""
         if self.world == 1:
             return [payload]
         if self.rank == 0:
             parts = [payload] + [self._recv_msg(p) for p in self._peers]
-            blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+            blob = struct.pack("<q", len(parts)) + b"".join(struct.pack("<q", len(x)) for x in parts) + b"".join(parts)
             for p in self._peers:
                 self._send_msg(p, blob)
             return parts
         self._send_msg(self._sock, payload)
-        return pickle.loads(self._recv_msg(self._sock))
+        blob = self._recv_msg(self._sock)
+        cnt = struct.unpack_from("<q", blob, 0)[0]
+        if cnt != self.world:
+            raise RuntimeError("SocketComm: malformed gather message")
+        lens = struct.unpack_from("<%dq" % cnt, blob, 8)
+        off = 8 + 8 * cnt
+        if any(x < 0 for x in lens) or off + sum(lens) != len(blob):
+            raise RuntimeError("SocketComm: malformed gather message")
+        parts = []
+        for x in lens:
+            parts.append(blob[off:off + x])
+            off += x
+        return parts
 
     def allgather_array(self, a):
         a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(-1)
@@ -195,7 +269,7 @@ class SocketComm(object):
         return np.stack([np.frombuffer(p, dtype=np.float64) for p in parts])
 
     def allgather_object(self, obj):
-        return [pickle.loads(p) for p in self._allgather_bytes(pickle.dumps(obj))]
+        return [_dec(p) for p in self._allgather_bytes(_enc(obj))]
 
     def barrier(self):
         self._allgather_bytes(b"")

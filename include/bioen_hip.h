@@ -208,8 +208,16 @@ int bioen_hip_opt_lbfgs_forces_batch(bioen_hip_ctx* ctx, int ntheta, const doubl
 
 /* ---- shared pieces --------------------------------------------------------- */
 /* _bioen_chi_squared (c_bioen_common.c:70-108) / _getAve (c_bioen_kernels_forces.c:93-109):
- * yave[m] = yTilde . w ; *chi2 = 0.5 |yave - YTilde|^2.  Either output may be NULL. */
+ * yave[m] = yTilde . w ; *chi2 = 0.5 |yave - YTilde|^2.  Either output may be NULL.
+ * With an affine row model set (bioen_hip_ctx_set_affine) chi2 is that of the EFFECTIVE observables
+ * off_i + sc_i (yTilde . w)_i (sum w = 1 assumed, as everywhere in BioEn), while yave stays the RAW product
+ * of the resident matrix -- the quantity a nuisance refit needs; bioen_hip_last_average hands out both. */
 int bioen_hip_chi_squared(bioen_hip_ctx* ctx, const double* w, double* yave, double* chi2);
+/* Averages left on the device by the most recent SINGLE-problem call (bioen_hip_chi_squared, *_fdf,
+ * bioen_hip_opt_lbfgs_logw, bioen_hip_opt_gsl_logw): yraw[m] = yTilde . w of the resident matrix at the
+ * point that call ended on, yeff[m] = off + sc * yraw.  Either may be NULL.  2 m doubles cross PCIe -- a
+ * refit between two optimizations (analyze/procedure.py:82-83) never moves the N weights. */
+int bioen_hip_last_average(bioen_hip_ctx* ctx, double* yraw, double* yeff);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------- */
 /* Average device time (HIP events on the context's stream) and launch count of the

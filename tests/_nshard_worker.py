@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import bioen_amd                      # noqa: E402
 from bioen_amd import sweep            # noqa: E402
-from conftest import load_golden, LBFGS_DEFAULTS   # noqa: E402
+from conftest import load_golden, LBFGS_DEFAULTS, LBFGS_CONV   # noqa: E402
 
 
 def main():
@@ -28,6 +28,8 @@ def main():
     w, logs = ctx.logw_weights(g)
     f, grad = ctx.logw_fdf(g, d["G"], d["theta"])
     res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    # the converged run the reference's golden pins (tests/golden: lbfgs_conv_*)
+    gconv, wconv, iconv = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_CONV)
     chi2, yave = ctx.chi_squared(w)
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
@@ -41,6 +43,7 @@ def main():
     ff, fgrad = fctx.forces_fdf(f0, fd["w0"], 10.0)
     fthetas = [100.0, 10.0, 1000.0]
     fres, fw, finfos = fctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
+    fconv, fwconv, ficonv = fctx.opt_lbfgs_forces(fd["forces_init"], fd["w0"], fd["theta"], LBFGS_CONV)
     fctx.close()
     comm.barrier()
     np.savez(out_path % comm.rank, w=w, logs=logs, f=f, grad=grad, res=res, wopt=wopt,
@@ -50,7 +53,9 @@ def main():
              block=block, col0=col0, n_local=n_local, chi2w=chi2, yave=yave,
              ff=ff, fgrad=fgrad, fres=fres, fw=fw, ffmin=np.array([i.fmin for i in finfos]),
              fiters=np.array([i.iterations for i in finfos]), fcodes=np.array([i.lbfgs_code for i in finfos]),
-             fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]))
+             fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]),
+             wconv=wconv, fminconv=iconv.fmin, codeconv=iconv.lbfgs_code,
+             fwconv=fwconv, ffminconv=ficonv.fmin, fcodeconv=ficonv.lbfgs_code)
     comm.close()
 
 

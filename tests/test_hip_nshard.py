@@ -1,6 +1,7 @@
 """GPU test of structure (column) sharding: W processes each keep a column block of yTilde,
 complete every reduction over structures through one all-gather per stage, and must (a) agree
-with each other to the last bit and (b) reproduce the single-GPU run within rounding."""
+with each other to the last bit, (b) reproduce the ORACLE's evaluations and the REFERENCE's converged
+L-BFGS runs (tests/golden: lbfgs_conv_*) to north_star's tolerances, and (c) the single-GPU run within rounding."""
 import os
 import socket
 import subprocess
@@ -41,7 +42,7 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     # (a) every rank holds identical (gathered) results
     for r in range(1, world):
         for key in ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
-                    "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2"):
+                    "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv"):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
         assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
 
@@ -51,10 +52,21 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     assert np.array_equal(full, d["yTilde"])
     assert [int(z[r]["col0"]) for r in range(world)] == list(np.cumsum([0] + [int(z[r]["n_local"]) for r in range(world - 1)]))
 
-    # (b) against the single-GPU run: same mathematics, different reduction tree
+    # (b) against the checker: the oracle's evaluation at the same point, the reference's converged run
+    from oracle import oracle_binding as O
     thetas = [50.0, 5.0, 500.0, 1.0, 20.0]
     rng = np.random.default_rng(99)
     g = d["GInit"].ravel() + 0.2 * rng.standard_normal(d["GInit"].size)
+    f_o, grad_o, w_o = O.logw_fdf(g, d["G"], d["yTilde"], d["YTilde"], d["theta"])
+    assert abs(z[0]["f"] - f_o) <= 1e-12 * abs(f_o)
+    assert np.abs(z[0]["grad"] - grad_o).max() <= 1e-10 * np.abs(grad_o).max()
+    assert np.abs(z[0]["w"] - w_o).max() <= 1e-13 * w_o.max()
+    wref = d["lbfgs_conv_wopt"]
+    assert int(z[0]["codeconv"]) in (0, -998) and int(d["lbfgs_conv_code"]) in (0, -998)
+    assert abs(float(z[0]["fminconv"]) - float(d["lbfgs_conv_fmin"])) <= 1e-6 * abs(float(d["lbfgs_conv_fmin"]))
+    assert np.abs(z[0]["wconv"] - wref).max() <= 1e-5 * wref.max()
+
+    # (c) against the single-GPU run: same mathematics, different reduction tree
     with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
         w1, logs1 = ctx.logw_weights(g)
         f1, grad1 = ctx.logw_fdf(g, d["G"], d["theta"])
@@ -74,9 +86,16 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         assert abs(int(z[0]["iters"][i]) - info.iterations) <= max(5, info.iterations // 4)
         assert abs(z[0]["wopt"][i].sum() - 1.0) < 1e-12
 
-    # forces method: sharded strip passes against the single-GPU run
+    # forces method: sharded strip passes against the oracle, the reference's converged run, the single-GPU run
     fd = load_golden("synth_forces_M96xN3000.npz")
     f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
+    ff_o, fgrad_o, _ = O.forces_fdf(f0, fd["w0"], fd["yTilde"], fd["YTilde"], 10.0)
+    assert abs(z[0]["ff"] - ff_o) <= 1e-12 * abs(ff_o)
+    assert np.abs(z[0]["fgrad"] - fgrad_o).max() <= 1e-9 * np.abs(fgrad_o).max()
+    fwref = fd["lbfgs_conv_wopt"]
+    assert int(z[0]["fcodeconv"]) in (0, -998)
+    assert abs(float(z[0]["ffminconv"]) - float(fd["lbfgs_conv_fmin"])) <= 1e-6 * abs(float(fd["lbfgs_conv_fmin"]))
+    assert np.abs(z[0]["fwconv"] - fwref).max() <= 1e-5 * fwref.max()
     fthetas = [100.0, 10.0, 1000.0]
     with bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as ctx:
         ff1, fgrad1 = ctx.forces_fdf(f0, fd["w0"], 10.0)

@@ -209,3 +209,53 @@ def test_context_cache_fingerprint_is_content_sensitive():
     assert c_bioen._fingerprint(a) == c_bioen._fingerprint(b)
     b[1, 2] += 1.0
     assert c_bioen._fingerprint(a) != c_bioen._fingerprint(b)
+    # EVERY element takes part up to the full-check size: a one-element finite-difference perturbation anywhere
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal((257, 1031))
+    fp = c_bioen._fingerprint(big)
+    for (i, j) in ((0, 1), (128, 517), (256, 1029), (13, 14)):
+        old = big[i, j]
+        big[i, j] += 1e-6
+        assert c_bioen._fingerprint(big) != fp, (i, j)
+        big[i, j] = old
+    assert c_bioen._fingerprint(big) == fp
+
+
+def test_context_cache_needs_the_same_live_object_and_the_same_content(monkeypatch):
+    """a hit needs the very same host object (no address reuse) AND an unchanged content check."""
+    made = []
+
+    class FakeContext(object):
+        def __init__(self, yT, YT):
+            self.closed = False
+            made.append(self)
+
+        def set_target(self, YT):
+            self.target = YT.copy()
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(c_bioen._lib, "Context", FakeContext)
+    c_bioen.clear_cache()
+    y = np.arange(20.0).reshape(4, 5)
+    YT = np.ones(4)
+    c1, cached = c_bioen._context_for(y, YT)
+    c2, _ = c_bioen._context_for(y, YT)
+    assert cached and c1 is c2 and len(made) == 1
+    c3, _ = c_bioen._context_for(y, YT * 2)                   # new targets: same context, targets replaced
+    assert c3 is c1 and np.array_equal(c1.target, YT * 2)
+    y[2, 3] += 1e-7                                            # in-place edit of ONE element -> miss, old context freed
+    c4, _ = c_bioen._context_for(y, YT)
+    assert c4 is not c1 and c1.closed and len(made) == 2
+    twin = y.copy()                                            # equal content, other object -> its own context
+    c5, _ = c_bioen._context_for(twin, YT)
+    assert c5 is not c4 and len(made) == 3
+    m = np.matrix(y)                                           # np.matrix callers (bioen.analyze) are cached too
+    c6, cached6 = c_bioen._context_for(m, YT)
+    c7, _ = c_bioen._context_for(m, YT)
+    assert cached6 and c6 is c7
+    c8, cached8 = c_bioen._context_for(y.tolist(), YT)         # no weak reference possible: never cached
+    assert not cached8
+    c_bioen.clear_cache()
+    assert all(c.closed for c in made if c is not c8)

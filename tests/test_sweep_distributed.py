@@ -95,3 +95,53 @@ def test_two_rank_sweep_socketcomm(tmp_path):
     for p in procs:
         assert p.wait(timeout=100) == 0
     check(tmp_path, "sock")
+
+
+def test_socketcomm_control_messages_are_not_pickled():
+    """Control objects travel as JSON (bytes hex-wrapped); anything else is refused at the sender and a
+    forged payload at the receiver -- nothing from the network is unpickled."""
+    msg = (b"\x00\x01" * 64, None, True, 1.5, float("inf"), "text", [1, 2])
+    back = sweep._dec(sweep._enc(msg))
+    assert back == [b"\x00\x01" * 64, None, True, 1.5, float("inf"), "text", [1, 2]]
+    with pytest.raises(TypeError):
+        sweep._enc(object())
+    with pytest.raises(ValueError):
+        sweep._dec(b'{"__reduce__": "os.system"}')
+    import inspect
+    assert "pickle" not in inspect.getsource(sweep).replace("unpickled", "").replace("no pickle", "")
+
+
+@pytest.mark.timeout(60)
+def test_socketcomm_refuses_a_peer_without_the_token(tmp_path):
+    """Rank 0 keeps waiting for the real rank 1 when a stranger that knows the port and the magic
+    (but not the 32-byte token of the private rendezvous file) connects first."""
+    import struct
+    import threading
+    import time
+    port = free_port()
+    run_id = "tok%d" % os.getpid()
+    env0 = dict(os.environ, RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                TORCHELASTIC_RUN_ID=run_id)
+    code = ("import sys; sys.path.insert(0, %r); from bioen_amd import sweep; c = sweep.SocketComm(timeout=40);"
+            "print(c.allgather_object(c.rank)); c.close()" % ROOT)
+    p0 = subprocess.Popen([sys.executable, "-c", code], env=env0, stdout=subprocess.PIPE, text=True)
+    path = os.path.join("/tmp", "bioen_amd_%d" % os.getuid(), "rdzv_%d_%s" % (port, run_id))
+    for _ in range(200):
+        if os.path.exists(path):
+            break
+        time.sleep(0.05)
+    st = os.stat(path)
+    assert st.st_mode & 0o077 == 0 and os.stat(os.path.dirname(path)).st_mode & 0o077 == 0
+    listen_port = int(open(path).read().split()[0])
+    s = socket.create_connection(("127.0.0.1", listen_port), timeout=5)
+    s.sendall(sweep.SocketComm.MAGIC + struct.pack("<i", 1) + b"\x00" * 32)      # right magic, wrong token
+    s.settimeout(5)
+    try:
+        assert s.recv(8) == b""          # closed without the acknowledgement
+    except (ConnectionResetError, socket.timeout):
+        pass
+    s.close()
+    env1 = dict(env0, RANK="1")
+    p1 = subprocess.Popen([sys.executable, "-c", code], env=env1, stdout=subprocess.PIPE, text=True)
+    assert p1.wait(timeout=45) == 0 and p0.wait(timeout=45) == 0
+    assert p0.stdout.read().strip() == "[0, 1]" and p1.stdout.read().strip() == "[0, 1]"

@@ -4,7 +4,9 @@ profiles/ (kernel-trace --stats table; PMC FETCH_SIZE / WRITE_SIZE per kernel, c
 bytes per launch with the gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE is in KiB
 and counts a wide coalesced read stream at HALF its bytes -> x2; WRITE_SIZE is in KiB).
 
-usage: tools/summarize_profiles.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>] [--key N M]
+usage: tools/summarize_profiles.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>] [--key N M] [--fkey N M]
+       --key: size of the log-weights workload (k_fwd_partial / k_adj), --fkey: of the forces workload (k_strip);
+       traffic.json also records the sha of the kernel sources the passes were taken with (bench.kernel_source_sha).
 """
 import collections
 import csv
@@ -68,6 +70,15 @@ def main():
             sel = [v for k, v in traffic.items() if k.split("<")[0] == base]
             if sel:
                 tj["%s_N%d_M%d" % (base, N, M)] = sum(b * n for b, n in sel) / max(sum(n for _, n in sel), 1)
+        if "--fkey" in sys.argv:
+            j = sys.argv.index("--fkey")
+            FN, FM = int(sys.argv[j + 1]), int(sys.argv[j + 2])
+            sel = [v for k, v in traffic.items() if k.split("<")[0] == "k_strip"]
+            if sel:
+                tj["k_strip_N%d_M%d" % (FN, FM)] = sum(b * n for b, n in sel) / max(sum(n for _, n in sel), 1)
+        sys.path.insert(0, ROOT)
+        import bench
+        tj["_source_sha"] = bench.kernel_source_sha()
         tj["_note"] = ("HBM bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 from separate rocprofv3 --pmc "
                        "passes (gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream), see *_rocprof_summary.md")
         json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
