@@ -191,3 +191,40 @@ def test_deer_nuisance_series_at_config4_scale():
         assert abs(r["w"].sum() - 1.0) < 1e-12
     m_fit = res[-1]["scales"][0]
     assert abs(m_fit - m_true) < abs(m0 - m_true) and abs(m_fit - m_true) < 0.03
+
+
+# ---------------------------------------------------------------------------------------
+# "bitwise reproducible" means exactly this: the bench workload (BASELINE configs[2]; generator seed, sizes,
+# thetas and settings of bench.py) gives the same per-theta iteration / evaluation counts and the same fmin
+# to the last digit on every box and in every run of ONE build.  The constants belong to the kernel sources
+# at this commit (the sums' fixed reduction shapes are part of them): a change of a reduction order moves
+# them and must update them here, together with profiles/.
+# ---------------------------------------------------------------------------------------
+BENCH_PINNED = [   # theta, iterations, evaluations, fmin        (r02; equal to the r01 driver run BENCH_r01.json)
+    (1000.0, 8, 13, 502.2320552598044),
+    (316.2277660168379, 76, 129, 477.09444674720265),
+    (100.0, 43, 63, 411.94752740733867),
+    (31.622776601683793, 219, 251, 291.05741543216055),
+    (10.0, 334, 393, 181.45161723057947),
+    (3.1622776601683795, 338, 378, 133.30321991134883),
+    (1.0, 280, 316, 116.9405898452082),
+    (0.31622776601683794, 459, 509, 111.57536604329019),
+]
+
+
+def test_bench_workload_is_pinned():
+    import bioen_amd
+    from bioen_amd import sweep
+    M, N = 1024, 1000000
+    YTrue, sig_sim, sig_exp, YTilde = _targets(M)
+    thetas = np.logspace(3, -0.5, 8)
+    G = np.zeros(N)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=8)
+        again = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=3)     # another batch schedule, same bits
+    assert sum(r["iterations"] for r in res) == sum(p[1] for p in BENCH_PINNED) == 1757
+    for r, r2, (theta, it, ev, fmin) in zip(res, again, BENCH_PINNED):
+        assert rel(r["theta"], theta) < 1e-15 and r["code"] in (0, 1)
+        assert (r["iterations"], r["evaluations"]) == (it, ev), (theta, r["iterations"], r["evaluations"])
+        assert r["fmin"] == fmin, (theta, repr(r["fmin"]))
+        assert (r2["iterations"], r2["evaluations"], r2["fmin"]) == (it, ev, fmin)
