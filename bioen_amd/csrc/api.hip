@@ -146,6 +146,8 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     {
         const char* e = std::getenv("BIOEN_HIP_STRIP_OLD");
         c->strip_old = (e && e[0] == '1') ? 1 : 0;
+        e = std::getenv("BIOEN_HIP_FWD_STREAM");       // A/B: the streaming forward kernel on the row-major matrix
+        c->fwd_stream = (e && e[0] == '1') ? 1 : 0;
     }
 
     int rc = 0;
@@ -318,6 +320,18 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     launch_logw_exp(c, r);                 // A1: e = exp(x - m_r) + prior partials (shift: this rank's own maximum)
     Vec8 w{};
     for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
+    const int nblk = fwd_strip_blocks(c);
+    if (nblk > 0) {
+        // M <= 1024: matrix pass 1 streams the strip-major centred copy straight into the matrix cores
+        // (kernels_strip.hip: k_strip_fwd) -- the same time for every batch width; the centre returns in
+        // k_rows_combine, which leaves the RAW ybar in ybar_c for the centred adjoint below
+        if ((rc = ensure_strip_copy(c))) return rc;
+        launch_fwd_strip(c, r.n, w, nblk);
+        launch_fwd_rows_local(c, r.n, true, nblk);
+        if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, r.n, true)))) return rc;
+        launch_rows_combine(c, r, true, c->strip_center, true);
+        return with_grad ? enqueue_logw_adjoint(c, r) : 0;
+    }
     launch_fwd_partial(c, r.n, w);         // A4: this rank's share of yTilde . e_a            [matrix pass 1]
     launch_fwd_rows_local(c, r.n, true);   //     + this rank's {sum e, sum e (x - G), m_r}
     if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, r.n, true)))) return rc;
@@ -398,7 +412,7 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         if ((rc = ensure_strip_copy(c))) return rc;
         launch_forces_xy(c, fr, nblk);        // F1 + F2: x, online softmax, this rank's ybar   [matrix pass 1]
         if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
-        launch_rows_combine(c, r, true, c->strip_center);   //     normalisation, ybar, r, chi^2, KL, f
+        launch_rows_combine(c, r, true, c->strip_center, false);   //     normalisation, ybar (centred), r, chi^2, KL, f
         if (with_grad) {
             launch_forces_bt(c, fr, nblk);    // F3: b, t, product with t            [matrix pass 2]
             if (c->world == 1) {

@@ -153,6 +153,7 @@ struct bioen_hip_ctx {
     double* Ys = nullptr;            // [ld / 16][strip rows][16]
     double* strip_center = nullptr;  // mp: YTilde at the time of the copy
     double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
+    int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)
     int strip_old = 0;               // BIOEN_HIP_STRIP_OLD=1: the r01 strip kernels on the row-major matrix (A/B)
     double* YT = nullptr;      // mp   experimental targets (YTilde)
     // affine observable model: yTilde_eff[i][j] = row_offset[i] + row_scale[i] * Y[i][j]

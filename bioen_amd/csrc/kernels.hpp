@@ -44,12 +44,15 @@ int rows_grid(const bioen_hip_ctx* c);
 // forward: fwd_partial[(row*K + a)*ctiles + tile] = sum_{j in tile} (Y[row][j] - [centred] ybar_c[row*K+a]) v_a[j]
 void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred = false);
 // reduce the column tiles -> this rank's share of ybar in its X_YBAR segment   [exchange X_YBAR]
-void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw);   // logw: + {sum e, sum e (x-G), m_r} per problem
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles = 0);   // logw: + {sum e, sum e (x-G), m_r} per problem; ctiles: partials per (row, problem), default the streaming kernel's
 int ybar_payload(const bioen_hip_ctx* c, int K, bool logw);        // doubles per rank in the X_YBAR stage
 void launch_scale_w(bioen_hip_ctx* c, const Round& r);              // w = e * scal[S_INV] (when a result is handed out)
 // add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
+// center != NULL: the shares are sums over the CENTRED copy (kernels_strip.hip): ybar_raw = share + center;
+// ybar_c keeps ybar_raw (store_raw: what k_adj's centring and the callers expect) or the centred share (the
+// forces strip pass 2, whose gradient correction is written in terms of it)
 void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw,   // logw: also chi^2, c, f -> scal
-                         const double* row_offset = nullptr);            // != NULL: instead of the context's affine offset
+                         const double* center = nullptr, bool store_raw = true);
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 // tsum = true (strip passes on the centred copy): gm = sum of partials - ybar_c * T, T = sum of the blocks' P_KL shares
@@ -64,6 +67,8 @@ void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
 void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr);   // sharded: -> X_YBAR segment
 int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
+int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
+void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk);
 void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 int forces_fused_blocks_old(const bioen_hip_ctx* c);   // r01 strip kernels (A/B only)
 void launch_forces_xy_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);

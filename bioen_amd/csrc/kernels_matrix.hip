@@ -189,6 +189,7 @@ template <bool LOGW>
 __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, const double* __restrict__ YT,
                                                          const double* __restrict__ row_offset,
                                                          const double* __restrict__ row_scale,
+                                                         const double* __restrict__ center, bool store_raw,
                                                          double* __restrict__ ybar_c, double* __restrict__ r_c,
                                                          MVec8 part, Round rd) {
     __shared__ double sh[kWaves];
@@ -227,13 +228,15 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             else s += v;
         }
         const double sc = row_scale[row];
-        const double eff = fma(sc, s, row_offset[row]);
+        const double cen = center ? center[row] : 0.0;            // shares of the centred copy: ybar_raw = s + center
+        const double raw = s + cen;
+        const double eff = fma(sc, raw, row_offset[row]);
         const double res = eff - YT[row];
-        ybar_c[(size_t)row * K + a] = s;
+        ybar_c[(size_t)row * K + a] = store_raw ? raw : s;
         r_c[(size_t)row * K + a] = res * sc;
         chi = fma(res, res, chi);
         cc = fma(eff, res, cc);
-        b0 = fma(row_offset[row], res * sc, b0);
+        b0 = fma(cen, res * sc, b0);
     }
     chi = block_sum(chi, sh);
     cc = block_sum(cc, sh);
@@ -429,15 +432,16 @@ void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
 
 int ybar_payload(const bioen_hip_ctx* c, int K, bool logw) { return c->mp * K + (logw ? 3 * K : 0); }
 
-void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw) {
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles) {
     const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, K, logw));
     const Xch xe = make_xch(c, X_EXP, 3 * K * vec_grid(c));
+    const int ct = ctiles > 0 ? ctiles : c->fwd_ctiles;
     if (logw)
         hipLaunchKernelGGL(k_fwd_rows_local<true>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                           c->fwd_ctiles, c->mp, K, xo, xe);
+                           ct, c->mp, K, xo, xe);
     else
         hipLaunchKernelGGL(k_fwd_rows_local<false>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream,
-                           c->fwd_partial, c->fwd_ctiles, c->mp, K, xo, xe);
+                           c->fwd_partial, ct, c->mp, K, xo, xe);
 }
 
 // w = e * scal[S_INV]: the weights themselves are only needed when a result is handed out
@@ -459,18 +463,17 @@ void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
 
 int combine_grid(const bioen_hip_ctx*) { return 1; }
 
-void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw, const double* row_offset) {
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw, const double* center, bool store_raw) {
     MVec8 part;
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
-    const double* off = row_offset ? row_offset : c->row_offset;
     if (logw)
         hipLaunchKernelGGL(k_rows_combine<true>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
-                           make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, off, c->row_scale,
-                           c->ybar_c, c->r_c, part, r);
+                           make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           center, store_raw, c->ybar_c, c->r_c, part, r);
     else
         hipLaunchKernelGGL(k_rows_combine<false>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
-                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, off, c->row_scale,
-                           c->ybar_c, c->r_c, part, r);
+                           make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
+                           center, store_raw, c->ybar_c, c->r_c, part, r);
 }
 
 static MVec8 tsum_parts(const ForcesRound* fr) {

@@ -62,6 +62,19 @@ constexpr int kWaveRows = 64;
 __device__ __forceinline__ int strip_swz(int row) { return (((row >> 1) & 7) << 1) ^ ((row >> 4) & 1); }
 
 // ---- one-time construction of the strip-major copy -------------------------------------------------
+// Within a strip the 64-row slice of wave w is stored in the order the ROW-SUM product wants its matrix
+// operand, so a wave-load (1 KiB, 16 B per lane) lands in the operand registers with no further movement:
+//   chunk i = 2 h + qp (h = 16-row block 0..3, qp = column octet 0..1), lane l = 16 lq + lr:
+//     .x = Y'[64 w + 16 h + lr][8 qp + lq]        (operand of column quad qq = 2 qp)
+//     .y = Y'[64 w + 16 h + lr][8 qp + 4 + lq]    (                      qq = 2 qp + 1)
+// The column-sum product reads the same data through an LDS image (row-major, 16 doubles per row, columns
+// XOR-swizzled by strip_swz(row)), which the waves fill from those registers.
+__device__ __forceinline__ size_t strip_pos(int row, int col) {          // index inside a strip (doubles)
+    const int w = row >> 6, h = (row >> 4) & 3, lr = row & 15;
+    const int qp = col >> 3, hi = (col >> 2) & 1, lq = col & 3;
+    return ((size_t)((w * 4 + h) * 2 + qp) * 64 + (lq * 16 + lr)) * 2 + hi;
+}
+
 __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__ Y, size_t ld, int mp, int mps, int n,
                                                       const double* __restrict__ center, double* __restrict__ Ys,
                                                       int nstrips) {
@@ -77,9 +90,8 @@ __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__
                 v.x = col < (size_t)n ? v.x - cen : 0.0;
                 v.y = col + 1 < (size_t)n ? v.y - cen : 0.0;
             }
-            const int sw = strip_swz(row);      // bit 0 swaps the two columns inside their aligned pair
-            if (sw & 1) v = d2{v.y, v.x};
-            *reinterpret_cast<d2*>(dst + (size_t)row * kStripCols + ((part * 2) ^ (sw & ~1))) = v;
+            dst[strip_pos(row, part * 2)] = v.x;
+            dst[strip_pos(row, part * 2 + 1)] = v.y;
         }
     }
 }
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #if STRIP_DEPTH == 2
     d2 preB[kWaveRows / 8];
 #endif
-    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
+    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
     auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
 #if !(STRIP_DIAG & 2)
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
@@ -170,10 +182,21 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #define STAMP(i)
 #endif
     auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
+        // registers -> LDS image (row-major, swizzled) for the column sums; the same 16 rows x 2 columns per
+        // 32 lanes as the row-sum operand fetch used to read: conflict-free.  The registers themselves ARE the
+        // row-sum operands: kept in a3 until P3 (the prefetch below reuses `pre`).
+        double a3[4][kWaveRows / 16];
         if (owner) {
-            double* dst = tile + wave_off;
+            const int sw3 = strip_swz(lr);          // row rbase + 16 h + lr: only bit 0 of its swizzle depends on h
+            double* img = tile + (size_t)(rbase + lr) * kStripCols;
 #pragma unroll
-            for (int i = 0; i < kWaveRows / 8; ++i) *reinterpret_cast<d2*>(dst + i * 128) = pre[i];
+            for (int i = 0; i < kWaveRows / 8; ++i) {
+                const int h = i >> 1, qp = i & 1;
+                a3[2 * qp][h] = pre[i].x;
+                a3[2 * qp + 1][h] = pre[i].y;
+                img[h * 256 + (((8 * qp + lq) ^ sw3) ^ (h & 1))] = pre[i].x;
+                img[h * 256 + (((8 * qp + 4 + lq) ^ sw3) ^ (h & 1))] = pre[i].y;
+            }
         }
         // wave-private slice of the tile: the wave's own program order is the synchronisation
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -224,17 +247,6 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq)
                 redw[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
-        }
-        // P3's matrix operands do not depend on P2: fetched here, they arrive behind the two barriers
-        // row rbase + 16 h + lr: only bit 0 of its swizzle depends on h
-        double a3[4][kWaveRows / 16];
-        if (owner) {
-            const double* p3 = tile + (size_t)(rbase + lr) * kStripCols;
-            const int sw3 = strip_swz(lr);
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-                for (int h = 0; h < kWaveRows / 16; ++h) a3[qq][h] = p3[h * 256 + (((4 * qq + lq) ^ sw3) ^ (h & 1))];
         }
         STAMP(1)    // issued the prefetch, P1
         __syncthreads();
@@ -358,6 +370,98 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     }
 }
 
+// ---- log-weights forward pass on the strip copy: partial[(row K + k) nblk + block] = sum_{j in the block's strips} Y'[row][j] e_k[j]
+// (A4, c_bioen_common.c:70-108; replaces k_fwd_partial for M <= 1024).  The copy is stored in the operand
+// order of this product, so the matrix goes HBM -> registers -> matrix cores: no LDS image, no shuffles, and the
+// K vectors e_k enter once per BLOCK and strip (16 K doubles through LDS, loaded one strip ahead) instead of once
+// per wave and KiB as in the streaming kernel, whose K = 8 launch took 1.28 x its K = 1 time for that reason.
+// A block = all rows of a strip, one wave per 64 rows (up to 16 waves: 128 registers each); one barrier per
+// strip, for the 16 K values of e.
+template <int K, bool NT>
+__global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
+    constexpr int NK = (K + 3) / 4;
+    __shared__ double tv[2][8 * kStripCols];                      // [parity][problem][column]
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int rbase = wave * kWaveRows;
+    const bool owner = rbase < q.mps;
+    const int lq = lane >> 4, lj = lane & 3;
+    const int G = gridDim.x;
+
+    double acc[kWaveRows / 16][NK];
+#pragma unroll
+    for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) acc[h][kq] = 0.0;
+    for (int i = t; i < 2 * 8 * kStripCols; i += blockDim.x) (&tv[0][0])[i] = 0.0;   // problems k >= K of a quad stay zero
+
+    const bool p2 = t < kStripCols * K;                           // problem t / 16, column t % 16
+    const int pk = p2 ? t >> 4 : 0, pc = t & 15;
+    const double* vk = v.p[pk];
+    d2 preA[kWaveRows / 8];
+#if STRIP_DEPTH == 2
+    d2 preB[kWaveRows / 8];
+#endif
+    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
+    auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
+        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+#pragma unroll
+        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
+    };
+    int s = blockIdx.x;
+    double ecur = (p2 && s < q.nstrips) ? vk[(size_t)s * kStripCols + pc] : 0.0;
+    if (owner && s < q.nstrips) fetch(s, preA);
+#if STRIP_DEPTH == 2
+    if (owner && s + G < q.nstrips) fetch(s + G, preB);
+#endif
+    __syncthreads();
+    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
+        if (p2) tv[par][pk * 16 + pc] = ecur;                     // loaded during the previous strip
+        if (p2 && s + G < q.nstrips) ecur = vk[(size_t)(s + G) * kStripCols + pc];
+        __syncthreads();                                           // this strip's e is in place; the buffer of parity
+                                                                   // `par` is rewritten two strips on, behind another barrier
+        if (owner) {
+            double bv[4][NK];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tv[par][(4 * kq + lj) * 16 + 4 * qq + lq];
+            // consecutive instructions go to different accumulators (a result is ready three issue slots later)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int h = 0; h < kWaveRows / 16; ++h) {
+                    const d2 y = pre[2 * h + (qq >> 1)];
+                    const double a = (qq & 1) ? y.y : y.x;
+#pragma unroll
+                    for (int kq = 0; kq < NK; ++kq)
+                        acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
+                }
+            if (s + STRIP_DEPTH * G < q.nstrips) fetch(s + STRIP_DEPTH * G, pre);   // the operands are consumed at issue
+        }
+    };
+#if STRIP_DEPTH == 2
+    for (; s < q.nstrips; s += 2 * G) {
+        one_strip(s, preA, 0);
+        if (s + G < q.nstrips) one_strip(s + G, preB, 1);
+    }
+#else
+    for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
+#endif
+    if (owner) {
+        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
+        const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
+#pragma unroll
+        for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const int row = rr + 16 * h, k = 4 * kq + lj;
+                if (row < q.mp && k < K) q.partial[((size_t)row * K + k) * q.nblk + blockIdx.x] = acc[h][kq];
+            }
+    }
+}
+
 // ---- geometry ------------------------------------------------------------------------------------
 static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->mp, kWaveRows); }
 static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_rows(c) / kWaveRows); }
@@ -416,6 +520,51 @@ static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
         case 7: strip_launch_k<7, NT, XY>(c, q, fr, block, lds); break;
         default: strip_launch_k<8, NT, XY>(c, q, fr, block, lds); break;
     }
+}
+
+// forward pass of the log-weights method on the strip copy (all K <= 8; M <= 1024: up to 16 waves per block)
+int fwd_strip_blocks(const bioen_hip_ctx* c) {
+    if (c->mp > 1024 || c->fwd_stream) return 0;
+    const int nstrips = (int)(c->ld / kStripCols);
+    const int waves = std::max(2, strip_rows(c) / kWaveRows);
+    const int per_cu = std::max(1, 16 / waves);                   // 128 registers per wave: 16 waves per CU
+    return std::min(std::min(256 * per_cu, kFusedBlocks), nstrips);
+}
+
+template <int K, bool NT>
+static void fwd_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const Vec8& v, dim3 block) {
+    hipLaunchKernelGGL((k_strip_fwd<K, NT>), dim3(q.nblk), block, 0, c->stream, q, v);
+}
+
+template <bool NT>
+static void fwd_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const Vec8& v, dim3 block) {
+    switch (q.K) {
+        case 1: fwd_strip_launch_k<1, NT>(c, q, v, block); break;
+        case 2: fwd_strip_launch_k<2, NT>(c, q, v, block); break;
+        case 3: fwd_strip_launch_k<3, NT>(c, q, v, block); break;
+        case 4: fwd_strip_launch_k<4, NT>(c, q, v, block); break;
+        case 5: fwd_strip_launch_k<5, NT>(c, q, v, block); break;
+        case 6: fwd_strip_launch_k<6, NT>(c, q, v, block); break;
+        case 7: fwd_strip_launch_k<7, NT>(c, q, v, block); break;
+        default: fwd_strip_launch_k<8, NT>(c, q, v, block); break;
+    }
+}
+
+// partial[(row K + a) nblk + block] of Y' . v_a; the caller adds the centre back (k_rows_combine's `center`)
+void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk) {
+    TimedLaunch tl(c, 0, K);
+    StripArgs q{};
+    q.Ys = c->Ys;
+    q.mps = strip_rows(c);
+    q.mp = c->mp;
+    q.nstrips = (int)(c->ld / kStripCols);
+    q.n = c->n;
+    q.K = K;
+    q.nblk = nblk;
+    q.partial = c->fwd_partial;
+    const dim3 block(64 * std::max(2, strip_rows(c) / kWaveRows));
+    if (c->nontemporal) fwd_strip_launch_nt<true>(c, q, v, block);
+    else fwd_strip_launch_nt<false>(c, q, v, block);
 }
 
 template <bool XY>
