@@ -345,7 +345,15 @@ static int enqueue_logw_adjoint(bioen_hip_ctx* c, const Round& r) {
     int rc;
     MVec8 out{};
     for (int a = 0; a < r.n; ++a) out.p[a] = r.a[a];
-    launch_adj(c, r.n, c->r_c, out, true);       // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
+    const int nblk = fwd_strip_blocks(c);
+    if (nblk > 0) {                              // matrix pass 2 on the column-sum strip copy (kernels_strip.hip)
+        if ((rc = ensure_strip_copy_colsum(c))) return rc;
+        MVec8 sc{};
+        for (int a = 0; a < r.n; ++a) sc.p[a] = r.scal[a];
+        launch_adj_strip(c, r.n, c->r_c, out, sc, nblk);
+    } else {
+        launch_adj(c, r.n, c->r_c, out, true);   // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
+    }
     launch_logw_grad(c, r);                //     gradient epilogue + g.d, g.g, x.x
     if ((rc = exchange(c, X_GRAD, 3 * r.n * (size_t)vec_grid(c)))) return rc;
     launch_finish_eval(c, r);
@@ -661,7 +669,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    double* bufs[] = {c->Y, c->Ys, c->strip_center, c->strip_stamps, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed,
+    double* bufs[] = {c->Y, c->Ys, c->Ys1, c->strip_center, c->strip_stamps, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed,
                       c->t, c->g0, c->fwd_partial, c->part, c->scal};
     for (double* p : bufs)
         if (p) hipFree(p);

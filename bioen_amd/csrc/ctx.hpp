@@ -62,7 +62,8 @@ enum ScalarSlot : int {
     S_YSH,                         // [kHistory] y.s per history slot
     S_ALPHA = S_YSH + kHistory,    // [kHistory]
     S_INV = S_ALPHA + kHistory,    // w_j = e_j * S_INV on this rank (deferred softmax normalisation)
-    S_B0,                          // sum_i row_offset_i r_i  (forces strip passes: the adjoint's constant)
+    S_B0,                          // sum_i center_i r_i   (strip passes on the centred copy: the adjoint's constant)
+    S_UY,                          // sum_i ybar_raw_i r_i
     S_COUNT
 };
 static_assert(S_COUNT <= kScalStride, "scalar slots");
@@ -150,7 +151,8 @@ struct bioen_hip_ctx {
 
     double* Y = nullptr;       // mp x ld
     // forces method, M <= 1024 (kernels_strip.hip): strip-major copy centred on the targets, built on first use
-    double* Ys = nullptr;            // [ld / 16][strip rows][16]
+    double* Ys = nullptr;            // [ld / 16][strip rows][16], row-sum operand order (forces, log-weights forward)
+    double* Ys1 = nullptr;           // the same strips in column-sum operand order (log-weights adjoint)
     double* strip_center = nullptr;  // mp: YTilde at the time of the copy
     double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
     int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)

@@ -69,6 +69,8 @@ void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, cons
 int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
 int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
 void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk);
+int ensure_strip_copy_colsum(bioen_hip_ctx* c);        // builds ctx->Ys1 (column-sum operand order) on first use
+void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk);
 void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 int forces_fused_blocks_old(const bioen_hip_ctx* c);   // r01 strip kernels (A/B only)
 void launch_forces_xy_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             sc[S_INV] = exp(mown - gmax) * invS;
         }
     }
-    double chi = 0.0, cc = 0.0, b0 = 0.0;
+    double chi = 0.0, cc = 0.0, b0 = 0.0, uy = 0.0;
     for (int row = threadIdx.x; row < mp; row += kBlock) {
         double s = 0.0;
         for (int r = 0; r < xi.world; ++r) {
@@ -237,16 +237,19 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
         chi = fma(res, res, chi);
         cc = fma(eff, res, cc);
         b0 = fma(cen, res * sc, b0);
+        uy = fma(raw, res * sc, uy);
     }
     chi = block_sum(chi, sh);
     cc = block_sum(cc, sh);
     b0 = block_sum(b0, sh);
+    uy = block_sum(uy, sh);
     if (threadIdx.x == 0) {
         if (LOGW) {
             double* sc = rd.scal[a];            // S_P, S_LOGS: written above by this same thread
             sc[S_CHI] = chi;
             sc[S_C] = cc;
             sc[S_B0] = b0;
+            sc[S_UY] = uy;
             sc[S_KL] = sc[S_P] - sc[S_LOGS] + sc[S_LOGS0];     // theta's factor: KL(w || w0) in both methods
             sc[S_F] = rd.theta[a] * sc[S_KL] + 0.5 * chi;
         } else {

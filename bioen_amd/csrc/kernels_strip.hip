@@ -44,6 +44,12 @@
 #ifndef STRIP_WAVES_PER_SIMD
 #define STRIP_WAVES_PER_SIMD 2
 #endif
+#ifndef FWD_DEPTH
+#define FWD_DEPTH 1        // k_strip_fwd: register sets per wave (16 waves per CU keep 128 KB in flight with one)
+#endif
+#ifndef ADJ_DEPTH
+#define ADJ_DEPTH 1
+#endif
 #ifndef STRIP_DEPTH
 #define STRIP_DEPTH 2      // strips in flight per wave (register sets)
 #endif
@@ -75,6 +81,15 @@ __device__ __forceinline__ size_t strip_pos(int row, int col) {          // inde
     return ((size_t)((w * 4 + h) * 2 + qp) * 64 + (lq * 16 + lr)) * 2 + hi;
 }
 
+// The same strips in the operand order of the COLUMN-SUM product (the log-weights adjoint streams this one):
+//   chunk i (row groups 2 i, 2 i + 1 of the wave's 64 rows), lane l = 16 lq + lr:
+//     .x = Y'[64 w + 8 i + lq][lr]      .y = Y'[64 w + 8 i + 4 + lq][lr]
+__device__ __forceinline__ size_t strip_pos_colsum(int row, int col) {
+    const int w = row >> 6, g = (row >> 2) & 15, lq = row & 3;
+    return ((size_t)(w * 8 + (g >> 1)) * 64 + (lq * 16 + col)) * 2 + (g & 1);
+}
+
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__ Y, size_t ld, int mp, int mps, int n,
                                                       const double* __restrict__ center, double* __restrict__ Ys,
                                                       int nstrips) {
@@ -90,8 +105,8 @@ __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__
                 v.x = col < (size_t)n ? v.x - cen : 0.0;
                 v.y = col + 1 < (size_t)n ? v.y - cen : 0.0;
             }
-            dst[strip_pos(row, part * 2)] = v.x;
-            dst[strip_pos(row, part * 2 + 1)] = v.y;
+            dst[COLSUM ? strip_pos_colsum(row, part * 2) : strip_pos(row, part * 2)] = v.x;
+            dst[COLSUM ? strip_pos_colsum(row, part * 2 + 1) : strip_pos(row, part * 2 + 1)] = v.y;
         }
     }
 }
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             w0v = q.w0[col];
             if (!XY) xv = fr.a[pk][col];
         }
-        if (owner && s + STRIP_DEPTH * G < q.nstrips) fetch(s + STRIP_DEPTH * G, pre);
+        if (owner) fetch(s + STRIP_DEPTH * G < q.nstrips ? s + STRIP_DEPTH * G : s, pre);    // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
         if (owner) {
@@ -322,14 +337,16 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
     };
     int s = blockIdx.x;
-    if (owner && s < q.nstrips) fetch(s, preA);
+    if (owner) fetch(s, preA);                                     // grid <= strips: every block has a first strip
 #if STRIP_DEPTH == 2
-    if (owner && s + G < q.nstrips) fetch(s + G, preB);
+    if (owner) fetch(s + G < q.nstrips ? s + G : s, preB);
     __syncthreads();                                              // ul / tv / scale initialised
-    for (; s < q.nstrips; s += 2 * G) {
+    // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
+    for (; s + G < q.nstrips; s += 2 * G) {
         one_strip(s, preA, 0);
-        if (s + G < q.nstrips) one_strip(s + G, preB, 1);
+        one_strip(s + G, preB, 1);
     }
+    if (s < q.nstrips) one_strip(s, preA, 0);
 #else
     __syncthreads();
     for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     const int pk = p2 ? t >> 4 : 0, pc = t & 15;
     const double* vk = v.p[pk];
     d2 preA[kWaveRows / 8];
-#if STRIP_DEPTH == 2
+#if FWD_DEPTH == 2
     d2 preB[kWaveRows / 8];
 #endif
     const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
@@ -411,9 +428,9 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     };
     int s = blockIdx.x;
     double ecur = (p2 && s < q.nstrips) ? vk[(size_t)s * kStripCols + pc] : 0.0;
-    if (owner && s < q.nstrips) fetch(s, preA);
-#if STRIP_DEPTH == 2
-    if (owner && s + G < q.nstrips) fetch(s + G, preB);
+    if (owner) fetch(s, preA);                                     // grid <= strips: every block has a first strip
+#if FWD_DEPTH == 2
+    if (owner) fetch(s + G < q.nstrips ? s + G : s, preB);
 #endif
     __syncthreads();
     auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
@@ -438,14 +455,16 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
                     for (int kq = 0; kq < NK; ++kq)
                         acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
                 }
-            if (s + STRIP_DEPTH * G < q.nstrips) fetch(s + STRIP_DEPTH * G, pre);   // the operands are consumed at issue
+            fetch(s + FWD_DEPTH * G < q.nstrips ? s + FWD_DEPTH * G : s, pre);   // unconditional, see k_strip_adj; operands consumed at issue
         }
     };
-#if STRIP_DEPTH == 2
-    for (; s < q.nstrips; s += 2 * G) {
+#if FWD_DEPTH == 2
+    // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
+    for (; s + G < q.nstrips; s += 2 * G) {
         one_strip(s, preA, 0);
-        if (s + G < q.nstrips) one_strip(s + G, preB, 1);
+        one_strip(s + G, preB, 1);
     }
+    if (s < q.nstrips) one_strip(s, preA, 0);
 #else
     for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
 #endif
@@ -460,6 +479,98 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
                 if (row < q.mp && k < K) q.partial[((size_t)row * K + k) * q.nblk + blockIdx.x] = acc[h][kq];
             }
     }
+}
+
+// ---- log-weights adjoint pass on the strip copy (column-sum operand order):
+//   out_k[j] = sum_i u_ik (Y_ij - ybar_ik) = sum_i Y'_ij u_ik + shift_k,   shift_k = sum_i u_ik (center_i - ybar_ik)
+// (A6, c_bioen_kernels_logw.c:185-205; replaces k_adj for M <= 1024).  HBM -> registers -> matrix cores as in the
+// forward pass; u = r (compact [row K + k]) sits in an LDS table in B-operand reach, the waves' partial column
+// sums meet in LDS (two buffers by strip parity: one barrier per strip), 16 K threads add the shift and store.
+template <int K, bool NT>
+__global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec8 scal) {
+    constexpr int NK = (K + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwaves = blockDim.x >> 6;
+    double* ul = lds;                                             // u[row][8], zero beyond K and mp
+    double* red = ul + (size_t)q.mps * 8;                         // [parity][wave][problem 8][column 16]
+    const int rbase = wave * kWaveRows;
+    const bool owner = rbase < q.mps;
+    const int lq = lane >> 4, lj = lane & 3;
+    const int G = gridDim.x;
+    for (int i = t; i < q.mps * 8; i += blockDim.x) {
+        const int row = i >> 3, k = i & 7;
+        ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
+    }
+    const bool p2 = t < kStripCols * K;                           // problem t / 16, column t % 16
+    const int pk = p2 ? t >> 4 : 0, pc = t & 15;
+    double shift = 0.0;
+    double* outk = out.p[pk];
+    if (p2) shift = scal.p[pk][S_B0] - scal.p[pk][S_UY];
+    d2 preA[kWaveRows / 8];
+#if ADJ_DEPTH == 2
+    d2 preB[kWaveRows / 8];                                       // two strips in flight per wave
+#endif
+    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
+    auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
+        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+#pragma unroll
+        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
+    };
+    int s = blockIdx.x;
+    if (owner) fetch(s, preA);                                     // grid <= strips: every block has a first strip
+#if ADJ_DEPTH == 2
+    if (owner) fetch(s + G < q.nstrips ? s + G : s, preB);
+#endif
+    __syncthreads();                                              // ul in place
+    const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
+    const int nown = q.mps / kWaveRows;
+    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
+        double* redw = red + (size_t)par * nwaves * 128;
+        if (owner) {
+            double d[4][NK];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) d[ch][kq] = 0.0;
+            double b1[kWaveRows / 4][NK];
+#pragma unroll
+            for (int g = 0; g < kWaveRows / 4; ++g)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) b1[g][kq] = pu[g * 32 + 4 * kq];
+#pragma unroll
+            for (int g = 0; g < kWaveRows / 4; ++g) {
+                const double a = (g & 1) ? pre[g >> 1].y : pre[g >> 1].x;
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq)
+                    d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1[g][kq], d[g & 3][kq], 0, 0, 0);
+            }
+            // unconditional (the tail re-reads its own strip): a conditional prefetch makes the compiler's vmcnt
+            // bookkeeping assume the other register set's loads may not exist, and every wait then drains BOTH sets
+            fetch(s + ADJ_DEPTH * G < q.nstrips ? s + ADJ_DEPTH * G : s, pre);    // the operands are consumed at issue
+            const int c = 4 * ((lane >> 2) & 3) + lq;             // result lane 16 i + 4 blk + j: column 4 blk + i, problem 4 kq + j
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq)
+                redw[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
+        }
+        __syncthreads();            // the buffer of this parity is rewritten two strips on, behind the next barrier
+        if (p2) {
+            double colsum = 0.0;
+            for (int wv = 0; wv < nown; ++wv) colsum += redw[wv * 128 + pk * 16 + pc];
+            outk[(size_t)s * kStripCols + pc] = colsum + shift;
+        }
+    };
+#if ADJ_DEPTH == 2
+    for (; s + G < q.nstrips; s += 2 * G) {
+        one_strip(s, preA, 0);
+        one_strip(s + G, preB, 1);
+    }
+    if (s < q.nstrips) one_strip(s, preA, 0);
+#else
+    for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
+#endif
 }
 
 // ---- geometry ------------------------------------------------------------------------------------
@@ -492,7 +603,7 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
     e = hipMemcpyAsync(c->strip_center, c->YT, (size_t)c->mp * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
-    hipLaunchKernelGGL(k_build_strips, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
+    hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
                        c->n, c->strip_center, c->Ys, nstrips);
     return 0;
 }
@@ -565,6 +676,72 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk) {
     const dim3 block(64 * std::max(2, strip_rows(c) / kWaveRows));
     if (c->nontemporal) fwd_strip_launch_nt<true>(c, q, v, block);
     else fwd_strip_launch_nt<false>(c, q, v, block);
+}
+
+// adjoint pass of the log-weights method on the column-sum copy (built on first use)
+int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
+    if (c->Ys1) return 0;
+    int rc = ensure_strip_copy(c);                               // the centre is shared
+    if (rc) return rc;
+    const int mps = strip_rows(c);
+    const int nstrips = (int)(c->ld / kStripCols);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->Ys1), (size_t)nstrips * mps * kStripCols * sizeof(double));
+    if (e != hipSuccess) {
+        c->Ys1 = nullptr;
+        return hip_fail(e, "hipMalloc (column-sum strip copy of yTilde for the log-weights adjoint)", __FILE__, __LINE__);
+    }
+    hipLaunchKernelGGL(k_build_strips<true>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
+                       c->n, c->strip_center, c->Ys1, nstrips);
+    return 0;
+}
+
+static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c) {
+    const int waves = std::max(2, strip_rows(c) / kWaveRows);
+    return ((size_t)strip_rows(c) * 8 + (size_t)2 * waves * 128) * sizeof(double);
+}
+
+template <int K, bool NT>
+static void adj_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const MVec8& out, const MVec8& scal, dim3 block, size_t lds) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_adj<K, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_strip_adj<K, NT>), dim3(q.nblk), block, lds, c->stream, q, out, scal);
+}
+
+template <bool NT>
+static void adj_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const MVec8& out, const MVec8& scal, dim3 block, size_t lds) {
+    switch (q.K) {
+        case 1: adj_strip_launch_k<1, NT>(c, q, out, scal, block, lds); break;
+        case 2: adj_strip_launch_k<2, NT>(c, q, out, scal, block, lds); break;
+        case 3: adj_strip_launch_k<3, NT>(c, q, out, scal, block, lds); break;
+        case 4: adj_strip_launch_k<4, NT>(c, q, out, scal, block, lds); break;
+        case 5: adj_strip_launch_k<5, NT>(c, q, out, scal, block, lds); break;
+        case 6: adj_strip_launch_k<6, NT>(c, q, out, scal, block, lds); break;
+        case 7: adj_strip_launch_k<7, NT>(c, q, out, scal, block, lds); break;
+        default: adj_strip_launch_k<8, NT>(c, q, out, scal, block, lds); break;
+    }
+}
+
+// out_a[j] = sum_i u_c[i K + a] (Y_ij - ybar_c[i K + a]) with the RAW ybar in ybar_c; needs S_B0 / S_UY of this
+// round in the problems' scalars (k_rows_combine with the strip centre)
+void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk) {
+    TimedLaunch tl(c, 1, K);
+    StripArgs q{};
+    q.Ys = c->Ys1;
+    q.mps = strip_rows(c);
+    q.mp = c->mp;
+    q.nstrips = (int)(c->ld / kStripCols);
+    q.n = c->n;
+    q.K = K;
+    q.nblk = nblk;
+    q.u_c = u_c;
+    const dim3 block(64 * std::max(2, strip_rows(c) / kWaveRows));
+    const size_t lds = adj_strip_lds_bytes(c);
+    if (c->nontemporal) adj_strip_launch_nt<true>(c, q, out, scal, block, lds);
+    else adj_strip_launch_nt<false>(c, q, out, scal, block, lds);
 }
 
 template <bool XY>

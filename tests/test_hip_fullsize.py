@@ -200,15 +200,15 @@ def test_deer_nuisance_series_at_config4_scale():
 # at this commit (the sums' fixed reduction shapes are part of them): a change of a reduction order moves
 # them and must update them here, together with profiles/.
 # ---------------------------------------------------------------------------------------
-BENCH_PINNED = [   # theta, iterations, evaluations, fmin   (r02, forward pass on the strip copy; r01 / streaming forward: 1757 iterations)
-    (1000.0, 8, 13, 502.2320552598045),
-    (316.2277660168379, 76, 129, 477.0944238775443),
-    (100.0, 43, 63, 411.9475274073352),
-    (31.622776601683793, 214, 247, 291.0565424960753),
-    (10.0, 282, 323, 181.47278313758633),
-    (3.1622776601683795, 382, 430, 133.2749498945835),
-    (1.0, 281, 320, 116.93605332123852),
-    (0.31622776601683794, 493, 542, 111.56430754135982),
+BENCH_PINNED = [   # theta, iterations, evaluations, fmin   (r02: both matrix passes on the strip copies; r01 / streaming kernels: 1757 iterations)
+    (1000.0, 8, 13, 502.23205525980427),
+    (316.2277660168379, 74, 129, 477.0944501069913),
+    (100.0, 43, 63, 411.9475274073552),
+    (31.622776601683793, 225, 256, 291.0548556771664),
+    (10.0, 312, 351, 181.4596956620428),
+    (3.1622776601683795, 277, 314, 133.33532828848814),
+    (1.0, 277, 314, 116.93818368079735),
+    (0.31622776601683794, 389, 435, 111.6260668722825),
 ]
 
 
@@ -222,7 +222,7 @@ def test_bench_workload_is_pinned():
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
         res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=8)
         again = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=3)     # another batch schedule, same bits
-    assert sum(r["iterations"] for r in res) == sum(p[1] for p in BENCH_PINNED) == 1779
+    assert sum(r["iterations"] for r in res) == sum(p[1] for p in BENCH_PINNED) == 1605
     for r, r2, (theta, it, ev, fmin) in zip(res, again, BENCH_PINNED):
         assert rel(r["theta"], theta) < 1e-15 and r["code"] in (0, 1)
         assert (r["iterations"], r["evaluations"]) == (it, ev), (theta, r["iterations"], r["evaluations"])

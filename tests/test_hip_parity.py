@@ -318,7 +318,9 @@ def test_ragged_shapes_vs_oracle(hip, M, N):
         back = ctx.read_ytilde()
     assert np.array_equal(back, yTilde)
     assert rel(f, f_o) < F_RTOL and maxrel(w, w_o) < 1e-13
-    assert np.abs(grad - grad_o).max() <= G_RTOL * max(np.abs(grad_o).max(), 1e-12)
+    # absolute floor: the strip kernels form sum_i r_i (Y_ij - c_i) + sum_i r_i (c_i - ybar_i) -- two sums that cancel
+    # to rounding where the reference's single centred sum is exactly zero (a single structure: N = 1)
+    assert np.abs(grad - grad_o).max() <= G_RTOL * max(np.abs(grad_o).max(), 1e-12) + 1e-14 * np.abs(yTilde).max() * (abs(f_o) + 1)
     assert rel(ff, ff_o) < F_RTOL and maxrel(fw, fw_o) < 1e-12
     # the forces gradient is a difference of O(|yTilde| |t|) terms: absolute scale, not its own size
     assert np.abs(fg - fg_o).max() <= 1e-9 * max(np.abs(fg_o).max(), 1e-12) + 1e-13 * np.abs(yTilde).max() * (abs(ff_o) + 1)
