@@ -374,7 +374,9 @@ def main():
             avg_ms = s["total_ms"] / launches
             avg_k = s["problem_passes"] / launches
             alg = mat_bytes + avg_k * (8.0 * n_rank + 8.0 * M)
-            kern[name] = {"kernel": "k_fwd_partial" if name == "forward" else "k_adj",
+            strip = M <= 1024 and not os.environ.get("BIOEN_HIP_FWD_STREAM") == "1"     # kernels_strip.hip serves M <= 1024
+            kern[name] = {"kernel": ("k_strip_fwd" if strip else "k_fwd_partial") if name == "forward"
+                                    else ("k_strip_adj" if strip else "k_adj"),
                           "launches": s["launches"], "avg_ms": avg_ms, "avg_batch_width": avg_k,
                           "algorithmic_bytes": alg,
                           "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}

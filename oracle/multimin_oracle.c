@@ -12,12 +12,13 @@
  *   multimin/vector_bfgs2.c, linear_minimize.c, linear_wrapper.c                (Fletcher line search)
  *   poly/solve_quadratic.c, cblas/source_nrm2_r.h, cblas/source_dot_r.h
  *
- * Parity status: GSL itself is UNBUILDABLE in this image (its sources need the generated
- * config.h and the gsl/ header tree its own build system creates), so this restatement is pinned
- * by GSL's own multimin test programme only (multimin/test.c:56-76,106-160: Roth, Wood,
- * Rosenbrock x2, SimpleAbs under all five minimizers with the pass criterion of test_fdf),
- * and by the loose (1e-1) known answers of the reference's optimiser tests -- "parity unpinned"
- * as far as bit-level agreement with a GSL build is concerned.
+ * Parity status: PINNED bit for bit (r02).  GSL cannot be compiled from its sources where they lie (its
+ * build needs the generated config.h and the gsl/ header tree), so it is not part of oracle/_ref; but
+ * tests/golden/gsl_*.npz hold 72 runs of the REAL GSL 2.5 through the reference's bioen.optimize (built once
+ * in the build container under /tmp, tests/golden/make_golden_gsl.py), and driven by the reference's own
+ * objective functions (oracle_opt_gsl_refobj below) this restatement reproduces every one of them -- status,
+ * iteration count, fmin, x -- to the last bit (tests/test_gsl_golden.py).  Also kept: GSL's own multimin test
+ * programme (multimin/test.c:56-76,106-160: Roth, Wood, Rosenbrock x2, SimpleAbs under all five minimizers).
  */
 #include <float.h>
 #include <math.h>
