@@ -218,6 +218,41 @@ def forces_record(bioen_amd, thetas, seed, max_batch):
                            "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "seconds": i.seconds} for t, i in zip(thetas, infos)]}
 
 
+def deer_record(bioen_amd, seed):
+    """BASELINE configs[3] on one GPU: DEER refinement with a modulation-depth nuisance parameter, N = 5e5 rotamers
+    x M = 205 time points (y~(m) = 1/sigma + m (F - 1)/sigma).  The m-independent matrix (F - 1)/sigma is
+    resident; per theta the reference alternates `iterations` = 10 times between a BioEn optimisation and a 1-D
+    least-squares refit of m that REBUILDS y~ on the host (procedure.py:62-83, observables.py:110-171); here a refit is
+    2 m doubles back from the device and a closed form, the new m enters through the affine row model."""
+    from bioen_amd import nuisance
+    N, M = 500000, 205
+    rng = np.random.default_rng(seed)
+    d = np.where(rng.random(N) < 0.6, rng.normal(3.2, 0.35, N), rng.normal(4.8, 0.5, N)).clip(2.0, 6.0)   # nm
+    t = np.linspace(0.0, 3.0, M)                                                                           # us
+    F = 0.5 * (1.0 + np.cos(2 * np.pi * 52.04 * t[:, None] / d[None, :] ** 3)) * np.exp(-0.15 * t[:, None])
+    sigma, m_true, m0 = 0.01, 0.23, 0.15
+    w_true = rng.dirichlet(np.ones(N) * 0.5)
+    YT = (1.0 - m_true + m_true * F.dot(w_true) + sigma * rng.standard_normal(M)) / sigma
+    F -= 1.0
+    F /= sigma
+    off = np.full(M, 1.0 / sigma)
+    G = np.zeros(N)
+    thetas, iterations = [100.0, 10.0, 1.0], 10
+    with bioen_amd.Context(F, YT) as ctx:
+        nuisance.series(ctx, thetas[:1], G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=1)      # warm-up, builds the strip copies
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        res = nuisance.series(ctx, thetas, G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=iterations)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+    its = int(sum(sum(x["iterations"] for x in r["trace"]) for r in res))
+    return {"workload": "DEER rotamer refinement, N=%d x M=%d, thetas %s, %d optimise/refit iterations each (cold starts), "
+                        "yaml-default liblbfgs, modulation depth refitted on the resident matrix" % (N, M, thetas, iterations),
+            "seconds": dt, "iterations": its, "value": its * float(N) * M / dt, "unit": "iter*N*M/s",
+            "refits": len(thetas) * iterations, "moddepth_true": m_true, "moddepth_start": m0,
+            "moddepth_fit": [r["scales"][0] for r in res], "fmin": [r["fmin"] for r in res]}
+
+
 class stdout_to_stderr(object):
     """librccl prints a version banner on stdout when a communicator is created; keep this
     process' stdout for the ONE JSON line."""
@@ -248,6 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forces", action="store_true", help="skip the forces-method record (configs[4])")
     ap.add_argument("--no-matched", action="store_true", help="skip the matched CPU/GPU sweep at configs[1] size")
+    ap.add_argument("--no-deer", action="store_true", help="skip the DEER nuisance-refit record (configs[3])")
     ap.add_argument("--cpu-cols", type=int, default=524288, help="columns of the matrix the CPU baseline runs on")
     ap.add_argument("--cpu-iters", type=int, default=120, help="L-BFGS iterations the CPU baseline is capped at")
     args = ap.parse_args()
@@ -416,6 +452,12 @@ def main():
                     forces["roofline"]["traffic"] = tj_f.get("k_strip_N1000000_M512")
             except Exception as e:
                 forces = {"error": repr(e)}
+        deer = None
+        if world == 1 and not args.no_deer and not args.no_forces:
+            try:
+                deer = deer_record(bioen_amd, SEED)
+            except Exception as e:
+                deer = {"error": repr(e)}
         if cpu is not None and world == 1 and not args.no_matched and not args.no_cpu_baseline:
             try:
                 cpu["matched_sweep"] = cpu_matched(bioen_amd, thetas, SEED)
@@ -450,6 +492,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "forces": forces,
+            "deer": deer,
             "sweep_wall_s": dt / max(args.steps, 1),
             "iterations_per_sweep": iters_per_sweep,
             "evaluations_per_sweep": evals_per_sweep,
