@@ -92,6 +92,7 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats_ex": (C.c_int, [ctx_p, C.c_int, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_kernel_stats_reset": (C.c_int, [ctx_p]),
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_speculation_stats": (C.c_int, [ctx_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_debug_strip_stamps": (C.c_int, [ctx_p, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
     "bioen_hip_ctx_create_raw": (C.c_int, [C.c_int, C.c_longlong, C.c_int, dp, dp, dp, C.c_int, C.POINTER(ctx_p)]),
     "bioen_hip_gsl_strerror": (C.c_char_p, [C.c_int]),
@@ -565,6 +566,12 @@ class Context(object):
             check(lib().bioen_hip_kernel_stats_ex(self._h, which, C.byref(ms), C.byref(cnt), C.byref(pp)))
             out[name] = {"total_ms": ms.value, "launches": cnt.value, "problem_passes": pp.value}
         return out
+
+    def speculation_stats(self):
+        """(issued, adopted): speculative line-search evaluations of the log-weights batch engine so far"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        check(lib().bioen_hip_speculation_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # -- RCCL ------------------------------------------------------------------------
     @staticmethod

@@ -872,6 +872,13 @@ int bioen_hip_forces_fdf(bioen_hip_ctx* c, const double* forces, const double* w
     return 0;
 }
 
+int bioen_hip_speculation_stats(bioen_hip_ctx* c, long long* issued, long long* adopted) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    if (issued) *issued = c->spec_launched;
+    if (adopted) *adopted = c->spec_used;
+    return 0;
+}
+
 // diagnostic builds (-DSTRIP_DIAG=4): phase-cycle sums of the last forces strip launch, [blocks][16][8]
 int bioen_hip_debug_strip_stamps(bioen_hip_ctx* c, int enable, long long* out, int nblocks) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");

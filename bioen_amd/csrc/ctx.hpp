@@ -184,6 +184,7 @@ struct bioen_hip_ctx {
     double* host_scal = nullptr;     // pinned mirror
     double* host_m = nullptr;        // pinned, 2 x mp*kMaxBatch: forces up / gradients down (lazy)
 
+    long long spec_launched = 0, spec_used = 0;   // speculative line-search evaluations issued / adopted (engine_logw.inl)
     bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)
     bioen::KernelTimer timer;
 

@@ -20,9 +20,14 @@ struct LogwBatchEngine {
     const bioen_lbfgs_config& cfg;
     bool verbose;
     int rc = 0;
+    bool speculate = true;
+    long long spec_launched = 0, spec_used = 0;      // shadow evaluations issued / adopted
 
     LogwBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
-        : c(ctx), cfg(config), verbose(verb) {}
+        : c(ctx), cfg(config), verbose(verb) {
+        const char* e = std::getenv("BIOEN_HIP_SPECULATE");
+        speculate = !(e && e[0] == '0');
+    }
 
     void note(int e) { if (e && !rc) rc = e; }
     void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
@@ -187,15 +192,20 @@ struct LogwBatchEngine {
             if (rc) return rc;
             note(upload_n(c, c->g0, g0_host));
         }
+        // Idle batch slots evaluate the steps a backtracking line search may ask for next (see the round loop):
+        // they need the N-vectors of an evaluation (x, g, w, a), no history
+        const int nslots = speculate && cfg.linesearch >= 1 && cfg.linesearch <= 3 ? kMaxBatch : kb;
+        for (int s = kb; s < nslots; ++s) note(alloc_slot(c, s, false));
+        if (rc) return rc;
         {   // log sum exp(G) once, written into every slot of the batch
             int all[kMaxBatch];
-            for (int s = 0; s < kb; ++s) all[s] = s;
-            const Round r = make_round(c, all, kb, nullptr, nullptr);
+            for (int s = 0; s < nslots; ++s) all[s] = s;
+            const Round r = make_round(c, all, nslots, nullptr, nullptr);
             if (c->world == 1) {
                 launch_logw_logs0(c, r);
             } else {   // G is sharded on the device but whole on the host: same value on every rank
                 const double v = host_logsumexp(G_host, c->n_global);
-                for (int s = 0; s < kb; ++s)
+                for (int s = 0; s < nslots; ++s)
                     note(hipMemcpyAsync(c->slot[s].scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream),
                          "logs0");
                 note(hipStreamSynchronize(c->stream), "sync");
@@ -273,6 +283,9 @@ struct LogwBatchEngine {
 
         for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
 
+        // The evaluation-owned entries of a slot's scalars (the rest -- y.s, alpha, gp.d -- belongs to the problem)
+        static const int kEvalScal[][2] = {{S_F, 4}, {S_LOGS, 4}, {S_KL, 2}, {S_INV, 3}};
+
         while (active > 0 && !rc) {
             // ---- one round: every active problem evaluates its next point -------------------------
             int list[kMaxBatch];
@@ -285,7 +298,42 @@ struct LogwBatchEngine {
                 th[k] = slots[s].theta;
                 ++k;
             }
-            const Round r = make_round(c, list, k, stp, th);
+            // Speculation: a backtracking search that rejects its trial asks for stp/2 or 2.1 stp next -- known
+            // now.  Slots no problem occupies evaluate those points in the SAME matrix passes (their cost does
+            // not depend on the batch width); if the search then asks for one of them, its evaluation is already
+            // there.  Same point, same kernels, same order of operations as the round that is saved: results
+            // do not change by a bit (tests: BIOEN_HIP_SPECULATE=0 against the default).
+            int shadow_owner[kMaxBatch], shadow_slot[kMaxBatch];
+            double shadow_stp[kMaxBatch];
+            int nshadow = 0;
+            if (speculate && (nslots > kb || active < kb)) {
+                int free_slots[kMaxBatch], nfree = 0;
+                for (int s = 0; s < nslots; ++s)
+                    if (s >= kb || !occupied[s]) free_slots[nfree++] = s;
+                for (int pass = 0; pass < 2 && nfree > 0; ++pass)            // first everybody's stp/2, then 2.1 stp
+                    for (int a = 0; a < k && nfree > 0; ++a) {
+                        BatchProblem& p = slots[list[a]];
+                        double cand[2];
+                        if (p.initial || pass >= p.machine->speculative_steps(cand)) continue;
+                        note(alloc_slot(c, free_slots[nfree - 1], false));
+                        shadow_owner[nshadow] = a;
+                        shadow_slot[nshadow] = free_slots[--nfree];
+                        shadow_stp[nshadow] = cand[pass];
+                        ++nshadow;
+                    }
+            }
+            Round r = make_round(c, list, k, stp, th);
+            for (int q = 0; q < nshadow; ++q) {
+                const int a = k + q;
+                const ProblemSlot& own = c->slot[list[shadow_owner[q]]];
+                const ProblemSlot& sh = c->slot[shadow_slot[q]];
+                r.x[a] = sh.x; r.g[a] = sh.g; r.w[a] = sh.w; r.a[a] = sh.a; r.scal[a] = sh.scal; r.part[a] = sh.part;
+                r.xp[a] = own.xp; r.gp[a] = own.gp; r.d[a] = own.d;
+                r.stp[a] = shadow_stp[q];
+                r.theta[a] = th[shadow_owner[q]];
+            }
+            r.n = k + nshadow;
+            spec_launched += nshadow;
             launch_trial(c, r);
             note(enqueue_logw_eval(c, r, true));
             note(read_scalars(c, kMaxBatch));
@@ -313,6 +361,28 @@ struct LogwBatchEngine {
                 } else {
                     TrialResult t{h[S_F], h[S_DG], h[S_GG], h[S_XX], h[S_DGINIT]};
                     act = p.machine->on_trial(t);
+                    if (act.kind == LbfgsMachine::TRIAL) {
+                        // rejected: is the step it asks for next among this round's shadows?
+                        for (int q = 0; q < nshadow; ++q) {
+                            if (shadow_owner[q] != a || shadow_stp[q] != p.machine->trial_step()) continue;
+                            ProblemSlot& sh = c->slot[shadow_slot[q]];
+                            std::swap(sl.x, sh.x);           // the shadow's point, gradient, e and adjoint become the trial's
+                            std::swap(sl.g, sh.g);
+                            std::swap(sl.w, sh.w);
+                            std::swap(sl.a, sh.a);
+                            double* hs = c->host_scal + (size_t)shadow_slot[q] * kScalStride;
+                            double* ho = c->host_scal + (size_t)s * kScalStride;
+                            for (const auto& rg : kEvalScal) {
+                                note(hipMemcpyAsync(sl.scal + rg[0], sh.scal + rg[0], rg[1] * sizeof(double),
+                                                    hipMemcpyDeviceToDevice, c->stream), "adopt scalars");
+                                std::memcpy(ho + rg[0], hs + rg[0], rg[1] * sizeof(double));
+                            }
+                            ++spec_used;
+                            TrialResult t2{ho[S_F], ho[S_DG], ho[S_GG], ho[S_XX], ho[S_DGINIT]};
+                            act = p.machine->on_trial(t2);
+                            break;
+                        }
+                    }
                     if (act.kind == LbfgsMachine::ACCEPT) {
                         p.need_direction = true;
                         p.accept = true;
@@ -330,6 +400,11 @@ struct LogwBatchEngine {
         }
         note(hipStreamSynchronize(c->stream), "sync");
         note(check_launch());
+        c->spec_launched += spec_launched;
+        c->spec_used += spec_used;
+        if (verbose && spec_launched)
+            std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n",
+                        spec_launched, spec_used);
         return rc;
     }
 };

@@ -138,6 +138,21 @@ class LbfgsMachine {
     Action on_initial(double f, double gg, double xx);
     // Step length of the next point to evaluate: x = xp + step * d
     double trial_step() const { return stp_; }
+    // Steps the backtracking searches (linesearch 1..3) can ask for NEXT, should the pending trial be
+    // rejected: stp * 0.5 (sufficient-decrease or strong-Wolfe failure) and, for the Wolfe variants,
+    // stp * 2.1 (curvature failure) -- formed exactly as report_backtracking forms them (lbfgs.c:686-727).
+    // Lets an owner with idle batch slots evaluate them alongside the trial; More-Thuente steps depend on
+    // the trial's values and cannot be foreseen (returns 0).
+    int speculative_steps(double out[2]) const {
+        if (cfg_.linesearch < 1 || cfg_.linesearch > 3) return 0;
+        double dec = stp_, inc = stp_;
+        dec *= 0.5;
+        inc *= 2.1;
+        out[0] = dec;
+        if (cfg_.linesearch == 1) return 1;
+        out[1] = inc;
+        return 2;
+    }
     // Result of that evaluation.
     Action on_trial(const TrialResult& t);
 

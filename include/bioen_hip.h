@@ -229,6 +229,12 @@ int bioen_hip_kernel_stats_ex(bioen_hip_ctx* ctx, int which, double* total_ms, l
 int bioen_hip_kernel_stats_reset(bioen_hip_ctx* ctx);
 int bioen_hip_kernel_stats_enable(bioen_hip_ctx* ctx, int enable);
 
+/* Line-search evaluations the log-weights batch engine issued speculatively in idle batch slots (the steps a
+ * backtracking search asks for after a rejected trial, evaluated in the same matrix passes as the trial) and how
+ * many of them it adopted, summed over the context's life.  BIOEN_HIP_SPECULATE=0 switches the mechanism off;
+ * results are the same to the last bit either way. */
+int bioen_hip_speculation_stats(bioen_hip_ctx* ctx, long long* issued, long long* adopted);
+
 /* Diagnostic builds only (-DSTRIP_DIAG=4, tools/strip_probe.py): per-phase cycle sums of the last forces strip
  * launch, out[nblocks][16 waves][8 phases]; a normal build leaves the buffer untouched. */
 int bioen_hip_debug_strip_stamps(bioen_hip_ctx* ctx, int enable, long long* out, int nblocks);

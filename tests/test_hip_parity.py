@@ -503,3 +503,53 @@ def test_forces_lbfgs_beyond_the_strip_limit_vs_oracle(hip):
             assert info.lbfgs_code in (0, 1, -998) and code_o in (0, 1, -998)
             assert rel(info.fmin, fmin_o) < 2e-5
             assert abs(ws.sum() - 1.0) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------
+# speculative line-search trials in idle batch slots: same bits, fewer rounds
+# ---------------------------------------------------------------------------------------
+_SPEC_SNIPPET = r'''
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import bioen_amd
+from conftest import load_golden, LBFGS_DEFAULTS
+d = load_golden(%(name)r)
+thetas = [200.0, 0.3, 50.0, 7.0, 1.0, 20.0, 2.0, 0.7, 100.0, 3.0, 0.5]
+out = {}
+with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+    for ls in (2, 3, 1, 0):
+        params = dict(LBFGS_DEFAULTS, linesearch=ls)
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], params, max_batch=%(mb)d)
+        single = ctx.opt_lbfgs_logw(d["GInit"], d["G"], 0.3, params)
+        out[str(ls)] = dict(res=res.tobytes().hex(), w=w.tobytes().hex(), fmin=[i.fmin for i in infos],
+                            it=[i.iterations for i in infos], ev=[i.evaluations for i in infos],
+                            code=[i.lbfgs_code for i in infos], single=single[0].tobytes().hex(), single_fmin=single[2].fmin)
+    out["stats"] = ctx.speculation_stats()
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("name,mb", [("synth_logw_M37xN500.npz", 3), ("synth_logw_M129xN257.npz", 8)])
+def test_speculative_line_search_changes_no_bit(hip, name, mb):
+    """The batch engine evaluates the steps a backtracking search may ask for next (stp/2, 2.1 stp) in idle batch
+    slots, alongside the trial; a rejected trial then finds its successor already evaluated.  With the mechanism
+    off (BIOEN_HIP_SPECULATE=0) every result -- optimum, weights, fmin, iteration and evaluation counts, status --
+    must be the same to the last bit, for all three backtracking variants; More-Thuente never speculates."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = _SPEC_SNIPPET % dict(root=ROOT, tests=os.path.join(ROOT, "tests"), name=name, mb=mb)
+    runs = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, BIOEN_HIP_SPECULATE=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    on, off = runs["1"], runs["0"]
+    assert off["stats"] == [0, 0]
+    assert on["stats"][0] > 0 and on["stats"][1] > 0, on["stats"]          # issued and adopted
+    for ls in ("2", "3", "1", "0"):
+        assert on[ls] == off[ls], ls
