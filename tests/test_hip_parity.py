@@ -553,3 +553,4 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
     assert on["stats"][0] > 0 and on["stats"][1] > 0, on["stats"]          # issued and adopted
     for ls in ("2", "3", "1", "0"):
         assert on[ls] == off[ls], ls
+
