@@ -317,6 +317,8 @@ static int enqueue_logw_adjoint(bioen_hip_ctx* c, const Round& r);
 
 static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     int rc;
+    c->last_width = r.n;
+    c->last_pos = 0;
     launch_logw_exp(c, r);                 // A1: e = exp(x - m_r) + prior partials (shift: this rank's own maximum)
     Vec8 w{};
     for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
@@ -388,6 +390,8 @@ static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
 static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
     int nblk = forces_fused_blocks(c);
     int rc;
+    c->last_width = r.n;
+    c->last_pos = 0;
     if ((nblk > 0 && c->strip_old) || (nblk == 0 && forces_fused_blocks_old(c) > 0)) {        // r01 kernels on the row-major matrix, kept for A/B measurements
         nblk = forces_fused_blocks_old(c);
         launch_forces_xy_old(c, fr, nblk);
@@ -958,6 +962,8 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     if ((rc = upload_n(c, s0.w, w))) return rc;       // sharded: this rank's block of the (global) w
     const int one[1] = {0};
     const Round r = make_round(c, one, 1, nullptr, nullptr);
+    c->last_width = 1;
+    c->last_pos = 0;
     Vec8 v{};
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);
@@ -977,7 +983,10 @@ int bioen_hip_last_average(bioen_hip_ctx* c, double* yraw, double* yeff) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     std::vector<double> raw((size_t)c->m), off((size_t)c->m), sc((size_t)c->m);
-    BIOEN_HIP_CHECK(hipMemcpyAsync(raw.data(), c->ybar_c, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // compact layout of the round that wrote it: ybar_c[row * width + column]
+    BIOEN_HIP_CHECK(hipMemcpy2DAsync(raw.data(), sizeof(double), c->ybar_c + c->last_pos,
+                                     (size_t)c->last_width * sizeof(double), sizeof(double), (size_t)c->m,
+                                     hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipMemcpyAsync(off.data(), c->row_offset, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipMemcpyAsync(sc.data(), c->row_scale, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -165,6 +165,8 @@ struct bioen_hip_ctx {
     double* row_scale = nullptr;    // mp
     bool affine = false;            // anything but (0, 1)
     double* ybar_c = nullptr;  // mp * kMaxBatch, compact per round
+    int last_width = 1, last_pos = 0;   // width of the round that wrote ybar_c last / column of the problem
+                                        // bioen_hip_last_average hands out (a finished problem's, else 0)
     double* r_c = nullptr;     // mp * kMaxBatch
     double* um = nullptr;      // mp * kMaxBatch  forces of the round's problems, compact [row*K + a]
     double* gm = nullptr;      // mp * kMaxBatch  forces gradients, compact

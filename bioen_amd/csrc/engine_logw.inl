@@ -243,9 +243,10 @@ struct LogwBatchEngine {
             ++active;
             ++next;
         };
-        auto finish_problem = [&](int s, int code, bool keep_trial) {
+        auto finish_problem = [&](int s, int code, bool keep_trial, int column) {
             BatchProblem& p = slots[s];
             ProblemSlot& sl = c->slot[s];
+            c->last_pos = column;                    // where this problem's averages sit in ybar_c (bioen_hip_last_average)
             bioen_opt_result& info = infos[p.id];
             info.lbfgs_code = code;
             info.iterations = p.machine->iterations();
@@ -346,6 +347,7 @@ struct LogwBatchEngine {
                 BatchProblem& p = slots[s];
                 ProblemSlot& sl = c->slot[s];
                 const double* h = c->host_scal + (size_t)s * kScalStride;
+                int column = a;                      // of the evaluation the problem ends up with
                 LbfgsMachine::Action act;
                 if (p.initial) {
                     act = p.machine->on_initial(h[S_F], h[S_GG], h[S_XX]);
@@ -378,6 +380,7 @@ struct LogwBatchEngine {
                                 std::memcpy(ho + rg[0], hs + rg[0], rg[1] * sizeof(double));
                             }
                             ++spec_used;
+                            column = k + q;
                             TrialResult t2{ho[S_F], ho[S_DG], ho[S_GG], ho[S_XX], ho[S_DGINIT]};
                             act = p.machine->on_trial(t2);
                             break;
@@ -392,7 +395,7 @@ struct LogwBatchEngine {
                     }
                 }
                 if (act.kind == LbfgsMachine::DONE) {
-                    finish_problem(s, act.code, act.keep_trial);
+                    finish_problem(s, act.code, act.keep_trial, column);
                     if (next < ntheta && !rc) start_problem(s);
                 }
             }

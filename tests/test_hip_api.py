@@ -270,6 +270,29 @@ def test_affine_model_equals_explicit_matrix(optimize):
     assert rel(f_plain, f_plain_o) < 1e-12             # switched back to the plain model
 
 
+@pytest.mark.parametrize("linesearch", [0, 2])
+def test_last_average_is_that_of_the_returned_point(optimize, linesearch):
+    """bioen_hip_last_average after an optimisation = yTilde . w_opt, whichever column of the round's compact
+    layout the final evaluation sat in (with trial steps speculated in idle slots the round is wider than 1)."""
+    import bioen_amd
+    rng = np.random.default_rng(5)
+    M, N = 23, 1500
+    Y = rng.standard_normal((M, N))
+    YT = Y.dot(rng.dirichlet(np.ones(N))) + 0.05 * rng.standard_normal(M)
+    G = np.zeros(N)
+    for theta in (0.5, 50.0):
+        with bioen_amd.Context(Y, YT) as ctx:
+            g, w, info = ctx.opt_lbfgs_logw(G, G, theta, dict(linesearch=linesearch, max_iterations=5000, epsilon=1e-8, delta=0.0, past=0,
+                                                             ftol=1e-5, gtol=0.9, wolfe=0.9, max_linesearch=100))
+            yraw, yeff = ctx.last_average()
+            assert info.lbfgs_code in (0, 1, 2, -998, -1001)
+            ref = Y.dot(w)
+            assert np.abs(yraw - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-14
+            assert np.array_equal(yraw, yeff)
+            f, _ = ctx.logw_fdf(g, G, theta)
+            assert np.abs(ctx.last_average()[0] - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-14
+
+
 def test_nuisance_series_matches_host_rebuild_loop(optimize):
     """The device loop (matrix resident, parameters through set_affine) against the reference's
     protocol done the slow way: rebuild yTilde(m) on the host every iteration, optimise with the
