@@ -1,23 +1,26 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): the default bench unprofiled, then the same command under
-# rocprofv3 --kernel-trace --stats, then the two PMC passes the MI355X guide prescribes for HBM
-# traffic (FETCH_SIZE and WRITE_SIZE cannot share a pass).  usage: tools/profile_round.sh <tag>
+# Run ON THE GPU BOX (through gpurun): the default bench under rocprofv3 --kernel-trace --stats, the two PMC
+# passes the MI355X guide prescribes for HBM traffic (FETCH_SIZE and WRITE_SIZE cannot share a pass; the DEER
+# record is left out of them so that only the two headline sizes launch the strip kernels), then the default
+# bench unprofiled with those traffic figures in place.  usage: tools/profile_round.sh <tag>
 set -e
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout -k 10 600 python bench.py > $OUT/bench_N1.json 2> $OUT/bench_N1.err
-echo "bench done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 echo "stats done"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python3 bench.py --no-cpu-baseline --warmup 0 > $OUT/fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python3 bench.py --no-cpu-baseline --no-deer --warmup 0 > $OUT/fetch.log 2>&1
 echo "fetch done"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- python3 bench.py --no-cpu-baseline --warmup 0 > $OUT/write.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- python3 bench.py --no-cpu-baseline --no-deer --warmup 0 > $OUT/write.log 2>&1
 echo "write done"
 mkdir -p $OUT/profiles
 cp profiles/traffic.json $OUT/profiles/ 2>/dev/null || true
 PROFILES_OUT=$OUT/profiles python tools/summarize_profiles.py $TAG $OUT/stats $OUT/fetch $OUT/write --key 1000000 1024 --fkey 1000000 512 > $OUT/summary.log
 cp $OUT/stats/${TAG}_kernel_stats.csv $OUT/kernel_stats.csv
+# the default bench last, with the traffic figures of THESE sources in place (bench.py copies them into roofline.traffic)
+cp $OUT/profiles/traffic.json profiles/traffic.json
+timeout -k 10 600 python bench.py > $OUT/bench_N1.json 2> $OUT/bench_N1.err
+echo "bench done"
 rm -f $OUT/*/*_kernel_trace.csv $OUT/*/*_counter_collection.csv     # tens of MB; the summaries are what is kept
 tail -1 $OUT/bench_N1.json | cut -c1-400
