@@ -329,7 +329,7 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
         // k_rows_combine, which leaves the RAW ybar in ybar_c for the centred adjoint below
         if ((rc = ensure_strip_copy(c))) return rc;
         launch_fwd_strip(c, r.n, w, nblk);
-        launch_fwd_rows_local(c, r.n, true, nblk);
+        launch_fwd_rows_local(c, r.n, true, nblk, true);
         if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, r.n, true)))) return rc;
         launch_rows_combine(c, r, true, c->strip_center, true);
         return with_grad ? enqueue_logw_adjoint(c, r) : 0;
@@ -428,9 +428,9 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         if (with_grad) {
             launch_forces_bt(c, fr, nblk);    // F3: b, t, product with t            [matrix pass 2]
             if (c->world == 1) {
-                launch_fwd_rows_forces_grad(c, fr.n, nblk, &fr);
+                launch_fwd_rows_forces_grad(c, fr.n, nblk, &fr, true);
             } else {
-                launch_fwd_rows_forces_grad_share(c, fr.n, nblk, &fr);
+                launch_fwd_rows_forces_grad_share(c, fr.n, nblk, &fr, true);
                 if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
                 launch_forces_grad_sum_ranks(c, fr.n);
             }

@@ -91,6 +91,38 @@ __device__ __forceinline__ double max_partials(const double* __restrict__ p, int
     return block_max(s, sh);
 }
 
+// ---- consumers of TRANSPOSED partials (the strip kernels): P[tile * stride + idx], idx = row K + a ---------------
+// A strip block writes its mp K sums as one contiguous run (a scattered 8-byte store per (row, problem, block) cost
+// the K = 8 launch 20 us of 70 at N = 1e5 x M = 256).  Here a block of 256 threads totals 16 consecutive entries
+// over all tiles: thread (jg, i) plays the lanes 4 jg .. 4 jg + 3 of the classic wave-per-entry consumer for entry
+// idx0 + i -- lane j adds tiles j, j + 64, ... in turn -- and the 64 lane sums meet in wave_sum's pair order
+// (32, 16, ..., 1) through LDS: bit for bit the classic result, from 128-byte coalesced reads.
+// Returns the total of entry idx0 + (threadIdx.x & 15) in threads < 16.
+template <class Term>
+__device__ __forceinline__ double tiles_sum16(const double* __restrict__ P, size_t stride, int ctiles, size_t idx,
+                                              bool valid, double* lds /* [64 * 16] */, Term term) {
+    const int i = threadIdx.x & 15, jg = threadIdx.x >> 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * jg + jj;
+        double s = 0.0;
+        if (valid)
+            for (int b = j; b < ctiles; b += 64) s = term(b, P[(size_t)b * stride + idx], s);
+        lds[j * 16 + i] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        for (int e = threadIdx.x; e < o * 16; e += kBlock) lds[e] += lds[e + o * 16];
+        __syncthreads();
+    }
+    return lds[i];
+}
+
+struct TermAdd {
+    __device__ __forceinline__ double operator()(int, double v, double s) const { return s + v; }
+};
+
 // ---- exchange-stage accessors (ctx.hpp: XStage).  Layout [rank][problem a][array q][block].
 // put: this rank's block partial.  sum/max: over all ranks and blocks in a fixed order
 // (rank-major), identical on every rank.

@@ -44,7 +44,7 @@ int rows_grid(const bioen_hip_ctx* c);
 // forward: fwd_partial[(row*K + a)*ctiles + tile] = sum_{j in tile} (Y[row][j] - [centred] ybar_c[row*K+a]) v_a[j]
 void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred = false);
 // reduce the column tiles -> this rank's share of ybar in its X_YBAR segment   [exchange X_YBAR]
-void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles = 0);   // logw: + {sum e, sum e (x-G), m_r} per problem; ctiles: partials per (row, problem), default the streaming kernel's
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles = 0, bool tposed = false);   // logw: + {sum e, sum e (x-G), m_r} per problem; ctiles: partials per (row, problem), default the streaming kernel's
 int ybar_payload(const bioen_hip_ctx* c, int K, bool logw);        // doubles per rank in the X_YBAR stage
 void launch_scale_w(bioen_hip_ctx* c, const Round& r);              // w = e * scal[S_INV] (when a result is handed out)
 // add the ranks' shares -> ybar_c, r_c (compact), chi^2 / ybar.r partials per problem
@@ -56,7 +56,7 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw,   // logw:
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 // tsum = true (strip passes on the centred copy): gm = sum of partials - ybar_c * T, T = sum of the blocks' P_KL shares
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr);
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);
 // forces evaluation in TWO matrix passes over LDS-resident column strips (M <= 512, unsharded):
 //   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
@@ -65,13 +65,13 @@ int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context doe
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
-void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr);   // sharded: -> X_YBAR segment
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);   // sharded: -> X_YBAR segment
 int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
 int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
 void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk);
 int ensure_strip_copy_colsum(bioen_hip_ctx* c);        // builds ctx->Ys1 (column-sum operand order) on first use
 void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk);
-void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
+void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk, bool tposed = false);
 int forces_fused_blocks_old(const bioen_hip_ctx* c);   // r01 strip kernels (A/B only)
 void launch_forces_xy_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);

@@ -176,6 +176,47 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restr
     }
 }
 
+// k_fwd_rows_local on transposed partials; the blocks beyond the entry tiles (one per problem) total the softmax partials
+template <bool WITH_EXP>
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __restrict__ partial, int ctiles, int mp,
+                                                             int K, int ntile, Xch xo, Xch xe) {
+    __shared__ double lds[64 * 16];
+    double* out = xo.base + (size_t)xo.rank * xo.payload;
+    if (WITH_EXP && (int)blockIdx.x >= ntile) {
+        const int a = blockIdx.x - ntile;
+        const double s = xsum_rank<3>(xe, xe.rank, a, 0, lds);
+        const double pp = xsum_rank<3>(xe, xe.rank, a, 1, lds);
+        if (threadIdx.x == 0) {
+            double* tail = out + (size_t)mp * K + 3 * a;
+            tail[0] = s;
+            tail[1] = pp;
+            tail[2] = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+        }
+        return;
+    }
+    const size_t n = (size_t)mp * K;
+    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = tiles_sum16(partial, n, ctiles, idx, idx < n, lds, TermAdd());
+    if (threadIdx.x < 16 && idx < n) out[idx] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double* __restrict__ partial, int ctiles,
+                                                                   int mp, int K, double* __restrict__ gm_c,
+                                                                   const double* __restrict__ ybar_c, MVec8 tpart) {
+    __shared__ double lds[64 * 16];
+    __shared__ double T[kMaxBatch];
+    if (ybar_c)
+        for (int a = 0; a < K; ++a) {
+            const double t = sum_partials(tpart.p[a] + (size_t)P_KL * kMaxPartials, ctiles, lds);
+            if (threadIdx.x == 0) T[a] = t;
+        }
+    __syncthreads();
+    const size_t n = (size_t)mp * K;
+    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = tiles_sum16(partial, n, ctiles, idx, idx < n, lds, TermAdd());
+    if (threadIdx.x < 16 && idx < n) gm_c[idx] = ybar_c ? fma(-ybar_c[idx], T[idx % K], s) : s;
+}
+
 // add the ranks' shares (rank order) -> ybar, r = ybar - YT (compact) ; per-block partials of
 // sum r^2 and sum ybar r.  Every rank computes the same numbers.
 // Affine observable model (ctx.hpp): ybar_eff_i = off_i + sc_i (Y w)_i  (sum w = 1), while ybar_c
@@ -435,10 +476,20 @@ void launch_fwd_partial(bioen_hip_ctx* c, int K, const Vec8& v, bool centred) {
 
 int ybar_payload(const bioen_hip_ctx* c, int K, bool logw) { return c->mp * K + (logw ? 3 * K : 0); }
 
-void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles) {
+void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, K, logw));
     const Xch xe = make_xch(c, X_EXP, 3 * K * vec_grid(c));
     const int ct = ctiles > 0 ? ctiles : c->fwd_ctiles;
+    if (tposed) {
+        const int ntile = (c->mp * K + 15) / 16;
+        if (logw)
+            hipLaunchKernelGGL(k_fwd_rows_local_t<true>, dim3(ntile + K), dim3(kBlock), 0, c->stream, c->fwd_partial, ct,
+                               c->mp, K, ntile, xo, xe);
+        else
+            hipLaunchKernelGGL(k_fwd_rows_local_t<false>, dim3(ntile), dim3(kBlock), 0, c->stream, c->fwd_partial, ct,
+                               c->mp, K, ntile, xo, xe);
+        return;
+    }
     if (logw)
         hipLaunchKernelGGL(k_fwd_rows_local<true>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
                            ct, c->mp, K, xo, xe);
@@ -486,15 +537,26 @@ static MVec8 tsum_parts(const ForcesRound* fr) {
     return t;
 }
 
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum) {
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum, bool tposed) {
+    if (tposed) {
+        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, ctiles, c->mp, K, c->gm, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
+        return;
+    }
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
                        ctiles, c->mp, K, c->gm, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
 }
 
 // sharded: this rank's share of the forces gradient -> its X_YBAR segment; after the exchange
 // k_sum_ranks adds the shares in rank order (identical on every rank) -> gm
-void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum) {
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, c->mp * K);
+    if (tposed) {
+        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload,
+                           tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
+        return;
+    }
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
                        ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, tsum ? c->ybar_c : nullptr,
                        tsum_parts(tsum));

@@ -121,7 +121,7 @@ struct StripArgs {
     int nblk;
     const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
     const double* w0;
-    double* partial;        // [(row * K + k) * nblk + block]
+    double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
     long long* stamps;      // diagnostic builds (STRIP_DIAG & 4): per wave 8 phase-cycle sums
 };
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
-                if (row < q.mp && k < K) q.partial[((size_t)row * K + k) * q.nblk + blockIdx.x] = acc[h][kq];
+                if (row < q.mp && k < K) q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = acc[h][kq];   // transposed: a block's sums are one run
             }
     }
     // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     }
 }
 
-// ---- log-weights forward pass on the strip copy: partial[(row K + k) nblk + block] = sum_{j in the block's strips} Y'[row][j] e_k[j]
+// ---- log-weights forward pass on the strip copy: partial[block mp K + row K + k] = sum_{j in the block's strips} Y'[row][j] e_k[j]
 // (A4, c_bioen_common.c:70-108; replaces k_fwd_partial for M <= 1024).  The copy is stored in the operand
 // order of this product, so the matrix goes HBM -> registers -> matrix cores: no LDS image, no shuffles, and the
 // K vectors e_k enter once per BLOCK and strip (16 K doubles through LDS, loaded one strip ahead) instead of once
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
-                if (row < q.mp && k < K) q.partial[((size_t)row * K + k) * q.nblk + blockIdx.x] = acc[h][kq];
+                if (row < q.mp && k < K) q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = acc[h][kq];   // transposed: a block's sums are one run
             }
     }
 }
@@ -813,6 +813,26 @@ __global__ __launch_bounds__(kBlock) void k_forces_rows_weighted(const double* _
     }
 }
 
+// the same on transposed partials (the strip kernels of this file)
+struct TermWeighted {
+    const double* wb;
+    __device__ __forceinline__ double operator()(int b, double v, double s) const { return fma(wb[b], v, s); }
+};
+
+__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted_t(const double* __restrict__ partial, int nblk, int mp,
+                                                                   int K, ForcesRound fr, Xch xo) {
+    __shared__ double lds[64 * 16];
+    const size_t n = (size_t)mp * K;
+    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int a = (int)(idx % K);
+    const double* wb = fr.part[0];
+#pragma unroll
+    for (int k = 1; k < kMaxBatch; ++k)
+        if (k == a) wb = fr.part[k];
+    const double s = tiles_sum16(partial, n, nblk, idx, idx < n, lds, TermWeighted{wb + (size_t)P_MAX * kMaxPartials});
+    if (threadIdx.x < 16 && idx < n) (xo.base + (size_t)xo.rank * xo.payload)[idx] = s;
+}
+
 // w_j = w0_j exp(x_j - S_LOGS): the weights themselves, when a result is handed out
 __global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, const double* __restrict__ w0, int n) {
     const int a = blockIdx.y;
@@ -822,9 +842,14 @@ __global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, cons
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] = w0[j] * exp(x[j] - logz);
 }
 
-void launch_forces_blockmerge(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
+void launch_forces_blockmerge(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, fr.n, true));
     hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk, c->mp, fr.n, xo);
+    if (tposed) {
+        hipLaunchKernelGGL(k_forces_rows_weighted_t, dim3((c->mp * fr.n + 15) / 16), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, nblk, c->mp, fr.n, fr, xo);
+        return;
+    }
     hipLaunchKernelGGL(k_forces_rows_weighted, dim3(rows_grid(c), fr.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
                        nblk, c->mp, fr.n, fr, xo);
 }
@@ -835,7 +860,7 @@ void launch_forces_xy(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
         TimedLaunch tl(c, 1, fr.n);
         strip_launch<true>(c, fr, nblk, c->um);
     }
-    launch_forces_blockmerge(c, fr, nblk);
+    launch_forces_blockmerge(c, fr, nblk, true);
 }
 
 // pass 2: b' = Y'^T r, t, Y' . t
