@@ -203,6 +203,14 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
         bioen_hip_ctx_destroy(c);
         return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
     }
+    e = hipHostMalloc(reinterpret_cast<void**>(&c->live), (size_t)kMaxBatch * (kScalStride + 1) * sizeof(double),
+                      hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        bioen_hip_ctx_destroy(c);
+        return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
+    std::memset(c->live, 0, (size_t)kMaxBatch * (kScalStride + 1) * sizeof(double));
+    if (const char* v = std::getenv("BIOEN_HIP_LIVE")) c->live_off = (v[0] == '0');
     *out = c;
     return 0;
 }
@@ -268,6 +276,33 @@ static int read_scalars(bioen_hip_ctx* c, int nslots = 1) {
     BIOEN_HIP_CHECK(hipMemcpyAsync(c->host_scal, c->scal, (size_t)nslots * kScalStride * sizeof(double),
                                    hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The scalars of a round whose last kernel published them live (k_finish_eval): wait for the n flags to reach the
+// round number, then mirror the slots where read_scalars would have put them.  The stream is polled now and then,
+// so that a failed launch ends the wait with its error instead of hanging the caller.
+static int await_live(bioen_hip_ctx* c, unsigned long long round, const int* slots, int n) {
+    const volatile unsigned long long* flag =
+        reinterpret_cast<const volatile unsigned long long*>(c->live + (size_t)kMaxBatch * kScalStride);
+    for (int a = 0; a < n; ++a) {
+        unsigned spins = 0;
+        while (flag[a] != round) {
+            if ((++spins & 0xfffu) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) {
+                    if (flag[a] == round) break;
+                    return fail(BIOEN_HIP_ESTATE, "round finished without publishing its scalars");
+                }
+                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int a = 0; a < n; ++a)
+        std::memcpy(c->host_scal + (size_t)slots[a] * kScalStride, c->live + (size_t)a * kScalStride,
+                    kScalStride * sizeof(double));
     return 0;
 }
 
@@ -691,6 +726,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         if (c->xbuf[st]) hipFree(c->xbuf[st]);
     if (c->exchange_host) hipHostFree(c->exchange_host);
     if (c->host_scal) hipHostFree(c->host_scal);
+    if (c->live) hipHostFree(c->live);
     if (c->host_m) hipHostFree(c->host_m);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -184,6 +184,13 @@ struct bioen_hip_ctx {
     double* gram = nullptr;          // kMaxBatch * kGramStride
     int direction_mode = 0;          // 0 auto (= Gram form), 1 two-loop on the vectors, 2 Gram form
     double* host_scal = nullptr;     // pinned mirror
+    // Live hand-off of a round's scalars (log-weights batch engine): the round's last kernel stores each problem's
+    // slot straight into this host-mapped page and then the round number into its flag; the host spins on the flags
+    // instead of queueing a copy and sleeping on the stream (saves the copy kernel and the wake-up, ~15 us a round).
+    double* live = nullptr;                        // pinned, coherent: kMaxBatch * kScalStride values | kMaxBatch flags
+    unsigned long long live_seq = 0;               // last round number handed out
+    unsigned long long live_round = 0;             // != 0: the next launch_finish_eval publishes under this number
+    int live_off = 0;                              // BIOEN_HIP_LIVE=0: copy + stream synchronisation as before (A/B)
     double* host_m = nullptr;        // pinned, 2 x mp*kMaxBatch: forces up / gradients down (lazy)
 
     long long spec_launched = 0, spec_used = 0;   // speculative line-search evaluations issued / adopted (engine_logw.inl)

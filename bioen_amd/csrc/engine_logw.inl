@@ -336,9 +336,20 @@ struct LogwBatchEngine {
             r.n = k + nshadow;
             spec_launched += nshadow;
             launch_trial(c, r);
-            note(enqueue_logw_eval(c, r, true));
-            note(read_scalars(c, kMaxBatch));
-            note(check_launch());
+            if (!c->live_off) {
+                // the round's scalars come back through the host-mapped page (ctx.hpp: live); positions k.. are shadows
+                int where[kMaxBatch];
+                for (int a = 0; a < k; ++a) where[a] = list[a];
+                for (int q = 0; q < nshadow; ++q) where[k + q] = shadow_slot[q];
+                const unsigned long long round = c->live_round = ++c->live_seq;
+                note(enqueue_logw_eval(c, r, true));
+                note(check_launch());
+                if (!rc) note(await_live(c, round, where, r.n));
+            } else {
+                note(enqueue_logw_eval(c, r, true));
+                note(read_scalars(c, kMaxBatch));
+                note(check_launch());
+            }
             if (rc) break;
 
             std::vector<int> dir_list;

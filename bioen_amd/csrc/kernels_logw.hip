@@ -174,17 +174,32 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg) {
+// live != NULL: the problem's whole scalar slot also goes to the host-mapped page (ctx.hpp: live), then -- after a
+// system-scope fence -- the round number into the problem's flag, which the host is spinning on.
+__global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg, double* __restrict__ live,
+                                                        unsigned long long round) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double dg = xsum<3>(xg, a, 0, sh);
     const double gg = xsum<3>(xg, a, 1, sh);
     const double xx = xsum<3>(xg, a, 2, sh);
+    double* sc = r.scal[a];
     if (threadIdx.x == 0) {
-        double* sc = r.scal[a];
         sc[S_DG] = dg;
         sc[S_GG] = gg;
         sc[S_XX] = xx;
+    }
+    if (live && threadIdx.x < kScalStride) {      // one wave: its stores are fenced before lane 0 raises the flag
+        const int t = threadIdx.x;
+        double v = sc[t];                         // the other entries were written by earlier kernels
+        if (t == S_DG) v = dg;
+        if (t == S_GG) v = gg;
+        if (t == S_XX) v = xx;
+        live[(size_t)a * kScalStride + t] = v;
+        __threadfence_system();
+        if (t == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(live + (size_t)kMaxBatch * kScalStride) + a, round,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -513,7 +528,8 @@ void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
 
 void launch_finish_eval(bioen_hip_ctx* c, const Round& r) {
     hipLaunchKernelGGL(k_finish_eval, dim3(1, r.n), dim3(kBlock), 0, c->stream, r,
-                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), c->live_round ? c->live : nullptr, c->live_round);
+    c->live_round = 0;
 }
 
 void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal) {
