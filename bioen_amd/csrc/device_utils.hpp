@@ -102,14 +102,26 @@ template <class Term>
 __device__ __forceinline__ double tiles_sum16(const double* __restrict__ P, size_t stride, int ctiles, size_t idx,
                                               bool valid, double* lds /* [64 * 16] */, Term term) {
     const int i = threadIdx.x & 15, jg = threadIdx.x >> 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < ctiles; base += 1024) {     // 1024 tiles per trip: all 64 loads of a thread in flight at once
+        double v[4][16];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = 4 * jg + jj;
-        double s = 0.0;
-        if (valid)
-            for (int b = j; b < ctiles; b += 64) s = term(b, P[(size_t)b * stride + idx], s);
-        lds[j * 16 + i] = s;
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int b = base + 64 * m + 4 * jg + jj;
+                v[jj][m] = (valid && b < ctiles) ? P[(size_t)b * stride + idx] : 0.0;
+            }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int b = base + 64 * m + 4 * jg + jj;
+                if (valid && b < ctiles) s[jj] = term(b, v[jj][m], s[jj]);
+            }
     }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) lds[(4 * jg + jj) * 16 + i] = s[jj];
     __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -405,21 +405,34 @@ template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
     __shared__ double dots[kGramDots];
     __shared__ double Gs[kBasis * kBasis];
-    __shared__ double coef[kBasis];
     __shared__ double alpha[kHistory];
     const int a = blockIdx.y;
     double* G = q.gram[a];
     for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
     if (FUSED) {
+        // a wave's sums side by side: their loads are all in flight together (one after the other, each sum waited
+        // for its own loads: 10 round trips to L2 in a row); every sum is still formed in the same order
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int c = wave; c < kGramDots; c += kWaves) {
-            double s = 0.0;
-            for (int r = 0; r < xi.world; ++r) {
-                const double* p = xi.base + (size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl;
-                for (int k = lane; k < xi.npl; k += 64) s += p[k];
+        constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
+        double acc[kPerWave];
+#pragma unroll
+        for (int u = 0; u < kPerWave; ++u) acc[u] = 0.0;
+        for (int r = 0; r < xi.world; ++r)
+            for (int k = lane; k < xi.npl; k += 64) {
+                double v[kPerWave];
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) {
+                    const int c = wave + u * kWaves;
+                    v[u] = c < kGramDots ? xi.base[(size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl + k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) acc[u] += v[u];
             }
-            s = wave_sum(s);
-            if (lane == 0) dots[c] = s;
+#pragma unroll
+        for (int u = 0; u < kPerWave; ++u) {
+            const int c = wave + u * kWaves;
+            const double t = wave_sum(acc[u]);
+            if (lane == 0 && c < kGramDots) dots[c] = t;
         }
     } else {
         for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = G[kGramSums + i];
@@ -438,29 +451,50 @@ __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
         G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
         G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
     }
-    // q = -g as coefficients over {S, Y, g}
-    for (int c = 0; c < kBasis; ++c) coef[c] = 0.0;
-    coef[rg] = -1.0;
+    // q = -g as coefficients over {S, Y, g}.  The coefficients stay in registers (an LDS array put a store -> load
+    // round trip into every step of the two dependent chains); slot numbers are run-time values, so the one entry a
+    // step changes is picked by comparison.  Same operations in the same order as before.
+    double cf[kBasis];
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] = c == rg ? -1.0 : 0.0;
     for (int b = 0; b < bound; ++b) {         // first loop, newest -> oldest
         const int i = (e + kHistory - b) % kHistory;
+        double row[kBasis];
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) row[c] = Gs[i * kBasis + c];
+        const double diag = Gs[(kHistory + i) * kBasis + i];
         double sq = 0.0;
-        for (int c = 0; c < kBasis; ++c) sq = fma(coef[c], Gs[i * kBasis + c], sq);
-        const double al = sq / Gs[(kHistory + i) * kBasis + i];
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) sq = fma(cf[c], row[c], sq);
+        const double al = sq / diag;
         alpha[i] = al;
-        coef[kHistory + i] -= al;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c)
+            if (c == kHistory + i) cf[c] -= al;
     }
     const double scale = Gs[ry * kBasis + rs] / Gs[ry * kBasis + ry];   // ys / yy of the newest pair
-    for (int c = 0; c < kBasis; ++c) coef[c] *= scale;
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] *= scale;
     for (int b = bound - 1; b >= 0; --b) {    // second loop, oldest -> newest
         const int i = (e + kHistory - b) % kHistory;
+        double row[kBasis];
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) row[c] = Gs[(kHistory + i) * kBasis + c];
+        const double diag = Gs[(kHistory + i) * kBasis + i];
+        const double al = alpha[i];
         double yq = 0.0;
-        for (int c = 0; c < kBasis; ++c) yq = fma(coef[c], Gs[(kHistory + i) * kBasis + c], yq);
-        const double beta = yq / Gs[(kHistory + i) * kBasis + i];
-        coef[i] += alpha[i] - beta;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) yq = fma(cf[c], row[c], yq);
+        const double beta = yq / diag;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c)
+            if (c == i) cf[c] += al - beta;
     }
     double dg = 0.0;
-    for (int c = 0; c < kBasis; ++c) dg = fma(coef[c], Gs[rg * kBasis + c], dg);
-    for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = coef[c];
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) dg = fma(cf[c], Gs[rg * kBasis + c], dg);
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = cf[c];
     q.scal[a][S_DGINIT] = dg;
 }
 

@@ -15,14 +15,17 @@ for (M, N) in sizes:
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED) as ctx:
         G = np.zeros(N)
         sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
-        ctx.kernel_stats_enable(True)
-        ctx.kernel_stats_reset()
         ctx.synchronize()
         t0 = time.perf_counter()
-        res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
+        res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)       # wall time without the stats' event pairs
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        ctx.kernel_stats_enable(True)
+        ctx.kernel_stats_reset()
+        sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
+        ctx.synchronize()
         ks = ctx.kernel_stats()
+        ctx.kernel_stats_enable(False)
         rounds = ks["forward"]["launches"]
         mat = ks["forward"]["total_ms"] + ks["adjoint"]["total_ms"]
         print("M=%d N=%d: sweep %.4f s, %d iterations, %d rounds -> %.1f us/round, matrix kernels %.1f us/round (%.0f %%)" % (
