@@ -139,16 +139,21 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nwaves = blockDim.x >> 6;
+    // Every wave of the block runs the same straight-line code (a branch around the prefetch makes the compiler's
+    // vmcnt bookkeeping drain BOTH register sets at every wait, see k_strip_adj): LDS regions are sized for
+    // 64 rows per wave, and the second wave of a 64-row strip (blocks have at least two waves: P2 needs up to 128
+    // threads) re-reads the first wave's rows against zero operands and stores nothing.
+    const int lrows = nwaves * kWaveRows;
     double* tile = lds;
-    double* ul = tile + (size_t)q.mps * kStripCols;  // u[row][8]: forces | residuals, zero beyond K and mp
-    double* red = ul + (size_t)q.mps * 8;           // [wave][problem 8][column 16]: the waves' partial column sums
+    double* ul = tile + (size_t)lrows * kStripCols;  // u[row][8]: forces | residuals, zero beyond K and mp
+    double* red = ul + (size_t)lrows * 8;           // [wave][problem 8][column 16]: the waves' partial column sums
     double* tv = red + nwaves * 128;                // v[problem 8][column 16]: e | t of the strip
     double* scale = tv + 128;
     const int rbase = wave * kWaveRows;
-    const bool owner = rbase < q.mps;               // a block has at least two waves; the second may own no rows
+    const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
 
-    for (int i = t; i < q.mps * 8; i += blockDim.x) {
+    for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
         ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
     }
@@ -169,10 +174,24 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     const int pk = p2 ? t >> 4 : 0, pc = t & 15;
     double m_run = -DBL_MAX, zacc = 0.0, pxacc = 0.0;             // xy: running maximum, sum e, sum e x | bt: zacc = sum t
     double logs = 0.0, theta = 0.0, b0 = 0.0;
+    // per-lane choice among the K kernel arguments by comparison (indexing the argument block with a lane value is
+    // a vector load whose pending state forces vmcnt(0) -- a drain of the prefetch -- wherever the pointer is used)
+    double* ak = fr.a[0];
+    double* sck = fr.scal[0];
+    double* pak = fr.part[0];
+    double thk = fr.theta[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (pk == k) {
+            ak = fr.a[k];
+            sck = fr.scal[k];
+            pak = fr.part[k];
+            thk = fr.theta[k];
+        }
     if (!XY && p2) {
-        logs = fr.scal[pk][S_LOGS];
-        b0 = fr.scal[pk][S_B0];
-        theta = fr.theta[pk];
+        logs = sck[S_LOGS];
+        b0 = sck[S_B0];
+        theta = thk;
     }
 
     // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #if STRIP_DEPTH == 2
     d2 preB[kWaveRows / 8];
 #endif
-    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
+    const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
     auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
 #if !(STRIP_DIAG & 2)
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         // 32 lanes as the row-sum operand fetch used to read: conflict-free.  The registers themselves ARE the
         // row-sum operands: kept in a3 until P3 (the prefetch below reuses `pre`).
         double a3[4][kWaveRows / 16];
-        if (owner) {
+        {
             const int sw3 = strip_swz(lr);          // row rbase + 16 h + lr: only bit 0 of its swizzle depends on h
             double* img = tile + (size_t)(rbase + lr) * kStripCols;
 #pragma unroll
@@ -224,12 +243,12 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         double w0v = 0.0, xv = 0.0;
         if (p2) {
             w0v = q.w0[col];
-            if (!XY) xv = fr.a[pk][col];
+            if (!XY) xv = ak[col];
         }
-        if (owner) fetch(s + STRIP_DEPTH * G < q.nstrips ? s + STRIP_DEPTH * G : s, pre);    // unconditional, see k_strip_adj
+        fetch(s + STRIP_DEPTH * G < q.nstrips ? s + STRIP_DEPTH * G : s, pre);    // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
-        if (owner) {
+        {
             double d[4][NK];                        // four chains over the row groups: the result latency is 3 issues
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch)
@@ -240,19 +259,26 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             const double* p1 = tile + (size_t)(rbase + lq) * kStripCols;
             const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
 #if !(STRIP_DIAG & 1)
-            // all operand fetches first (one LDS round trip instead of sixteen), then the matrix instructions
-            double a1[kWaveRows / 4], b1[kWaveRows / 4][NK];
+            // all operand fetches of a batch first (one LDS round trip instead of sixteen), then its matrix
+            // instructions; K > 4 takes two batches of eight row groups: one batch of 16 x 3 operands does not fit
+            // beside the two register sets in flight (the compiler spilled 2..22 values per strip)
+            constexpr int NB = NK > 1 ? 2 : 1, GB = kWaveRows / 4 / NB;
 #pragma unroll
-            for (int g = 0; g < kWaveRows / 4; ++g) {
-                a1[g] = p1[g * 64 + (lr ^ (((((lq >> 1) + 2 * g) & 7) << 1) ^ ((g >> 2) & 1)))];
+            for (int hb = 0; hb < NB; ++hb) {
+                double a1[GB], b1[GB][NK];
 #pragma unroll
-                for (int kq = 0; kq < NK; ++kq) b1[g][kq] = pu[g * 32 + 4 * kq];
+                for (int gg = 0; gg < GB; ++gg) {
+                    const int g = hb * GB + gg;
+                    a1[gg] = p1[g * 64 + (lr ^ (((((lq >> 1) + 2 * g) & 7) << 1) ^ ((g >> 2) & 1)))];
+#pragma unroll
+                    for (int kq = 0; kq < NK; ++kq) b1[gg][kq] = pu[g * 32 + 4 * kq];
+                }
+#pragma unroll
+                for (int gg = 0; gg < GB; ++gg)
+#pragma unroll
+                    for (int kq = 0; kq < NK; ++kq)
+                        d[gg & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[gg], b1[gg][kq], d[gg & 3][kq], 0, 0, 0);
             }
-#pragma unroll
-            for (int g = 0; g < kWaveRows / 4; ++g)
-#pragma unroll
-                for (int kq = 0; kq < NK; ++kq)
-                    d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[g][kq], d[g & 3][kq], 0, 0, 0);
 #else
             d[0][0] = p1[lr] * pu[0];
 #endif
@@ -275,7 +301,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             }
             if (XY) {
                 const bool valid = p2 && col < (size_t)q.n;
-                if (p2) fr.a[pk][col] = valid ? colsum : 0.0;
+                if (p2) ak[col] = valid ? colsum : 0.0;
                 double smax = valid ? colsum : -DBL_MAX;          // the strip's maximum: over the 16 lanes of the problem
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         STAMP(4)    // second barrier
         // ---- P3: acc[row][k] (+)= sum_c Y'[row][c] v[c][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + 4 blk + i = r0 + lr][c = 4 qq + lq]; B: lane (kk, blk, j) = v[4 qq + lq][4 kq + j]
-        if (owner) {
+        {
             if (XY) {
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq) {
@@ -337,9 +363,9 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
     };
     int s = blockIdx.x;
-    if (owner) fetch(s, preA);                                     // grid <= strips: every block has a first strip
+    fetch(s, preA);                                                // grid <= strips: every block has a first strip
 #if STRIP_DEPTH == 2
-    if (owner) fetch(s + G < q.nstrips ? s + G : s, preB);
+    fetch(s + G < q.nstrips ? s + G : s, preB);
     __syncthreads();                                              // ul / tv / scale initialised
     // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
     for (; s + G < q.nstrips; s += 2 * G) {
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     if (q.stamps && lane == 0)
         for (int i = 0; i < 8; ++i) q.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + i] = tacc[i];
 #endif
-    if (owner) {
+    {
         // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
         const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
 #pragma unroll
@@ -375,7 +401,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             px += __shfl_xor(px, o, 64);
         }
         if (p2 && pc == 0) {
-            double* pa = fr.part[pk];
+            double* pa = pak;
             if (XY) {
                 pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;
                 pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
@@ -402,7 +428,8 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int rbase = wave * kWaveRows;
-    const bool owner = rbase < q.mps;
+    const int rsrc = rbase < q.mps ? rbase : 0;                   // every wave runs the same code (see k_strip): the second
+                                                                  // wave of a 64-row strip re-reads the first one's rows, stores nothing
     const int lq = lane >> 4, lj = lane & 3;
     const int G = gridDim.x;
 
@@ -415,12 +442,15 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 
     const bool p2 = t < kStripCols * K;                           // problem t / 16, column t % 16
     const int pk = p2 ? t >> 4 : 0, pc = t & 15;
-    const double* vk = v.p[pk];
+    const double* vk = v.p[0];                                    // chosen by comparison, not by a lane-indexed (vector) load
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (pk == k) vk = v.p[k];
     d2 preA[kWaveRows / 8];
 #if FWD_DEPTH == 2
     d2 preB[kWaveRows / 8];
 #endif
-    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
+    const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
     auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
@@ -428,9 +458,9 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     };
     int s = blockIdx.x;
     double ecur = (p2 && s < q.nstrips) ? vk[(size_t)s * kStripCols + pc] : 0.0;
-    if (owner) fetch(s, preA);                                     // grid <= strips: every block has a first strip
+    fetch(s, preA);                                                // grid <= strips: every block has a first strip
 #if FWD_DEPTH == 2
-    if (owner) fetch(s + G < q.nstrips ? s + G : s, preB);
+    fetch(s + G < q.nstrips ? s + G : s, preB);
 #endif
     __syncthreads();
     auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
         if (p2 && s + G < q.nstrips) ecur = vk[(size_t)(s + G) * kStripCols + pc];
         __syncthreads();                                           // this strip's e is in place; the buffer of parity
                                                                    // `par` is rewritten two strips on, behind another barrier
-        if (owner) {
+        {
             double bv[4][NK];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
@@ -468,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 #else
     for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
 #endif
-    if (owner) {
+    {
         // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
         const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
 #pragma unroll
@@ -494,42 +524,50 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nwaves = blockDim.x >> 6;
+    const int lrows = nwaves * kWaveRows;                         // LDS tables hold 64 rows per wave (see k_strip)
     double* ul = lds;                                             // u[row][8], zero beyond K and mp
-    double* red = ul + (size_t)q.mps * 8;                         // [parity][wave][problem 8][column 16]
+    double* red = ul + (size_t)lrows * 8;                         // [parity][wave][problem 8][column 16]
     const int rbase = wave * kWaveRows;
-    const bool owner = rbase < q.mps;
+    const int rsrc = rbase < q.mps ? rbase : 0;                   // the second wave of a 64-row strip re-reads the first one's rows
     const int lq = lane >> 4, lj = lane & 3;
     const int G = gridDim.x;
-    for (int i = t; i < q.mps * 8; i += blockDim.x) {
+    for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
         ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
     }
     const bool p2 = t < kStripCols * K;                           // problem t / 16, column t % 16
     const int pk = p2 ? t >> 4 : 0, pc = t & 15;
     double shift = 0.0;
-    double* outk = out.p[pk];
-    if (p2) shift = scal.p[pk][S_B0] - scal.p[pk][S_UY];
+    double* outk = out.p[0];                                      // chosen by comparison, not by a lane-indexed (vector) load
+    const double* sck = scal.p[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (pk == k) {
+            outk = out.p[k];
+            sck = scal.p[k];
+        }
+    if (p2) shift = sck[S_B0] - sck[S_UY];
     d2 preA[kWaveRows / 8];
 #if ADJ_DEPTH == 2
     d2 preB[kWaveRows / 8];                                       // two strips in flight per wave
 #endif
-    const size_t wave_off = (size_t)rbase * kStripCols + (size_t)lane * 2;
+    const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
     auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
         for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
     };
     int s = blockIdx.x;
-    if (owner) fetch(s, preA);                                     // grid <= strips: every block has a first strip
+    fetch(s, preA);                                                // grid <= strips: every block has a first strip
 #if ADJ_DEPTH == 2
-    if (owner) fetch(s + G < q.nstrips ? s + G : s, preB);
+    fetch(s + G < q.nstrips ? s + G : s, preB);
 #endif
     __syncthreads();                                              // ul in place
     const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
     const int nown = q.mps / kWaveRows;
     auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
         double* redw = red + (size_t)par * nwaves * 128;
-        if (owner) {
+        {
             double d[4][NK];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch)
@@ -577,7 +615,8 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
 static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->mp, kWaveRows); }
 static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_rows(c) / kWaveRows); }
 static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
-    return ((size_t)strip_rows(c) * (kStripCols + 8) + (size_t)(strip_threads(c) / 64) * 128 + 128 + 16) * sizeof(double);
+    const size_t waves = strip_threads(c) / 64;          // LDS regions hold 64 rows per wave (k_strip)
+    return (waves * kWaveRows * (kStripCols + 8) + waves * 128 + 128 + 16) * sizeof(double);
 }
 
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
@@ -697,7 +736,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
 
 static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c) {
     const int waves = std::max(2, strip_rows(c) / kWaveRows);
-    return ((size_t)strip_rows(c) * 8 + (size_t)2 * waves * 128) * sizeof(double);
+    return ((size_t)waves * kWaveRows * 8 + (size_t)2 * waves * 128) * sizeof(double);
 }
 
 template <int K, bool NT>

@@ -47,7 +47,7 @@ if os.environ.get("STAMPS"):
     names = ["wait+copy", "prefetch+P1", "barrier1", "P2", "barrier2", "P3", "-", "-"]
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
         fn(ctx._h, 1, None, 0)
-        for K in (1, 4, 8):
+        for K in (1, 2, 3, 4, 8):
             res = {}
             for need_grad, tag in ((False, "xy"), (True, "bt")):
                 ctx.forces_fdf_batch(forces[:K], w0, thetas[:K], need_grad=need_grad)
