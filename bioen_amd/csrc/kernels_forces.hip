@@ -123,12 +123,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
         acc1[k] = 0.0;
     }
     double m_run = -DBL_MAX, zacc = 0.0, pxacc = 0.0;           // live in the threads t < C*K
+    double* ak = fr.a[0];                                       // this thread's problem t % K: chosen by comparison, once
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (t % K == k) ak = fr.a[k];
     d2 pre[PIECES];
     auto fetch = [&](int strip) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int p = t + THREADS * i, row = p >> 3, part = p & 7;
-            pre[i] = row < mp ? ldg2<NT>(Y + (size_t)row * ld + (size_t)strip * C + part * 2) : d2{0.0, 0.0};
+            // rows beyond mp re-read the last row (their operands f / r are zero, their sums are never stored):
+            // no branch around a load, so that the compiler can count the loads in flight (kernels_strip.hip, "pitfall")
+            pre[i] = ldg2<NT>(Y + (size_t)(row < mp ? row : mp - 1) * ld + (size_t)strip * C + part * 2);
         }
     };
     auto stash = [&]() {
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
         }
     };
     int s = blockIdx.x;
-    if (s < nstrips) fetch(s);
+    fetch(s < nstrips ? s : 0);
     for (; s < nstrips; s += gridDim.x) {
         __syncthreads();
         stash();
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
         double w0v = 0.0;                                       // before the prefetch (vmcnt retires in order)
         const size_t col = (size_t)s * C + t / K;
         if (t < C * K) w0v = w0[col];
-        if (s + (int)gridDim.x < nstrips) fetch(s + gridDim.x);
+        fetch(s + (int)gridDim.x < nstrips ? s + (int)gridDim.x : s);         // unconditional: the tail re-reads its own strip
         // ---- phase 1: x_c = sum_i Y_ic f_i ----
 #pragma unroll
         for (int q = 0; q < C / CB; ++q) {
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
             const int c = t / K, k = t % K;
             x = sum_waves<WAVES>([&](int wv_) { return red[wv_][c][k]; });
             valid = col < (size_t)n;
-            fr.a[k][col] = valid ? x : 0.0;
+            ak[col] = valid ? x : 0.0;
             xs[c][k] = valid ? x : -DBL_MAX;
         }
         __syncthreads();
@@ -231,7 +237,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_xy(const double* __restri
             z += red[0][c][t];
             px += red[1][c][t];
         }
-        double* pa = fr.part[t];
+        double* pa = fr.part[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k)
+            if (t == k) pa = fr.part[k];
         pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;   // thread t = (c 0, k t)
         pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
         pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = px;
@@ -270,12 +279,29 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_bt(const double* __restri
         acc0[k] = 0.0;
         acc1[k] = 0.0;
     }
+    const double* ak = fr.a[0];                                 // this thread's problem t % K: chosen by comparison, once
+    const double* wk = fr.w[0];
+    double logsk = 0.0, thk = fr.theta[0];
+    {
+        const double* sck = fr.scal[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k)
+            if (t % K == k) {
+                ak = fr.a[k];
+                wk = fr.w[k];
+                sck = fr.scal[k];
+                thk = fr.theta[k];
+            }
+        if (FROMX && t < C * K) logsk = sck[S_LOGS];
+    }
     d2 pre[PIECES];
     auto fetch = [&](int strip) {                               // global -> registers, 8 lanes per row segment
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int p = t + THREADS * i, row = p >> 3, part = p & 7;
-            pre[i] = row < mp ? ldg2<NT>(Y + (size_t)row * ld + (size_t)strip * C + part * 2) : d2{0.0, 0.0};
+            // rows beyond mp re-read the last row (their operands f / r are zero, their sums are never stored):
+            // no branch around a load, so that the compiler can count the loads in flight (kernels_strip.hip, "pitfall")
+            pre[i] = ldg2<NT>(Y + (size_t)(row < mp ? row : mp - 1) * ld + (size_t)strip * C + part * 2);
         }
     };
     auto stash = [&]() {                                        // registers -> LDS
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_bt(const double* __restri
         }
     };
     int s = blockIdx.x;
-    if (s < nstrips) fetch(s);
+    fetch(s < nstrips ? s : 0);
     for (; s < nstrips; s += gridDim.x) {
         __syncthreads();                                        // phase 3 of the previous strip is done with the tile
         stash();
@@ -299,13 +325,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_bt(const double* __restri
             const size_t col = (size_t)s * C + t / K;           // < ld; padded columns carry w0 = w = 0
             w0v = w0[col];
             if (FROMX) {                                        // weights from x (k_forces_xy): no log needed
-                lr = fr.a[t % K][col] - fr.scal[t % K][S_LOGS];
+                lr = ak[col] - logsk;
                 wv = w0v * exp(lr);
             } else {
-                wv = fr.w[t % K][col];
+                wv = wk[col];
             }
         }
-        if (s + (int)gridDim.x < nstrips) fetch(s + gridDim.x); // in flight during the three phases
+        fetch(s + (int)gridDim.x < nstrips ? s + (int)gridDim.x : s);         // unconditional: the tail re-reads its own strip // in flight during the three phases
         // ---- phase 1 ----
 #pragma unroll
         for (int q = 0; q < C / CB; ++q) {
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_forces_bt(const double* __restri
             const double b = sum_waves<WAVES>([&](int wv_) { return red[wv_][c][k]; });
             double dd = 1.0;
             if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += FROMX ? lr : log(wv) - log(w0v);
-            tv[c][k] = (dd * fr.theta[k] + b) * wv;
+            tv[c][k] = (dd * thk + b) * wv;
         }
         __syncthreads();
         // ---- phase 3 ----
