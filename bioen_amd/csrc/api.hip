@@ -10,7 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include "ctx.hpp"
 #include "kernels.hpp"
@@ -727,6 +730,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
     if (c->exchange_host) hipHostFree(c->exchange_host);
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->live) hipHostFree(c->live);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->host_m) hipHostFree(c->host_m);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -148,6 +148,7 @@ struct bioen_hip_ctx {
     size_t exchange_host_count = 0;
     int exchange_error = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // results of finished problems leave on this one (engine_logw.inl: deliveries)
 
     double* Y = nullptr;       // mp x ld
     // forces method, M <= 1024 (kernels_strip.hip): strip-major copy centred on the targets, built on first use

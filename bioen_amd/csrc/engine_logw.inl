@@ -23,10 +23,60 @@ struct LogwBatchEngine {
     bool speculate = true;
     long long spec_launched = 0, spec_used = 0;      // shadow evaluations issued / adopted
 
+    // Deliveries: the optimum and the weights of a finished problem (2 N doubles into the caller's pageable arrays,
+    // 1.5 ms at N = 1e6) leave on a second stream, driven by a helper thread that blocks in the copy while this
+    // thread goes on launching rounds for the other problems.  The slot's vectors stay untouched until its delivery
+    // is done (no shadow evaluations in it, start_problem waits).  Unsharded contexts only; BIOEN_HIP_DELIVERY=0
+    // copies on the compute stream as before.
+    struct Delivery {
+        std::thread th;
+        std::atomic<int> done{0};
+        int rc = 0;
+    };
+    std::unique_ptr<Delivery> pending[kMaxBatch];
+    bool async_delivery = true;
+
     LogwBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
         : c(ctx), cfg(config), verbose(verb) {
         const char* e = std::getenv("BIOEN_HIP_SPECULATE");
         speculate = !(e && e[0] == '0');
+        const char* d = std::getenv("BIOEN_HIP_DELIVERY");
+        async_delivery = c->world == 1 && !(d && d[0] == '0');
+    }
+    ~LogwBatchEngine() {
+        for (int s = 0; s < kMaxBatch; ++s) settle(s);
+    }
+
+    bool slot_busy(int s) const { return pending[s] && !pending[s]->done.load(std::memory_order_acquire); }
+    void settle(int s) {
+        if (!pending[s]) return;
+        pending[s]->th.join();
+        note(pending[s]->rc);
+        pending[s].reset();
+    }
+    // x (and w) of slot s -> the caller's arrays, behind everything enqueued on the compute stream so far
+    void deliver(int s, double* dst_x, const double* src_x, double* dst_w, const double* src_w) {
+        settle(s);
+        if (!c->copy_stream) note(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+        hipEvent_t ev = nullptr;
+        note(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        if (rc) return;
+        note(hipEventRecord(ev, c->stream), "hipEventRecord");
+        Delivery* d = new Delivery;
+        pending[s].reset(d);
+        const int dev = c->device;
+        hipStream_t cs = c->copy_stream;
+        const size_t bytes = (size_t)c->n * sizeof(double);
+        d->th = std::thread([=]() {
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(dst_x, src_x, bytes, hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess && dst_w) e = hipMemcpyAsync(dst_w, src_w, bytes, hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess) e = hipStreamSynchronize(cs);
+            (void)hipEventDestroy(ev);
+            d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
+            d->done.store(1, std::memory_order_release);
+        });
     }
 
     void note(int e) { if (e && !rc) rc = e; }
@@ -227,6 +277,7 @@ struct LogwBatchEngine {
             p.machine = &machines[next];
             p.t0 = std::chrono::steady_clock::now();
             ProblemSlot& sl = c->slot[s];
+            settle(s);                               // the previous tenant's results have left
             if (shared_start)
                 note(hipMemcpyAsync(sl.xp, c->g0, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "copy g0");
             else
@@ -266,13 +317,18 @@ struct LogwBatchEngine {
             const double* h = c->host_scal + (size_t)s * kScalStride;
             info.chi2 = 0.5 * h[S_CHI];
             info.kl = h[S_P] - h[S_LOGS] + h[S_LOGS0];
-            note(download_n(c, results + (size_t)p.id * c->n_global, res));
             if (w_opt) {
                 const int one[1] = {s};
                 launch_scale_w(c, make_round(c, one, 1, nullptr, &p.theta));   // e -> w, only now
-                note(download_n(c, w_opt + (size_t)p.id * c->n_global, sl.w));
             }
-            note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
+            if (async_delivery) {
+                deliver(s, results + (size_t)p.id * c->n_global, res, w_opt ? w_opt + (size_t)p.id * c->n_global : nullptr,
+                        sl.w);
+            } else {
+                note(download_n(c, results + (size_t)p.id * c->n_global, res));
+                if (w_opt) note(download_n(c, w_opt + (size_t)p.id * c->n_global, sl.w));
+                note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
+            }
             info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
             if (verbose) {
                 std::printf("\ttheta = %g\n", p.theta);
@@ -310,7 +366,7 @@ struct LogwBatchEngine {
             if (speculate && (nslots > kb || active < kb)) {
                 int free_slots[kMaxBatch], nfree = 0;
                 for (int s = 0; s < nslots; ++s)
-                    if (s >= kb || !occupied[s]) free_slots[nfree++] = s;
+                    if ((s >= kb || !occupied[s]) && !slot_busy(s)) free_slots[nfree++] = s;
                 for (int pass = 0; pass < 2 && nfree > 0; ++pass)            // first everybody's stp/2, then 2.1 stp
                     for (int a = 0; a < k && nfree > 0; ++a) {
                         BatchProblem& p = slots[list[a]];
@@ -414,6 +470,7 @@ struct LogwBatchEngine {
         }
         note(hipStreamSynchronize(c->stream), "sync");
         note(check_launch());
+        for (int s = 0; s < kMaxBatch; ++s) settle(s);
         c->spec_launched += spec_launched;
         c->spec_used += spec_used;
         if (verbose && spec_launched)
