@@ -114,6 +114,7 @@ struct KernelTimer {
     struct Pair { hipEvent_t a, b; int which; int k; };
     std::vector<Pair> pending;
     std::vector<Pair> pool;
+    hipEvent_t cur_a = nullptr, cur_b = nullptr;   // events of the enclosing TimedLaunch (device_utils.hpp), else NULL
 };
 
 struct ProblemSlot {

@@ -4,6 +4,8 @@
 
 #include "kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <cfloat>
 
 namespace bioen {
@@ -190,6 +192,10 @@ __device__ __forceinline__ d2 ldg2(const double* p) {
 constexpr int next_pow2(int v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : 8)); }
 
 
+// Kernel durations for bioen_hip_kernel_stats: the two events ride on the kernel's own dispatch packet
+// (hipExtLaunchKernelGGL) instead of being recorded around it -- an event record is a barrier packet of its own, and
+// the pair cost ~6 us of idle queue per launch (rocprofv3: 4 x 2.4 ms over the headline sweep).  A launch inside the
+// scope of a TimedLaunch goes through BIOEN_LAUNCH_TIMED; with the stats off both events are NULL = a plain launch.
 struct TimedLaunch {
     bioen_hip_ctx* c;
     KernelTimer::Pair pr;
@@ -206,13 +212,17 @@ struct TimedLaunch {
         }
         pr.which = which;
         pr.k = k;
-        (void)hipEventRecord(pr.a, c->stream);
+        t.cur_a = pr.a;
+        t.cur_b = pr.b;
     }
     ~TimedLaunch() {
         if (!on) return;
-        (void)hipEventRecord(pr.b, c->stream);
+        c->timer.cur_a = c->timer.cur_b = nullptr;
         c->timer.pending.push_back(pr);
     }
 };
+
+#define BIOEN_LAUNCH_TIMED(ctx, kern, grid, block, lds, ...) \
+    hipExtLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, (ctx)->timer.cur_a, (ctx)->timer.cur_b, 0, __VA_ARGS__)
 
 }  // namespace bioen

@@ -50,7 +50,7 @@ struct LogwBatchEngine {
     bool slot_busy(int s) const { return pending[s] && !pending[s]->done.load(std::memory_order_acquire); }
     void settle(int s) {
         if (!pending[s]) return;
-        pending[s]->th.join();
+        if (pending[s]->th.joinable()) pending[s]->th.join();
         note(pending[s]->rc);
         pending[s].reset();
     }
@@ -67,7 +67,7 @@ struct LogwBatchEngine {
         const int dev = c->device;
         hipStream_t cs = c->copy_stream;
         const size_t bytes = (size_t)c->n * sizeof(double);
-        d->th = std::thread([=]() {
+        auto work = [=]() {
             hipError_t e = hipSetDevice(dev);
             if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev, 0);
             if (e == hipSuccess) e = hipMemcpyAsync(dst_x, src_x, bytes, hipMemcpyDeviceToHost, cs);
@@ -76,7 +76,14 @@ struct LogwBatchEngine {
             (void)hipEventDestroy(ev);
             d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
             d->done.store(1, std::memory_order_release);
-        });
+        };
+        try {
+            d->th = std::thread(work);
+        } catch (...) {            // no thread to be had: copy here, on the second stream all the same
+            work();
+            note(d->rc);
+            pending[s].reset();
+        }
     }
 
     void note(int e) { if (e && !rc) rc = e; }

@@ -406,10 +406,10 @@ template <int K, bool NT, int THREADS>
 static void forces_strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, int pass) {
     const int nstrips = (int)(c->ld / kOldStripCols);
     if (pass == 1)
-        hipLaunchKernelGGL((k_forces_xy<K, NT, THREADS>), dim3(nblk), dim3(THREADS), 0, c->stream, c->Y, c->ld, c->mp,
+        BIOEN_LAUNCH_TIMED(c, (k_forces_xy<K, NT, THREADS>), dim3(nblk), dim3(THREADS), 0, c->Y, c->ld, c->mp,
                            nstrips, c->n, c->um, fr, c->fixed, c->fwd_partial, nblk);
     else
-        hipLaunchKernelGGL((k_forces_bt<K, NT, true, THREADS>), dim3(nblk), dim3(THREADS), 0, c->stream, c->Y, c->ld,
+        BIOEN_LAUNCH_TIMED(c, (k_forces_bt<K, NT, true, THREADS>), dim3(nblk), dim3(THREADS), 0, c->Y, c->ld,
                            c->mp, nstrips, c->r_c, c->ybar_c, fr, c->fixed, c->fwd_partial, nblk);
 }
 

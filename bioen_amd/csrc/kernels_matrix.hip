@@ -444,7 +444,7 @@ template <int K, int STEPS, bool NT, bool CENTER>
 static void fwd_launch(bioen_hip_ctx* c, const Vec8& v) {
     const int total_steps = (int)(c->ld / 128);
     dim3 grid(c->mp / kRowAlign, c->fwd_ctiles);
-    hipLaunchKernelGGL((k_fwd_partial<8, K, STEPS, NT, CENTER>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld, v,
+    BIOEN_LAUNCH_TIMED(c, (k_fwd_partial<8, K, STEPS, NT, CENTER>), grid, dim3(kBlock), 0, c->Y, c->ld, v,
                        c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
 }
 
@@ -580,7 +580,7 @@ void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K) {
 template <int K, bool NT, bool CENTER>
 static void adj_launch(bioen_hip_ctx* c, const double* u_c, const MVec8& out) {
     dim3 grid((unsigned)(c->ld / 128));
-    hipLaunchKernelGGL((k_adj<8, K, NT, CENTER, (K >= 4 && K <= 7)>), grid, dim3(kBlock), 0, c->stream, c->Y, c->ld,
+    BIOEN_LAUNCH_TIMED(c, (k_adj<8, K, NT, CENTER, (K >= 4 && K <= 7)>), grid, dim3(kBlock), 0, c->Y, c->ld,
                        c->mp / kWaves, u_c, c->ybar_c, out);
 }
 

@@ -655,7 +655,7 @@ static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRou
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_strip<K, NT, XY>), dim3(q.nblk), block, lds, c->stream, q, fr);
+    BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY>), dim3(q.nblk), block, lds, q, fr);
 }
 
 template <bool NT, bool XY>
@@ -683,7 +683,7 @@ int fwd_strip_blocks(const bioen_hip_ctx* c) {
 
 template <int K, bool NT>
 static void fwd_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const Vec8& v, dim3 block) {
-    hipLaunchKernelGGL((k_strip_fwd<K, NT>), dim3(q.nblk), block, 0, c->stream, q, v);
+    BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT>), dim3(q.nblk), block, 0, q, v);
 }
 
 template <bool NT>
@@ -747,7 +747,7 @@ static void adj_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const MVec8
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_strip_adj<K, NT>), dim3(q.nblk), block, lds, c->stream, q, out, scal);
+    BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT>), dim3(q.nblk), block, lds, q, out, scal);
 }
 
 template <bool NT>
