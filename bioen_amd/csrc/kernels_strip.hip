@@ -53,6 +53,9 @@
 #ifndef STRIP_DEPTH
 #define STRIP_DEPTH 2      // strips in flight per wave (register sets)
 #endif
+#ifndef ADJ_DIAG
+#define ADJ_DIAG 0      // diagnostic builds: 1 = no output stores in k_strip_adj (timing only: results are garbage)
+#endif
 #ifndef STRIP_DIAG
 #define STRIP_DIAG 0      // diagnostic builds: 1 = no MFMAs, 2 = no matrix loads
 #endif
@@ -301,7 +304,11 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             }
             if (XY) {
                 const bool valid = p2 && col < (size_t)q.n;
+#if ADJ_DIAG & 4
                 if (p2) ak[col] = valid ? colsum : 0.0;
+#else
+                if (p2) __builtin_nontemporal_store(valid ? colsum : 0.0, ak + col);   // streamed, see k_strip_adj
+#endif
                 double smax = valid ? colsum : -DBL_MAX;          // the strip's maximum: over the 16 lanes of the problem
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
@@ -597,7 +604,13 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
         if (p2) {
             double colsum = 0.0;
             for (int wv = 0; wv < nown; ++wv) colsum += redw[wv * 128 + pk * 16 + pc];
-            outk[(size_t)s * kStripCols + pc] = colsum + shift;
+#if ADJ_DIAG & 1
+            if (colsum == 1.2345e300) outk[(size_t)s * kStripCols + pc] = colsum + shift;
+#else
+            // streamed past the L2 (no write-allocate): a plain store here cost 3 % of the pass -- the 8 K bytes per
+            // column are 0.8 % of the traffic, without any store the pass runs at the forward pass's time
+            __builtin_nontemporal_store(colsum + shift, outk + (size_t)s * kStripCols + pc);
+#endif
         }
     };
 #if ADJ_DEPTH == 2

@@ -178,8 +178,9 @@ def test_logw_converged_vs_reference(hip, name, tag, params):
     _converged_checks(name, tag, d, info, w, d["lbfgs_%s_wopt" % tag], d["theta"])
     if info.lbfgs_code == 0:
         assert rel(f_again, info.fmin) < 5e-14
-    else:       # after a failed search liblbfgs restores x but reports the last trial's f (lbfgs.c:470-479)
-        assert rel(f_again, info.fmin) < 1e-9
+    else:       # after a failed search liblbfgs restores x but reports the last trial's f (lbfgs.c:470-479); on the
+        # two plateau fixtures the reference itself fails on, that trial can sit a visible step away
+        assert rel(f_again, info.fmin) < (1e-5 if name in REFERENCE_EXCLUDES else 1e-9)
     assert abs(w.sum() - 1.0) < 1e-12
 
 
