@@ -304,11 +304,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             }
             if (XY) {
                 const bool valid = p2 && col < (size_t)q.n;
-#if ADJ_DIAG & 4
-                if (p2) ak[col] = valid ? colsum : 0.0;
-#else
-                if (p2) __builtin_nontemporal_store(valid ? colsum : 0.0, ak + col);   // streamed, see k_strip_adj
-#endif
+                if (p2) __builtin_nontemporal_store(valid ? colsum : 0.0, ak + col);   // streamed, see k_strip_adj (plain: +3..5 %)
                 double smax = valid ? colsum : -DBL_MAX;          // the strip's maximum: over the 16 lanes of the problem
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
@@ -472,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     __syncthreads();
     auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
         if (p2) tv[par][pk * 16 + pc] = ecur;                     // loaded during the previous strip
-        if (p2 && s + G < q.nstrips) ecur = vk[(size_t)(s + G) * kStripCols + pc];
+        if (p2 && s + G < q.nstrips) ecur = vk[(size_t)(s + G) * kStripCols + pc];   // (without these loads: -2 %; nontemporal: +1 %)
         __syncthreads();                                           // this strip's e is in place; the buffer of parity
                                                                    // `par` is rewritten two strips on, behind another barrier
         {
