@@ -44,12 +44,6 @@
 #ifndef STRIP_WAVES_PER_SIMD
 #define STRIP_WAVES_PER_SIMD 2
 #endif
-#ifndef FWD_DEPTH
-#define FWD_DEPTH 1        // k_strip_fwd: register sets per wave (16 waves per CU keep 128 KB in flight with one)
-#endif
-#ifndef ADJ_DEPTH
-#define ADJ_DEPTH 1
-#endif
 #ifndef STRIP_DEPTH
 #define STRIP_DEPTH 2      // strips in flight per wave (register sets)
 #endif
@@ -121,7 +115,8 @@ struct StripArgs {
     int nstrips;
     int n;                  // valid columns
     int K;
-    int nblk;
+    int nblk;               // partial sets (k_strip: = blocks)
+    int wps, spb;           // k_strip_fwd / k_strip_adj: waves per strip slot, strips per block and iteration
     const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
     const double* w0;
     double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
@@ -416,109 +411,105 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     }
 }
 
-// ---- log-weights forward pass on the strip copy: partial[block mp K + row K + k] = sum_{j in the block's strips} Y'[row][j] e_k[j]
+// ---- log-weights forward pass on the strip copy: partial[set mp K + row K + k] = sum_{j in the set's strips} Y'[row][j] e_k[j]
 // (A4, c_bioen_common.c:70-108; replaces k_fwd_partial for M <= 1024).  The copy is stored in the operand
 // order of this product, so the matrix goes HBM -> registers -> matrix cores: no LDS image, no shuffles, and the
 // K vectors e_k enter once per BLOCK and strip (16 K doubles through LDS, loaded one strip ahead) instead of once
 // per wave and KiB as in the streaming kernel, whose K = 8 launch took 1.28 x its K = 1 time for that reason.
-// A block = all rows of a strip, one wave per 64 rows (up to 16 waves: 128 registers each); one barrier per
-// strip, for the 16 K values of e.
+// Geometry: a wave owns 64 rows of one strip (128 registers: 16 waves per CU).  A block is `spb` strip slots of
+// `wps` waves each -- the whole CU for every M (M = 1024: 1 x 16, 512: 2 x 8, 256: 4 x 4, <= 128: 4 x 2) -- and does
+// `spb` strips per iteration behind ONE barrier: with one strip per block a 256-row problem ran 4 blocks of 4 waves
+// per CU, four times the barriers and per-strip bookkeeping per byte, at 4.8 TB/s instead of 6.9.  Slot `sub` of
+// block B is partial set B spb + sub and takes the strips set + it * (sets): the assignment, and therefore every
+// bit of the result, is that of one block per set.  A 64-row strip keeps a second, idle wave per slot (the 16 K
+// threads that stage e need up to two waves): it re-reads the first one's rows and stores nothing.
 template <int K, bool NT>
 __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     constexpr int NK = (K + 3) / 4;
-    __shared__ double tv[2][8 * kStripCols];                      // [parity][problem][column]
+    __shared__ double tv[2][4][8 * kStripCols];                   // [parity][slot][problem][column]
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int rbase = wave * kWaveRows;
-    const int rsrc = rbase < q.mps ? rbase : 0;                   // every wave runs the same code (see k_strip): the second
-                                                                  // wave of a 64-row strip re-reads the first one's rows, stores nothing
+    const int sub = wave / q.wps, rw = wave - sub * q.wps;
+    const int rbase = rw * kWaveRows;
+    const int rsrc = rbase < q.mps ? rbase : 0;
     const int lq = lane >> 4, lj = lane & 3;
-    const int G = gridDim.x;
+    const int stride = gridDim.x * q.spb;                          // strips between a slot's consecutive strips
 
     double acc[kWaveRows / 16][NK];
 #pragma unroll
     for (int h = 0; h < kWaveRows / 16; ++h)
 #pragma unroll
         for (int kq = 0; kq < NK; ++kq) acc[h][kq] = 0.0;
-    for (int i = t; i < 2 * 8 * kStripCols; i += blockDim.x) (&tv[0][0])[i] = 0.0;   // problems k >= K of a quad stay zero
+    for (int i = t; i < 2 * 4 * 8 * kStripCols; i += blockDim.x) (&tv[0][0][0])[i] = 0.0;   // problems k >= K of a quad stay zero
 
-    const bool p2 = t < kStripCols * K;                           // problem t / 16, column t % 16
-    const int pk = p2 ? t >> 4 : 0, pc = t & 15;
+    const bool p2 = t < q.spb * kStripCols * K;                   // slot t / 16 K, problem (t % 16 K) / 16, column t % 16
+    const int psub = p2 ? t / (kStripCols * K) : 0;
+    const int pk = p2 ? (t - psub * kStripCols * K) >> 4 : 0, pc = t & 15;
     const double* vk = v.p[0];                                    // chosen by comparison, not by a lane-indexed (vector) load
 #pragma unroll
     for (int k = 1; k < K; ++k)
         if (pk == k) vk = v.p[k];
-    d2 preA[kWaveRows / 8];
-#if FWD_DEPTH == 2
-    d2 preB[kWaveRows / 8];
-#endif
+    d2 pre[kWaveRows / 8];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
-    auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
+    auto fetch = [&](int strip) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
         for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
     };
-    int s = blockIdx.x;
-    double ecur = (p2 && s < q.nstrips) ? vk[(size_t)s * kStripCols + pc] : 0.0;
-    fetch(s, preA);                                                // grid <= strips: every block has a first strip
-#if FWD_DEPTH == 2
-    fetch(s + G < q.nstrips ? s + G : s, preB);
-#endif
+    int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
+    int sw = base + sub;                                           // this wave's strip (a slot beyond the last strip works on
+    int sp = base + psub;                                          //   a valid one against e = 0 and contributes nothing)
+    double ecur = (p2 && sp < q.nstrips) ? vk[(size_t)sp * kStripCols + pc] : 0.0;
+    fetch(sw < q.nstrips ? sw : base);
     __syncthreads();
-    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
-        if (p2) tv[par][pk * 16 + pc] = ecur;                     // loaded during the previous strip
-        if (p2 && s + G < q.nstrips) ecur = vk[(size_t)(s + G) * kStripCols + pc];   // (without these loads: -2 %; nontemporal: +1 %)
+    for (int par = 0; base < q.nstrips; base += stride, sw += stride, sp += stride, par ^= 1) {
+        if (p2) tv[par][psub][pk * 16 + pc] = ecur;               // loaded during the previous strip
+        ecur = (p2 && sp + stride < q.nstrips) ? vk[(size_t)(sp + stride) * kStripCols + pc] : 0.0;   // (without these loads: -2 %; nontemporal: +1 %)
         __syncthreads();                                           // this strip's e is in place; the buffer of parity
                                                                    // `par` is rewritten two strips on, behind another barrier
-        {
-            double bv[4][NK];
+        double bv[4][NK];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
+        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tv[par][(4 * kq + lj) * 16 + 4 * qq + lq];
-            // consecutive instructions go to different accumulators (a result is ready three issue slots later)
+            for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tv[par][sub][(4 * kq + lj) * 16 + 4 * qq + lq];
+        // consecutive instructions go to different accumulators (a result is ready three issue slots later)
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
+        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                for (int h = 0; h < kWaveRows / 16; ++h) {
-                    const d2 y = pre[2 * h + (qq >> 1)];
-                    const double a = (qq & 1) ? y.y : y.x;
+            for (int h = 0; h < kWaveRows / 16; ++h) {
+                const d2 y = pre[2 * h + (qq >> 1)];
+                const double a = (qq & 1) ? y.y : y.x;
 #pragma unroll
-                    for (int kq = 0; kq < NK; ++kq)
-                        acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
-                }
-            fetch(s + FWD_DEPTH * G < q.nstrips ? s + FWD_DEPTH * G : s, pre);   // unconditional, see k_strip_adj; operands consumed at issue
-        }
-    };
-#if FWD_DEPTH == 2
-    // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
-    for (; s + G < q.nstrips; s += 2 * G) {
-        one_strip(s, preA, 0);
-        one_strip(s + G, preB, 1);
+                for (int kq = 0; kq < NK; ++kq)
+                    acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
+            }
+        // unconditional (see k_strip_adj); the operands are consumed at issue.  Past its last strip a wave re-reads a
+        // strip it may touch (its own, or slot 0's)
+        const int nxt = sw + stride;
+        fetch(nxt < q.nstrips ? nxt : (sw < q.nstrips ? sw : base));
     }
-    if (s < q.nstrips) one_strip(s, preA, 0);
-#else
-    for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
-#endif
     {
         // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
+        const int set = blockIdx.x * q.spb + sub;
         const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
 #pragma unroll
         for (int h = 0; h < kWaveRows / 16; ++h)
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
-                if (row < q.mp && k < K) q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = acc[h][kq];   // transposed: a block's sums are one run
+                if (set < q.nblk && row < q.mp && k < K)
+                    q.partial[(size_t)set * q.mp * K + (size_t)row * K + k] = acc[h][kq];   // transposed: a set's sums are one run
             }
     }
 }
 
 // ---- log-weights adjoint pass on the strip copy (column-sum operand order):
 //   out_k[j] = sum_i u_ik (Y_ij - ybar_ik) = sum_i Y'_ij u_ik + shift_k,   shift_k = sum_i u_ik (center_i - ybar_ik)
-// (A6, c_bioen_kernels_logw.c:185-205; replaces k_adj for M <= 1024).  HBM -> registers -> matrix cores as in the
-// forward pass; u = r (compact [row K + k]) sits in an LDS table in B-operand reach, the waves' partial column
-// sums meet in LDS (two buffers by strip parity: one barrier per strip), 16 K threads add the shift and store.
+// (A6, c_bioen_kernels_logw.c:185-205; replaces k_adj for M <= 1024).  HBM -> registers -> matrix cores and the block
+// geometry as in the forward pass; u = r (compact [row K + k]) sits in an LDS table in B-operand reach, the partial
+// column sums of a slot's waves meet in LDS (two buffers by strip parity: one barrier per iteration), 16 K threads per
+// slot add the shift and store.
 template <int K, bool NT>
 __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec8 scal) {
     constexpr int NK = (K + 3) / 4;
@@ -527,19 +518,21 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int lrows = nwaves * kWaveRows;                         // LDS tables hold 64 rows per wave (see k_strip)
+    const int lrows = q.wps * kWaveRows;                          // the table holds 64 rows per wave of a slot
     double* ul = lds;                                             // u[row][8], zero beyond K and mp
     double* red = ul + (size_t)lrows * 8;                         // [parity][wave][problem 8][column 16]
-    const int rbase = wave * kWaveRows;
-    const int rsrc = rbase < q.mps ? rbase : 0;                   // the second wave of a 64-row strip re-reads the first one's rows
+    const int sub = wave / q.wps, rw = wave - sub * q.wps;
+    const int rbase = rw * kWaveRows;
+    const int rsrc = rbase < q.mps ? rbase : 0;                   // the idle second wave of a 64-row strip re-reads the first one's rows
     const int lq = lane >> 4, lj = lane & 3;
-    const int G = gridDim.x;
+    const int stride = gridDim.x * q.spb;
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
         ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
     }
-    const bool p2 = t < kStripCols * K;                           // problem t / 16, column t % 16
-    const int pk = p2 ? t >> 4 : 0, pc = t & 15;
+    const bool p2 = t < q.spb * kStripCols * K;                   // slot t / 16 K, problem (t % 16 K) / 16, column t % 16
+    const int psub = p2 ? t / (kStripCols * K) : 0;
+    const int pk = p2 ? (t - psub * kStripCols * K) >> 4 : 0, pc = t & 15;
     double shift = 0.0;
     double* outk = out.p[0];                                      // chosen by comparison, not by a lane-indexed (vector) load
     const double* sck = scal.p[0];
@@ -550,25 +543,20 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
             sck = scal.p[k];
         }
     if (p2) shift = sck[S_B0] - sck[S_UY];
-    d2 preA[kWaveRows / 8];
-#if ADJ_DEPTH == 2
-    d2 preB[kWaveRows / 8];                                       // two strips in flight per wave
-#endif
+    d2 pre[kWaveRows / 8];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
-    auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
+    auto fetch = [&](int strip) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
         for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
     };
-    int s = blockIdx.x;
-    fetch(s, preA);                                                // grid <= strips: every block has a first strip
-#if ADJ_DEPTH == 2
-    fetch(s + G < q.nstrips ? s + G : s, preB);
-#endif
+    int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
+    int sw = base + sub, sp = base + psub;                         // this wave's strip / the strip this thread stores for
+    fetch(sw < q.nstrips ? sw : base);
     __syncthreads();                                              // ul in place
     const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
     const int nown = q.mps / kWaveRows;
-    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
+    for (int par = 0; base < q.nstrips; base += stride, sw += stride, sp += stride, par ^= 1) {
         double* redw = red + (size_t)par * nwaves * 128;
         {
             double d[4][NK];
@@ -588,36 +576,28 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
                 for (int kq = 0; kq < NK; ++kq)
                     d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1[g][kq], d[g & 3][kq], 0, 0, 0);
             }
-            // unconditional (the tail re-reads its own strip): a conditional prefetch makes the compiler's vmcnt
-            // bookkeeping assume the other register set's loads may not exist, and every wait then drains BOTH sets
-            fetch(s + ADJ_DEPTH * G < q.nstrips ? s + ADJ_DEPTH * G : s, pre);    // the operands are consumed at issue
+            // unconditional (past its last strip a wave re-reads one it may touch): a conditional prefetch makes the
+            // compiler's vmcnt bookkeeping assume the loads may not exist, and every wait then drains them all
+            const int nxt = sw + stride;
+            fetch(nxt < q.nstrips ? nxt : (sw < q.nstrips ? sw : base));   // the operands are consumed at issue
             const int c = 4 * ((lane >> 2) & 3) + lq;             // result lane 16 i + 4 blk + j: column 4 blk + i, problem 4 kq + j
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq)
                 redw[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
         }
         __syncthreads();            // the buffer of this parity is rewritten two strips on, behind the next barrier
-        if (p2) {
+        if (p2 && sp < q.nstrips) {
             double colsum = 0.0;
-            for (int wv = 0; wv < nown; ++wv) colsum += redw[wv * 128 + pk * 16 + pc];
+            for (int wv = 0; wv < nown; ++wv) colsum += redw[(psub * q.wps + wv) * 128 + pk * 16 + pc];
 #if ADJ_DIAG & 1
-            if (colsum == 1.2345e300) outk[(size_t)s * kStripCols + pc] = colsum + shift;
+            if (colsum == 1.2345e300) outk[(size_t)sp * kStripCols + pc] = colsum + shift;
 #else
             // streamed past the L2 (no write-allocate): a plain store here cost 3 % of the pass -- the 8 K bytes per
             // column are 0.8 % of the traffic, without any store the pass runs at the forward pass's time
-            __builtin_nontemporal_store(colsum + shift, outk + (size_t)s * kStripCols + pc);
+            __builtin_nontemporal_store(colsum + shift, outk + (size_t)sp * kStripCols + pc);
 #endif
         }
-    };
-#if ADJ_DEPTH == 2
-    for (; s + G < q.nstrips; s += 2 * G) {
-        one_strip(s, preA, 0);
-        one_strip(s + G, preB, 1);
     }
-    if (s < q.nstrips) one_strip(s, preA, 0);
-#else
-    for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
-#endif
 }
 
 // ---- geometry ------------------------------------------------------------------------------------
@@ -681,18 +661,20 @@ static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
     }
 }
 
-// forward pass of the log-weights method on the strip copy (all K <= 8; M <= 1024: up to 16 waves per block)
+// geometry of the 16-wave kernels (k_strip_fwd / k_strip_adj): waves per strip slot, slots per block
+static int fa_wps(const bioen_hip_ctx* c) { return std::max(2, strip_rows(c) / kWaveRows); }
+static int fa_spb(const bioen_hip_ctx* c) { return std::max(1, std::min(16 / fa_wps(c), 4)); }
+
+// forward pass of the log-weights method on the strip copy (all K <= 8; M <= 1024): the number of partial sets
 int fwd_strip_blocks(const bioen_hip_ctx* c) {
     if (c->mp > 1024 || c->fwd_stream) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
-    const int waves = std::max(2, strip_rows(c) / kWaveRows);
-    const int per_cu = std::max(1, 16 / waves);                   // 128 registers per wave: 16 waves per CU
-    return std::min(std::min(256 * per_cu, kFusedBlocks), nstrips);
+    return std::min(256 * fa_spb(c), nstrips);
 }
 
 template <int K, bool NT>
 static void fwd_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const Vec8& v, dim3 block) {
-    BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT>), dim3(q.nblk), block, 0, q, v);
+    BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT>), dim3((q.nblk + q.spb - 1) / q.spb), block, 0, q, v);
 }
 
 template <bool NT>
@@ -721,7 +703,9 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk) {
     q.K = K;
     q.nblk = nblk;
     q.partial = c->fwd_partial;
-    const dim3 block(64 * std::max(2, strip_rows(c) / kWaveRows));
+    q.wps = fa_wps(c);
+    q.spb = fa_spb(c);
+    const dim3 block(64 * q.wps * q.spb);
     if (c->nontemporal) fwd_strip_launch_nt<true>(c, q, v, block);
     else fwd_strip_launch_nt<false>(c, q, v, block);
 }
@@ -744,8 +728,8 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
 }
 
 static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c) {
-    const int waves = std::max(2, strip_rows(c) / kWaveRows);
-    return ((size_t)waves * kWaveRows * 8 + (size_t)2 * waves * 128) * sizeof(double);
+    const int wps = fa_wps(c), waves = wps * fa_spb(c);          // u table of one slot's rows | two parity buffers of partial sums
+    return ((size_t)wps * kWaveRows * 8 + (size_t)2 * waves * 128) * sizeof(double);
 }
 
 template <int K, bool NT>
@@ -756,7 +740,7 @@ static void adj_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const MVec8
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT>), dim3(q.nblk), block, lds, q, out, scal);
+    BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT>), dim3((q.nblk + q.spb - 1) / q.spb), block, lds, q, out, scal);
 }
 
 template <bool NT>
@@ -786,7 +770,9 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
     q.K = K;
     q.nblk = nblk;
     q.u_c = u_c;
-    const dim3 block(64 * std::max(2, strip_rows(c) / kWaveRows));
+    q.wps = fa_wps(c);
+    q.spb = fa_spb(c);
+    const dim3 block(64 * q.wps * q.spb);
     const size_t lds = adj_strip_lds_bytes(c);
     if (c->nontemporal) adj_strip_launch_nt<true>(c, q, out, scal, block, lds);
     else adj_strip_launch_nt<false>(c, q, out, scal, block, lds);
