@@ -228,3 +228,60 @@ def test_bench_workload_is_pinned():
         assert (r["iterations"], r["evaluations"]) == (it, ev), (theta, r["iterations"], r["evaluations"])
         assert r["fmin"] == fmin, (theta, repr(r["fmin"]))
         assert (r2["iterations"], r2["evaluations"], r2["fmin"]) == (it, ev, fmin)
+
+
+def test_configs1_converged_against_the_reference_binary():
+    """BASELINE configs[1] (N = 1e5 x M = 256) against the REFERENCE's own C + liblbfgs path (oracle/_ref, built from
+    /root/reference in the build container; the .so travels with the repository), both run to convergence
+    (epsilon = 1e-9, delta = 0, past = 0): north_star's tolerances as they stand -- 1e-6 on the negative
+    log-posterior, 1e-5 max(w) on the weights -- at a size no golden fixture reaches.  Three thetas the reference
+    converges on in seconds; the device solves them as one lock-step batch."""
+    import bioen_amd
+    from oracle import ref_binding as R
+    from oracle import cpus
+    if not R.available():
+        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    M, N = 256, 100000
+    conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
+    thetas = [316.0, 100.0, 31.6]
+    YTrue, sig_sim, sig_exp, YTilde = _targets(M)
+    G = np.zeros(N)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, G, G, conv)
+        yT = np.ascontiguousarray(ctx.read_ytilde())
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cpus.usable_cpus())
+    for k, theta in enumerate(thetas):
+        g_ref, fmin_ref, code_ref = R.opt_lbfgs_logw(G, G, yT, YTilde, theta, conv)
+        assert code_ref == 0 and infos[k].lbfgs_code == 0, (theta, code_ref, infos[k].lbfgs_code)
+        assert rel(infos[k].fmin, fmin_ref) < 1e-6, (theta, infos[k].fmin, fmin_ref)
+        w_ref = np.asarray(R.get_weights(g_ref)[0]).ravel()          # the reference's own softmax (_get_weights)
+        assert abs(w_ref.sum() - 1.0) < 1e-9
+        assert np.abs(w[k] - w_ref).max() <= 1e-5 * w_ref.max(), (theta, np.abs(w[k] - w_ref).max() / w_ref.max())
+
+
+def test_configs1_forces_converged_against_the_reference_binary():
+    """The same size through the forces method: the reference's _opt_lbfgs_forces and the device's lock-step batch,
+    both with epsilon = 1e-9, delta = 0, past = 0.  Both end at the rounding floor of the line search (-998) or on
+    the gradient test; 1e-6 on the negative log-posterior and 1e-5 max(w) on the weights, as they stand."""
+    import bioen_amd
+    from oracle import ref_binding as R
+    from oracle import cpus
+    if not R.available():
+        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    M, N = 256, 100000
+    conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
+    thetas = [316.0, 100.0, 31.6]
+    YTrue, sig_sim, sig_exp, YTilde = _targets(M)
+    w0 = np.full(N, 1.0 / N)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, conv)
+        yT = np.ascontiguousarray(ctx.read_ytilde())
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cpus.usable_cpus())
+    for k, theta in enumerate(thetas):
+        f_ref, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, yT, YTilde, theta, conv)
+        assert code_ref in (0, -998, -1001) and infos[k].lbfgs_code in (0, -998, -1001), (theta, code_ref, infos[k].lbfgs_code)
+        assert rel(infos[k].fmin, fmin_ref) < 1e-6, (theta, infos[k].fmin, fmin_ref)
+        w_ref = np.asarray(R.forces_weights(f_ref, w0, yT)).ravel()
+        assert np.abs(w[k] - w_ref).max() <= 1e-5 * w_ref.max(), (theta, np.abs(w[k] - w_ref).max() / w_ref.max())
