@@ -230,8 +230,10 @@ def test_bench_workload_is_pinned():
         assert (r2["iterations"], r2["evaluations"], r2["fmin"]) == (it, ev, fmin)
 
 
-@pytest.mark.parametrize("prior", ["uniform", "random"])
-def test_configs1_converged_against_the_reference_binary(prior):
+@pytest.mark.parametrize("prior,M,N", [("uniform", 256, 100000), ("random", 256, 100000),
+                                       ("uniform", 1024, 20000),      # the headline's 16-wave strip geometry
+                                       ("uniform", 205, 50000)])      # configs[3]'s row count (padded strips)
+def test_configs1_converged_against_the_reference_binary(prior, M, N):
     """BASELINE configs[1] (N = 1e5 x M = 256) against the REFERENCE's own C + liblbfgs path (oracle/_ref, built from
     /root/reference in the build container; the .so travels with the repository), both run to convergence
     (epsilon = 1e-9, delta = 0, past = 0): north_star's tolerances as they stand -- 1e-6 on the negative
@@ -242,9 +244,8 @@ def test_configs1_converged_against_the_reference_binary(prior):
     from oracle import cpus
     if not R.available():
         pytest.skip("oracle/_ref/libbioen_ref.so not built")
-    M, N = 256, 100000
     conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
-    thetas = [316.0, 100.0, 31.6]
+    thetas = [316.0, 100.0, 31.6] if (M, N) == (256, 100000) else [316.0, 100.0]
     YTrue, sig_sim, sig_exp, YTilde = _targets(M)
     if prior == "uniform":
         G = np.zeros(N)
@@ -271,7 +272,8 @@ def test_configs1_converged_against_the_reference_binary(prior):
         assert np.abs(w[k] - w_ref).max() <= 1e-5 * w_ref.max(), (theta, np.abs(w[k] - w_ref).max() / w_ref.max())
 
 
-def test_configs1_forces_converged_against_the_reference_binary():
+@pytest.mark.parametrize("M,N", [(256, 100000), (512, 50000), (96, 30000)])
+def test_configs1_forces_converged_against_the_reference_binary(M, N):
     """The same size through the forces method: the reference's _opt_lbfgs_forces and the device's lock-step batch,
     both with epsilon = 1e-9, delta = 0, past = 0.  Both end at the rounding floor of the line search (-998) or on
     the gradient test; 1e-6 on the negative log-posterior and 1e-5 max(w) on the weights, as they stand."""
@@ -280,7 +282,6 @@ def test_configs1_forces_converged_against_the_reference_binary():
     from oracle import cpus
     if not R.available():
         pytest.skip("oracle/_ref/libbioen_ref.so not built")
-    M, N = 256, 100000
     conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
     thetas = [316.0, 100.0, 31.6]
     YTrue, sig_sim, sig_exp, YTilde = _targets(M)
