@@ -297,3 +297,37 @@ def test_configs1_forces_converged_against_the_reference_binary(M, N):
         assert rel(infos[k].fmin, fmin_ref) < 1e-6, (theta, infos[k].fmin, fmin_ref)
         w_ref = np.asarray(R.forces_weights(f_ref, w0, yT)).ravel()
         assert np.abs(w[k] - w_ref).max() <= 1e-5 * w_ref.max(), (theta, np.abs(w[k] - w_ref).max() / w_ref.max())
+
+
+@pytest.mark.parametrize("M,N", [(256, 100000), (1024, 20000), (512, 50000), (205, 50000), (1056, 12000)])
+def test_objective_and_gradient_against_the_reference_binary(M, N):
+    """One evaluation of both methods at random points with a non-uniform prior, device against the reference's C
+    functions (_bioen_log_posterior_*, _grad_bioen_log_posterior_*): every matrix-pass variant (strip kernels with 4, 8,
+    16 waves per strip and padded rows; streaming kernels at M = 1056) at sizes the golden fixtures do not reach."""
+    import bioen_amd
+    from oracle import ref_binding as R
+    from oracle import cpus
+    if not R.available():
+        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    YTrue, sig_sim, sig_exp, YTilde = _targets(M)
+    rng = np.random.default_rng(7 + M)
+    G = np.log(rng.gamma(2.0, 1.0, N))
+    G -= G.max()
+    g = G + 0.5 * rng.standard_normal(N)
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    forces = 1e-3 * rng.standard_normal(M)
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cpus.usable_cpus())
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        yT = np.ascontiguousarray(ctx.read_ytilde())
+        for theta in (0.7, 40.0):
+            f, grad = ctx.logw_fdf(g, G, theta)
+            f_ref = R.logw_f(g, G, yT, YTilde, theta)
+            grad_ref = np.asarray(R.logw_df(g, G, yT, YTilde, theta)).ravel()
+            assert rel(f, f_ref) < 1e-12, (theta, f, f_ref)
+            assert np.abs(grad - grad_ref).max() <= 1e-10 * np.abs(grad_ref).max(), theta
+            ff, fgrad = ctx.forces_fdf(forces, w0, theta)
+            ff_ref = R.forces_f(forces, w0, yT, YTilde, theta)
+            fgrad_ref = np.asarray(R.forces_df(forces, w0, yT, YTilde, theta)).ravel()
+            assert rel(ff, ff_ref) < 1e-12, (theta, ff, ff_ref)
+            assert np.abs(fgrad - fgrad_ref).max() <= 1e-10 * np.abs(fgrad_ref).max(), theta
