@@ -66,6 +66,8 @@ _SIGNATURES = {
     "bioen_hip_ctx_set_exchange_callback": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p]),
     "bioen_hip_ctx_shard": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "bioen_hip_ctx_set_force_exchange": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_exchange_counts": (C.c_int, [ctx_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_ctx_destroy": (C.c_int, [ctx_p]),
     "bioen_hip_ctx_shape": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bioen_hip_ctx_read_ytilde": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
@@ -583,6 +585,17 @@ class Context(object):
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(lib().bioen_hip_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def set_force_exchange(self, on=True):
+        """world = 1 only: execute the stage all-gathers of the sharded code path anyway (needs comm_init(id, 0, 1)
+        or set_exchange); results do not change by a bit.  Puts the RCCL stage path under single-GPU tests."""
+        check(lib().bioen_hip_ctx_set_force_exchange(self._h, 1 if on else 0))
+
+    def exchange_counts(self):
+        """(through RCCL, through the host callback): stage all-gathers executed on this context so far"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        check(lib().bioen_hip_exchange_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def exchange_probe(self, count=1024, reps=50):
         """microseconds per stage exchange (all-gather of `count` doubles per rank)"""

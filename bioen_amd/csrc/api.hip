@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <atomic>
 #include <memory>
@@ -71,7 +72,7 @@ static void choose_fwd_tiling(bioen_hip_ctx* c) {
     c->fwd_ctiles = (total_steps + spt - 1) / spt;
 }
 
-static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history) {
+static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history, bool with_spare = false) {
     ProblemSlot& sl = c->slot[s];
     int rc = 0;
     if (!sl.allocated) {
@@ -93,6 +94,10 @@ static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history) {
             if ((rc = dalloc_zero(&sl.Yh[i], c->ld, c->stream)) != 0) return rc;
         }
         sl.history = true;
+    }
+    if (with_spare && !sl.Ssp) {        // the pending (s, y) pair of the device-resident engine
+        if ((rc = dalloc_zero(&sl.Ssp, c->ld, c->stream)) != 0) return rc;
+        if ((rc = dalloc_zero(&sl.Ysp, c->ld, c->stream)) != 0) return rc;
     }
     return 0;
 }
@@ -146,6 +151,7 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     choose_fwd_tiling(c);
     // stream yTilde with non-temporal loads once it no longer fits the 256 MiB Infinity Cache
     c->nontemporal = (size_t)c->mp * c->ld * sizeof(double) > (size_t)192 * 1024 * 1024;
+    if (const char* e = std::getenv("BIOEN_HIP_FORCE_EXCHANGE")) c->force_exchange = (e[0] == '1') ? 1 : 0;
     {
         const char* e = std::getenv("BIOEN_HIP_STRIP_OLD");
         c->strip_old = (e && e[0] == '1') ? 1 : 0;
@@ -192,7 +198,7 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
         for (int st = 0; st < X_COUNT; ++st) {
             size_t cap = arrays[st] * kMaxBatch * npl;
             if (st == X_YBAR) cap = (size_t)(c->mp + 3) * kMaxBatch;
-            if (st == X_GRAMR) cap = world > 1 ? (size_t)kGramDots * kMaxBatch : 0;
+            if (st == X_GRAMR) cap = world > 1 ? (size_t)kDevRankSums * kMaxBatch : 0;
             if (st == X_VEC) cap = world > 1 ? c->ld : 0;
             c->xcap[st] = cap;
             if (cap) TRY(dalloc_zero(&c->xbuf[st], cap * world, c->stream));
@@ -230,11 +236,22 @@ static int upload_n(bioen_hip_ctx* c, double* dst, const double* src) {
 static int rccl_allgather_inplace(bioen_hip_ctx* c, double* base, size_t count);   // defined with the RCCL glue
 
 // One in-place all-gather of an exchange stage ([world][payload] doubles).  world == 1: nothing.
+// world == 1 with force_exchange (bioen_hip_ctx_set_force_exchange / BIOEN_HIP_FORCE_EXCHANGE=1) and a communicator
+// or callback in place: the one-rank all-gather is executed all the same -- a copy of the rank's segment onto
+// itself, same bits -- so the stage path can run under test on a single GPU.
+static bool exchanges_forced(const bioen_hip_ctx* c) {
+    return c->world == 1 && c->force_exchange && (c->comm || c->exchange_cb);
+}
+
 static int exchange(bioen_hip_ctx* c, int stage, size_t payload) {
-    if (c->world == 1) return 0;
+    if (c->world == 1 && !exchanges_forced(c)) return 0;
     double* base = c->xbuf[stage];
-    if (c->comm) return rccl_allgather_inplace(c, base, payload);
+    if (c->comm) {
+        ++c->n_rccl_exchanges;
+        return rccl_allgather_inplace(c, base, payload);
+    }
     if (!c->exchange_cb) return fail(BIOEN_HIP_ESTATE, "sharded context without a communicator");
+    ++c->n_host_exchanges;
     // host-staged path (processes that cannot share an RCCL communicator, e.g. tests on one GPU)
     const size_t total = payload * c->world;
     if (c->exchange_host_count < total) {
@@ -359,15 +376,23 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     int rc;
     c->last_width = r.n;
     c->last_pos = 0;
+    c->last_centered = false;
     launch_logw_exp(c, r);                 // A1: e = exp(x - m_r) + prior partials (shift: this rank's own maximum)
     Vec8 w{};
     for (int a = 0; a < r.n; ++a) w.p[a] = r.w[a];
-    const int nblk = fwd_strip_blocks(c);
+    int nblk = fwd_strip_blocks(c);
+    if (nblk > 0) {
+        // both strip copies before the first pass, so that one evaluation never mixes the two kernel families; a
+        // copy that cannot be allocated switches the context to the streaming kernels for good (strips_unavailable)
+        rc = ensure_strip_copy(c);
+        if (!rc && with_grad) rc = ensure_strip_copy_colsum(c);
+        if (rc && !c->strips_unavailable) return rc;
+        if (rc) nblk = 0;
+    }
     if (nblk > 0) {
         // M <= 1024: matrix pass 1 streams the strip-major centred copy straight into the matrix cores
         // (kernels_strip.hip: k_strip_fwd) -- the same time for every batch width; the centre returns in
         // k_rows_combine, which leaves the RAW ybar in ybar_c for the centred adjoint below
-        if ((rc = ensure_strip_copy(c))) return rc;
         launch_fwd_strip(c, r.n, w, nblk);
         launch_fwd_rows_local(c, r.n, true, nblk, true);
         if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, r.n, true)))) return rc;
@@ -430,8 +455,13 @@ static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
 static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
     int nblk = forces_fused_blocks(c);
     int rc;
+    if (nblk > 0 && !c->strip_old && (rc = ensure_strip_copy(c))) {
+        if (!c->strips_unavailable) return rc;
+        nblk = forces_fused_blocks(c);        // = 0 now: the kernels on the row-major matrix take over
+    }
     c->last_width = r.n;
     c->last_pos = 0;
+    c->last_centered = false;
     if ((nblk > 0 && c->strip_old) || (nblk == 0 && forces_fused_blocks_old(c) > 0)) {        // r01 kernels on the row-major matrix, kept for A/B measurements
         nblk = forces_fused_blocks_old(c);
         launch_forces_xy_old(c, fr, nblk);
@@ -461,13 +491,13 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         // the same k_rows_combine), the shares of the gradient in a second one.
         // Both passes read the strip-major copy centred on the targets (kernels_strip.hip); ybar_c then holds
         // ybar - center, the row offset of k_rows_combine puts the centre back for r, chi^2 and f.
-        if ((rc = ensure_strip_copy(c))) return rc;
         launch_forces_xy(c, fr, nblk);        // F1 + F2: x, online softmax, this rank's ybar   [matrix pass 1]
         if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
         launch_rows_combine(c, r, true, c->strip_center, false);   //     normalisation, ybar (centred), r, chi^2, KL, f
+        c->last_centered = true;               // ybar_c = ybar - strip_center (bioen_hip_last_average adds it back)
         if (with_grad) {
             launch_forces_bt(c, fr, nblk);    // F3: b, t, product with t            [matrix pass 2]
-            if (c->world == 1) {
+            if (c->world == 1 && !exchanges_forced(c)) {
                 launch_fwd_rows_forces_grad(c, fr.n, nblk, &fr, true);
             } else {
                 launch_fwd_rows_forces_grad_share(c, fr.n, nblk, &fr, true);
@@ -500,6 +530,7 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
 }
 
 #include "engine_logw.inl"
+#include "engine_devls.inl"
 #include "engine_forces.inl"
 #include "selftest_lbfgs.inl"
 
@@ -692,6 +723,19 @@ int bioen_hip_ctx_set_exchange_callback(bioen_hip_ctx* c, bioen_hip_exchange_fn 
     return 0;
 }
 
+int bioen_hip_ctx_set_force_exchange(bioen_hip_ctx* c, int on) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    c->force_exchange = on ? 1 : 0;
+    return 0;
+}
+
+int bioen_hip_exchange_counts(const bioen_hip_ctx* c, long long* rccl, long long* host_staged) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    if (rccl) *rccl = c->n_rccl_exchanges;
+    if (host_staged) *host_staged = c->n_host_exchanges;
+    return 0;
+}
+
 int bioen_hip_ctx_shard(const bioen_hip_ctx* c, int* rank, int* world, long long* n_global, long long* col0,
                         int* n_local) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
@@ -719,7 +763,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         if (p) hipFree(p);
     for (int s = 0; s < kMaxBatch; ++s) {
         ProblemSlot& sl = c->slot[s];
-        double* v[] = {sl.xa, sl.xb, sl.ga, sl.gb, sl.d, sl.w, sl.a};
+        double* v[] = {sl.xa, sl.xb, sl.ga, sl.gb, sl.d, sl.w, sl.a, sl.Ssp, sl.Ysp};
         for (double* p : v)
             if (p) hipFree(p);
         for (int i = 0; i < kHistory; ++i) {
@@ -732,6 +776,8 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
     if (c->exchange_host) hipHostFree(c->exchange_host);
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->live) hipHostFree(c->live);
+    if (c->live2) hipHostFree(c->live2);
+    if (c->dev_tab) hipFree(c->dev_tab);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->host_m) hipHostFree(c->host_m);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -864,7 +910,9 @@ int bioen_hip_opt_lbfgs_logw_batch(bioen_hip_ctx* c, int ntheta, const double* t
         print_config(*config);
     }
     LogwBatchEngine eng(c, *config, verbose);
-    return eng.run(ntheta, thetas, g0, g0_stride, G, max_batch, results, w_opt, infos);
+    const int rc = eng.run(ntheta, thetas, g0, g0_stride, G, max_batch, results, w_opt, infos);
+    if (ntheta > 1) c->last_width = 0;       // bioen_hip_last_average: single-problem calls only
+    return rc;
 }
 
 int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* c, const double* g0, const double* G, double theta,
@@ -965,6 +1013,7 @@ int bioen_hip_forces_fdf_batch(bioen_hip_ctx* c, int k, const double* forces, co
             for (int i = 0; i < c->m; ++i) grad[(size_t)a * c->m + i] = eng.gm_h[(size_t)i * k + a];
         if (f) f[a] = c->host_scal[(size_t)a * kScalStride + S_F];
     }
+    if (k > 1) c->last_width = 0;
     return 0;
 }
 
@@ -985,7 +1034,9 @@ int bioen_hip_opt_lbfgs_forces_batch(bioen_hip_ctx* c, int ntheta, const double*
         print_config(*config);
     }
     ForcesBatchEngine eng(c, *config, verbose);
-    return eng.run(ntheta, thetas, forces0, f0_stride, w0, max_batch, results, w_opt, infos);
+    rc = eng.run(ntheta, thetas, forces0, f0_stride, w0, max_batch, results, w_opt, infos);
+    if (ntheta > 1) c->last_width = 0;       // bioen_hip_last_average: single-problem calls only
+    return rc;
 }
 
 int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const double* w0, double theta,
@@ -1006,6 +1057,7 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     const Round r = make_round(c, one, 1, nullptr, nullptr);
     c->last_width = 1;
     c->last_pos = 0;
+    c->last_centered = false;
     Vec8 v{};
     v.p[0] = s0.w;
     launch_fwd_partial(c, 1, v);
@@ -1024,7 +1076,13 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
 int bioen_hip_last_average(bioen_hip_ctx* c, double* yraw, double* yeff) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    std::vector<double> raw((size_t)c->m), off((size_t)c->m), sc((size_t)c->m);
+    if (c->last_width <= 0)
+        return fail(BIOEN_HIP_ESTATE, "no single-problem call to take the averages from (a multi-problem call ran last)");
+    std::vector<double> raw((size_t)c->m), off((size_t)c->m), sc((size_t)c->m), cen;
+    if (c->last_centered) {        // the forces strip passes keep ybar - centre; the centre goes back here
+        cen.resize((size_t)c->m);
+        BIOEN_HIP_CHECK(hipMemcpyAsync(cen.data(), c->strip_center, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     // compact layout of the round that wrote it: ybar_c[row * width + column]
     BIOEN_HIP_CHECK(hipMemcpy2DAsync(raw.data(), sizeof(double), c->ybar_c + c->last_pos,
                                      (size_t)c->last_width * sizeof(double), sizeof(double), (size_t)c->m,
@@ -1033,6 +1091,7 @@ int bioen_hip_last_average(bioen_hip_ctx* c, double* yraw, double* yeff) {
     BIOEN_HIP_CHECK(hipMemcpyAsync(sc.data(), c->row_scale, (size_t)c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < c->m; ++i) {
+        if (c->last_centered) raw[i] += cen[i];
         if (yraw) yraw[i] = raw[i];
         if (yeff) yeff[i] = off[i] + sc[i] * raw[i];
     }

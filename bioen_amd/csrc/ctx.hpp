@@ -35,6 +35,7 @@ constexpr int kRowAlign = 32;
 constexpr int kMaxPartials = 1024; // upper bound on any reduction grid
 constexpr int kMaxBatch = 8;       // thetas sharing one matrix pass
 constexpr int kScalStride = 32;    // doubles per slot in `scal`
+constexpr int kLiveRing = 4;       // pages of the device engine's live ring (rounds in flight + being read)
 constexpr int kBasis = 2 * kHistory + 1;   // S[6], Y[6], g
 constexpr int kGramDots = 3 * kBasis;      // new s, new y, new g against the basis
 constexpr int kGramStride = 256;           // doubles per slot: 13x13 Gram matrix + 13 coefficients + 39 sums
@@ -126,6 +127,7 @@ struct ProblemSlot {
     double* S[kHistory] = {};
     double* Yh[kHistory] = {};
     double* scal = nullptr;   // kScalStride doubles inside ctx->scal
+    double *Ssp = nullptr, *Ysp = nullptr;   // spare (s, y) pair of the device-resident engine (kernels.hpp: DevSlot)
     double* part = nullptr;   // P_COUNT * kMaxPartials doubles inside ctx->part (local partials)
     double* gram = nullptr;   // kGramStride doubles inside ctx->gram
 };
@@ -148,6 +150,9 @@ struct bioen_hip_ctx {
     double* exchange_host = nullptr;
     size_t exchange_host_count = 0;
     int exchange_error = 0;
+    int force_exchange = 0;              // world == 1: run the stage exchanges all the same (through the communicator or the
+                                         // callback, if there is one) -- puts the RCCL stage path under single-GPU tests
+    long long n_rccl_exchanges = 0, n_host_exchanges = 0;   // stage all-gathers executed so far, by transport
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // results of finished problems leave on this one (engine_logw.inl: deliveries)
 
@@ -159,6 +164,7 @@ struct bioen_hip_ctx {
     double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
     int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)
     int strip_old = 0;               // BIOEN_HIP_STRIP_OLD=1: the r01 strip kernels on the row-major matrix (A/B)
+    int strips_unavailable = 0;      // a strip copy could not be allocated: the streaming kernels serve this context
     double* YT = nullptr;      // mp   experimental targets (YTilde)
     // affine observable model: yTilde_eff[i][j] = row_offset[i] + row_scale[i] * Y[i][j]
     // (default 0, 1).  DEER / SAXS nuisance parameters enter exactly like this, so a refit never
@@ -168,7 +174,9 @@ struct bioen_hip_ctx {
     bool affine = false;            // anything but (0, 1)
     double* ybar_c = nullptr;  // mp * kMaxBatch, compact per round
     int last_width = 1, last_pos = 0;   // width of the round that wrote ybar_c last / column of the problem
-                                        // bioen_hip_last_average hands out (a finished problem's, else 0)
+                                        // bioen_hip_last_average hands out (a finished problem's, else 0);
+                                        // width 0: nothing to hand out (a multi-problem call ran last)
+    bool last_centered = false;         // ybar_c holds ybar - strip_center (forces strip passes), not the raw average
     double* r_c = nullptr;     // mp * kMaxBatch
     double* um = nullptr;      // mp * kMaxBatch  forces of the round's problems, compact [row*K + a]
     double* gm = nullptr;      // mp * kMaxBatch  forces gradients, compact
@@ -177,6 +185,10 @@ struct bioen_hip_ctx {
     double* g0 = nullptr;      // ld   shared start vector of a batch run (lazy)
 
     bioen::ProblemSlot slot[bioen::kMaxBatch];
+    // device-resident line-search decisions (kernels.hpp: DevSlot; engine_devls.inl)
+    void* dev_tab = nullptr;             // DevSlot[kMaxBatch], device memory
+    double* live2 = nullptr;             // host-mapped: kLiveRing pages of kMaxBatch records | kLiveRing x kMaxBatch flags
+    unsigned long long dev_round = 0;    // last round number handed out
 
     double* fwd_partial = nullptr;   // kMaxBatch * mp * fwd_ctiles, compact per round
     int fwd_ctiles = 0;              // column tiles of the forward pass

@@ -183,6 +183,70 @@ __device__ __forceinline__ double xmax_local(const Xch& x, int a, int q, double*
     return block_max(s, sh);
 }
 
+// The scalar part of the Gram-form direction (kernels_logw.hip: k_gram_solve; kernels_devls.hip: k_dev_decide), run by
+// ONE thread: the 39 finished sums `dots` update rows / columns s_e, y_e, g of the 13 x 13 Gram matrix (G in HBM, Gs
+// its LDS image), then the two-loop recursion (lbfgs.c:571-598) runs on 13 coefficients over {S_0..5, Y_0..5, g};
+// the coefficients go to G[169..181], gp . d to scal[S_DGINIT].
+__device__ __forceinline__ void gram_solve_thread0(double* G, double* Gs, const double* dots, double* alpha, int e,
+                                                   int bound, double* scal) {
+    const int rs = e, ry = kHistory + e, rg = 2 * kHistory;
+    for (int c = 0; c < kBasis; ++c) {
+        Gs[rs * kBasis + c] = Gs[c * kBasis + rs] = dots[c];
+        Gs[ry * kBasis + c] = Gs[c * kBasis + ry] = dots[kBasis + c];
+    }
+    for (int c = 0; c < kBasis; ++c) Gs[rg * kBasis + c] = Gs[c * kBasis + rg] = dots[2 * kBasis + c];
+    for (int c = 0; c < kBasis; ++c) {        // the three rows/columns that changed go back to HBM
+        G[rs * kBasis + c] = G[c * kBasis + rs] = Gs[rs * kBasis + c];
+        G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
+        G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
+    }
+    // q = -g as coefficients over {S, Y, g}.  The coefficients stay in registers (an LDS array put a store -> load
+    // round trip into every step of the two dependent chains); slot numbers are run-time values, so the one entry a
+    // step changes is picked by comparison.  Same operations in the same order as before.
+    double cf[kBasis];
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] = c == rg ? -1.0 : 0.0;
+    for (int b = 0; b < bound; ++b) {         // first loop, newest -> oldest
+        const int i = (e + kHistory - b) % kHistory;
+        double row[kBasis];
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) row[c] = Gs[i * kBasis + c];
+        const double diag = Gs[(kHistory + i) * kBasis + i];
+        double sq = 0.0;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) sq = fma(cf[c], row[c], sq);
+        const double al = sq / diag;
+        alpha[i] = al;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c)
+            if (c == kHistory + i) cf[c] -= al;
+    }
+    const double scale = Gs[ry * kBasis + rs] / Gs[ry * kBasis + ry];   // ys / yy of the newest pair
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] *= scale;
+    for (int b = bound - 1; b >= 0; --b) {    // second loop, oldest -> newest
+        const int i = (e + kHistory - b) % kHistory;
+        double row[kBasis];
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) row[c] = Gs[(kHistory + i) * kBasis + c];
+        const double diag = Gs[(kHistory + i) * kBasis + i];
+        const double al = alpha[i];
+        double yq = 0.0;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) yq = fma(cf[c], row[c], yq);
+        const double beta = yq / diag;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c)
+            if (c == i) cf[c] += al - beta;
+    }
+    double dg = 0.0;
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) dg = fma(cf[c], Gs[rg * kBasis + c], dg);
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = cf[c];
+    scal[S_DGINIT] = dg;
+}
+
 template <bool NT>
 __device__ __forceinline__ d2 ldg2(const double* p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));

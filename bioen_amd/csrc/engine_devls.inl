@@ -1,0 +1,366 @@
+// Device-resident variant of the log-weights batch engine (part of api.hip's translation unit; kernels:
+// kernels_devls.hip).  Replaces the per-round host decisions of LogwBatchEngine::run -- liblbfgs' iteration logic,
+// third-party/liblbfgs-1.10/lib/lbfgs.c:460-616, and its line searches -- by a decision kernel per round, so that
+//   * a round is 8 launches instead of 11 and ends without a host turn-around,
+//   * the host enqueues round r + 1 while round r runs (`depth` rounds ahead) and only watches a host-mapped page for
+//     finished problems: it composes rounds (who is in the batch, which idle slots shadow whom), starts and finishes
+//     problems, nothing else,
+//   * a sharded context exchanges twice per round (ybar; gradient sums + Gram products) instead of three times.
+// Results equal the host-driven engine's to the last bit (same kernels' arithmetic in the same order; the tests run
+// both).  BIOEN_HIP_DEVICE_LS=0 selects the host-driven engine, BIOEN_HIP_QUEUE=0 makes the host wait for every round.
+
+struct DevFlight {                   // a round in flight, as the host composed it
+    unsigned long long round = 0;
+    int n = 0, nown = 0;
+    int slot[kMaxBatch] = {};
+    int prob[kMaxBatch] = {};        // owners: index of the problem (theta) that occupied the slot at enqueue time
+};
+
+bool LogwBatchEngine::device_engine_applies() const {
+    const char* e = std::getenv("BIOEN_HIP_DEVICE_LS");
+    if (e && e[0] == '0') return false;
+    if (c->live_off) return false;                      // no coherent host memory to publish into
+    if (!use_gram()) return false;                      // liblbfgs' literal two-loop on the vectors: host-driven engine
+    if (cfg.past > kMaxPast) return false;
+    return true;
+}
+
+int LogwBatchEngine::ensure_device_state() {
+    if (!c->dev_tab) {
+        void* p = nullptr;
+        const size_t bytes = (size_t)kMaxBatch * sizeof(DevSlot) + 64;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (role table)", __FILE__, __LINE__);
+        BIOEN_HIP_CHECK(hipMemsetAsync(p, 0, bytes, c->stream));
+        c->dev_tab = p;
+    }
+    if (!c->live2) {
+        const size_t cnt = (size_t)kLiveRing * kMaxBatch * (kLiveRec + 1);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->live2), cnt * sizeof(double),
+                                     hipHostMallocCoherent | hipHostMallocMapped);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c->live2 = nullptr;
+            return BIOEN_HIP_ENOMEM;
+        }
+        std::memset(c->live2, 0, cnt * sizeof(double));
+    }
+    return 0;
+}
+
+// wait until the `nown` decisions of round `f` are published; -> rc
+int LogwBatchEngine::await_flight(const DevFlight& f) {
+    const int pg = (int)(f.round % kLiveRing);
+    const volatile unsigned long long* flag =
+        reinterpret_cast<const volatile unsigned long long*>(c->live2 + (size_t)kLiveRing * kMaxBatch * kLiveRec) +
+        (size_t)pg * kMaxBatch;
+    for (int a = 0; a < f.nown; ++a) {
+        unsigned spins = 0;
+        while (flag[a] != f.round) {
+            if ((++spins & 0xfffu) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) {
+                    if (flag[a] == f.round) break;
+                    return fail(BIOEN_HIP_ESTATE, "round finished without publishing its decisions");
+                }
+                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 0;
+}
+
+int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride,
+                                const double* G_host, int max_batch, double* results, double* w_opt,
+                                bioen_opt_result* infos) {
+    const int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
+    const bool can_speculate = speculate && cfg.linesearch >= 1 && cfg.linesearch <= 3;
+    const int nslots = can_speculate ? kMaxBatch : kb;
+    for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, true));
+    note(ensure_device_state());
+    if (rc) return rc;
+    note(upload_n(c, c->fixed, G_host));
+    const bool shared_start = (g0_stride == 0) || ntheta == 1;
+    if (shared_start) {
+        if (!c->g0) note(dalloc_zero(&c->g0, c->ld, c->stream));
+        if (rc) return rc;
+        note(upload_n(c, c->g0, g0_host));
+    }
+    {   // log sum exp(G) once, written into every slot of the batch
+        int all[kMaxBatch];
+        for (int s = 0; s < nslots; ++s) all[s] = s;
+        const Round r = make_round(c, all, nslots, nullptr, nullptr);
+        if (c->world == 1) {
+            launch_logw_logs0(c, r);
+        } else {   // G is sharded on the device but whole on the host: same value on every rank
+            const double v = host_logsumexp(G_host, c->n_global);
+            for (int s = 0; s < nslots; ++s)
+                note(hipMemcpyAsync(c->slot[s].scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream),
+                     "logs0");
+            note(hipStreamSynchronize(c->stream), "sync");
+        }
+    }
+    DevSlot* tab = static_cast<DevSlot*>(c->dev_tab);
+    unsigned long long* spec_dev = reinterpret_cast<unsigned long long*>(tab + kMaxBatch);
+    launch_dev_table_init(c, nslots);
+    note(hipMemsetAsync(spec_dev, 0, 2 * sizeof(unsigned long long), c->stream), "memset");   // adopted shadows | problems alive
+
+    int depth = 1;
+    if (const char* e = std::getenv("BIOEN_HIP_QUEUE")) depth = std::max(0, std::min(kLiveRing - 2, std::atoi(e)));
+
+    // host view of the slots
+    bool occupied[kMaxBatch] = {};
+    int prob[kMaxBatch];                               // problem index per occupied slot
+    unsigned long long initial_round[kMaxBatch] = {};  // the round that evaluates the slot's start point
+    std::chrono::steady_clock::time_point t0[kMaxBatch];
+    int shadow_owner[kMaxBatch], shadow_cand[kMaxBatch];   // idle slots: slot of the owner they shadow (-1: none)
+    for (int s = 0; s < kMaxBatch; ++s) { prob[s] = -1; shadow_owner[s] = -1; shadow_cand[s] = 0; }
+    int next = 0, active = 0;
+    std::deque<DevFlight> inflight;
+
+    auto start_problem = [&](int s) {
+        settle(s);                                   // the previous tenant's results have left
+        ProblemSlot& sl = c->slot[s];
+        DevStart st{};
+        st.n = 1;
+        st.slot[0] = s;
+        st.d[0] = sl.d;
+        st.gram[0] = sl.gram;
+        st.tab = tab;
+        if (shared_start) {
+            st.g0[0] = c->g0;
+        } else {                                     // staged in the slot's adjoint buffer (scratch between rounds)
+            note(upload_n(c, sl.a, g0_host + (size_t)next * g0_stride));
+            st.g0[0] = sl.a;
+        }
+        launch_dev_start(c, st, cfg);
+        occupied[s] = true;
+        prob[s] = next;
+        initial_round[s] = c->dev_round + 1;         // the next round enqueued
+        t0[s] = std::chrono::steady_clock::now();
+        shadow_owner[s] = -1;
+        ++active;
+        ++next;
+    };
+
+    auto finish_problem = [&](int s, const DevRecord& rec, int column) {
+        ProblemSlot& sl = c->slot[s];
+        const double theta = thetas[prob[s]];
+        c->last_pos = column;                        // where this problem's averages sit in ybar_c (bioen_hip_last_average)
+        bioen_opt_result& info = infos[prob[s]];
+        info.lbfgs_code = rec.code;
+        info.iterations = rec.iterations;
+        info.evaluations = rec.evaluations;
+        info.fmin = rec.fx;
+        const double* res = rec.keep_trial ? rec.x : rec.xp;
+        const double* h = rec.scal;
+        const double* wsrc = rec.w;
+        Round rr{};
+        rr.n = 1;
+        rr.x[0] = rec.x; rr.xp[0] = rec.xp; rr.g[0] = rec.g; rr.gp[0] = rec.gp;
+        rr.d[0] = sl.d; rr.w[0] = sl.w; rr.a[0] = sl.a; rr.scal[0] = sl.scal; rr.part[0] = sl.part;
+        rr.theta[0] = theta;
+        if (!rec.keep_trial && !rec.was_initial) {
+            // line search failed: liblbfgs returns the previous point; re-establish w, chi^2, KL there
+            note(hipMemcpyAsync(rec.x, rec.xp, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "revert");
+            launch_max(c, rr);
+            note(enqueue_logw_eval(c, rr, false));
+            note(read_scalars(c, kMaxBatch));
+            res = rec.x;
+            h = c->host_scal + (size_t)s * kScalStride;
+            wsrc = sl.w;
+        }
+        info.chi2 = 0.5 * h[S_CHI];
+        info.kl = h[S_P] - h[S_LOGS] + h[S_LOGS0];
+        if (w_opt) {
+            if (wsrc != sl.w)                        // the evaluation the problem stands on was an adopted shadow's
+                note(hipMemcpyAsync(sl.w, wsrc, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "adopt e");
+            launch_scale_w(c, rr);                   // e -> w, only now
+        }
+        if (async_delivery) {
+            deliver(s, results + (size_t)prob[s] * c->n_global, res,
+                    w_opt ? w_opt + (size_t)prob[s] * c->n_global : nullptr, sl.w);
+        } else {
+            note(download_n(c, results + (size_t)prob[s] * c->n_global, res));
+            if (w_opt) note(download_n(c, w_opt + (size_t)prob[s] * c->n_global, sl.w));
+            note(hipStreamSynchronize(c->stream), "sync");   // pageable destination: complete before the slot is reused
+        }
+        info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0[s]).count();
+        if (verbose) {
+            std::printf("\ttheta = %g\n", theta);
+            print_summary(c, info);
+        }
+        occupied[s] = false;
+        prob[s] = -1;
+        --active;
+    };
+
+    // compose and enqueue one round from what the host knows now
+    auto enqueue_round = [&]() {
+        DevRound r{};
+        DevFlight f;
+        r.tab = tab;
+        const unsigned long long round = c->dev_round + 1;
+        int pos_of_slot[kMaxBatch];
+        for (int s = 0; s < kMaxBatch; ++s) pos_of_slot[s] = -1;
+        int k = 0, first_mask = 0;
+        for (int s = 0; s < kb; ++s) {
+            if (!occupied[s]) continue;
+            pos_of_slot[s] = k;
+            r.slot[k] = s;
+            r.owner[k] = k;
+            r.cand[k] = 0;
+            f.prob[k] = prob[s];
+            if (initial_round[s] == round) first_mask |= 1 << k;
+            ++k;
+        }
+        r.nown = k;
+        // Speculation: idle slots evaluate the steps a backtracking search may ask for next.  Assignments persist from
+        // round to round (a slot changes its owner only once that owner is known to be finished -- the host runs a
+        // round behind the device, and a shadow adopted in a round it has not seen yet must not be handed on)
+        if (can_speculate) {
+            const int ncand = cfg.linesearch == 1 ? 1 : 2;
+            bool has[kMaxBatch][3] = {};
+            for (int s = 0; s < nslots; ++s) {
+                if (shadow_owner[s] < 0) continue;
+                const int o = shadow_owner[s];
+                if ((s < kb && occupied[s]) || !occupied[o] || slot_busy(s)) { shadow_owner[s] = -1; continue; }
+                has[o][shadow_cand[s]] = true;
+            }
+            for (int pass = 1; pass <= ncand; ++pass)
+                for (int o = 0; o < kb; ++o) {
+                    if (!occupied[o] || has[o][pass]) continue;
+                    for (int s = nslots - 1; s >= 0; --s) {
+                        if ((s < kb && occupied[s]) || shadow_owner[s] >= 0 || slot_busy(s)) continue;
+                        shadow_owner[s] = o;
+                        shadow_cand[s] = pass;
+                        has[o][pass] = true;
+                        break;
+                    }
+                }
+            for (int s = 0; s < nslots && k < kMaxBatch; ++s) {
+                if (shadow_owner[s] < 0) continue;
+                const int o = shadow_owner[s];
+                if (initial_round[o] >= round) continue;          // the start point is evaluated alone
+                r.slot[k] = s;
+                r.owner[k] = pos_of_slot[o];
+                r.cand[k] = shadow_cand[s];
+                ++k;
+                ++spec_launched;
+            }
+        }
+        r.n = k;
+        Vec8 wv{};
+        MVec8 av{}, sv{};
+        Round rd{};
+        DevGate gate{};
+        rd.n = k;
+        gate.tab = tab;
+        for (int a = 0; a < k; ++a) {
+            const ProblemSlot& sl = c->slot[r.slot[a]];
+            const ProblemSlot& ow = c->slot[r.slot[r.owner[a]]];
+            r.theta[a] = thetas[prob[r.slot[r.owner[a]]]];
+            r.d[a] = ow.d;
+            r.gram[a] = sl.gram;
+            r.w[a] = sl.w;
+            r.a[a] = sl.a;
+            r.scal[a] = sl.scal;
+            wv.p[a] = sl.w;
+            av.p[a] = sl.a;
+            sv.p[a] = sl.scal;
+            rd.scal[a] = sl.scal;
+            rd.part[a] = sl.part;
+            rd.theta[a] = r.theta[a];
+            gate.slot[a] = r.slot[r.owner[a]];
+            gate.cand[a] = r.cand[a];
+            f.slot[a] = r.slot[a];
+        }
+        c->dev_round = round;
+        f.round = round;
+        f.n = k;
+        f.nown = r.nown;
+        c->last_width = k;
+        c->last_pos = 0;
+        c->last_centered = false;
+
+        launch_dev_step(c, r);
+        launch_dev_exp(c, r);
+        int nblk = fwd_strip_blocks(c);
+        if (nblk > 0) {
+            int e = ensure_strip_copy(c);
+            if (!e) e = ensure_strip_copy_colsum(c);
+            if (e && !c->strips_unavailable) note(e);
+            if (e) nblk = 0;
+        }
+        if (nblk > 0) {
+            launch_fwd_strip(c, k, wv, nblk);
+            launch_fwd_rows_local(c, k, true, nblk, true);
+            note(exchange(c, X_YBAR, (size_t)ybar_payload(c, k, true)));
+            launch_rows_combine(c, rd, true, c->strip_center, true, &gate);
+            launch_adj_strip(c, k, c->r_c, av, sv, nblk);
+        } else {
+            launch_fwd_partial(c, k, wv);
+            launch_fwd_rows_local(c, k, true);
+            note(exchange(c, X_YBAR, (size_t)ybar_payload(c, k, true)));
+            launch_rows_combine(c, rd, true, nullptr, true, &gate);
+            launch_adj(c, k, c->r_c, av, true);
+        }
+        launch_dev_grad_gram(c, r);
+        if (c->world > 1) {
+            launch_dev_rank_reduce(c, r);
+            note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
+        } else {                                    // one rank: nothing to do unless the exchanges are forced (tests)
+            note(exchange(c, X_GRAD, 3 * k * (size_t)vec_grid(c)));
+            note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));
+        }
+        launch_dev_decide(c, r, cfg, round);
+        if (first_mask) {
+            launch_dev_first_direction(c, r, first_mask);
+            note(exchange(c, X_DGI, (size_t)r.nown * vec_grid(c)));
+            launch_dev_store_dginit(c, r, first_mask);
+        }
+        note(check_launch());
+        inflight.push_back(f);
+    };
+
+    for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
+
+    while (active > 0 && !rc) {
+        while ((int)inflight.size() <= depth && !rc) enqueue_round();
+        if (rc) break;
+        const DevFlight f = inflight.front();
+        inflight.pop_front();
+        note(await_flight(f));
+        if (rc) break;
+        const double* page = c->live2 + (size_t)(f.round % kLiveRing) * kMaxBatch * kLiveRec;
+        for (int a = 0; a < f.nown; ++a) {
+            const int s = f.slot[a];
+            if (!occupied[s] || prob[s] != f.prob[a]) continue;      // finished before; the slot may have a new tenant
+            DevRecord rec;
+            std::memcpy(&rec, page + (size_t)a * kLiveRec, sizeof rec);
+            if (rec.status != DS_DONE) continue;
+            int column = a;
+            if (rec.adopted)
+                for (int q = f.nown; q < f.n; ++q)
+                    if (c->slot[f.slot[q]].w == rec.w) column = q;
+            finish_problem(s, rec, column);
+            if (next < ntheta && !rc) start_problem(s);
+        }
+    }
+    note(hipStreamSynchronize(c->stream), "sync");      // rounds still in flight are dead ones: every problem has finished
+    note(check_launch());
+    for (int s = 0; s < kMaxBatch; ++s) settle(s);
+    if (!rc) {
+        unsigned long long used = 0;
+        note(hipMemcpy(&used, spec_dev, sizeof used, hipMemcpyDeviceToHost), "spec");
+        spec_used += (long long)used;
+    }
+    c->spec_launched += spec_launched;
+    c->spec_used += spec_used;
+    if (verbose && spec_launched)
+        std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n",
+                    spec_launched, spec_used);
+    return rc;
+}

@@ -60,8 +60,11 @@ struct LogwBatchEngine {
         if (!c->copy_stream) note(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
         hipEvent_t ev = nullptr;
         note(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
-        if (rc) return;
-        note(hipEventRecord(ev, c->stream), "hipEventRecord");
+        if (!rc) note(hipEventRecord(ev, c->stream), "hipEventRecord");
+        if (rc) {
+            if (ev) (void)hipEventDestroy(ev);
+            return;
+        }
         Delivery* d = new Delivery;
         pending[s].reset(d);
         const int dev = c->device;
@@ -93,6 +96,13 @@ struct LogwBatchEngine {
         return c->direction_mode != 1;   // auto = Gram form
     }
 
+    // device-resident line-search decisions (engine_devls.inl)
+    bool device_engine_applies() const;
+    int ensure_device_state();
+    int await_flight(const struct DevFlight& f);
+    int run_device(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride, const double* G_host,
+                   int max_batch, double* results, double* w_opt, bioen_opt_result* infos);
+
     // Gram form (see kernels.hpp: GramArgs): 3 launches and one exchange for all accepting problems
     void directions_gram(BatchProblem* slots, const std::vector<int>& list) {
         GramArgs ga{};
@@ -115,6 +125,8 @@ struct LogwBatchEngine {
         if (c->world > 1) {                       // ship 39 totals per problem, not 39 x blocks partials
             launch_gram_rank_reduce(c, ga.n);
             note(exchange(c, X_GRAMR, (size_t)kGramDots * ga.n));
+        } else {                                  // one rank: nothing to do unless the exchanges are forced (tests)
+            note(exchange(c, X_GRAM, (size_t)kGramDots * ga.n * vec_grid(c)));
         }
         launch_gram_solve(c, ga);
         launch_combine(c, ga);
@@ -239,6 +251,8 @@ struct LogwBatchEngine {
             }
             return 0;
         }
+        if (device_engine_applies())
+            return run_device(ntheta, thetas, g0_host, g0_stride, G_host, max_batch, results, w_opt, infos);
         int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
         for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, true));
         if (rc) return rc;
@@ -413,7 +427,10 @@ struct LogwBatchEngine {
                 note(read_scalars(c, kMaxBatch));
                 note(check_launch());
             }
-            if (rc) break;
+            if (rc) {
+                c->live_round = 0;        // a round that failed before its last kernel must not lend its number to the next one
+                break;
+            }
 
             std::vector<int> dir_list;
             for (int a = 0; a < k; ++a) {

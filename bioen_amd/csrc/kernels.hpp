@@ -9,6 +9,7 @@
 #pragma once
 
 #include "ctx.hpp"
+#include "lbfgs_state.hpp"
 
 namespace bioen {
 
@@ -51,8 +52,13 @@ void launch_scale_w(bioen_hip_ctx* c, const Round& r);              // w = e * s
 // center != NULL: the shares are sums over the CENTRED copy (kernels_strip.hip): ybar_raw = share + center;
 // ybar_c keeps ybar_raw (store_raw: what k_adj's centring and the callers expect) or the centred share (the
 // forces strip pass 2, whose gradient correction is written in terms of it)
+struct DevGate {                      // device-resident engine: skip the problems the device has finished (kernels.hpp: DevSlot)
+    const struct DevSlot* tab;        // NULL: no gating
+    int slot[kMaxBatch];              // position -> slot of its OWNER
+    int cand[kMaxBatch];              // != 0: a speculative trial (needs a line search in progress)
+};
 void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw,   // logw: also chi^2, c, f -> scal
-                         const double* center = nullptr, bool store_raw = true);
+                         const double* center = nullptr, bool store_raw = true, const DevGate* gate = nullptr);
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 // tsum = true (strip passes on the centred copy): gm = sum of partials - ybar_c * T, T = sum of the blocks' P_KL shares
@@ -172,6 +178,77 @@ void launch_gram(bioen_hip_ctx* c, const GramArgs& a);          // [exchange X_G
 void launch_gram_rank_reduce(bioen_hip_ctx* c, int k);   // sharded: X_GRAM block partials -> X_GRAMR rank totals
 void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a);
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a);
+
+// ---- device-resident line-search decisions (kernels_devls.hip, engine_devls.inl) ---------------------------------
+// The log-weights batch engine keeps each problem's L-BFGS state machine, the ROLES of its vectors (which buffer is
+// the trial point, which the accepted one, which history buffer the next pair goes to) and its status in HBM; a
+// one-block kernel per problem takes the line-search decision a round ends with.  The host composes rounds, enqueues
+// them ahead of the results and watches a host-mapped page for finished problems.
+constexpr int kMaxPast = 64;          // lbfgs `past` entries kept on the device (yaml default 10); beyond: host engine
+enum DevStatus : int { DS_IDLE = 0, DS_INITIAL = 1, DS_RUNNING = 2, DS_DONE = 3 };
+
+struct DevSlot {                      // one per problem slot, device memory (ctx->dev_tab)
+    double *x, *xp, *g, *gp;          // trial point / accepted point, their gradients
+    double* S[kHistory];              // history ring
+    double* Y[kHistory];
+    double *Ssp, *Ysp;                // spare pair: (s, y) of the PENDING trial, written by the gradient sweep before
+                                      //   the decision is known; an accepted trial swaps it into the ring
+    LbfgsState m;
+    double pf[kMaxPast];
+    int status;                       // DevStatus
+    int combine;                      // the next step kernel forms d from the Gram coefficients first (a step was accepted)
+    int code, keep_trial;             // DS_DONE: liblbfgs status / result is the trial point
+    int was_initial;                  // DS_DONE: ... reached at the evaluation of the start point
+    int pad;
+};
+
+constexpr int kLiveRec = 48;          // doubles per published record
+struct DevRecord {                    // what a decision publishes per position and round (host-mapped page)
+    double scal[kScalStride];         // the problem's scalar slot (chi^2, KL pieces, ...) as it stands
+    double* x; double* xp; double* g; double* gp;   // the roles after the decision
+    double* w;                        // buffer holding e of the evaluation the problem stands on (own, or an adopted shadow's)
+    double fx, stp;
+    int status, code, keep_trial, was_initial;
+    int iterations, evaluations;
+    int adopted, pad;
+};
+static_assert(sizeof(DevRecord) <= kLiveRec * sizeof(double), "live record");
+
+struct DevRound {                     // a round as the kernels see it (by value)
+    int n;                            // positions: owners first (0 .. nown - 1), then shadows
+    int nown;
+    int slot[kMaxBatch];              // position -> problem slot whose buffers / scalars the evaluation uses
+    int owner[kMaxBatch];             // position -> position of its owner (itself for owners)
+    int cand[kMaxBatch];              // 0: the owner's own trial; 1: stp * 0.5; 2: stp * 2.1 (speculative trials)
+    double theta[kMaxBatch];
+    double* d[kMaxBatch];             // fixed per-slot buffers of the position's OWNER: direction
+    double* gram[kMaxBatch];          //   ... Gram matrix + coefficients (owner), finished sums (position)
+    double* w[kMaxBatch];             // fixed per-slot buffers of the position: e = exp(x - m)
+    double* a[kMaxBatch];             //   adjoint output
+    double* scal[kMaxBatch];          //   scalar slot
+    DevSlot* tab;                     // ctx->dev_tab
+};
+
+struct DevStart {                     // (re)start of problems: by value to k_dev_start
+    int n;
+    int slot[kMaxBatch];
+    const double* g0[kMaxBatch];      // device start vectors
+    double* d[kMaxBatch];
+    double* gram[kMaxBatch];
+    DevSlot* tab;
+};
+
+void launch_dev_table_init(bioen_hip_ctx* c, int nslots);                // roles <- the slots' own buffers
+void launch_dev_start(bioen_hip_ctx* c, const DevStart& s, const bioen_lbfgs_config& cfg);
+void launch_dev_step(bioen_hip_ctx* c, const DevRound& r);               // [d = sum cf B ;] x = xp + stp d ; block maxima
+void launch_dev_exp(bioen_hip_ctx* c, const DevRound& r);                // e = exp(x - m) ; prior partials
+void launch_dev_grad_gram(bioen_hip_ctx* c, const DevRound& r);          // gradient + 3 dots ; (s, y) -> spare ; 39 Gram dots
+void launch_dev_decide(bioen_hip_ctx* c, const DevRound& r, const bioen_lbfgs_config& cfg, unsigned long long round);
+void launch_dev_first_direction(bioen_hip_ctx* c, const DevRound& r, int mask);   // d = -gp, partials of gp.d for the owners in `mask`
+void launch_dev_store_dginit(bioen_hip_ctx* c, const DevRound& r, int mask);      //   ... finished -> scal[S_DGINIT]   [after the X_DGI exchange]
+int dev_all_fused(const bioen_hip_ctx* c);                               // the decision kernel finishes the Gram sums itself
+void launch_dev_rank_reduce(bioen_hip_ctx* c, const DevRound& r);        // sharded: this rank's totals of the 39 + 3 sums -> X_GRAMR
+constexpr int kDevRankSums = kGramDots + 3;
 
 // ---- misc ---------------------------------------------------------------------------
 void launch_generate(bioen_hip_ctx* c, const double* YTrue, const double* sig_sim, const double* sig_exp,

@@ -1,0 +1,648 @@
+// Kernels of the device-resident log-weights L-BFGS engine (engine_devls.inl): the line-search decision of a round is
+// taken ON THE DEVICE by a one-block kernel per problem, so rounds are enqueued back to back and the host only watches
+// a host-mapped page for finished problems.
+//
+// Reference: the iteration logic of liblbfgs-1.10's lbfgs() (third-party/liblbfgs-1.10/lib/lbfgs.c:460-616) and its
+// backtracking / More-Thuente searches (:645-734, :812-1123) -- the decisions are the plain functions of
+// lbfgs_state.hpp, the same source the host engines run.  BioEn's per-evaluation work (c_bioen_kernels_logw.c:525-561)
+// is unchanged; what changes is who strings the kernels together:
+//
+//   k_dev_step       [an accepted step: d = sum_c cf_c B_c ;]  x = xp + stp d ; block maxima        (k_combine + k_trial)
+//   k_dev_exp        e = exp(x - m) ; prior partials                                                 (k_logw_exp)
+//   k_strip_fwd, k_fwd_rows_local_t, k_rows_combine (gated), k_strip_adj                             (unchanged)
+//   k_dev_grad_gram  gradient epilogue + g.d, g.g, x.x ; (s, y) of the PENDING trial -> spare pair ; the 39 Gram
+//                    products -- before the decision is known                                        (k_logw_grad + k_gram)
+//   k_dev_decide     finish the sums ; line-search decision ; accepted: Gram update + two-loop recursion on 13
+//                    coefficients, the spare pair joins the history ring, the roles of x/xp and g/gp swap ; publish
+//                                                                                (k_finish_eval + host + k_gram_solve)
+//
+// Eight launches per round instead of eleven plus a host turn-around, and on sharded contexts the Gram products ride
+// on the gradient's exchange.  Every sum is formed in exactly the order of the host-driven engine (engine_logw.inl):
+// the two engines agree to the last bit (tests/test_hip_parity.py: test_speculative_line_search_changes_no_bit runs
+// both), which is what keeps the pinned bench workload where it was.
+//
+// Roles live in HBM (DevSlot): which buffer is the trial point, which the accepted one, where the next (s, y) pair
+// goes.  A round's kernels read them through the table, only the decision kernel writes them.  Dead problems (finished,
+// not yet noticed by the host that runs a round ahead) are skipped by every N-vector kernel of the round.
+//
+// Speculative trials (engine_logw.inl) carry over: idle batch slots evaluate stp / 2 and 2.1 stp of their owner's
+// pending trial in the same matrix passes; a rejected trial whose successor is among them ADOPTS it inside the decision
+// kernel -- the owner and the shadow swap the buffers of x, g and the spare pair, the evaluation scalars are copied over.
+#include "device_utils.hpp"
+
+namespace bioen {
+
+__device__ __forceinline__ bool dev_alive(int status) { return status == DS_INITIAL || status == DS_RUNNING; }
+
+// behind the kMaxBatch table entries: [0] adopted shadows (64-bit counter), [2] (as int) problems alive
+__device__ __forceinline__ int* dev_alive_word(DevSlot* tab) { return reinterpret_cast<int*>(tab + kMaxBatch) + 2; }
+
+// position a of the round takes part: its owner is alive, and a speculative trial needs a line search in progress
+__device__ __forceinline__ bool dev_pos_live(const DevRound& r, int a, int* owner_status) {
+    const int st = r.tab[r.slot[r.owner[a]]].status;
+    *owner_status = st;
+    if (!dev_alive(st)) return false;
+    return r.cand[a] == 0 || st == DS_RUNNING;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct DevTableInit {
+    int n;
+    double* x[kMaxBatch]; double* xp[kMaxBatch]; double* g[kMaxBatch]; double* gp[kMaxBatch];
+    double* S[kMaxBatch][kHistory]; double* Y[kMaxBatch][kHistory];
+    double* Ssp[kMaxBatch]; double* Ysp[kMaxBatch];
+};
+
+__global__ void k_dev_table_init(DevTableInit t, DevSlot* tab) {
+    const int s = threadIdx.x;
+    if (s >= t.n) return;
+    DevSlot& T = tab[s];
+    T.x = t.x[s]; T.xp = t.xp[s]; T.g = t.g[s]; T.gp = t.gp[s];
+    for (int k = 0; k < kHistory; ++k) {
+        T.S[k] = t.S[s][k];
+        T.Y[k] = t.Y[s][k];
+    }
+    T.Ssp = t.Ssp[s]; T.Ysp = t.Ysp[s];
+    T.status = DS_IDLE;
+    T.combine = 0;
+    T.code = 0; T.keep_trial = 0; T.was_initial = 0;
+}
+
+// (re)start: accepted point <- start vector; direction, history and Gram state zeroed (the Gram sweep multiplies
+// with every history buffer, live or not: leftovers of an earlier tenant -- possibly non-finite -- must not reach
+// 0 * x); state machine reset; status = INITIAL (the next round evaluates the start point with stp = 0, d = 0).
+__global__ __launch_bounds__(kBlock) void k_dev_start(DevStart s, bioen_lbfgs_config cfg, int n2) {
+    const int i = blockIdx.y;
+    DevSlot& T = s.tab[s.slot[i]];
+    double* __restrict__ xp = T.xp;
+    const double* __restrict__ g0 = s.g0[i];
+    double* __restrict__ d = s.d[i];
+    const d2 zero = {0.0, 0.0};
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        *reinterpret_cast<d2*>(xp + j) = *reinterpret_cast<const d2*>(g0 + j);
+        *reinterpret_cast<d2*>(d + j) = zero;
+#pragma unroll
+        for (int k = 0; k < kHistory; ++k) {
+            *reinterpret_cast<d2*>(T.S[k] + j) = zero;
+            *reinterpret_cast<d2*>(T.Y[k] + j) = zero;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int q = threadIdx.x; q < kGramStride; q += kBlock) s.gram[i][q] = 0.0;
+        if (threadIdx.x == 0) {
+            lb::machine_reset(T.m, cfg, T.pf);
+            atomicAdd(dev_alive_word(s.tab), 1);
+            T.status = DS_INITIAL;
+            T.combine = 0;
+            T.code = 0;
+            T.keep_trial = 0;
+            T.was_initial = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// x = xp + stp d ; block maxima of x (k_trial).  After an accepted step d is formed first from the Gram coefficients
+// (k_combine: d = sum_c cf_c B_c over {S_0..5, Y_0..5, gp}); a shadow position forms its owner's d in registers too
+// (it runs beside the owner's blocks, which are the ones that store it).
+__global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    int ost;
+    if (!dev_pos_live(r, a, &ost)) return;
+    const int o = r.owner[a];
+    const DevSlot& T = r.tab[r.slot[o]];
+    double stp = T.m.stp;                       // INITIAL: 0 (and d = 0): x = xp
+    if (r.cand[a] == 1) stp *= 0.5;             // as lb::speculative_steps / report_backtracking form them
+    if (r.cand[a] == 2) stp *= 2.1;
+    double* __restrict__ x = r.tab[r.slot[a]].x;
+    const double* __restrict__ xp = T.xp;
+    double* __restrict__ d = r.d[o];
+    const bool combine = T.combine != 0;
+    const bool store_d = r.cand[a] == 0;
+    double cf[kBasis];
+#pragma unroll
+    for (int c = 0; c < kBasis; ++c) cf[c] = 0.0;
+    const double* __restrict__ gn = T.gp;
+    const double* Sk[kHistory];
+    const double* Yk[kHistory];
+#pragma unroll
+    for (int k = 0; k < kHistory; ++k) {
+        Sk[k] = T.S[k];
+        Yk[k] = T.Y[k];
+    }
+    if (combine) {
+        const double* coef = r.gram[o] + kBasis * kBasis;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) cf[c] = coef[c];
+    }
+    double mx = -DBL_MAX;
+    const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        d2 dv;
+        if (combine) {
+            const d2 gv = *reinterpret_cast<const d2*>(gn + j);
+            dv = d2{cf[2 * kHistory] * gv.x, cf[2 * kHistory] * gv.y};
+#pragma unroll
+            for (int k = 0; k < kHistory; ++k) {
+                if (cf[k] != 0.0) {               // unused history slots may hold another problem's leftovers
+                    const d2 v = *reinterpret_cast<const d2*>(Sk[k] + j);
+                    dv.x = fma(cf[k], v.x, dv.x);
+                    dv.y = fma(cf[k], v.y, dv.y);
+                }
+                if (cf[kHistory + k] != 0.0) {
+                    const d2 v = *reinterpret_cast<const d2*>(Yk[k] + j);
+                    dv.x = fma(cf[kHistory + k], v.x, dv.x);
+                    dv.y = fma(cf[kHistory + k], v.y, dv.y);
+                }
+            }
+            if (store_d) *reinterpret_cast<d2*>(d + j) = dv;
+        } else {
+            dv = *reinterpret_cast<const d2*>(d + j);
+        }
+        const d2 pv = *reinterpret_cast<const d2*>(xp + j);
+        d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
+        *reinterpret_cast<d2*>(x + j) = v;
+        mx = fmax(mx, v.x);
+        if (j + 1 < n) mx = fmax(mx, v.y);
+    }
+    mx = block_max(mx, sh);
+    if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
+}
+
+// e = exp(x - m) ; partials of sum e and sum e (x - G): k_logw_exp with the trial point taken from the role table
+__global__ __launch_bounds__(kBlock) void k_dev_exp(DevRound r, const double* __restrict__ G, int n, Xch xmx, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    int ost;
+    if (!dev_pos_live(r, a, &ost)) return;
+    const double* __restrict__ x = r.tab[r.slot[a]].x;
+    double* __restrict__ e = r.w[a];
+    const double gmax = xmax_local<1>(xmx, a, 0, sh);
+    double s = 0.0, pp = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 xv = *reinterpret_cast<const d2*>(x + j);
+        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        d2 ev;
+        ev.x = exp(xv.x - gmax);
+        ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
+        *reinterpret_cast<d2*>(e + j) = ev;
+        s += ev.x;
+        pp = fma(ev.x, xv.x - Gv.x, pp);
+        s += ev.y;
+        pp = fma(ev.y, xv.y - Gv.y, pp);
+    }
+    s = block_sum(s, sh);
+    pp = block_sum(pp, sh);
+    if (threadIdx.x == 0) {
+        xput<3>(xo, a, 0, s);
+        xput<3>(xo, a, 1, pp);
+        if (blockIdx.x == 0) xput<3>(xo, a, 2, gmax);
+    }
+}
+
+// Gradient epilogue (k_logw_grad) and, in the same sweep, the Gram sweep of the PENDING trial (k_gram): s = x - xp,
+// y = g - gp go to the position's spare pair -- the history ring is untouched until the trial is accepted -- and the 39
+// inner products of (s, y, g) with the basis {S_0..5, Y_0..5, g} (slot `end` standing for the new pair) are left as
+// block partials.  A rejected trial wasted the Gram part (13 % of the evaluations of the headline sweep); an accepted
+// one saved a launch and the re-reading of x, xp, g, gp.
+__global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const double* __restrict__ G, int n, Xch xg, Xch xm) {
+    __shared__ double sh[kWaves];
+    __shared__ double shg[kWaves][64];
+    const int a = blockIdx.y;
+    int ost;
+    if (!dev_pos_live(r, a, &ost)) return;
+    const int o = r.owner[a];
+    const DevSlot& T = r.tab[r.slot[o]];
+    const DevSlot& P = r.tab[r.slot[a]];
+    const double* __restrict__ x = P.x;
+    const double* __restrict__ w = r.w[a];
+    const double* __restrict__ av = r.a[a];
+    const double* __restrict__ d = r.d[o];
+    double* __restrict__ g = P.g;
+    const double theta = r.theta[a];
+    const double Pp = r.scal[a][S_P];
+    const double inv = r.scal[a][S_INV];      // w = e * inv
+    const bool gram = ost == DS_RUNNING;      // the evaluation of the start point has no pair to form
+    const int e = T.m.end;                    // history slot the pair would take
+    const double* __restrict__ xo_ = T.xp;
+    const double* __restrict__ go = T.gp;
+    double* __restrict__ Ssp = P.Ssp;
+    double* __restrict__ Ysp = P.Ysp;
+    const double* Sk[kHistory];
+    const double* Yk[kHistory];
+#pragma unroll
+    for (int k = 0; k < kHistory; ++k) {
+        Sk[k] = T.S[k];
+        Yk[k] = T.Y[k];
+    }
+    double dg = 0.0, gg = 0.0, xx = 0.0;
+    double acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 xv = *reinterpret_cast<const d2*>(x + j);
+        d2 wv = *reinterpret_cast<const d2*>(w + j);           // pad: e = 0  =>  g = 0
+        wv.x *= inv;
+        wv.y *= inv;
+        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        const d2 aa = *reinterpret_cast<const d2*>(av + j);
+        const d2 dv = *reinterpret_cast<const d2*>(d + j);
+        d2 gv;
+        gv.x = wv.x * (theta * ((xv.x - Gv.x) - Pp) + aa.x);
+        gv.y = wv.y * (theta * ((xv.y - Gv.y) - Pp) + aa.y);
+        *reinterpret_cast<d2*>(g + j) = gv;
+        dg = fma(gv.x, dv.x, dg);
+        gg = fma(gv.x, gv.x, gg);
+        xx = fma(xv.x, xv.x, xx);
+        dg = fma(gv.y, dv.y, dg);
+        gg = fma(gv.y, gv.y, gg);
+        xx = fma(xv.y, xv.y, xx);
+        if (gram) {
+            const d2 a1 = *reinterpret_cast<const d2*>(xo_ + j);
+            const d2 g1 = *reinterpret_cast<const d2*>(go + j);
+            const d2 sv = {xv.x - a1.x, xv.y - a1.y};
+            const d2 yv = {gv.x - g1.x, gv.y - g1.y};
+            d2 B[kBasis];
+#pragma unroll
+            for (int k = 0; k < kHistory; ++k) {
+                B[k] = (k == e) ? sv : *reinterpret_cast<const d2*>(Sk[k] + j);
+                B[kHistory + k] = (k == e) ? yv : *reinterpret_cast<const d2*>(Yk[k] + j);
+            }
+            B[2 * kHistory] = gv;
+            *reinterpret_cast<d2*>(Ssp + j) = sv;
+            *reinterpret_cast<d2*>(Ysp + j) = yv;
+#pragma unroll
+            for (int c = 0; c < kBasis; ++c) {
+                acc[c] = fma(sv.x, B[c].x, acc[c]);
+                acc[c] = fma(sv.y, B[c].y, acc[c]);
+                acc[kBasis + c] = fma(yv.x, B[c].x, acc[kBasis + c]);
+                acc[kBasis + c] = fma(yv.y, B[c].y, acc[kBasis + c]);
+                acc[2 * kBasis + c] = fma(gv.x, B[c].x, acc[2 * kBasis + c]);
+                acc[2 * kBasis + c] = fma(gv.y, B[c].y, acc[2 * kBasis + c]);
+            }
+        }
+    }
+    dg = block_sum(dg, sh);
+    gg = block_sum(gg, sh);
+    xx = block_sum(xx, sh);
+    if (threadIdx.x == 0) {
+        xput<3>(xg, a, 0, dg);
+        xput<3>(xg, a, 1, gg);
+        xput<3>(xg, a, 2, xx);
+    }
+    if (gram) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        wave_multi_reduce<64>(acc, lane);          // lane l now holds the wave total of value l
+        shg[wave][lane] = acc[0];
+        __syncthreads();
+        if (threadIdx.x < kGramDots) {
+            const double v = (shg[0][threadIdx.x] + shg[1][threadIdx.x]) + (shg[2][threadIdx.x] + shg[3][threadIdx.x]);
+            xm.base[(size_t)xm.rank * xm.payload + (size_t)(a * kGramDots + threadIdx.x) * xm.npl + blockIdx.x] = v;
+        }
+    }
+}
+
+// k_gram_reduce for the positions of a device round (many partials per sum: one block per (sum, position))
+__global__ __launch_bounds__(kBlock) void k_dev_gram_reduce(DevRound r, Xch xi) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    int ost;
+    if (!dev_pos_live(r, a, &ost) || ost != DS_RUNNING) return;
+    const double v = xsum<kGramDots>(xi, a, c, sh);
+    if (threadIdx.x == 0) r.gram[a][kGramSums + c] = v;
+}
+
+// Sharded contexts: one block per (sum, position) totals THIS rank's block partials of the 39 Gram products and of
+// g.d, g.g, x.x into the compact X_GRAMR stage -- ONE all-gather of 42 doubles per position and rank then serves both
+// the line-search decision and the direction (the host-driven engine exchanges the gradient's sums and the Gram
+// products separately: three all-gathers per round instead of two).
+__global__ __launch_bounds__(kBlock) void k_dev_rank_reduce(DevRound r, Xch xg, Xch xm, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    int ost;
+    if (!dev_pos_live(r, a, &ost)) return;
+    double v = 0.0;
+    if (c < kGramDots) {
+        if (ost == DS_RUNNING) v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
+    } else {
+        v = xsum_rank<3>(xg, xg.rank, a, c - kGramDots, sh);
+    }
+    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kDevRankSums + c] = v;
+}
+
+// sum over the ranks' totals (rank order: identical on every rank); every thread computes it for itself
+__device__ __forceinline__ double dev_ranks_sum(const Xch& xr, int a, int c) {
+    double s = 0.0;
+    for (int rk = 0; rk < xr.world; ++rk) s += xr.base[(size_t)rk * xr.payload + (size_t)a * kDevRankSums + c];
+    return s;
+}
+
+// d = -gp and the partials of gp . d for the owners in `mask` whose start point was not already minimal
+// (k_recur mode 0 with bound = 0); k_dev_store_dginit finishes the sum (k_store_dginit).
+__global__ __launch_bounds__(kBlock) void k_dev_first_direction(DevRound r, int mask, int n, Xch xdgi) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    if (!((mask >> a) & 1)) return;
+    const DevSlot& T = r.tab[r.slot[a]];
+    if (T.status != DS_RUNNING) return;
+    double* __restrict__ d = r.d[a];
+    const double* __restrict__ gp = T.gp;
+    double acc = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 gv = *reinterpret_cast<const d2*>(gp + j);
+        d2 dv;
+        dv.x = -gv.x;
+        dv.y = -gv.y;
+        *reinterpret_cast<d2*>(d + j) = dv;
+        acc = fma(gv.x, dv.x, acc);
+        acc = fma(gv.y, dv.y, acc);
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) xput<1>(xdgi, a, 0, acc);
+}
+
+__global__ __launch_bounds__(kBlock) void k_dev_store_dginit(DevRound r, int mask, Xch xd) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.y;
+    if (!((mask >> a) & 1)) return;
+    if (r.tab[r.slot[a]].status != DS_RUNNING) return;
+    const double di = xsum<1>(xd, a, 0, sh);
+    if (threadIdx.x == 0) r.scal[a][S_DGINIT] = di;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The decision.  One block per OWNER position:
+//   * finish g.d, g.g, x.x of the evaluation (k_finish_eval's sums, same order);
+//   * INITIAL: lb::on_initial; the gradient becomes the accepted one (roles of g / gp swap);
+//   * RUNNING: lb::on_trial; a rejected trial whose next step is one of the owner's shadow positions adopts that
+//     evaluation on the spot (second on_trial): x, g and the spare pair change hands, the evaluation-owned scalars are
+//     copied;
+//   * ACCEPT: finish the 39 Gram sums of the evaluation the problem stands on (in-block when there are few partials,
+//     else k_dev_gram_reduce has left them), update the Gram matrix, two-loop recursion on coefficients
+//     (gram_solve_thread0 = k_gram_solve), the spare pair takes slot `end` of the ring, x <-> xp, g <-> gp, and the next
+//     k_dev_step forms d;
+//   * publish the problem's record into the round's page of the host-mapped ring, then the round number into its flag.
+// `spec` counts adopted shadows (device word, read by the host at the end of the run).
+// MODE 0: few block partials per sum, finished in-block; 1: k_dev_gram_reduce has left the Gram sums; 2: sharded
+// context, every sum = the ranks' totals out of the X_GRAMR stage (`xm`)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_config cfg, Xch xg, Xch xm,
+                                                       double* __restrict__ page, unsigned long long* __restrict__ flags,
+                                                       unsigned long long round, unsigned long long* __restrict__ spec) {
+    __shared__ double sh[kWaves];
+    __shared__ double dots[kGramDots];
+    __shared__ double Gs[kBasis * kBasis];
+    __shared__ double alpha[kHistory];
+    __shared__ int ctl[8];                    // kind, adopt position, end, bound
+    __shared__ double rec[kLiveRec];
+    const int a = blockIdx.y;
+    const int so = r.slot[a];
+    DevSlot& T = r.tab[so];
+    double* sc = r.scal[a];
+    const int status = T.status;
+    int kind = ACT_DONE, evalpos = a;
+    if (dev_alive(status)) {
+        double dg, gg, xx;
+        if (MODE == 2) {
+            dg = dev_ranks_sum(xm, a, kGramDots + 0);
+            gg = dev_ranks_sum(xm, a, kGramDots + 1);
+            xx = dev_ranks_sum(xm, a, kGramDots + 2);
+        } else {
+            dg = xsum<3>(xg, a, 0, sh);
+            gg = xsum<3>(xg, a, 1, sh);
+            xx = xsum<3>(xg, a, 2, sh);
+        }
+        if (threadIdx.x == 0) {
+            LbfgsAction act;
+            int adopt = -1;
+            if (status == DS_INITIAL) {
+                act = lb::on_initial(T.m, cfg, sc[S_F], gg, xx);
+                T.was_initial = 1;
+                if (act.kind != ACT_DONE) {
+                    double* t = T.g; T.g = T.gp; T.gp = t;      // gradient at the accepted (= start) point
+                    T.status = DS_RUNNING;
+                    T.was_initial = 0;
+                    act.kind = ACT_TRIAL;
+                }
+            } else {
+                const double prev = T.m.stp;
+                const TrialResult t{sc[S_F], dg, gg, xx, sc[S_DGINIT]};
+                act = lb::on_trial(T.m, cfg, t);
+                if (act.kind == ACT_TRIAL) {
+                    // rejected: is the step it asks for next among this round's shadows?
+                    double cand[2];
+                    const int nc = lb::speculative_steps(prev, cfg.linesearch, cand);
+                    for (int q = r.nown; q < r.n && adopt < 0; ++q)
+                        if (r.owner[q] == a && r.cand[q] >= 1 && r.cand[q] <= nc && cand[r.cand[q] - 1] == T.m.stp) adopt = q;
+                }
+            }
+            sc[S_DG] = dg;
+            sc[S_GG] = gg;
+            sc[S_XX] = xx;
+            ctl[0] = act.kind; ctl[1] = adopt; ctl[2] = act.end; ctl[3] = act.bound; ctl[4] = act.code; ctl[5] = act.keep_trial;
+        }
+        __syncthreads();
+        const int adopt = ctl[1];
+        if (adopt >= 0) {                      // block-uniform
+            if (MODE == 2) {
+                dg = dev_ranks_sum(xm, adopt, kGramDots + 0);
+                gg = dev_ranks_sum(xm, adopt, kGramDots + 1);
+                xx = dev_ranks_sum(xm, adopt, kGramDots + 2);
+            } else {
+                dg = xsum<3>(xg, adopt, 0, sh);
+                gg = xsum<3>(xg, adopt, 1, sh);
+                xx = xsum<3>(xg, adopt, 2, sh);
+            }
+            if (threadIdx.x == 0) {
+                DevSlot& Q = r.tab[r.slot[adopt]];
+                double* t;
+                t = T.x; T.x = Q.x; Q.x = t;                   // the shadow's point, gradient and pending pair become the trial's
+                t = T.g; T.g = Q.g; Q.g = t;
+                t = T.Ssp; T.Ssp = Q.Ssp; Q.Ssp = t;
+                t = T.Ysp; T.Ysp = Q.Ysp; Q.Ysp = t;
+                const double* qs = r.scal[adopt];
+                // the evaluation-owned entries of a slot's scalars (the rest -- y.s, alpha, gp.d -- belongs to the problem)
+                for (int i = S_F; i < S_F + 4; ++i) sc[i] = qs[i];
+                for (int i = S_LOGS; i < S_LOGS + 4; ++i) sc[i] = qs[i];
+                for (int i = S_KL; i < S_KL + 2; ++i) sc[i] = qs[i];
+                for (int i = S_INV; i < S_INV + 3; ++i) sc[i] = qs[i];
+                sc[S_DG] = dg;
+                sc[S_GG] = gg;
+                sc[S_XX] = xx;
+                const TrialResult t2{sc[S_F], dg, gg, xx, sc[S_DGINIT]};
+                const LbfgsAction act = lb::on_trial(T.m, cfg, t2);
+                ctl[0] = act.kind; ctl[2] = act.end; ctl[3] = act.bound; ctl[4] = act.code; ctl[5] = act.keep_trial;
+                atomicAdd(spec, 1ull);
+            }
+            __syncthreads();
+            evalpos = adopt;
+        }
+        kind = ctl[0];
+        if (kind == ACT_ACCEPT) {              // block-uniform
+            double* G = r.gram[a];
+            for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
+            if (MODE == 2) {
+                for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = dev_ranks_sum(xm, evalpos, i);
+            } else if (MODE == 0) {
+                // as k_gram_solve<true>: a wave's sums side by side, every sum formed in the same order
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
+                double acc[kPerWave];
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) acc[u] = 0.0;
+                for (int rk = 0; rk < xm.world; ++rk)
+                    for (int k = lane; k < xm.npl; k += 64) {
+                        double v[kPerWave];
+#pragma unroll
+                        for (int u = 0; u < kPerWave; ++u) {
+                            const int c = wave + u * kWaves;
+                            v[u] = c < kGramDots
+                                       ? xm.base[(size_t)rk * xm.payload + (size_t)(evalpos * kGramDots + c) * xm.npl + k]
+                                       : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kPerWave; ++u) acc[u] += v[u];
+                    }
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) {
+                    const int c = wave + u * kWaves;
+                    const double t = wave_sum(acc[u]);
+                    if (lane == 0 && c < kGramDots) dots[c] = t;
+                }
+            } else {
+                const double* Gq = r.gram[evalpos];
+                for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = Gq[kGramSums + i];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                gram_solve_thread0(G, Gs, dots, alpha, ctl[2], ctl[3], sc);
+                const int e = ctl[2];
+                double* t;
+                t = T.S[e]; T.S[e] = T.Ssp; T.Ssp = t;         // the pending pair joins the ring
+                t = T.Y[e]; T.Y[e] = T.Ysp; T.Ysp = t;
+                t = T.x; T.x = T.xp; T.xp = t;                 // the trial point becomes the accepted point
+                t = T.g; T.g = T.gp; T.gp = t;
+                T.combine = 1;
+            }
+        } else if (threadIdx.x == 0) {
+            T.combine = 0;
+            if (kind == ACT_DONE) {
+                atomicAdd(dev_alive_word(r.tab), -1);     // the matrix passes of a round without live problems return at once
+                T.status = DS_DONE;
+                T.code = ctl[4];
+                T.keep_trial = ctl[5];
+            }
+        }
+    }
+    // ---- publish ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DevRecord* R = reinterpret_cast<DevRecord*>(rec);
+        for (int i = 0; i < kScalStride; ++i) R->scal[i] = sc[i];
+        R->x = T.x; R->xp = T.xp; R->g = T.g; R->gp = T.gp;
+        R->w = r.w[evalpos];
+        R->fx = T.m.fx; R->stp = T.m.stp;
+        R->status = T.status; R->code = T.code; R->keep_trial = T.keep_trial; R->was_initial = T.was_initial;
+        R->iterations = T.m.iterations; R->evaluations = T.m.evaluations;
+        R->adopted = evalpos != a; R->pad = 0;
+    }
+    __syncthreads();
+    static_assert(kLiveRec <= 64, "the record is published by ONE wave: its fence covers the stores of all its lanes");
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < kLiveRec) page[(size_t)a * kLiveRec + threadIdx.x] = rec[threadIdx.x];
+        __threadfence_system();               // wave-wide: s_waitcnt vmcnt(0) + write-back cover every lane's store
+        if (threadIdx.x == 0)
+            __hip_atomic_store(flags + a, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------
+void launch_dev_table_init(bioen_hip_ctx* c, int nslots) {
+    DevTableInit t{};
+    t.n = nslots;
+    for (int s = 0; s < nslots; ++s) {
+        const ProblemSlot& sl = c->slot[s];
+        t.x[s] = sl.xa; t.xp[s] = sl.xb; t.g[s] = sl.ga; t.gp[s] = sl.gb;
+        for (int k = 0; k < kHistory; ++k) {
+            t.S[s][k] = sl.S[k];
+            t.Y[s][k] = sl.Yh[k];
+        }
+        t.Ssp[s] = sl.Ssp; t.Ysp[s] = sl.Ysp;
+    }
+    hipLaunchKernelGGL(k_dev_table_init, dim3(1), dim3(64), 0, c->stream, t, static_cast<DevSlot*>(c->dev_tab));
+}
+
+void launch_dev_start(bioen_hip_ctx* c, const DevStart& s, const bioen_lbfgs_config& cfg) {
+    hipLaunchKernelGGL(k_dev_start, dim3(vec_grid(c), s.n), dim3(kBlock), 0, c->stream, s, cfg, (int)(c->ld / 2));
+}
+
+void launch_dev_step(bioen_hip_ctx* c, const DevRound& r) {
+    hipLaunchKernelGGL(k_dev_step, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+}
+
+void launch_dev_exp(bioen_hip_ctx* c, const DevRound& r) {
+    hipLaunchKernelGGL(k_dev_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+}
+
+void launch_dev_grad_gram(bioen_hip_ctx* c, const DevRound& r) {
+    hipLaunchKernelGGL(k_dev_grad_gram, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)));
+}
+
+int dev_all_fused(const bioen_hip_ctx* c) { return (long long)vec_grid(c) * c->world <= 256; }
+
+static Xch dev_rank_view(const bioen_hip_ctx* c, int n) {      // X_GRAMR: 42 values per (rank, position)
+    Xch x = make_xch(c, X_GRAMR, kDevRankSums * n);
+    x.npl = 1;
+    return x;
+}
+
+void launch_dev_rank_reduce(bioen_hip_ctx* c, const DevRound& r) {
+    hipLaunchKernelGGL(k_dev_rank_reduce, dim3(kDevRankSums, r.n), dim3(kBlock), 0, c->stream, r,
+                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)),
+                       dev_rank_view(c, r.n));
+}
+
+void launch_dev_decide(bioen_hip_ctx* c, const DevRound& r, const bioen_lbfgs_config& cfg, unsigned long long round) {
+    const Xch xg = make_xch(c, X_GRAD, 3 * r.n * vec_grid(c));
+    const Xch xm = make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c));
+    const int pg = (int)(round % kLiveRing);
+    double* page = c->live2 + (size_t)pg * kMaxBatch * kLiveRec;
+    unsigned long long* flags =
+        reinterpret_cast<unsigned long long*>(c->live2 + (size_t)kLiveRing * kMaxBatch * kLiveRec) + (size_t)pg * kMaxBatch;
+    unsigned long long* spec = reinterpret_cast<unsigned long long*>(static_cast<DevSlot*>(c->dev_tab) + kMaxBatch);
+    const dim3 grid(1, r.nown), block(kBlock);
+    if (c->world > 1) {                                  // the ranks' totals (after the X_GRAMR exchange)
+        hipLaunchKernelGGL(k_dev_decide<2>, grid, block, 0, c->stream, r, cfg, xg, dev_rank_view(c, r.n), page, flags, round, spec);
+    } else if (dev_all_fused(c)) {
+        hipLaunchKernelGGL(k_dev_decide<0>, grid, block, 0, c->stream, r, cfg, xg, xm, page, flags, round, spec);
+    } else {
+        hipLaunchKernelGGL(k_dev_gram_reduce, dim3(kGramDots, r.n), block, 0, c->stream, r, xm);
+        hipLaunchKernelGGL(k_dev_decide<1>, grid, block, 0, c->stream, r, cfg, xg, xm, page, flags, round, spec);
+    }
+}
+
+void launch_dev_first_direction(bioen_hip_ctx* c, const DevRound& r, int mask) {
+    hipLaunchKernelGGL(k_dev_first_direction, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, mask, c->n,
+                       make_xch(c, X_DGI, r.nown * vec_grid(c)));
+}
+
+void launch_dev_store_dginit(bioen_hip_ctx* c, const DevRound& r, int mask) {
+    hipLaunchKernelGGL(k_dev_store_dginit, dim3(1, r.nown), dim3(kBlock), 0, c->stream, r, mask,
+                       make_xch(c, X_DGI, r.nown * vec_grid(c)));
+}
+
+}  // namespace bioen

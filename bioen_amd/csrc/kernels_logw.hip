@@ -189,7 +189,9 @@ __global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg, double*
         sc[S_GG] = gg;
         sc[S_XX] = xx;
     }
-    if (live && threadIdx.x < kScalStride) {      // one wave: its stores are fenced before lane 0 raises the flag
+    static_assert(kScalStride <= 64, "the slot is published by ONE wave: its fence covers the stores of all its lanes");
+    if (live && threadIdx.x < kScalStride) {      // one wave: the fence below is a wave-wide wait for ALL its lanes' stores
+                                                  // (s_waitcnt vmcnt(0) + write-back), after which lane 0 raises the flag
         const int t = threadIdx.x;
         double v = sc[t];                         // the other entries were written by earlier kernels
         if (t == S_DG) v = dg;
@@ -439,63 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const int e = q.end[a], bound = q.bound[a];
-    const int rs = e, ry = kHistory + e, rg = 2 * kHistory;
-    for (int c = 0; c < kBasis; ++c) {
-        Gs[rs * kBasis + c] = Gs[c * kBasis + rs] = dots[c];
-        Gs[ry * kBasis + c] = Gs[c * kBasis + ry] = dots[kBasis + c];
-    }
-    for (int c = 0; c < kBasis; ++c) Gs[rg * kBasis + c] = Gs[c * kBasis + rg] = dots[2 * kBasis + c];
-    for (int c = 0; c < kBasis; ++c) {        // the three rows/columns that changed go back to HBM
-        G[rs * kBasis + c] = G[c * kBasis + rs] = Gs[rs * kBasis + c];
-        G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
-        G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
-    }
-    // q = -g as coefficients over {S, Y, g}.  The coefficients stay in registers (an LDS array put a store -> load
-    // round trip into every step of the two dependent chains); slot numbers are run-time values, so the one entry a
-    // step changes is picked by comparison.  Same operations in the same order as before.
-    double cf[kBasis];
-#pragma unroll
-    for (int c = 0; c < kBasis; ++c) cf[c] = c == rg ? -1.0 : 0.0;
-    for (int b = 0; b < bound; ++b) {         // first loop, newest -> oldest
-        const int i = (e + kHistory - b) % kHistory;
-        double row[kBasis];
-#pragma unroll
-        for (int c = 0; c < kBasis; ++c) row[c] = Gs[i * kBasis + c];
-        const double diag = Gs[(kHistory + i) * kBasis + i];
-        double sq = 0.0;
-#pragma unroll
-        for (int c = 0; c < kBasis; ++c) sq = fma(cf[c], row[c], sq);
-        const double al = sq / diag;
-        alpha[i] = al;
-#pragma unroll
-        for (int c = 0; c < kBasis; ++c)
-            if (c == kHistory + i) cf[c] -= al;
-    }
-    const double scale = Gs[ry * kBasis + rs] / Gs[ry * kBasis + ry];   // ys / yy of the newest pair
-#pragma unroll
-    for (int c = 0; c < kBasis; ++c) cf[c] *= scale;
-    for (int b = bound - 1; b >= 0; --b) {    // second loop, oldest -> newest
-        const int i = (e + kHistory - b) % kHistory;
-        double row[kBasis];
-#pragma unroll
-        for (int c = 0; c < kBasis; ++c) row[c] = Gs[(kHistory + i) * kBasis + c];
-        const double diag = Gs[(kHistory + i) * kBasis + i];
-        const double al = alpha[i];
-        double yq = 0.0;
-#pragma unroll
-        for (int c = 0; c < kBasis; ++c) yq = fma(cf[c], row[c], yq);
-        const double beta = yq / diag;
-#pragma unroll
-        for (int c = 0; c < kBasis; ++c)
-            if (c == i) cf[c] += al - beta;
-    }
-    double dg = 0.0;
-#pragma unroll
-    for (int c = 0; c < kBasis; ++c) dg = fma(cf[c], Gs[rg * kBasis + c], dg);
-#pragma unroll
-    for (int c = 0; c < kBasis; ++c) G[kBasis * kBasis + c] = cf[c];
-    q.scal[a][S_DGINIT] = dg;
+    gram_solve_thread0(G, Gs, dots, alpha, q.end[a], q.bound[a], q.scal[a]);
 }
 
 // d = sum_c coef_c B_c

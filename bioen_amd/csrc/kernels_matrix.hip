@@ -232,9 +232,13 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
                                                          const double* __restrict__ row_scale,
                                                          const double* __restrict__ center, bool store_raw,
                                                          double* __restrict__ ybar_c, double* __restrict__ r_c,
-                                                         MVec8 part, Round rd) {
+                                                         MVec8 part, Round rd, DevGate gate) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
+    if (gate.tab) {      // device-resident engine: a finished problem keeps the scalars of its last evaluation
+        const int st = gate.tab[gate.slot[a]].status;
+        if (!(st == DS_INITIAL || st == DS_RUNNING) || (gate.cand[a] != 0 && st != DS_RUNNING)) return;
+    }
     // LOGW: the shares are yTilde . e_r with e_r = exp(x - m_r) unnormalised; global shift
     // M = max_r m_r, S = sum_r e^{m_r - M} S_r, and rank r's share enters with e^{m_r - M} / S
     // (exactly 1 / S on one GPU).  _get_weights' normalisation (c_bioen_kernels_logw.c:84-90) is
@@ -517,17 +521,20 @@ void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
 
 int combine_grid(const bioen_hip_ctx*) { return 1; }
 
-void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw, const double* center, bool store_raw) {
+void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw, const double* center, bool store_raw,
+                         const DevGate* gatep) {
     MVec8 part;
     for (int a = 0; a < kMaxBatch; ++a) part.p[a] = a < r.n ? r.part[a] : nullptr;
+    DevGate gate{};
+    if (gatep) gate = *gatep;
     if (logw)
         hipLaunchKernelGGL(k_rows_combine<true>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
                            make_xch(c, X_YBAR, ybar_payload(c, r.n, true)), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
-                           center, store_raw, c->ybar_c, c->r_c, part, r);
+                           center, store_raw, c->ybar_c, c->r_c, part, r, gate);
     else
         hipLaunchKernelGGL(k_rows_combine<false>, dim3(1, r.n), dim3(kBlock), 0, c->stream,
                            make_xch(c, X_YBAR, c->mp * r.n), c->mp, r.n, c->YT, c->row_offset, c->row_scale,
-                           center, store_raw, c->ybar_c, c->r_c, part, r);
+                           center, store_raw, c->ybar_c, c->r_c, part, r, gate);
 }
 
 static MVec8 tsum_parts(const ForcesRound* fr) {

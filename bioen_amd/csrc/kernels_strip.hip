@@ -609,7 +609,7 @@ static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
 }
 
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
-    if (c->mp > 512) return 0;
+    if (c->mp > 512 || c->strips_unavailable) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
     // blocks per CU: LDS (160 KiB) and the waves per SIMD the kernel's register budget admits
     const int by_lds = (int)((size_t)160 * 1024 / strip_lds_bytes(c));
@@ -618,21 +618,40 @@ int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on t
     return std::min(std::min(256 * per_cu, kFusedBlocks), nstrips);
 }
 
+// A failed allocation leaves the context WITHOUT strip copies (strips_unavailable): fwd_strip_blocks /
+// forces_fused_blocks then answer 0 and every caller takes the streaming kernels on the row-major matrix, which
+// need no extra memory.  The copy pointers are published only after the build kernel is enqueued.
+static int strip_copy_failed(bioen_hip_ctx* c, double* ys, hipError_t e, const char* what) {
+    if (ys) (void)hipFree(ys);
+    (void)hipGetLastError();                       // an out-of-memory error must not surface at the next launch check
+    c->strips_unavailable = 1;
+    return hip_fail(e, what, __FILE__, __LINE__);
+}
+
 int ensure_strip_copy(bioen_hip_ctx* c) {
     if (c->Ys) return 0;
+    if (c->strips_unavailable) return BIOEN_HIP_ENOMEM;
     const int mps = strip_rows(c);
     const int nstrips = (int)(c->ld / kStripCols);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->Ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
-    if (e != hipSuccess) {
-        c->Ys = nullptr;
-        return hip_fail(e, "hipMalloc (strip-major copy of yTilde for the forces method)", __FILE__, __LINE__);
+    double* ys = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
+    if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (strip-major copy of yTilde)");
+    if (!c->strip_center) {
+        double* cen = nullptr;
+        e = hipMalloc(reinterpret_cast<void**>(&cen), (size_t)c->mp * sizeof(double));
+        if (e != hipSuccess) return strip_copy_failed(c, ys, e, "hipMalloc (strip centre)");
+        e = hipMemcpyAsync(cen, c->YT, (size_t)c->mp * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(cen);
+            return strip_copy_failed(c, ys, e, "hipMemcpyAsync (strip centre)");
+        }
+        c->strip_center = cen;
     }
-    e = hipMalloc(reinterpret_cast<void**>(&c->strip_center), (size_t)c->mp * sizeof(double));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
-    e = hipMemcpyAsync(c->strip_center, c->YT, (size_t)c->mp * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
     hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
-                       c->n, c->strip_center, c->Ys, nstrips);
+                       c->n, c->strip_center, ys, nstrips);
+    e = hipGetLastError();
+    if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
+    c->Ys = ys;
     return 0;
 }
 
@@ -667,7 +686,7 @@ static int fa_spb(const bioen_hip_ctx* c) { return std::max(1, std::min(16 / fa_
 
 // forward pass of the log-weights method on the strip copy (all K <= 8; M <= 1024): the number of partial sets
 int fwd_strip_blocks(const bioen_hip_ctx* c) {
-    if (c->mp > 1024 || c->fwd_stream) return 0;
+    if (c->mp > 1024 || c->fwd_stream || c->strips_unavailable) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
     return std::min(256 * fa_spb(c), nstrips);
 }
@@ -717,13 +736,14 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     if (rc) return rc;
     const int mps = strip_rows(c);
     const int nstrips = (int)(c->ld / kStripCols);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->Ys1), (size_t)nstrips * mps * kStripCols * sizeof(double));
-    if (e != hipSuccess) {
-        c->Ys1 = nullptr;
-        return hip_fail(e, "hipMalloc (column-sum strip copy of yTilde for the log-weights adjoint)", __FILE__, __LINE__);
-    }
+    double* ys = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
+    if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (column-sum strip copy of yTilde)");
     hipLaunchKernelGGL(k_build_strips<true>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
-                       c->n, c->strip_center, c->Ys1, nstrips);
+                       c->n, c->strip_center, ys, nstrips);
+    e = hipGetLastError();
+    if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
+    c->Ys1 = ys;
     return 0;
 }
 

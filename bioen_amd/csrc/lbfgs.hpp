@@ -21,105 +21,25 @@
 #include <vector>
 
 #include "../../include/bioen_hip.h"
+#include "lbfgs_state.hpp"
 
 namespace bioen {
 
-// liblbfgs status codes (include/lbfgs.h:76-147)
-enum LbfgsCode : int {
-    LBFGS_CONVERGED = 0,
-    LBFGS_STOPPED = 1,
-    LBFGS_ALREADY_MINIMIZED = 2,
-    LBFGSERR_UNKNOWN = -1024,
-    LBFGSERR_LOGIC = -1023,
-    LBFGSERR_OUTOFMEMORY = -1022,
-    LBFGSERR_CANCELED = -1021,
-    LBFGSERR_INVALID_N = -1020,
-    LBFGSERR_INVALID_N_SSE = -1019,
-    LBFGSERR_INVALID_X_SSE = -1018,
-    LBFGSERR_INVALID_EPSILON = -1017,
-    LBFGSERR_INVALID_TESTPERIOD = -1016,
-    LBFGSERR_INVALID_DELTA = -1015,
-    LBFGSERR_INVALID_LINESEARCH = -1014,
-    LBFGSERR_INVALID_MINSTEP = -1013,
-    LBFGSERR_INVALID_MAXSTEP = -1012,
-    LBFGSERR_INVALID_FTOL = -1011,
-    LBFGSERR_INVALID_WOLFE = -1010,
-    LBFGSERR_INVALID_GTOL = -1009,
-    LBFGSERR_INVALID_XTOL = -1008,
-    LBFGSERR_INVALID_MAXLINESEARCH = -1007,
-    LBFGSERR_INVALID_ORTHANTWISE = -1006,
-    LBFGSERR_INVALID_ORTHANTWISE_START = -1005,
-    LBFGSERR_INVALID_ORTHANTWISE_END = -1004,
-    LBFGSERR_OUTOFINTERVAL = -1003,
-    LBFGSERR_INCORRECT_TMINMAX = -1002,
-    LBFGSERR_ROUNDING_ERROR = -1001,
-    LBFGSERR_MINIMUMSTEP = -1000,
-    LBFGSERR_MAXIMUMSTEP = -999,
-    LBFGSERR_MAXIMUMLINESEARCH = -998,
-    LBFGSERR_MAXIMUMITERATION = -997,
-    LBFGSERR_WIDTHTOOSMALL = -996,
-    LBFGSERR_INVALIDPARAMETERS = -995,
-    LBFGSERR_INCREASEGRADIENT = -994
-};
-
-// liblbfgs defaults BioEn leaves untouched (lbfgs.c:113-118)
-constexpr int kLbfgsM = 6;   // history length
-constexpr double kMinStep = 1e-20;
-constexpr double kMaxStep = 1e20;
-constexpr double kXtol = 1e-16;
-
 const char* lbfgs_code_string(int code);
-
-// Values a backend reports for one evaluated trial point.
-struct TrialResult {
-    double f;       // objective at the trial point
-    double dg;      // gradient(trial) . d
-    double gg;      // |gradient(trial)|^2
-    double xx;      // |x(trial)|^2
-    double dginit;  // gradient(accepted) . d   (constant during a line search)
-};
-
-// ------------------------------------------------------------------------------------
-// Line searches as resumable state machines: `first()` / `next()` hand out the trial
-// step, `report()` consumes the evaluation.  Keeping them free of any vector work lets
-// the device backend launch x = xp + stp*d and the evaluation without a host copy.
-// ------------------------------------------------------------------------------------
-class LineSearch {
-  public:
-    LineSearch(const bioen_lbfgs_config& cfg) : c_(cfg) {}
-    // returns <0 on immediate error, otherwise 0 and sets `stp` to the first trial step
-    int begin(double finit, double stp0, double* stp);
-    // Feed the evaluation of the last trial. Returns: >0 = number of evaluations (done),
-    // 0 = continue with *stp updated, <0 = liblbfgs error code.
-    int report(const TrialResult& t, double* stp);
-    int count() const { return count_; }
-
-  private:
-    int report_backtracking(const TrialResult& t, double* stp);
-    int report_morethuente(const TrialResult& t, double* stp);
-    void mt_prepare(double* stp);
-
-    bioen_lbfgs_config c_;   // by value: machines are stored in containers
-    int count_ = 0;
-    bool have_dginit_ = false;
-    double finit_ = 0, dginit_ = 0, dgtest_ = 0;
-    // More-Thuente state
-    int brackt_ = 0, stage1_ = 1, uinfo_ = 0;
-    double stx_ = 0, fx_ = 0, dgx_ = 0, sty_ = 0, fy_ = 0, dgy_ = 0;
-    double stmin_ = 0, stmax_ = 0, width_ = 0, prev_width_ = 0;
-};
 
 int validate_lbfgs_config(int n, const bioen_lbfgs_config& c);
 
 // ------------------------------------------------------------------------------------
-// One L-BFGS problem as a state machine (lbfgs.c:245-641 without the vector work).
-// The owner evaluates points and builds directions; the machine decides.  Used by the
-// single-problem loop below AND by the lock-step batch engine (several thetas advancing
-// one evaluation per round against the same matrix pass).
+// One L-BFGS problem as a state machine (lbfgs.c:245-641 without the vector work): the host-side owner of an
+// LbfgsState (lbfgs_state.hpp -- the decisions themselves are plain functions that also run inside the decision kernel
+// of the device-resident engine).  The owner evaluates points and builds directions; the machine decides.  Used by the
+// single-problem loop below AND by the lock-step batch engines (several thetas advancing one evaluation per round
+// against the same matrix pass).  Line searches are resumable: trial_step() hands out the step, on_trial() consumes the
+// evaluation -- no vector work in here, so a device backend launches x = xp + stp d without a host copy.
 // ------------------------------------------------------------------------------------
 class LbfgsMachine {
   public:
-    enum Kind { TRIAL, ACCEPT, DONE };
+    enum Kind { TRIAL = ACT_TRIAL, ACCEPT = ACT_ACCEPT, DONE = ACT_DONE };
     struct Action {
         Kind kind;
         int end;          // ACCEPT: history slot receiving the new (s, y) pair
@@ -128,49 +48,40 @@ class LbfgsMachine {
         bool keep_trial;  // DONE: result is the trial point (else the accepted point)
     };
 
-    LbfgsMachine(int n, const bioen_lbfgs_config& cfg) : n_(n), cfg_(cfg), ls_(cfg_) {}
+    LbfgsMachine(int n, const bioen_lbfgs_config& cfg) : n_(n), cfg_(cfg) { lb::machine_reset(st_, cfg_, nullptr); }
 
     // 0 = parameters fine, else the liblbfgs error code (no evaluation happens)
     int validate() const { return validate_lbfgs_config(n_, cfg_); }
 
     // Result of the evaluation at the start point (d = -g is built by the owner afterwards
     // unless the answer is DONE).  Returns TRIAL (go on) or DONE (already minimal).
-    Action on_initial(double f, double gg, double xx);
-    // Step length of the next point to evaluate: x = xp + step * d
-    double trial_step() const { return stp_; }
-    // Steps the backtracking searches (linesearch 1..3) can ask for NEXT, should the pending trial be
-    // rejected: stp * 0.5 (sufficient-decrease or strong-Wolfe failure) and, for the Wolfe variants,
-    // stp * 2.1 (curvature failure) -- formed exactly as report_backtracking forms them (lbfgs.c:686-727).
-    // Lets an owner with idle batch slots evaluate them alongside the trial; More-Thuente steps depend on
-    // the trial's values and cannot be foreseen (returns 0).
-    int speculative_steps(double out[2]) const {
-        if (cfg_.linesearch < 1 || cfg_.linesearch > 3) return 0;
-        double dec = stp_, inc = stp_;
-        dec *= 0.5;
-        inc *= 2.1;
-        out[0] = dec;
-        if (cfg_.linesearch == 1) return 1;
-        out[1] = inc;
-        return 2;
+    Action on_initial(double f, double gg, double xx) {
+        pf_.assign(cfg_.past > 0 ? cfg_.past : 0, 0.0);
+        lb::machine_reset(st_, cfg_, pf_.data());
+        return convert(lb::on_initial(st_, cfg_, f, gg, xx));
     }
+    // Step length of the next point to evaluate: x = xp + step * d
+    double trial_step() const { return st_.stp; }
+    // Steps the backtracking searches can ask for NEXT, should the pending trial be rejected (lbfgs_state.hpp)
+    int speculative_steps(double out[2]) const { return lb::speculative_steps(st_.stp, cfg_.linesearch, out); }
     // Result of that evaluation.
-    Action on_trial(const TrialResult& t);
+    Action on_trial(const TrialResult& t) {
+        st_.pf = pf_.data();          // machines live in containers: the storage may have moved with them
+        return convert(lb::on_trial(st_, cfg_, t));
+    }
 
-    double fx() const { return fx_; }
-    int iterations() const { return iterations_; }
-    int evaluations() const { return evaluations_; }
+    double fx() const { return st_.fx; }
+    int iterations() const { return st_.iterations; }
+    int evaluations() const { return st_.evaluations; }
 
   private:
-    void begin_linesearch(double step0);
-
+    static Action convert(const LbfgsAction& a) {
+        return Action{static_cast<Kind>(a.kind), a.end, a.bound, a.code, a.keep_trial != 0};
+    }
     int n_;
     bioen_lbfgs_config cfg_;
-    LineSearch ls_;
+    LbfgsState st_;
     std::vector<double> pf_;
-    double fx_ = 0.0, stp_ = 0.0;
-    int k_ = 1, end_ = 0;
-    int iterations_ = 0, evaluations_ = 0;
-    int ls_error_ = 0;
 };
 
 // Backend concept (xp/gp = accepted point and gradient, x/g = trial point and gradient):

@@ -125,6 +125,15 @@ typedef int (*bioen_hip_exchange_fn)(void* user, double* host_buf, size_t count_
 int bioen_hip_ctx_set_exchange_callback(bioen_hip_ctx* ctx, bioen_hip_exchange_fn fn, void* user);
 int bioen_hip_ctx_shard(const bioen_hip_ctx* ctx, int* rank, int* world, long long* n_global,
                         long long* col0, int* n_local);
+/* Test hook for the stage exchanges: on an UNSHARDED context (world = 1) that has a communicator
+ * (bioen_hip_comm_init(ctx, id, 0, 1)) or an exchange callback, every stage all-gather of the sharded
+ * code path -- ybar + softmax totals, gradient dot products, Gram products; the forces method's two --
+ * is executed although there is nobody to exchange with: a one-rank ncclAllGather on the context's stream,
+ * between the same kernels as on 8 GPUs, leaving every bit of the result unchanged.  Also switched on by
+ * BIOEN_HIP_FORCE_EXCHANGE=1 in the environment at context creation.  bioen_hip_exchange_counts tells how
+ * many stage all-gathers went through RCCL / through the host callback so far. */
+int bioen_hip_ctx_set_force_exchange(bioen_hip_ctx* ctx, int on);
+int bioen_hip_exchange_counts(const bioen_hip_ctx* ctx, long long* rccl, long long* host_staged);
 int bioen_hip_ctx_destroy(bioen_hip_ctx* ctx);
 int bioen_hip_ctx_shape(const bioen_hip_ctx* ctx, int* m, int* n);
 /* copy rows [row0,row0+rows) x cols [col0,col0+cols) of the resident matrix to host (row-major) */

@@ -293,6 +293,38 @@ def test_last_average_is_that_of_the_returned_point(optimize, linesearch):
             assert np.abs(ctx.last_average()[0] - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-14
 
 
+@pytest.mark.parametrize("M", [23, 600, 1100])
+def test_last_average_after_forces_calls(optimize, M):
+    """forces_fdf / opt_lbfgs_forces -> last_average hands out yTilde . w at the point the call ended on, on all three
+    matrix-pass families (M <= 512: strip passes on the centred copy, which keep ybar - centre on the device; M <= 1024:
+    the row-major strip kernels; beyond: streaming passes).  After a multi-problem call there is nothing to hand out."""
+    import bioen_amd
+    rng = np.random.default_rng(11)
+    N = 900
+    Y = rng.standard_normal((M, N)) + 3.0
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    YT = Y.dot(rng.dirichlet(np.ones(N))) + 0.05 * rng.standard_normal(M)
+    with bioen_amd.Context(Y, YT) as ctx:
+        f = 1e-3 * rng.standard_normal(M)
+        ctx.forces_fdf(f, w0, 5.0)
+        w = ctx.forces_weights(f, w0)
+        ctx.forces_fdf(f, w0, 5.0)
+        yraw, yeff = ctx.last_average()
+        ref = Y.dot(w)
+        assert np.abs(yraw - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.array_equal(yraw, yeff)
+        fopt, wopt, info = ctx.opt_lbfgs_forces(np.zeros(M), w0, 50.0, dict(linesearch=2, max_iterations=200, delta=1e-8,
+                                                                           epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9,
+                                                                           past=10, max_linesearch=100))
+        ref = Y.dot(wopt)
+        assert np.abs(ctx.last_average()[0] - ref).max() <= 1e-12 * np.abs(ref).max()
+        ctx.forces_fdf_batch(np.stack([f, 2 * f]), w0, [5.0, 1.0])
+        with pytest.raises(bioen_amd.BioenHipError):
+            ctx.last_average()
+        ctx.chi_squared(w)                                     # a single-problem call makes it valid again
+        assert np.abs(ctx.last_average()[0] - Y.dot(w)).max() <= 1e-12 * np.abs(ref).max()
+
+
 def test_nuisance_series_matches_host_rebuild_loop(optimize):
     """The device loop (matrix resident, parameters through set_affine) against the reference's
     protocol done the slow way: rebuild yTilde(m) on the host every iteration, optimise with the

@@ -543,15 +543,26 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
     import sys
     from conftest import ROOT
     code = _SPEC_SNIPPET % dict(root=ROOT, tests=os.path.join(ROOT, "tests"), name=name, mb=mb)
+    variants = {"default": {}, "nospec": {"BIOEN_HIP_SPECULATE": "0"}, "nodelivery": {"BIOEN_HIP_DELIVERY": "0"},
+                # the helper thread's timing decides which slots are free for shadows: without speculation AND
+                # without it the schedule is the plainest one
+                "plain": {"BIOEN_HIP_SPECULATE": "0", "BIOEN_HIP_DELIVERY": "0"},
+                # line-search decisions taken by the host from the round's scalars (the r02 engine) instead of on the device
+                "hostls": {"BIOEN_HIP_DEVICE_LS": "0"},
+                "hostls-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
+                # device-resident decisions without the round queued ahead of the host
+                "noqueue": {"BIOEN_HIP_QUEUE": "0"}}
     runs = {}
-    for flag in ("1", "0"):
-        env = dict(os.environ, BIOEN_HIP_SPECULATE=flag)
+    for tag, flags in variants.items():
+        env = dict(os.environ, **flags)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        runs[flag] = json.loads(p.stdout.strip().splitlines()[-1])
-    on, off = runs["1"], runs["0"]
-    assert off["stats"] == [0, 0]
-    assert on["stats"][0] > 0 and on["stats"][1] > 0, on["stats"]          # issued and adopted
-    for ls in ("2", "3", "1", "0"):
-        assert on[ls] == off[ls], ls
-
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        runs[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+    on = runs["default"]
+    for tag in ("nospec", "plain", "hostls-nospec"):
+        assert runs[tag]["stats"] == [0, 0], tag
+    for tag in ("default", "nodelivery", "hostls", "noqueue"):
+        assert runs[tag]["stats"][0] > 0 and runs[tag]["stats"][1] > 0, (tag, runs[tag]["stats"])   # issued and adopted
+    for tag, other in runs.items():
+        for ls in ("2", "3", "1", "0"):
+            assert on[ls] == other[ls], (tag, ls)
