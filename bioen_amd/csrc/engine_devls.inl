@@ -16,13 +16,26 @@ struct DevFlight {                   // a round in flight, as the host composed 
     int prob[kMaxBatch] = {};        // owners: index of the problem (theta) that occupied the slot at enqueue time
 };
 
+// Which engine.  Measured in one process on one context (tools/engine_ab.py, r03; best of 4 sweeps, 8 thetas):
+//     M x N             host-driven (r02)   device-resident
+//     64 x 2e4            9.6 ms              8.5 ms
+//     256 x 1e5 (cfg 1)   195.7 ms            185.4 ms
+//     1024 x 1.25e5       480.3 ms            473.3 ms      (a rank's share of the headline at 8 GPUs)
+//     1024 x 1e6          1158.5 ms           1179.0 ms     (headline)
+// A round of the device engine has fewer launches and no host turn-around; a round of the host engine evaluates
+// speculative trials in EVERY idle slot, which only pays where the matrix passes dwarf the N-vector work (the
+// headline: -5 % rounds for +3.5 % per round; configs[1]: -3 % rounds for +8 % per round).  So the device engine
+// takes the problems whose two matrix passes move less than 4 GB per round and every sharded context (one exchange
+// less per round, no host decision between the ranks' collectives); BIOEN_HIP_DEVICE_LS=1 / 0 forces the choice.
 bool LogwBatchEngine::device_engine_applies() const {
-    const char* e = std::getenv("BIOEN_HIP_DEVICE_LS");
-    if (e && e[0] == '0') return false;
     if (c->live_off) return false;                      // no coherent host memory to publish into
     if (!use_gram()) return false;                      // liblbfgs' literal two-loop on the vectors: host-driven engine
     if (cfg.past > kMaxPast) return false;
-    return true;
+    const char* e = std::getenv("BIOEN_HIP_DEVICE_LS");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    if (c->world > 1) return true;
+    return 2.0 * c->mp * (double)c->ld * sizeof(double) < 4e9;
 }
 
 int LogwBatchEngine::ensure_device_state() {
@@ -78,7 +91,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     const int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
     const bool can_speculate = speculate && cfg.linesearch >= 1 && cfg.linesearch <= 3;
     const int nslots = can_speculate ? kMaxBatch : kb;
-    for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, true));
+    for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, s < kb));   // history + spare pair: owners only
     note(ensure_device_state());
     if (rc) return rc;
     note(upload_n(c, c->fixed, G_host));
@@ -116,7 +129,16 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     unsigned long long initial_round[kMaxBatch] = {};  // the round that evaluates the slot's start point
     std::chrono::steady_clock::time_point t0[kMaxBatch];
     int shadow_owner[kMaxBatch], shadow_cand[kMaxBatch];   // idle slots: slot of the owner they shadow (-1: none)
+    unsigned long long release_round[kMaxBatch] = {};      // ... the round in which they lost their owner
     for (int s = 0; s < kMaxBatch; ++s) { prob[s] = -1; shadow_owner[s] = -1; shadow_cand[s] = 0; }
+    int seen_ev[kMaxBatch] = {}, seen_dec[kMaxBatch] = {}, seen_inc[kMaxBatch] = {};   // from the newest record of each owner
+    double shadow_rate = 0.08;
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOW_RATE")) shadow_rate = std::atof(e);
+    // default: no shadows -- at the sizes this engine takes by default they cost more than they save (table above);
+    // BIOEN_HIP_SHADOWS=n lets up to n idle slots shadow (tests run the adoption paths that way)
+    int max_positions = kMaxBatch, max_shadows = 0;
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOW_MAXPOS")) max_positions = std::max(1, std::min((int)kMaxBatch, std::atoi(e)));
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(e)));
     int next = 0, active = 0;
     std::deque<DevFlight> inflight;
 
@@ -140,7 +162,9 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         prob[s] = next;
         initial_round[s] = c->dev_round + 1;         // the next round enqueued
         t0[s] = std::chrono::steady_clock::now();
+        if (shadow_owner[s] >= 0) release_round[s] = c->dev_round + 1;
         shadow_owner[s] = -1;
+        seen_ev[s] = seen_dec[s] = seen_inc[s] = 0;
         ++active;
         ++next;
     };
@@ -217,39 +241,78 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             ++k;
         }
         r.nown = k;
-        // Speculation: idle slots evaluate the steps a backtracking search may ask for next.  Assignments persist from
-        // round to round (a slot changes its owner only once that owner is known to be finished -- the host runs a
-        // round behind the device, and a shadow adopted in a round it has not seen yet must not be handed on)
-        if (can_speculate) {
+        for (int a = 0; a < kMaxBatch; ++a) r.shadow[a][0] = r.shadow[a][1] = -1;
+        // Speculation: idle slots evaluate the steps a backtracking search may ask for next (stp / 2, 2.1 stp) in the
+        // round's matrix passes.  A shadow costs ten N-vector passes, widens the batch and adds the two (gated) late-Gram
+        // launches to the round; it pays only where a saved evaluation shortens the SERIES -- for the stragglers -- and
+        // where trials are rejected often enough.  Measured (tools/spec_probe.py, r03): shadows in every idle slot made
+        // the N = 1e5 x M = 256 series (4-5 % of the stragglers' trials rejected) 8 % slower than none, while the
+        // headline series (10-12 %) gains 3 %.  So: a problem is shadowed once it has shown a rejection rate of
+        // `shadow_rate` (8 %) over >= 24 evaluations, and at most `max_shadows` (2) slots shadow at a time: both steps of
+        // the smallest theta that qualifies (the series' rounds are the evaluations of its slowest member, which is
+        // the smallest theta in every series measured; rejections are spread over the whole run, so waiting for the
+        // tail of the series -- when slots abound -- catches almost none of them).
+        // Assignments persist from round to round, and a slot that loses its owner rests until the host has seen the
+        // rounds it took part in (the host runs `depth` rounds behind the device: the shadow may have been adopted there).
+        if (can_speculate && r.nown < max_positions) {
             const int ncand = cfg.linesearch == 1 ? 1 : 2;
-            bool has[kMaxBatch][3] = {};
-            for (int s = 0; s < nslots; ++s) {
-                if (shadow_owner[s] < 0) continue;
-                const int o = shadow_owner[s];
-                if ((s < kb && occupied[s]) || !occupied[o] || slot_busy(s)) { shadow_owner[s] = -1; continue; }
-                has[o][shadow_cand[s]] = true;
+            int order[kMaxBatch], no = 0;                    // owners worth shadowing, by ascending theta
+            for (int s = 0; s < kb; ++s) {
+                if (!occupied[s] || initial_round[s] >= round) continue;
+                const int rejected = seen_dec[s] + seen_inc[s];
+                if (seen_ev[s] < 24 || rejected < shadow_rate * seen_ev[s]) continue;
+                order[no++] = s;
             }
-            for (int pass = 1; pass <= ncand; ++pass)
-                for (int o = 0; o < kb; ++o) {
-                    if (!occupied[o] || has[o][pass]) continue;
-                    for (int s = nslots - 1; s >= 0; --s) {
-                        if ((s < kb && occupied[s]) || shadow_owner[s] >= 0 || slot_busy(s)) continue;
-                        shadow_owner[s] = o;
-                        shadow_cand[s] = pass;
-                        has[o][pass] = true;
-                        break;
-                    }
+            std::sort(order, order + no, [&](int x, int y) { return thetas[prob[x]] < thetas[prob[y]]; });
+            int want_owner[kMaxBatch], want_cand[kMaxBatch], nwant = 0;
+            const int room = std::min(std::min(max_positions - r.nown, kMaxBatch - r.nown), max_shadows);
+            for (int i = 0; i < no && nwant < room; ++i)
+                for (int pass = 0; pass < ncand && nwant < room; ++pass) {
+                    const int first = (ncand == 2 && seen_inc[order[i]] > seen_dec[order[i]]) ? 2 : 1;
+                    want_owner[nwant] = order[i];
+                    want_cand[nwant] = pass == 0 ? first : 3 - first;
+                    ++nwant;
                 }
+            bool have[kMaxBatch] = {};
+            for (int s = 0; s < nslots; ++s) {               // keep what is still wanted, release the rest
+                if (shadow_owner[s] < 0) continue;
+                bool keep = !(s < kb && occupied[s]) && !slot_busy(s);
+                int w = -1;
+                for (int i = 0; keep && i < nwant; ++i)
+                    if (!have[i] && want_owner[i] == shadow_owner[s] && want_cand[i] == shadow_cand[s]) w = i;
+                if (w < 0) {
+                    shadow_owner[s] = -1;
+                    release_round[s] = round;
+                } else {
+                    have[w] = true;
+                }
+            }
+            for (int i = 0; i < nwant; ++i) {
+                if (have[i]) continue;
+                for (int s = nslots - 1; s >= 0; --s) {
+                    if ((s < kb && occupied[s]) || shadow_owner[s] >= 0 || slot_busy(s)) continue;
+                    if (round < release_round[s] + (unsigned long long)depth + 1) continue;
+                    shadow_owner[s] = want_owner[i];
+                    shadow_cand[s] = want_cand[i];
+                    break;
+                }
+            }
             for (int s = 0; s < nslots && k < kMaxBatch; ++s) {
                 if (shadow_owner[s] < 0) continue;
                 const int o = shadow_owner[s];
-                if (initial_round[o] >= round) continue;          // the start point is evaluated alone
                 r.slot[k] = s;
                 r.owner[k] = pos_of_slot[o];
                 r.cand[k] = shadow_cand[s];
+                r.shadow[pos_of_slot[o]][shadow_cand[s] - 1] = k;
                 ++k;
                 ++spec_launched;
             }
+        } else {
+            for (int s = 0; s < nslots; ++s)
+                if (shadow_owner[s] >= 0) {
+                    shadow_owner[s] = -1;
+                    release_round[s] = round;
+                }
         }
         r.n = k;
         Vec8 wv{};
@@ -316,6 +379,12 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));
         }
         launch_dev_decide(c, r, cfg, round);
+        if (r.n > r.nown) {                         // a round with shadows: one of them may have been adopted and accepted
+            launch_dev_late_gram(c, r);
+            if (c->world > 1) note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
+            else note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));
+            launch_dev_late_solve(c, r);
+        }
         if (first_mask) {
             launch_dev_first_direction(c, r, first_mask);
             note(exchange(c, X_DGI, (size_t)r.nown * vec_grid(c)));
@@ -340,12 +409,11 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             if (!occupied[s] || prob[s] != f.prob[a]) continue;      // finished before; the slot may have a new tenant
             DevRecord rec;
             std::memcpy(&rec, page + (size_t)a * kLiveRec, sizeof rec);
+            seen_ev[s] = rec.evaluations;
+            seen_dec[s] = rec.rej_dec;
+            seen_inc[s] = rec.rej_inc;
             if (rec.status != DS_DONE) continue;
-            int column = a;
-            if (rec.adopted)
-                for (int q = f.nown; q < f.n; ++q)
-                    if (c->slot[f.slot[q]].w == rec.w) column = q;
-            finish_problem(s, rec, column);
+            finish_problem(s, rec, rec.evalpos);
             if (next < ntheta && !rc) start_problem(s);
         }
     }

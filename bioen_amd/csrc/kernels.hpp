@@ -196,9 +196,12 @@ struct DevSlot {                      // one per problem slot, device memory (ct
     LbfgsState m;
     double pf[kMaxPast];
     int status;                       // DevStatus
-    int combine;                      // the next step kernel forms d from the Gram coefficients first (a step was accepted)
+    int combine;                      // 1: the next step kernel forms d from the Gram coefficients first (a step was accepted);
+                                      // 2: ... whose Gram products are still to be formed (an adopted shadow: k_dev_late_*)
     int code, keep_trial;             // DS_DONE: liblbfgs status / result is the trial point
     int was_initial;                  // DS_DONE: ... reached at the evaluation of the start point
+    int late_end, late_bound;         // combine == 2: history slot / pairs in use of the accepted step
+    int rej_dec, rej_inc;             // rejected trials so far that asked for a shorter / a longer step next
     int pad;
 };
 
@@ -210,7 +213,8 @@ struct DevRecord {                    // what a decision publishes per position 
     double fx, stp;
     int status, code, keep_trial, was_initial;
     int iterations, evaluations;
-    int adopted, pad;
+    int adopted, evalpos;             // the evaluation the problem stands on was a shadow's / its position in the round
+    int rej_dec, rej_inc;
 };
 static_assert(sizeof(DevRecord) <= kLiveRec * sizeof(double), "live record");
 
@@ -220,6 +224,7 @@ struct DevRound {                     // a round as the kernels see it (by value
     int slot[kMaxBatch];              // position -> problem slot whose buffers / scalars the evaluation uses
     int owner[kMaxBatch];             // position -> position of its owner (itself for owners)
     int cand[kMaxBatch];              // 0: the owner's own trial; 1: stp * 0.5; 2: stp * 2.1 (speculative trials)
+    int shadow[kMaxBatch][2];         // owners: positions of their shadows with cand 1 / 2 (-1: none)
     double theta[kMaxBatch];
     double* d[kMaxBatch];             // fixed per-slot buffers of the position's OWNER: direction
     double* gram[kMaxBatch];          //   ... Gram matrix + coefficients (owner), finished sums (position)
@@ -246,6 +251,11 @@ void launch_dev_grad_gram(bioen_hip_ctx* c, const DevRound& r);          // grad
 void launch_dev_decide(bioen_hip_ctx* c, const DevRound& r, const bioen_lbfgs_config& cfg, unsigned long long round);
 void launch_dev_first_direction(bioen_hip_ctx* c, const DevRound& r, int mask);   // d = -gp, partials of gp.d for the owners in `mask`
 void launch_dev_store_dginit(bioen_hip_ctx* c, const DevRound& r, int mask);      //   ... finished -> scal[S_DGINIT]   [after the X_DGI exchange]
+// An ADOPTED shadow evaluation that is accepted has no Gram products yet (shadows skip that part of the sweep): the pair
+// and its 39 products are formed now (k_gram through the role table), then the recursion (k_gram_solve).  Gated on the
+// problems' `combine` word: both return at once in the usual round.
+void launch_dev_late_gram(bioen_hip_ctx* c, const DevRound& r);     // [exchange X_GRAM / X_GRAMR]
+void launch_dev_late_solve(bioen_hip_ctx* c, const DevRound& r);
 int dev_all_fused(const bioen_hip_ctx* c);                               // the decision kernel finishes the Gram sums itself
 void launch_dev_rank_reduce(bioen_hip_ctx* c, const DevRound& r);        // sharded: this rank's totals of the 39 + 3 sums -> X_GRAMR
 constexpr int kDevRankSums = kGramDots + 3;

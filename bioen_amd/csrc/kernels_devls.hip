@@ -66,6 +66,7 @@ __global__ void k_dev_table_init(DevTableInit t, DevSlot* tab) {
     T.status = DS_IDLE;
     T.combine = 0;
     T.code = 0; T.keep_trial = 0; T.was_initial = 0;
+    T.late_end = 0; T.late_bound = 0; T.rej_dec = 0; T.rej_inc = 0; T.pad = 0;
 }
 
 // (re)start: accepted point <- start vector; direction, history and Gram state zeroed (the Gram sweep multiplies
@@ -98,29 +99,34 @@ __global__ __launch_bounds__(kBlock) void k_dev_start(DevStart s, bioen_lbfgs_co
             T.code = 0;
             T.keep_trial = 0;
             T.was_initial = 0;
+            T.rej_dec = 0;
+            T.rej_inc = 0;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // x = xp + stp d ; block maxima of x (k_trial).  After an accepted step d is formed first from the Gram coefficients
-// (k_combine: d = sum_c cf_c B_c over {S_0..5, Y_0..5, gp}); a shadow position forms its owner's d in registers too
-// (it runs beside the owner's blocks, which are the ones that store it).
+// (k_combine: d = sum_c cf_c B_c over {S_0..5, Y_0..5, gp}).  One set of blocks per OWNER: the trial points of its
+// shadows (stp / 2, 2.1 stp) are written in the same sweep from the same d -- a shadow position with blocks of its own
+// would have to form d a second time (it runs beside the owner's blocks, not behind them).
 __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) {
     __shared__ double sh[kWaves];
-    const int a = blockIdx.y;
+    const int a = blockIdx.y;                   // owner position
     int ost;
     if (!dev_pos_live(r, a, &ost)) return;
-    const int o = r.owner[a];
-    const DevSlot& T = r.tab[r.slot[o]];
-    double stp = T.m.stp;                       // INITIAL: 0 (and d = 0): x = xp
-    if (r.cand[a] == 1) stp *= 0.5;             // as lb::speculative_steps / report_backtracking form them
-    if (r.cand[a] == 2) stp *= 2.1;
-    double* __restrict__ x = r.tab[r.slot[a]].x;
+    const DevSlot& T = r.tab[r.slot[a]];
+    const double stp = T.m.stp;                 // INITIAL: 0 (and d = 0): x = xp
+    const int q1 = ost == DS_RUNNING ? r.shadow[a][0] : -1, q2 = ost == DS_RUNNING ? r.shadow[a][1] : -1;
+    double stp1 = stp, stp2 = stp;
+    stp1 *= 0.5;                                // as lb::speculative_steps / report_backtracking form them
+    stp2 *= 2.1;
+    double* __restrict__ x = T.x;
+    double* __restrict__ x1 = q1 >= 0 ? r.tab[r.slot[q1]].x : nullptr;
+    double* __restrict__ x2 = q2 >= 0 ? r.tab[r.slot[q2]].x : nullptr;
     const double* __restrict__ xp = T.xp;
-    double* __restrict__ d = r.d[o];
+    double* __restrict__ d = r.d[a];
     const bool combine = T.combine != 0;
-    const bool store_d = r.cand[a] == 0;
     double cf[kBasis];
 #pragma unroll
     for (int c = 0; c < kBasis; ++c) cf[c] = 0.0;
@@ -133,11 +139,11 @@ __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) 
         Yk[k] = T.Y[k];
     }
     if (combine) {
-        const double* coef = r.gram[o] + kBasis * kBasis;
+        const double* coef = r.gram[a] + kBasis * kBasis;
 #pragma unroll
         for (int c = 0; c < kBasis; ++c) cf[c] = coef[c];
     }
-    double mx = -DBL_MAX;
+    double mx = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
     const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
@@ -158,18 +164,38 @@ __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) 
                     dv.y = fma(cf[kHistory + k], v.y, dv.y);
                 }
             }
-            if (store_d) *reinterpret_cast<d2*>(d + j) = dv;
+            *reinterpret_cast<d2*>(d + j) = dv;
         } else {
             dv = *reinterpret_cast<const d2*>(d + j);
         }
         const d2 pv = *reinterpret_cast<const d2*>(xp + j);
-        d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
+        const d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
         *reinterpret_cast<d2*>(x + j) = v;
         mx = fmax(mx, v.x);
         if (j + 1 < n) mx = fmax(mx, v.y);
+        if (x1) {
+            const d2 u = {fma(stp1, dv.x, pv.x), fma(stp1, dv.y, pv.y)};
+            *reinterpret_cast<d2*>(x1 + j) = u;
+            mx1 = fmax(mx1, u.x);
+            if (j + 1 < n) mx1 = fmax(mx1, u.y);
+        }
+        if (x2) {
+            const d2 u = {fma(stp2, dv.x, pv.x), fma(stp2, dv.y, pv.y)};
+            *reinterpret_cast<d2*>(x2 + j) = u;
+            mx2 = fmax(mx2, u.x);
+            if (j + 1 < n) mx2 = fmax(mx2, u.y);
+        }
     }
     mx = block_max(mx, sh);
     if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
+    if (x1) {
+        mx1 = block_max(mx1, sh);
+        if (threadIdx.x == 0) xput<1>(xo, q1, 0, mx1);
+    }
+    if (x2) {
+        mx2 = block_max(mx2, sh);
+        if (threadIdx.x == 0) xput<1>(xo, q2, 0, mx2);
+    }
 }
 
 // e = exp(x - m) ; partials of sum e and sum e (x - G): k_logw_exp with the trial point taken from the role table
@@ -227,7 +253,9 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
     const double theta = r.theta[a];
     const double Pp = r.scal[a][S_P];
     const double inv = r.scal[a][S_INV];      // w = e * inv
-    const bool gram = ost == DS_RUNNING;      // the evaluation of the start point has no pair to form
+    // the evaluation of the start point has no pair to form; a shadow's is formed only if it is adopted AND accepted
+    // (k_dev_late_gram): 14 vector passes per shadow and round for a pair that is used once in ten rounds
+    const bool gram = ost == DS_RUNNING && r.cand[a] == 0;
     const int e = T.m.end;                    // history slot the pair would take
     const double* __restrict__ xo_ = T.xp;
     const double* __restrict__ go = T.gp;
@@ -314,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_gram_reduce(DevRound r, Xch xi) 
     __shared__ double sh[kWaves];
     const int c = blockIdx.x, a = blockIdx.y;
     int ost;
-    if (!dev_pos_live(r, a, &ost) || ost != DS_RUNNING) return;
+    if (!dev_pos_live(r, a, &ost) || ost != DS_RUNNING || r.cand[a] != 0) return;
     const double v = xsum<kGramDots>(xi, a, c, sh);
     if (threadIdx.x == 0) r.gram[a][kGramSums + c] = v;
 }
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_rank_reduce(DevRound r, Xch xg, 
     if (!dev_pos_live(r, a, &ost)) return;
     double v = 0.0;
     if (c < kGramDots) {
-        if (ost == DS_RUNNING) v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
+        if (ost == DS_RUNNING && r.cand[a] == 0) v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
     } else {
         v = xsum_rank<3>(xg, xg.rank, a, c - kGramDots, sh);
     }
@@ -393,39 +421,114 @@ __global__ __launch_bounds__(kBlock) void k_dev_store_dginit(DevRound r, int mas
 //   * publish the problem's record into the round's page of the host-mapped ring, then the round number into its flag.
 // `spec` counts adopted shadows (device word, read by the host at the end of the run).
 // MODE 0: few block partials per sum, finished in-block; 1: k_dev_gram_reduce has left the Gram sums; 2: sharded
-// context, every sum = the ranks' totals out of the X_GRAMR stage (`xm`)
+// context, every sum = the ranks' totals out of the X_GRAMR stage (`xm`).
+//
+// Latency, not work, is what this kernel costs (one block per problem; its predecessor version took 15 us of a 160 us
+// round at N = 1e5 x M = 256): the problem's table entry, its scalar slot, the Gram matrix and ALL 42 sums of the
+// evaluation are fetched up front, side by side, into LDS -- one memory round trip -- and the single thread that then
+// walks the decision, the Gram update and the two-loop recursion touches LDS only; the entry is written back by the
+// whole block.  The sums are formed in the order of xsum / k_gram_solve: not a bit changes.
+__device__ __forceinline__ void dev_three_sums(const Xch& xg, int a, double (*sh3)[kWaves], double* out) {
+    // xsum<3> for q = 0, 1, 2 at once: per thread the partials k = t, t + 256, ... in turn, wave_sum, then the
+    // block's four wave totals as (w0 + w1) + (w2 + w3) -- block_sum's order
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int rk = 0; rk < xg.world; ++rk)
+        for (int k = threadIdx.x; k < xg.npl; k += kBlock) {
+            double v[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[q] = xg.base[(size_t)rk * xg.payload + (size_t)(a * 3 + q) * xg.npl + k];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) s[q] += v[q];
+        }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s[q] = wave_sum(s[q]);
+    __syncthreads();   // protect sh3 against its previous use
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sh3[q][threadIdx.x >> 6] = s[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = (sh3[q][0] + sh3[q][1]) + (sh3[q][2] + sh3[q][3]);
+}
+
+template <int MODE>
+__device__ __forceinline__ void dev_gram_dots(const DevRound& r, const Xch& xm, int pos, double* dots) {
+    if (MODE == 2) {
+        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = dev_ranks_sum(xm, pos, i);
+    } else if (MODE == 0) {
+        // as k_gram_solve<true>: a wave's sums side by side, every sum formed in the same order
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
+        double acc[kPerWave];
+#pragma unroll
+        for (int u = 0; u < kPerWave; ++u) acc[u] = 0.0;
+        for (int rk = 0; rk < xm.world; ++rk)
+            for (int k = lane; k < xm.npl; k += 64) {
+                double v[kPerWave];
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) {
+                    const int c = wave + u * kWaves;
+                    v[u] = c < kGramDots ? xm.base[(size_t)rk * xm.payload + (size_t)(pos * kGramDots + c) * xm.npl + k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) acc[u] += v[u];
+            }
+#pragma unroll
+        for (int u = 0; u < kPerWave; ++u) {
+            const int c = wave + u * kWaves;
+            const double t = wave_sum(acc[u]);
+            if (lane == 0 && c < kGramDots) dots[c] = t;
+        }
+    } else {
+        const double* Gq = r.gram[pos];
+        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = Gq[kGramSums + i];
+    }
+}
+
+constexpr int kSlotWords = (int)(sizeof(DevSlot) / sizeof(unsigned long long));
+static_assert(sizeof(DevSlot) % sizeof(unsigned long long) == 0, "DevSlot is copied in 8-byte words");
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_config cfg, Xch xg, Xch xm,
                                                        double* __restrict__ page, unsigned long long* __restrict__ flags,
                                                        unsigned long long round, unsigned long long* __restrict__ spec) {
-    __shared__ double sh[kWaves];
+    __shared__ double sh3[3][kWaves];
     __shared__ double dots[kGramDots];
-    __shared__ double Gs[kBasis * kBasis];
+    __shared__ double Gs[kBasis * kBasis + kBasis];   // the Gram matrix | the direction's 13 coefficients
     __shared__ double alpha[kHistory];
-    __shared__ int ctl[8];                    // kind, adopt position, end, bound
+    __shared__ int ctl[8];                    // kind, adopt position, end, bound, code, keep_trial
     __shared__ double rec[kLiveRec];
+    __shared__ double scs[kScalStride];       // the problem's scalar slot
+    __shared__ unsigned long long Tw[kSlotWords];   // the problem's table entry
     const int a = blockIdx.y;
-    const int so = r.slot[a];
-    DevSlot& T = r.tab[so];
-    double* sc = r.scal[a];
+    DevSlot* Tg = r.tab + r.slot[a];
+    DevSlot& T = *reinterpret_cast<DevSlot*>(Tw);
+    double* scg = r.scal[a];
+    double* G = r.gram[a];
+    // ---- everything the decision may need, fetched side by side ----
+    for (int i = threadIdx.x; i < kSlotWords; i += kBlock) Tw[i] = reinterpret_cast<const unsigned long long*>(Tg)[i];
+    if (threadIdx.x < kScalStride) scs[threadIdx.x] = scg[threadIdx.x];
+    for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
+    double sums[3];
+    if (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sums[q] = dev_ranks_sum(xm, a, kGramDots + q);
+        __syncthreads();
+    } else {
+        dev_three_sums(xg, a, sh3, sums);     // (two barriers: Tw, scs, Gs are in place after it)
+    }
     const int status = T.status;
+    const bool alive = dev_alive(status);
+    if (alive && status == DS_RUNNING) dev_gram_dots<MODE>(r, xm, a, dots);      // block-uniform
     int kind = ACT_DONE, evalpos = a;
-    if (dev_alive(status)) {
-        double dg, gg, xx;
-        if (MODE == 2) {
-            dg = dev_ranks_sum(xm, a, kGramDots + 0);
-            gg = dev_ranks_sum(xm, a, kGramDots + 1);
-            xx = dev_ranks_sum(xm, a, kGramDots + 2);
-        } else {
-            dg = xsum<3>(xg, a, 0, sh);
-            gg = xsum<3>(xg, a, 1, sh);
-            xx = xsum<3>(xg, a, 2, sh);
-        }
+    bool dirty = false;
+    if (alive) {
         if (threadIdx.x == 0) {
+            T.m.pf = T.pf;                    // the LDS copy's own array while the decision runs
             LbfgsAction act;
             int adopt = -1;
             if (status == DS_INITIAL) {
-                act = lb::on_initial(T.m, cfg, sc[S_F], gg, xx);
+                act = lb::on_initial(T.m, cfg, scs[S_F], sums[1], sums[2]);
                 T.was_initial = 1;
                 if (act.kind != ACT_DONE) {
                     double* t = T.g; T.g = T.gp; T.gp = t;      // gradient at the accepted (= start) point
@@ -435,9 +538,10 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
                 }
             } else {
                 const double prev = T.m.stp;
-                const TrialResult t{sc[S_F], dg, gg, xx, sc[S_DGINIT]};
+                const TrialResult t{scs[S_F], sums[0], sums[1], sums[2], scs[S_DGINIT]};
                 act = lb::on_trial(T.m, cfg, t);
                 if (act.kind == ACT_TRIAL) {
+                    if (T.m.stp < prev) ++T.rej_dec; else ++T.rej_inc;      // what the host's shadow policy goes by
                     // rejected: is the step it asks for next among this round's shadows?
                     double cand[2];
                     const int nc = lb::speculative_steps(prev, cfg.linesearch, cand);
@@ -445,40 +549,36 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
                         if (r.owner[q] == a && r.cand[q] >= 1 && r.cand[q] <= nc && cand[r.cand[q] - 1] == T.m.stp) adopt = q;
                 }
             }
-            sc[S_DG] = dg;
-            sc[S_GG] = gg;
-            sc[S_XX] = xx;
+            scs[S_DG] = sums[0];
+            scs[S_GG] = sums[1];
+            scs[S_XX] = sums[2];
             ctl[0] = act.kind; ctl[1] = adopt; ctl[2] = act.end; ctl[3] = act.bound; ctl[4] = act.code; ctl[5] = act.keep_trial;
+            ctl[6] = 0;
         }
         __syncthreads();
         const int adopt = ctl[1];
-        if (adopt >= 0) {                      // block-uniform
+        if (adopt >= 0) {                      // block-uniform, rare: the shadow's sums are fetched now
             if (MODE == 2) {
-                dg = dev_ranks_sum(xm, adopt, kGramDots + 0);
-                gg = dev_ranks_sum(xm, adopt, kGramDots + 1);
-                xx = dev_ranks_sum(xm, adopt, kGramDots + 2);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sums[q] = dev_ranks_sum(xm, adopt, kGramDots + q);
             } else {
-                dg = xsum<3>(xg, adopt, 0, sh);
-                gg = xsum<3>(xg, adopt, 1, sh);
-                xx = xsum<3>(xg, adopt, 2, sh);
+                dev_three_sums(xg, adopt, sh3, sums);
             }
             if (threadIdx.x == 0) {
-                DevSlot& Q = r.tab[r.slot[adopt]];
+                DevSlot* Q = r.tab + r.slot[adopt];           // the shadow's entry (nobody else touches it in this kernel)
                 double* t;
-                t = T.x; T.x = Q.x; Q.x = t;                   // the shadow's point, gradient and pending pair become the trial's
-                t = T.g; T.g = Q.g; Q.g = t;
-                t = T.Ssp; T.Ssp = Q.Ssp; Q.Ssp = t;
-                t = T.Ysp; T.Ysp = Q.Ysp; Q.Ysp = t;
+                t = T.x; T.x = Q->x; Q->x = t;                 // the shadow's point and gradient become the trial's
+                t = T.g; T.g = Q->g; Q->g = t;
                 const double* qs = r.scal[adopt];
                 // the evaluation-owned entries of a slot's scalars (the rest -- y.s, alpha, gp.d -- belongs to the problem)
-                for (int i = S_F; i < S_F + 4; ++i) sc[i] = qs[i];
-                for (int i = S_LOGS; i < S_LOGS + 4; ++i) sc[i] = qs[i];
-                for (int i = S_KL; i < S_KL + 2; ++i) sc[i] = qs[i];
-                for (int i = S_INV; i < S_INV + 3; ++i) sc[i] = qs[i];
-                sc[S_DG] = dg;
-                sc[S_GG] = gg;
-                sc[S_XX] = xx;
-                const TrialResult t2{sc[S_F], dg, gg, xx, sc[S_DGINIT]};
+                for (int i = S_F; i < S_F + 4; ++i) scs[i] = qs[i];
+                for (int i = S_LOGS; i < S_LOGS + 4; ++i) scs[i] = qs[i];
+                for (int i = S_KL; i < S_KL + 2; ++i) scs[i] = qs[i];
+                for (int i = S_INV; i < S_INV + 3; ++i) scs[i] = qs[i];
+                scs[S_DG] = sums[0];
+                scs[S_GG] = sums[1];
+                scs[S_XX] = sums[2];
+                const TrialResult t2{scs[S_F], sums[0], sums[1], sums[2], scs[S_DGINIT]};
                 const LbfgsAction act = lb::on_trial(T.m, cfg, t2);
                 ctl[0] = act.kind; ctl[2] = act.end; ctl[3] = act.bound; ctl[4] = act.code; ctl[5] = act.keep_trial;
                 atomicAdd(spec, 1ull);
@@ -487,81 +587,165 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
             evalpos = adopt;
         }
         kind = ctl[0];
-        if (kind == ACT_ACCEPT) {              // block-uniform
-            double* G = r.gram[a];
-            for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
-            if (MODE == 2) {
-                for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = dev_ranks_sum(xm, evalpos, i);
-            } else if (MODE == 0) {
-                // as k_gram_solve<true>: a wave's sums side by side, every sum formed in the same order
-                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-                constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
-                double acc[kPerWave];
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) acc[u] = 0.0;
-                for (int rk = 0; rk < xm.world; ++rk)
-                    for (int k = lane; k < xm.npl; k += 64) {
-                        double v[kPerWave];
-#pragma unroll
-                        for (int u = 0; u < kPerWave; ++u) {
-                            const int c = wave + u * kWaves;
-                            v[u] = c < kGramDots
-                                       ? xm.base[(size_t)rk * xm.payload + (size_t)(evalpos * kGramDots + c) * xm.npl + k]
-                                       : 0.0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < kPerWave; ++u) acc[u] += v[u];
-                    }
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) {
-                    const int c = wave + u * kWaves;
-                    const double t = wave_sum(acc[u]);
-                    if (lane == 0 && c < kGramDots) dots[c] = t;
-                }
-            } else {
-                const double* Gq = r.gram[evalpos];
-                for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = Gq[kGramSums + i];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                gram_solve_thread0(G, Gs, dots, alpha, ctl[2], ctl[3], sc);
+        if (threadIdx.x == 0) {
+            if (kind == ACT_ACCEPT) {
                 const int e = ctl[2];
+                if (evalpos == a) {
+                    // the LDS image is also the destination of the update (a single lane's ~90 stores to HBM would
+                    // sit in front of the publishing fence): the block writes it back below
+                    gram_solve_thread0(Gs, Gs, dots, alpha, e, ctl[3], scs);
+                    T.combine = 1;
+                    ctl[6] = 1;
+                } else {      // an adopted shadow carries no Gram products: k_dev_late_gram / _solve form them now
+                    T.combine = 2;
+                    T.late_end = e;
+                    T.late_bound = ctl[3];
+                }
                 double* t;
                 t = T.S[e]; T.S[e] = T.Ssp; T.Ssp = t;         // the pending pair joins the ring
                 t = T.Y[e]; T.Y[e] = T.Ysp; T.Ysp = t;
                 t = T.x; T.x = T.xp; T.xp = t;                 // the trial point becomes the accepted point
                 t = T.g; T.g = T.gp; T.gp = t;
-                T.combine = 1;
+            } else {
+                T.combine = 0;
+                if (kind == ACT_DONE) {
+                    atomicAdd(dev_alive_word(r.tab), -1);     // the matrix passes of a round without live problems return at once
+                    T.status = DS_DONE;
+                    T.code = ctl[4];
+                    T.keep_trial = ctl[5];
+                }
             }
-        } else if (threadIdx.x == 0) {
-            T.combine = 0;
-            if (kind == ACT_DONE) {
-                atomicAdd(dev_alive_word(r.tab), -1);     // the matrix passes of a round without live problems return at once
-                T.status = DS_DONE;
-                T.code = ctl[4];
-                T.keep_trial = ctl[5];
-            }
+            T.m.pf = Tg->pf;                  // back to the entry's own array
         }
+        dirty = true;
     }
-    // ---- publish ----
-    __syncthreads();
+    // ---- the record, built in LDS ----
     if (threadIdx.x == 0) {
         DevRecord* R = reinterpret_cast<DevRecord*>(rec);
-        for (int i = 0; i < kScalStride; ++i) R->scal[i] = sc[i];
+        for (int i = 0; i < kScalStride; ++i) R->scal[i] = scs[i];
         R->x = T.x; R->xp = T.xp; R->g = T.g; R->gp = T.gp;
         R->w = r.w[evalpos];
         R->fx = T.m.fx; R->stp = T.m.stp;
         R->status = T.status; R->code = T.code; R->keep_trial = T.keep_trial; R->was_initial = T.was_initial;
         R->iterations = T.m.iterations; R->evaluations = T.m.evaluations;
-        R->adopted = evalpos != a; R->pad = 0;
+        R->adopted = evalpos != a; R->evalpos = evalpos;
+        R->rej_dec = T.rej_dec; R->rej_inc = T.rej_inc;
     }
     __syncthreads();
+    // ---- write back (the whole block), then publish ----
+    if (dirty) {
+        for (int i = threadIdx.x; i < kSlotWords; i += kBlock) reinterpret_cast<unsigned long long*>(Tg)[i] = Tw[i];
+        if (threadIdx.x < kScalStride) scg[threadIdx.x] = scs[threadIdx.x];
+        if (ctl[6])
+            for (int i = threadIdx.x; i < kBasis * kBasis + kBasis; i += kBlock) G[i] = Gs[i];
+    }
     static_assert(kLiveRec <= 64, "the record is published by ONE wave: its fence covers the stores of all its lanes");
     if (threadIdx.x < 64) {
         if (threadIdx.x < kLiveRec) page[(size_t)a * kLiveRec + threadIdx.x] = rec[threadIdx.x];
         __threadfence_system();               // wave-wide: s_waitcnt vmcnt(0) + write-back cover every lane's store
         if (threadIdx.x == 0)
             __hip_atomic_store(flags + a, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Late Gram sweep (k_gram through the role table) for the owners whose accepted step was an adopted shadow's:
+// s = xp - x, y = gp - g (the roles are already swapped) go to ring slot `late_end`, the 39 products to the
+// owner's X_GRAM partials.  Returns at once for everybody else.
+__global__ __launch_bounds__(kBlock) void k_dev_late_gram(DevRound r, int n, Xch xo) {
+    __shared__ double sh[kWaves][64];
+    const int a = blockIdx.y;
+    const DevSlot& T = r.tab[r.slot[a]];
+    if (T.status != DS_RUNNING || T.combine != 2) return;
+    const int e = T.late_end;
+    const double* __restrict__ xn = T.xp;
+    const double* __restrict__ xo_ = T.x;
+    const double* __restrict__ gn = T.gp;
+    const double* __restrict__ go = T.g;
+    double* Sk[kHistory];
+    double* Yk[kHistory];
+#pragma unroll
+    for (int k = 0; k < kHistory; ++k) {
+        Sk[k] = T.S[k];
+        Yk[k] = T.Y[k];
+    }
+    double* __restrict__ Se = T.S[e];
+    double* __restrict__ Ye = T.Y[e];
+    double acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.0;
+    const int n2 = (n + 1) >> 1;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+        const int j = 2 * p;
+        const d2 a0 = *reinterpret_cast<const d2*>(xn + j), a1 = *reinterpret_cast<const d2*>(xo_ + j);
+        const d2 gv = *reinterpret_cast<const d2*>(gn + j), g1 = *reinterpret_cast<const d2*>(go + j);
+        const d2 sv = {a0.x - a1.x, a0.y - a1.y};
+        const d2 yv = {gv.x - g1.x, gv.y - g1.y};
+        d2 B[kBasis];
+#pragma unroll
+        for (int k = 0; k < kHistory; ++k) {
+            B[k] = (k == e) ? sv : *reinterpret_cast<const d2*>(Sk[k] + j);
+            B[kHistory + k] = (k == e) ? yv : *reinterpret_cast<const d2*>(Yk[k] + j);
+        }
+        B[2 * kHistory] = gv;
+        *reinterpret_cast<d2*>(Se + j) = sv;
+        *reinterpret_cast<d2*>(Ye + j) = yv;
+#pragma unroll
+        for (int c = 0; c < kBasis; ++c) {
+            acc[c] = fma(sv.x, B[c].x, acc[c]);
+            acc[c] = fma(sv.y, B[c].y, acc[c]);
+            acc[kBasis + c] = fma(yv.x, B[c].x, acc[kBasis + c]);
+            acc[kBasis + c] = fma(yv.y, B[c].y, acc[kBasis + c]);
+            acc[2 * kBasis + c] = fma(gv.x, B[c].x, acc[2 * kBasis + c]);
+            acc[2 * kBasis + c] = fma(gv.y, B[c].y, acc[2 * kBasis + c]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_multi_reduce<64>(acc, lane);          // lane l now holds the wave total of value l
+    sh[wave][lane] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < kGramDots) {
+        const double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        xo.base[(size_t)xo.rank * xo.payload + (size_t)(a * kGramDots + threadIdx.x) * xo.npl + blockIdx.x] = v;
+    }
+}
+
+// sharded: this rank's totals of the late sweep's 39 products -> X_GRAMR (the 3 gradient sums are not needed again)
+__global__ __launch_bounds__(kBlock) void k_dev_late_rank_reduce(DevRound r, Xch xm, Xch xo) {
+    __shared__ double sh[kWaves];
+    const int c = blockIdx.x, a = blockIdx.y;
+    const DevSlot& T = r.tab[r.slot[a]];
+    if (T.status != DS_RUNNING || T.combine != 2) return;
+    const double v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
+    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kDevRankSums + c] = v;
+}
+
+// ... and the recursion (k_gram_solve).  The 39 sums are formed in the order the decision kernel of this context forms
+// them (MODE as k_dev_decide; 1 = xsum's order, the one k_dev_gram_reduce / k_gram_reduce use), so a direction does not
+// depend on whether its step came out of a shadow.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_dev_late_solve(DevRound r, Xch xm) {
+    __shared__ double sh[kWaves];
+    __shared__ double dots[kGramDots];
+    __shared__ double Gs[kBasis * kBasis];
+    __shared__ double alpha[kHistory];
+    const int a = blockIdx.y;
+    DevSlot& T = r.tab[r.slot[a]];
+    if (T.status != DS_RUNNING || T.combine != 2) return;
+    double* G = r.gram[a];
+    for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
+    if (MODE == 1) {
+        for (int c = 0; c < kGramDots; ++c) {
+            const double v = xsum<kGramDots>(xm, a, c, sh);
+            if (threadIdx.x == 0) dots[c] = v;
+        }
+    } else {
+        dev_gram_dots<MODE>(r, xm, a, dots);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gram_solve_thread0(G, Gs, dots, alpha, T.late_end, T.late_bound, r.scal[a]);
+        T.combine = 1;
     }
 }
 
@@ -588,7 +772,7 @@ void launch_dev_start(bioen_hip_ctx* c, const DevStart& s, const bioen_lbfgs_con
 }
 
 void launch_dev_step(bioen_hip_ctx* c, const DevRound& r) {
-    hipLaunchKernelGGL(k_dev_step, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+    hipLaunchKernelGGL(k_dev_step, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
                        make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
@@ -633,6 +817,22 @@ void launch_dev_decide(bioen_hip_ctx* c, const DevRound& r, const bioen_lbfgs_co
         hipLaunchKernelGGL(k_dev_gram_reduce, dim3(kGramDots, r.n), block, 0, c->stream, r, xm);
         hipLaunchKernelGGL(k_dev_decide<1>, grid, block, 0, c->stream, r, cfg, xg, xm, page, flags, round, spec);
     }
+}
+
+void launch_dev_late_gram(bioen_hip_ctx* c, const DevRound& r) {
+    const Xch xm = make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c));
+    hipLaunchKernelGGL(k_dev_late_gram, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n, xm);
+    if (c->world > 1)
+        hipLaunchKernelGGL(k_dev_late_rank_reduce, dim3(kGramDots, r.nown), dim3(kBlock), 0, c->stream, r, xm,
+                           dev_rank_view(c, r.n));
+}
+
+void launch_dev_late_solve(bioen_hip_ctx* c, const DevRound& r) {
+    const Xch xm = make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c));
+    const dim3 grid(1, r.nown), block(kBlock);
+    if (c->world > 1) hipLaunchKernelGGL(k_dev_late_solve<2>, grid, block, 0, c->stream, r, dev_rank_view(c, r.n));
+    else if (dev_all_fused(c)) hipLaunchKernelGGL(k_dev_late_solve<0>, grid, block, 0, c->stream, r, xm);
+    else hipLaunchKernelGGL(k_dev_late_solve<1>, grid, block, 0, c->stream, r, xm);
 }
 
 void launch_dev_first_direction(bioen_hip_ctx* c, const DevRound& r, int mask) {

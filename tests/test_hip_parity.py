@@ -544,6 +544,7 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
     from conftest import ROOT
     code = _SPEC_SNIPPET % dict(root=ROOT, tests=os.path.join(ROOT, "tests"), name=name, mb=mb)
     variants = {"default": {}, "nospec": {"BIOEN_HIP_SPECULATE": "0"}, "nodelivery": {"BIOEN_HIP_DELIVERY": "0"},
+                "device": {"BIOEN_HIP_DEVICE_LS": "1"}, "device-shadows": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0.02"},
                 # the helper thread's timing decides which slots are free for shadows: without speculation AND
                 # without it the schedule is the plainest one
                 "plain": {"BIOEN_HIP_SPECULATE": "0", "BIOEN_HIP_DELIVERY": "0"},
@@ -551,7 +552,10 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
                 "hostls": {"BIOEN_HIP_DEVICE_LS": "0"},
                 "hostls-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
                 # device-resident decisions without the round queued ahead of the host
-                "noqueue": {"BIOEN_HIP_QUEUE": "0"}}
+                "noqueue": {"BIOEN_HIP_QUEUE": "0", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOWS": "2"},
+                # ... with every idle slot shadowing from the first round on (the default policy waits for a problem to
+                # show a rejection rate first), two rounds queued ahead
+                "eager": {"BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOWS": "8", "BIOEN_HIP_QUEUE": "2"}}
     runs = {}
     for tag, flags in variants.items():
         env = dict(os.environ, **flags)
@@ -559,9 +563,9 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
         assert p.returncode == 0, (tag, p.stderr[-2000:])
         runs[tag] = json.loads(p.stdout.strip().splitlines()[-1])
     on = runs["default"]
-    for tag in ("nospec", "plain", "hostls-nospec"):
+    for tag in ("nospec", "plain", "hostls-nospec", "default", "device"):
         assert runs[tag]["stats"] == [0, 0], tag
-    for tag in ("default", "nodelivery", "hostls", "noqueue"):
+    for tag in ("hostls", "noqueue", "eager"):
         assert runs[tag]["stats"][0] > 0 and runs[tag]["stats"][1] > 0, (tag, runs[tag]["stats"])   # issued and adopted
     for tag, other in runs.items():
         for ls in ("2", "3", "1", "0"):

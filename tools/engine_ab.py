@@ -1,0 +1,51 @@
+"""Development aid: A/B of the log-weights engine variants in ONE process on ONE context (boxes differ by several
+percent, and by 20 % at mid sizes): the environment switches are read at every call, so the variants are interleaved
+sweep by sweep.  SIZES="M:N,..."  REPS=3.  Prints the best and the median sweep time per variant."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bioen_amd
+from bioen_amd import sweep
+from bench import synthetic_targets, LBFGS_DEFAULTS, SEED
+
+VARIANTS = {
+    "device": {},
+    "device-nospec": {"BIOEN_HIP_SPECULATE": "0"},
+    "device-eager": {"BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOWS": "8"},
+    "device-noqueue": {"BIOEN_HIP_QUEUE": "0"},
+    "host": {"BIOEN_HIP_DEVICE_LS": "0"},
+    "host-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
+}
+KEYS = sorted({k for v in VARIANTS.values() for k in v})
+sizes = [tuple(int(v) for v in s.split(":")) for s in os.environ.get("SIZES", "256:100000").split(",")]
+reps = int(os.environ.get("REPS", "3"))
+only = os.environ.get("VARIANTS")
+names = [n for n in VARIANTS if not only or n in only.split(",")]
+thetas = np.logspace(3, -0.5, 8)
+for (M, N) in sizes:
+    YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED) as ctx:
+        G = np.zeros(N)
+        times = {n: [] for n in names}
+        rounds = {}
+        for rep in range(reps + 1):
+            for n in names:
+                for k in KEYS:
+                    os.environ.pop(k, None)
+                os.environ.update(VARIANTS[n])
+                ctx.kernel_stats_enable(rep == reps)
+                ctx.kernel_stats_reset()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
+                ctx.synchronize()
+                dt = time.perf_counter() - t0
+                if rep == reps:
+                    rounds[n] = ctx.kernel_stats()["forward"]["launches"]
+                elif rep > 0 or reps == 1:
+                    times[n].append(dt)
+        for n in names:
+            t = sorted(times[n])
+            print("M=%d N=%d %-16s best %.4f s  median %.4f s  rounds %d -> %.1f us/round" % (
+                M, N, n, t[0], t[len(t) // 2], rounds[n], 1e6 * t[0] / max(rounds[n], 1)))
+        sys.stdout.flush()
