@@ -11,6 +11,9 @@ is torch-free) and the per-theta results are all-gathered over RCCL/xGMI.
 
 value = (L-BFGS iterations of the whole job) * N * M / wall-clock, max over ranks.
 
+--method forces runs BASELINE.json configs[4] instead (forces method, N = 1e6 x M = 512, the theta series as one
+lock-step batch; with --gpus N the structures are split over the ranks, two small all-gathers per evaluation).
+
     python bench.py                      # 1 GPU, 1 warm-up + 1 timed sweep
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -111,6 +114,86 @@ def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
                   % (cols, M, N, theta, iters, dt, 1e3 * dt / max(iters, 1), cores),
         "ms_per_iteration": 1e3 * dt / max(iters, 1),
     }
+
+
+def cpu_fullsize(ctx, M, N, YTilde, thetas):
+    """A direct CPU number ON the headline config: the reference's own _opt_lbfgs_logw on the FULL matrix (read back
+    from HBM, transposed cache built blockwise) for the cheapest thetas of the series, next to the device solving the
+    same single problem.  Skipped when the host lacks the memory for matrix + transposed cache."""
+    from oracle import ref_binding as R
+    from oracle import cpus
+    if not R.available():
+        return None
+    need = 2.0 * M * N * 8 + 6.0 * N * 8
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    if avail < 1.4 * need:
+        return {"skipped": "host memory: %.1f GB free, %.1f GB needed for the matrix and the reference's transposed cache"
+                           % (avail / 1e9, 1.4 * need / 1e9)}
+    cores = cpus.usable_cpus()
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cores)
+    t0 = time.perf_counter()
+    yT = np.empty((M, N))
+    yTT = np.empty((N, M))
+    step = 65536
+    for c0 in range(0, N, step):
+        blk = ctx.read_ytilde(0, M, c0, min(step, N - c0))
+        yT[:, c0:c0 + blk.shape[1]] = blk
+        yTT[c0:c0 + blk.shape[1], :] = blk.T
+    t_read = time.perf_counter() - t0
+    G = np.zeros(N)
+    out = {"cores": cores, "readback_and_transpose_s": t_read, "per_theta": []}
+    for th in thetas:
+        gopt, fmin, code, cpu_s = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, th, LBFGS_DEFAULTS)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        _, _, info = ctx.opt_lbfgs_logw(G, G, th, LBFGS_DEFAULTS, want_weights=False)
+        ctx.synchronize()
+        gpu_s = time.perf_counter() - t0
+        out["per_theta"].append({"theta": float(th), "cpu_s": cpu_s, "cpu_code": code, "gpu_s": gpu_s,
+                                 "gpu_iterations": info.iterations, "gpu_evaluations": info.evaluations,
+                                 "cpu_ms_per_gpu_iteration": 1e3 * cpu_s / max(info.iterations, 1),
+                                 "fmin_rel_diff": abs(info.fmin - fmin) / abs(fmin), "speedup": cpu_s / gpu_s})
+    out["cpu_s"] = sum(r["cpu_s"] for r in out["per_theta"])
+    out["gpu_s"] = sum(r["gpu_s"] for r in out["per_theta"])
+    out["speedup"] = out["cpu_s"] / out["gpu_s"]
+    return out
+
+
+def cpu_baseline_forces(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
+    """--method forces: the reference's _opt_lbfgs_forces (else the oracle's restatement) on a column block of the
+    same matrix, capped."""
+    cols = int(min(N, budget_cols))
+    sample = ctx.read_ytilde(0, M, 0, cols)
+    w0 = np.full(cols, 1.0 / cols)
+    params = dict(LBFGS_DEFAULTS, max_iterations=cap_iterations)
+    from oracle import ref_binding as R
+    from oracle import oracle_binding as O
+    from oracle import cpus
+    cores = cpus.usable_cpus()
+    if R.available():
+        kind = "reference"
+        R.set_fast_openmp_flag(1)
+        R.omp_set_num_threads(cores)
+        R.forces_f(np.zeros(M), w0[:1024] * cols / 1024, sample[:, :1024].copy(), YTilde, theta)       # thread pool up
+        t0 = time.perf_counter()
+        _, _, code = R.opt_lbfgs_forces(np.zeros(M), w0, sample, YTilde, theta, params)
+        dt = time.perf_counter() - t0          # includes the transposed cache, as the reference's pyx builds it per call
+    else:
+        kind = "port"
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        t0 = time.perf_counter()
+        code = O.opt_lbfgs_forces(np.zeros(M), w0, sample, YTilde, theta, params)[2]
+        dt = time.perf_counter() - t0
+    iters = cap_iterations if code == -997 else O.opt_lbfgs_forces(np.zeros(M), w0, sample, YTilde, theta, params)[3]
+    return {"value": iters * float(cols) * M / dt, "unit": "iter*N*M/s", "cores": cores, "kind": kind,
+            "sample": "forces method, columns [0,%d) of the same %dx%d matrix, theta=%g, yaml-default liblbfgs, %d iterations "
+                      "in %.2f s (%.1f ms/iteration, transposed cache included), %s OpenMP threads"
+                      % (cols, M, N, theta, iters, dt, 1e3 * dt / max(iters, 1), cores),
+            "ms_per_iteration": 1e3 * dt / max(iters, 1)}
 
 
 def _ref_lbfgs_logw(R, yT, yTT, YT, G, theta, params):
@@ -274,7 +357,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--structures", type=int, default=1000000, help="N (default: BASELINE configs[2])")
-    ap.add_argument("--observables", type=int, default=1024, help="M")
+    ap.add_argument("--method", choices=("logw", "forces"), default="logw",
+                    help="logw: BASELINE configs[2] (default); forces: configs[4] (forces method, M = 512 unless given)")
+    ap.add_argument("--observables", type=int, default=None, help="M (default 1024; 512 with --method forces)")
     ap.add_argument("--thetas", type=int, default=8, help="points of the theta series")
     ap.add_argument("--max-batch", type=int, default=8, help="thetas sharing one matrix pass (1 = unbatched)")
     ap.add_argument("--shard", choices=("auto", "structures", "thetas"), default="auto",
@@ -286,6 +371,8 @@ def main():
     ap.add_argument("--no-deer", action="store_true", help="skip the DEER nuisance-refit record (configs[3])")
     ap.add_argument("--cpu-cols", type=int, default=524288, help="columns of the matrix the CPU baseline runs on")
     ap.add_argument("--cpu-iters", type=int, default=120, help="L-BFGS iterations the CPU baseline is capped at")
+    ap.add_argument("--no-cpu-fullsize", action="store_true",
+                    help="skip the reference run on the FULL headline matrix (two cheapest thetas, ~1 minute)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -297,7 +384,9 @@ def main():
     import bioen_amd
     from bioen_amd import sweep
 
-    N, M = args.structures, args.observables
+    forces_mode = args.method == "forces"
+    N = args.structures
+    M = args.observables if args.observables else (512 if forces_mode else 1024)
     thetas = np.logspace(3, -0.5, args.thetas)
     YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
 
@@ -341,7 +430,7 @@ def main():
         t_ex = max(comm.allgather_object(t_mine))
         t_pass_us = 2.0 * M * float(N) * 8 / 6.4e12 * 1e6
         gain_us = t_pass_us * (1.0 - 1.0 / world)
-        cost_us = 5.0 * t_ex + 150.0
+        cost_us = (3.0 * t_ex + 100.0) if forces_mode else (4.0 * t_ex + 150.0)   # 2 exchanges per round, with margin
         decision = {"exchange_us": t_ex if np.isfinite(t_ex) else None, "pass_saving_us": gain_us,
                     "exchange_cost_us": cost_us if np.isfinite(cost_us) else None,
                     "chosen": "structures" if gain_us > cost_us else "thetas", "probe_error": probe_error}
@@ -352,8 +441,14 @@ def main():
 
     G = np.zeros(N)          # w0 = 1/N  =>  G = 0 ; GInit = G
     g0 = np.zeros(N)
+    w0 = np.full(N, 1.0 / N)
+    f0 = np.zeros(M)
 
     def step():
+        if forces_mode:
+            if nshard:     # configs[4]'s decomposition: every rank a column block, all thetas batched everywhere
+                return sweep.sweep_forces_sharded(ctx, thetas, w0, f0, LBFGS_DEFAULTS, max_batch=args.max_batch)
+            return sweep.sweep_forces(ctx, thetas, w0, f0, LBFGS_DEFAULTS, comm=comm, rccl=rccl, max_batch=args.max_batch)
         if nshard:
             # every rank holds a column block of yTilde and takes part in every theta of the batch
             return sweep.sweep_log_weights_sharded(ctx, thetas, G, g0, LBFGS_DEFAULTS, max_batch=args.max_batch)
@@ -411,8 +506,13 @@ def main():
             avg_k = s["problem_passes"] / launches
             alg = mat_bytes + avg_k * (8.0 * n_rank + 8.0 * M)
             strip = M <= 1024 and not os.environ.get("BIOEN_HIP_FWD_STREAM") == "1"     # kernels_strip.hip serves M <= 1024
-            kern[name] = {"kernel": ("k_strip_fwd" if strip else "k_fwd_partial") if name == "forward"
-                                    else ("k_strip_adj" if strip else "k_adj"),
+            if forces_mode:      # timer slots of launch_forces_xy ("adjoint") / _bt ("forward")
+                kname = "k_strip<K, nt, %s>" % ("true" if name == "adjoint" else "false") if M <= 1024 else \
+                        ("k_adj + k_fwd_partial" if name == "adjoint" else "k_fwd_partial")
+            else:
+                kname = ("k_strip_fwd" if strip else "k_fwd_partial") if name == "forward" else \
+                        ("k_strip_adj" if strip else "k_adj")
+            kern[name] = {"kernel": kname,
                           "launches": s["launches"], "avg_ms": avg_ms, "avg_batch_width": avg_k,
                           "algorithmic_bytes": alg,
                           "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
@@ -423,7 +523,7 @@ def main():
             try:
                 with open(tpath) as fp:
                     tj = json.load(fp)
-                key = "%s_N%d_M%d" % (kern[dom]["kernel"], n_rank, M)
+                key = "%s_N%d_M%d" % ("k_strip" if forces_mode else kern[dom]["kernel"], n_rank, M)
                 # only a PMC pass of THESE kernel sources counts; a stale file yields null
                 traffic = tj.get(key) if tj.get("_source_sha") == kernel_source_sha() else None
             except Exception:
@@ -435,12 +535,21 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(ctx, M, N, YTilde, 10.0, args.cpu_cols, args.cpu_iters)
+                if forces_mode:
+                    cpu = cpu_baseline_forces(ctx, M, N, YTilde, 10.0, min(args.cpu_cols, 262144), 40)
+                else:
+                    cpu = cpu_baseline(ctx, M, N, YTilde, 10.0, args.cpu_cols, args.cpu_iters)
             except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
                 cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
+            if cpu is not None and not forces_mode and not args.no_cpu_fullsize and N * float(M) >= 5e8:
+                try:     # the same CONFIG on the CPU, not a sample: the two cheapest thetas of the series
+                    cheap = sorted(results, key=lambda r: r["evaluations"])[:2]
+                    cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap])
+                except Exception as e:
+                    cpu["full_size"] = {"error": repr(e)}
 
         forces = None
-        if world == 1 and not args.no_forces:
+        if world == 1 and not args.no_forces and not forces_mode:
             ctx.close()              # 8 GB back before the second workload (closed again below: idempotent)
             try:
                 forces = forces_record(bioen_amd, thetas, SEED, args.max_batch)
@@ -453,12 +562,12 @@ def main():
             except Exception as e:
                 forces = {"error": repr(e)}
         deer = None
-        if world == 1 and not args.no_deer and not args.no_forces:
+        if world == 1 and not args.no_deer and not args.no_forces and not forces_mode:
             try:
                 deer = deer_record(bioen_amd, SEED)
             except Exception as e:
                 deer = {"error": repr(e)}
-        if cpu is not None and world == 1 and not args.no_matched and not args.no_cpu_baseline:
+        if cpu is not None and world == 1 and not args.no_matched and not args.no_cpu_baseline and not forces_mode:
             try:
                 cpu["matched_sweep"] = cpu_matched(bioen_amd, thetas, SEED)
                 if cpu["matched_sweep"] and "single_thread" in cpu["matched_sweep"]:
@@ -467,7 +576,8 @@ def main():
                 cpu["matched_sweep"] = {"error": repr(e)}
 
         line = {
-            "metric": "L-BFGS iterations/sec x (N structures * M observables), log-weights theta sweep",
+            "metric": "L-BFGS iterations/sec x (N structures * M observables), %s theta sweep"
+                      % ("forces-method" if forces_mode else "log-weights"),
             "value": value,
             "unit": "iter*N*M/s",
             "n_gpus": world,
@@ -479,8 +589,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "log-weights theta sweep, N=%d structures x M=%d observables, %d thetas "
-                                   "logspace(3,-0.5), cold starts, liblbfgs yaml defaults" % (N, M, len(thetas)),
+            "config": {"workload": "%s theta sweep, N=%d structures x M=%d observables, %d thetas "
+                                   "logspace(3,-0.5), cold starts, liblbfgs yaml defaults"
+                                   % ("forces-method" if forces_mode else "log-weights", N, M, len(thetas)),
+                       "method": args.method,
                        "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
                        "sharding": ("structures (columns) split over %d rank(s), all thetas batched on every rank" % world)
                        if nshard else ("theta round-robin over %d rank(s)" % world), "gather": gather,
@@ -503,8 +615,15 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
 
+    # --shard structures was asked for explicitly: a run that ended on anything but RCCL-backed structure sharding has
+    # not measured what was asked -- the line above says so (sharding_fallback), the exit status too
+    failed = world > 1 and args.shard == "structures" and not (nshard and rccl)
     ctx.close()
     comm.close()
+    if failed:
+        print("bench.py: --shard structures requested, but the run fell back (RCCL ranks: %s, decomposition: %s)"
+              % (world if rccl else 0, "structures" if nshard else "thetas"), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

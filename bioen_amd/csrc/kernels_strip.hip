@@ -108,9 +108,18 @@ __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__
     }
 }
 
+// A wave loads its 64-row slice of a strip as 8 chunks of 1 KiB; chunks 2 h and 2 h + 1 hold row block h (16 rows)
+// in both operand orders.  Row blocks beyond the strip's last one (mps is a multiple of 16, not of 64) do not exist in
+// the copy: their chunks are redirected to the slice's first row block.  Offsets in doubles, wave-uniform.
+__device__ __forceinline__ void strip_chunk_offsets(int mps, int rsrc, int (&off)[kWaveRows / 8]) {
+    const int nh = min(kWaveRows / 16, (mps - rsrc) / 16);       // row blocks of this wave's slice
+#pragma unroll
+    for (int i = 0; i < kWaveRows / 8; ++i) off[i] = __builtin_amdgcn_readfirstlane(((i >> 1) < nh ? i : (i & 1)) * 128);
+}
+
 struct StripArgs {
     const double* Ys;       // strip-major centred copy
-    int mps;                // rows of a strip (multiple of 128)
+    int mps;                // rows of a strip (multiple of 16)
     int mp;                 // rows of the operands u_c / outputs
     int nstrips;
     int n;                  // valid columns
@@ -198,11 +207,13 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     d2 preB[kWaveRows / 8];
 #endif
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
+    int choff[kWaveRows / 8];                                                   // chunk -> chunk actually loaded (wave-uniform)
+    strip_chunk_offsets(q.mps, rsrc, choff);
     auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
 #if !(STRIP_DIAG & 2)
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
+        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
 #endif
     };
     const int G = gridDim.x;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
             double colsum = 0.0;
             if (p2) {
-                const int nown = q.mps / kWaveRows;
+                const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
                 for (int wv = 0; wv < nown; ++wv) colsum += red[wv * 128 + pk * 16 + pc];
             }
             if (XY) {
@@ -387,7 +398,10 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
-                if (row < q.mp && k < K) q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = acc[h][kq];   // transposed: a block's sums are one run
+                // transposed: a block's sums are one run; rows between the strip's last row block and mp exist only in
+                // the M-vectors: their sums are zero (the wave computed a redirected row block's there)
+                if (row < q.mp && k < K)
+                    q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
             }
     }
     // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
@@ -452,10 +466,12 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
         if (pk == k) vk = v.p[k];
     d2 pre[kWaveRows / 8];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
+    int choff[kWaveRows / 8];
+    strip_chunk_offsets(q.mps, rsrc, choff);
     auto fetch = [&](int strip) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
+        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
     };
     int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
     int sw = base + sub;                                           // this wave's strip (a slot beyond the last strip works on
@@ -498,8 +514,8 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
-                if (set < q.nblk && row < q.mp && k < K)
-                    q.partial[(size_t)set * q.mp * K + (size_t)row * K + k] = acc[h][kq];   // transposed: a set's sums are one run
+                if (set < q.nblk && row < q.mp && k < K)     // transposed: a set's sums are one run; rows beyond the strip: zero
+                    q.partial[(size_t)set * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
             }
     }
 }
@@ -545,17 +561,19 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
     if (p2) shift = sck[S_B0] - sck[S_UY];
     d2 pre[kWaveRows / 8];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
+    int choff[kWaveRows / 8];
+    strip_chunk_offsets(q.mps, rsrc, choff);
     auto fetch = [&](int strip) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + i * 128);
+        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
     };
     int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
     int sw = base + sub, sp = base + psub;                         // this wave's strip / the strip this thread stores for
     fetch(sw < q.nstrips ? sw : base);
     __syncthreads();                                              // ul in place
     const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
-    const int nown = q.mps / kWaveRows;
+    const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
     for (int par = 0; base < q.nstrips; base += stride, sw += stride, sp += stride, par ^= 1) {
         double* redw = red + (size_t)par * nwaves * 128;
         {
@@ -601,8 +619,14 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
 }
 
 // ---- geometry ------------------------------------------------------------------------------------
-static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->mp, kWaveRows); }
-static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_rows(c) / kWaveRows); }
+// Rows of a strip: M padded to the 16-row block of a matrix-core operand (r02 padded to a wave's 64 rows: M = 205
+// streamed 256 rows, 20 % of the traffic for nothing; M = 28 streamed 64).  A wave still owns 64 rows of a strip; the
+// last wave of a strip owns the 1..4 row blocks that exist, and the chunks of the others are redirected to its first
+// row block (cache hits, multiplied with zero operands or never stored), so that every wave runs the same
+// straight-line code and every sum is formed from the same terms in the same order as before.
+static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->m, 16); }
+static int strip_waves(const bioen_hip_ctx* c) { return (strip_rows(c) + kWaveRows - 1) / kWaveRows; }
+static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_waves(c)); }
 static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
     const size_t waves = strip_threads(c) / 64;          // LDS regions hold 64 rows per wave (k_strip)
     return (waves * kWaveRows * (kStripCols + 8) + waves * 128 + 128 + 16) * sizeof(double);
@@ -681,7 +705,7 @@ static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
 }
 
 // geometry of the 16-wave kernels (k_strip_fwd / k_strip_adj): waves per strip slot, slots per block
-static int fa_wps(const bioen_hip_ctx* c) { return std::max(2, strip_rows(c) / kWaveRows); }
+static int fa_wps(const bioen_hip_ctx* c) { return std::max(2, strip_waves(c)); }
 static int fa_spb(const bioen_hip_ctx* c) { return std::max(1, std::min(16 / fa_wps(c), 4)); }
 
 // forward pass of the log-weights method on the strip copy (all K <= 8; M <= 1024): the number of partial sets
