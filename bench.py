@@ -301,27 +301,69 @@ def forces_record(bioen_amd, thetas, seed, max_batch):
                            "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "seconds": i.seconds} for t, i in zip(thetas, infos)]}
 
 
-def deer_record(bioen_amd, seed):
-    """BASELINE configs[3] on one GPU: DEER refinement with a modulation-depth nuisance parameter, N = 5e5 rotamers
-    x M = 205 time points (y~(m) = 1/sigma + m (F - 1)/sigma).  The m-independent matrix (F - 1)/sigma is
-    resident; per theta the reference alternates `iterations` = 10 times between a BioEn optimisation and a 1-D
-    least-squares refit of m that REBUILDS y~ on the host (procedure.py:62-83, observables.py:110-171); here a refit is
-    2 m doubles back from the device and a closed form, the new m enters through the affine row model."""
-    from bioen_amd import nuisance
-    N, M = 500000, 205
+def deer_trace(d_nm, t_ns):
+    """DEER / PELDOR form factor of one spin pair at distance d (Fresnel form, the kernel of the reference's rotamer
+    example: examples/DEER/rotamer-refinement/POTRA/bioen_rotamer.py:113-143):
+        F(d, t) = [C(x) cos(pi x^2 / 6) + S(x) sin(pi x^2 / 6)] / x,   x = sqrt(6 D t / (pi d^3)),  D = 2 pi 52.04e-3 nm^3/ns,
+    C, S the Fresnel integrals (Abramowitz & Stegun convention, scipy.special.fresnel); F(d, 0) = 1.
+    d_nm: (N,), t_ns: (M,)  ->  (M, N)"""
+    from scipy.special import fresnel
+    D = 2.0 * np.pi * 52.04e-3
+    t = np.asarray(t_ns, dtype=np.float64)[:, None]
+    d = np.asarray(d_nm, dtype=np.float64)[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x = np.sqrt(6.0 * D * t / (np.pi * d ** 3))
+        sf, cf = fresnel(x)
+        F = (cf * np.cos(np.pi / 6.0 * x * x) + sf * np.sin(np.pi / 6.0 * x * x)) / x
+    F[t[:, 0] == 0.0, :] = 1.0
+    return F
+
+
+def deer_inputs(N, seed, sigma=0.01):
+    """BASELINE configs[3] as SURVEY 8(d) defines it: N rotamer distances (seeded mixture in 2-6 nm), the 205-point
+    time axis and the measured signal of exp-370-292-signal-deer.dat (tests/golden/deer_exp_370_292.npz: data taken
+    from the reference tree in the build container), traces by deer_trace, sigma = 0.01 (run_bioen.py:306).
+    -> (Ft = (F - 1) / sigma  [M x N, the modulation-depth-independent matrix], YTilde = signal / sigma, off = 1 / sigma)"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "deer_exp_370_292.npz"))
+    t_ns = z["t_us"] * 1000.0
     rng = np.random.default_rng(seed)
     d = np.where(rng.random(N) < 0.6, rng.normal(3.2, 0.35, N), rng.normal(4.8, 0.5, N)).clip(2.0, 6.0)   # nm
-    t = np.linspace(0.0, 3.0, M)                                                                           # us
-    F = 0.5 * (1.0 + np.cos(2 * np.pi * 52.04 * t[:, None] / d[None, :] ** 3)) * np.exp(-0.15 * t[:, None])
-    sigma, m_true, m0 = 0.01, 0.23, 0.15
-    w_true = rng.dirichlet(np.ones(N) * 0.5)
-    YT = (1.0 - m_true + m_true * F.dot(w_true) + sigma * rng.standard_normal(M)) / sigma
-    F -= 1.0
-    F /= sigma
-    off = np.full(M, 1.0 / sigma)
+    M = t_ns.size
+    Ft = np.empty((M, N))
+
+    def chunk(c0):                                 # (the ufuncs release the GIL: column chunks in threads)
+        blk = deer_trace(d[c0:c0 + 16384], t_ns)
+        blk -= 1.0
+        blk /= sigma
+        Ft[:, c0:c0 + 16384] = blk
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        nthreads = max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        nthreads = 4
+    with ThreadPoolExecutor(nthreads) as pool:
+        list(pool.map(chunk, range(0, N, 16384)))
+    return Ft, z["signal"] / sigma, np.full(M, 1.0 / sigma)
+
+
+def deer_record(bioen_amd, seed):
+    """BASELINE configs[3] on one GPU: DEER refinement with a modulation-depth nuisance parameter, N = 5e5 rotamers
+    x M = 205 time points of the measured trace exp-370-292 (y~(m) = 1/sigma + m (F - 1)/sigma, F the Fresnel
+    form of the reference's rotamer example).  The m-independent matrix (F - 1)/sigma is resident; per theta the
+    reference alternates `iterations` = 10 times between a BioEn optimisation and a 1-D least-squares refit of m that
+    REBUILDS y~ on the host (procedure.py:62-83, observables.py:110-171), the modulation depth starting at 0.15
+    (run_bioen.py:296) and carried across thetas (procedure.py:82-83); here a refit is 2 m doubles back from the device
+    and a closed form, the new m enters through the affine row model."""
+    from bioen_amd import nuisance
+    N = 500000
+    t0 = time.perf_counter()
+    Ft, YT, off = deer_inputs(N, seed)
+    t_inputs = time.perf_counter() - t0
+    M = Ft.shape[0]
+    m0 = 0.15
     G = np.zeros(N)
     thetas, iterations = [100.0, 10.0, 1.0], 10
-    with bioen_amd.Context(F, YT) as ctx:
+    with bioen_amd.Context(Ft, YT) as ctx:
         nuisance.series(ctx, thetas[:1], G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=1)      # warm-up, builds the strip copies
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -329,11 +371,75 @@ def deer_record(bioen_amd, seed):
         ctx.synchronize()
         dt = time.perf_counter() - t0
     its = int(sum(sum(x["iterations"] for x in r["trace"]) for r in res))
-    return {"workload": "DEER rotamer refinement, N=%d x M=%d, thetas %s, %d optimise/refit iterations each (cold starts), "
-                        "yaml-default liblbfgs, modulation depth refitted on the resident matrix" % (N, M, thetas, iterations),
+    return {"workload": "DEER rotamer refinement, N=%d x M=%d (trace exp-370-292, Fresnel kernel), thetas %s, %d optimise/refit "
+                        "iterations each (cold-started weights, modulation depth carried over), yaml-default liblbfgs, "
+                        "modulation depth refitted on the resident matrix" % (N, M, thetas, iterations),
             "seconds": dt, "iterations": its, "value": its * float(N) * M / dt, "unit": "iter*N*M/s",
-            "refits": len(thetas) * iterations, "moddepth_true": m_true, "moddepth_start": m0,
-            "moddepth_fit": [r["scales"][0] for r in res], "fmin": [r["fmin"] for r in res]}
+            "refits": len(thetas) * iterations, "moddepth_start": m0, "input_synthesis_s": t_inputs,
+            "moddepth_fit": [r["scales"][0] for r in res], "fmin": [r["fmin"] for r in res],
+            "chi2": [r["chi2"] for r in res]}
+
+
+ALA5_LBFGS = dict(linesearch=2, max_iterations=20000, delta=1e-6, epsilon=1e-5, ftol=1e-4, gtol=0.9, wolfe=0.9, past=10,
+                  max_linesearch=100)          # examples/ala5_optimize/lbfgs_2.yaml:34-49
+
+
+def ala5_record(bioen_amd, seed, with_cpu=True):
+    """The only timing inside the reference tree: the ala5 notebook's forces series -- N = 50001
+    structures x M = 28 observables, 80 thetas logspace(5, -1) (examples/ala5_optimize/thetas2.dat), liblbfgs with the
+    settings of lbfgs_2.yaml, every theta WARM-started from the previous optimum (ala5-bioen.ipynb, run_theta_series:
+    `forces_init = forces_opt`), 29.1 s in all on the notebook's workstation.  Same shape, settings and protocol on
+    synthetic data: the device (80 dependent single-problem runs, launch-bound), the reference's own C path on this
+    box's cores, and the cold-started series as ONE lock-step batch on the device."""
+    N, M = 50001, 28
+    thetas = np.logspace(5, -1, 80)
+    YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M, seed)
+    w0 = np.full(N, 1.0 / N)
+    out = {"workload": "forces theta series, N=%d x M=%d, 80 thetas logspace(5,-1), liblbfgs settings of lbfgs_2.yaml, "
+                       "warm starts (ala5-bioen.ipynb protocol), synthetic data" % (N, M),
+           "reference_notebook_s": 29.1}
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=seed) as ctx:
+        def warm_series():
+            f, fmins, its, codes = np.zeros(M), [], 0, []
+            for th in thetas:
+                f, _, info = ctx.opt_lbfgs_forces(f, w0, th, ALA5_LBFGS, want_weights=True)
+                fmins.append(info.fmin)
+                codes.append(info.lbfgs_code)
+                its += info.iterations
+            return fmins, its, codes
+        warm_series()                                   # builds the strip copy, warms the allocator
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        fmins, its, codes = warm_series()
+        ctx.synchronize()
+        out["gpu_warm_series_s"] = time.perf_counter() - t0
+        out["gpu_iterations"] = its
+        out["gpu_codes_not_0_1_2"] = sorted(set(c for c in codes if c not in (0, 1, 2)))
+        t0 = time.perf_counter()
+        _, _, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, ALA5_LBFGS, max_batch=8)
+        ctx.synchronize()
+        out["gpu_cold_batched_s"] = time.perf_counter() - t0
+        out["gpu_cold_iterations"] = int(sum(i.iterations for i in infos))
+        yT = np.ascontiguousarray(ctx.read_ytilde()) if with_cpu else None
+    if with_cpu:
+        from oracle import ref_binding as R
+        from oracle import cpus
+        if R.available():
+            cores = cpus.usable_cpus()
+            R.set_fast_openmp_flag(1)
+            R.omp_set_num_threads(cores)
+            R.forces_f(np.zeros(M), w0, yT, YTilde, 1.0)
+            f, rel, rcodes, t0 = np.zeros(M), [], [], time.perf_counter()
+            for th, fm in zip(thetas, fmins):
+                f, fmin, code = R.opt_lbfgs_forces(f, w0, yT, YTilde, th, ALA5_LBFGS)     # transposed cache per call, as c_bioen.pyx
+                rel.append(abs(fm - fmin) / abs(fmin))
+                rcodes.append(code)
+            out["cpu_codes_not_0_1_2"] = sorted(set(c for c in rcodes if c not in (0, 1, 2)))
+            out["cpu_warm_series_s"] = time.perf_counter() - t0
+            out["cpu_cores"] = cores
+            out["speedup"] = out["cpu_warm_series_s"] / out["gpu_warm_series_s"]
+            out["fmin_rel_diff_max"] = max(rel)
+    return out
 
 
 class stdout_to_stderr(object):
@@ -369,6 +475,7 @@ def main():
     ap.add_argument("--no-forces", action="store_true", help="skip the forces-method record (configs[4])")
     ap.add_argument("--no-matched", action="store_true", help="skip the matched CPU/GPU sweep at configs[1] size")
     ap.add_argument("--no-deer", action="store_true", help="skip the DEER nuisance-refit record (configs[3])")
+    ap.add_argument("--no-ala5", action="store_true", help="skip the ala5-shaped forces series (BASELINE.md's only reference timing)")
     ap.add_argument("--cpu-cols", type=int, default=524288, help="columns of the matrix the CPU baseline runs on")
     ap.add_argument("--cpu-iters", type=int, default=120, help="L-BFGS iterations the CPU baseline is capped at")
     ap.add_argument("--no-cpu-fullsize", action="store_true",
@@ -567,6 +674,12 @@ def main():
                 deer = deer_record(bioen_amd, SEED)
             except Exception as e:
                 deer = {"error": repr(e)}
+        ala5 = None
+        if world == 1 and not args.no_ala5 and not args.no_forces and not forces_mode:
+            try:
+                ala5 = ala5_record(bioen_amd, SEED, with_cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                ala5 = {"error": repr(e)}
         if cpu is not None and world == 1 and not args.no_matched and not args.no_cpu_baseline and not forces_mode:
             try:
                 cpu["matched_sweep"] = cpu_matched(bioen_amd, thetas, SEED)
@@ -605,6 +718,7 @@ def main():
             "cpu_baseline": cpu,
             "forces": forces,
             "deer": deer,
+            "ala5": ala5,
             "sweep_wall_s": dt / max(args.steps, 1),
             "iterations_per_sweep": iters_per_sweep,
             "evaluations_per_sweep": evals_per_sweep,

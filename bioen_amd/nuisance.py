@@ -33,7 +33,7 @@ def refit_scales(yraw, YTilde, row_offset, groups):
 
 
 def series(ctx, thetas, G, g_init, lbfgs_params, YTilde, groups=None, row_offset=None, scale0=1.0,
-           iterations=10, verbose=False):
+           iterations=10, verbose=False, accept_codes=(0, 1, 2)):
     """theta-series with per-group scale refits (DEER: scale = modulation depth of a trace and
     row_offset = 1/sigma, matrix = (F-1)/sigma; scattering: scale = c, row_offset = None,
     matrix = I/sigma).
@@ -42,6 +42,8 @@ def series(ctx, thetas, G, g_init, lbfgs_params, YTilde, groups=None, row_offset
     groups   : list of row-index arrays, one per nuisance parameter (default: one group = all rows)
     scale0   : start value(s); the parameters carry over between iterations AND thetas
                (procedure.py:82-83), the log-weights restart from g_init every time (:46,66)
+    accept_codes : liblbfgs status codes taken as success (the reference: 0, 1, 2 -- c_bioen.pyx:516-520; runs with
+               the plateau test off end at the rounding floor of the line search, -998 / -1000 / -1001, AT the optimum)
     Returns a list of dicts per theta: theta, w, g, fmin, chi2, S, scales, trace (per iteration)."""
     m = ctx.m
     if groups is None:
@@ -57,7 +59,7 @@ def series(ctx, thetas, G, g_init, lbfgs_params, YTilde, groups=None, row_offset
                 row_scale[ix] = s
             ctx.set_affine(row_offset, row_scale)
             g, w, info = ctx.opt_lbfgs_logw(g_init, G, float(theta), lbfgs_params, verbose=verbose)
-            if info.lbfgs_code not in (0, 1, 2):
+            if info.lbfgs_code not in accept_codes:
                 raise RuntimeError("nuisance.series, liblbfgs return code: %d" % info.lbfgs_code)
             yraw, _ = ctx.last_average()             # raw Y . w at the optimum: already on the device, 8 m bytes back
             trace.append({"scales": list(scales), "fmin": info.fmin, "chi2": info.chi2,

@@ -31,7 +31,7 @@ def golden_files(kind):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
         b = os.path.basename(p)
-        if b == "error_codes.npz" or b.startswith("gsl_") or b.startswith("bench_"):
+        if b == "error_codes.npz" or b.startswith("gsl_") or b.startswith("bench_") or b.startswith("deer_"):
             continue
         z = np.load(p, allow_pickle=False)
         if z["kind"].item() == kind:
