@@ -71,6 +71,7 @@ _SIGNATURES = {
     "bioen_hip_ctx_destroy": (C.c_int, [ctx_p]),
     "bioen_hip_ctx_shape": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bioen_hip_ctx_read_ytilde": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
+    "bioen_hip_ctx_footprint": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "bioen_hip_ctx_set_ytilde_target": (C.c_int, [ctx_p, dp]),
     "bioen_hip_ctx_set_affine": (C.c_int, [ctx_p, dp, dp]),
     "bioen_hip_ctx_set_direction_mode": (C.c_int, [ctx_p, C.c_int]),
@@ -371,6 +372,13 @@ class Context(object):
         out = np.empty((rows, cols))
         check(lib().bioen_hip_ctx_read_ytilde(self._h, row0, rows, col0, cols, ptr(out)))
         return out
+
+    def footprint(self):
+        """(forms, bytes) of the resident copies of the matrix: forms is a set out of {"rowmajor", "strips", "strips_colsum"}"""
+        f, b = C.c_int(0), C.c_longlong(0)
+        check(lib().bioen_hip_ctx_footprint(self._h, C.byref(f), C.byref(b)))
+        names = {1: "rowmajor", 2: "strips", 4: "strips_colsum"}
+        return {names[k] for k in names if f.value & k}, b.value
 
     def set_target(self, YTilde):
         check(lib().bioen_hip_ctx_set_ytilde_target(self._h, ptr(self._mvec(YTilde, "YTilde"))))

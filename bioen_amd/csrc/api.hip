@@ -155,6 +155,8 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     {
         const char* e = std::getenv("BIOEN_HIP_STRIP_OLD");
         c->strip_old = (e && e[0] == '1') ? 1 : 0;
+        e = std::getenv("BIOEN_HIP_KEEP_ROWMAJOR");    // A/B: keep the row-major matrix beside the strip copies
+        c->keep_rowmajor = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_FWD_STREAM");       // A/B: the streaming forward kernel on the row-major matrix
         c->fwd_stream = (e && e[0] == '1') ? 1 : 0;
     }
@@ -399,6 +401,7 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
         launch_rows_combine(c, r, true, c->strip_center, true);
         return with_grad ? enqueue_logw_adjoint(c, r) : 0;
     }
+    if ((rc = ensure_rowmajor(c))) return rc;
     launch_fwd_partial(c, r.n, w);         // A4: this rank's share of yTilde . e_a            [matrix pass 1]
     launch_fwd_rows_local(c, r.n, true);   //     + this rank's {sum e, sum e (x - G), m_r}
     if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, r.n, true)))) return rc;
@@ -419,6 +422,7 @@ static int enqueue_logw_adjoint(bioen_hip_ctx* c, const Round& r) {
         for (int a = 0; a < r.n; ++a) sc.p[a] = r.scal[a];
         launch_adj_strip(c, r.n, c->r_c, out, sc, nblk);
     } else {
+        if ((rc = ensure_rowmajor(c))) return rc;
         launch_adj(c, r.n, c->r_c, out, true);   // A6: a_k = sum_i r_i (yTilde_ik - ybar_i)  [matrix pass 2]
     }
     launch_logw_grad(c, r);                //     gradient epilogue + g.d, g.g, x.x
@@ -443,13 +447,16 @@ static ForcesRound make_forces_round(bioen_hip_ctx* c, const int* slots, int k, 
     return r;
 }
 
-static void enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
+static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
     MVec8 out{};
     for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
+    const int rc = ensure_rowmajor(c);        // streaming kernels: the row-major matrix (back from the strip copy if it was freed)
+    if (rc) return rc;
     launch_adj(c, fr.n, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
     launch_forces_max(c, fr);
     launch_forces_exp(c, fr);
     launch_forces_norm(c, fr);                // w ; KL partials
+    return 0;
 }
 
 static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
@@ -464,6 +471,7 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
     c->last_centered = false;
     if ((nblk > 0 && c->strip_old) || (nblk == 0 && forces_fused_blocks_old(c) > 0)) {        // r01 kernels on the row-major matrix, kept for A/B measurements
         nblk = forces_fused_blocks_old(c);
+        if ((rc = ensure_rowmajor(c))) return rc;
         launch_forces_xy_old(c, fr, nblk);
         if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
         launch_rows_combine(c, r, true);
@@ -510,7 +518,7 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         return 0;
     }
     if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "forces on a sharded context need M <= 1024 (strip passes)");
-    enqueue_forces_weights(c, fr);
+    if ((rc = enqueue_forces_weights(c, fr))) return rc;
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
     launch_fwd_partial(c, fr.n, v);           // F2: ybar                         [matrix pass 2]
@@ -757,7 +765,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    double* bufs[] = {c->Y, c->Ys, c->Ys1, c->strip_center, c->strip_stamps, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed,
+    double* bufs[] = {c->Y, c->Ys, c->Ys1, c->strip_center, c->zero_center, c->strip_stamps, c->YT, c->row_offset, c->row_scale, c->gram, c->ybar_c, c->r_c, c->um, c->gm, c->fixed,
                       c->t, c->g0, c->fwd_partial, c->part, c->scal};
     for (double* p : bufs)
         if (p) hipFree(p);
@@ -798,10 +806,45 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* c, int row0, int rows, int col0, in
     if (row0 < 0 || col0 < 0 || rows <= 0 || cols <= 0 || row0 + rows > c->m || col0 + cols > c->n)
         return fail(BIOEN_HIP_EINVAL, "block out of range");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
-    BIOEN_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), c->Y + (size_t)row0 * c->ld + col0,
-                                     c->ld * sizeof(double), (size_t)cols * sizeof(double), (size_t)rows,
-                                     hipMemcpyDeviceToHost, c->stream));
-    BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->Y) {
+        BIOEN_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), c->Y + (size_t)row0 * c->ld + col0,
+                                         c->ld * sizeof(double), (size_t)cols * sizeof(double), (size_t)rows,
+                                         hipMemcpyDeviceToHost, c->stream));
+        BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    // the row-major matrix has made way for the strip copy, which holds the same numbers: gathered back in column
+    // chunks through a bounded staging buffer
+    const int chunk = std::max(1, std::min(cols, (int)((64ll << 20) / ((long long)rows * 8))));
+    double* stage = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&stage), (size_t)rows * chunk * sizeof(double));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (read-back staging)", __FILE__, __LINE__);
+    int rc = 0;
+    for (int c0 = 0; c0 < cols && !rc; c0 += chunk) {
+        const int nc = std::min(chunk, cols - c0);
+        rc = gather_block(c, row0, rows, (size_t)col0 + c0, nc, stage);
+        if (!rc) {
+            e = hipMemcpy2DAsync(out + c0, (size_t)cols * sizeof(double), stage, (size_t)nc * sizeof(double),
+                                 (size_t)nc * sizeof(double), (size_t)rows, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "read-back", __FILE__, __LINE__);
+        }
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+int bioen_hip_ctx_footprint(const bioen_hip_ctx* c, int* forms, long long* bytes) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    const long long rowmajor = (long long)c->mp * (long long)c->ld * 8;
+    const long long strips = (long long)(c->ld / 16) * ((c->m + 15) / 16 * 16) * 16 * 8;
+    int f = 0;
+    long long b = 0;
+    if (c->Y) { f |= 1; b += rowmajor; }
+    if (c->Ys) { f |= 2; b += strips; }
+    if (c->Ys1) { f |= 4; b += strips; }
+    if (forms) *forms = f;
+    if (bytes) *bytes = b;
     return 0;
 }
 
@@ -941,7 +984,7 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
     if ((rc = upload_n(c, c->fixed, w0))) return rc;
     BIOEN_HIP_CHECK(hipMemcpyAsync(c->um, forces, (size_t)c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const int one[1] = {0};
-    enqueue_forces_weights(c, make_forces_round(c, one, 1, nullptr));
+    if ((rc = enqueue_forces_weights(c, make_forces_round(c, one, 1, nullptr)))) return rc;
     if ((rc = check_launch())) return rc;
     BIOEN_HIP_CHECK(hipMemcpyAsync(w, c->slot[0].w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1060,8 +1103,19 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     c->last_centered = false;
     Vec8 v{};
     v.p[0] = s0.w;
-    launch_fwd_partial(c, 1, v);
-    launch_fwd_rows_local(c, 1, false);
+    int nblk = fwd_strip_blocks(c);
+    if (nblk > 0 && (rc = ensure_strip_copy(c))) {
+        if (!c->strips_unavailable) return rc;
+        nblk = 0;
+    }
+    if (nblk > 0) {            // M <= 1024: the strip copy, uncentred (any w, not only normalised ones)
+        launch_fwd_strip(c, 1, v, nblk, true);
+        launch_fwd_rows_local(c, 1, false, nblk, true);
+    } else {
+        if ((rc = ensure_rowmajor(c))) return rc;
+        launch_fwd_partial(c, 1, v);
+        launch_fwd_rows_local(c, 1, false);
+    }
     if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, 1, false)))) return rc;   // the ranks' shares of yTilde . w
     launch_rows_combine(c, r, false);
     launch_forces_scalars(c, make_forces_round(c, one, 1, nullptr));   // S_CHI (the KL part is irrelevant here)

@@ -156,7 +156,11 @@ struct bioen_hip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // results of finished problems leave on this one (engine_logw.inl: deliveries)
 
-    double* Y = nullptr;       // mp x ld
+    double* Y = nullptr;       // mp x ld, row-major: the form data arrive in; M <= 1024: freed once the strip copy Ys
+                               // exists (kernels_strip.hip: ensure_strip_copy), back on demand (ensure_rowmajor)
+    int keep_rowmajor = 0;     // BIOEN_HIP_KEEP_ROWMAJOR=1: never free it (A/B)
+    int rowmajor_rebuilt = 0;  // it was freed and has been re-created since
+    double* zero_center = nullptr;   // mp zeros: "no centring" for the strip kernels (bioen_hip_chi_squared)
     // forces method, M <= 1024 (kernels_strip.hip): strip-major copy centred on the targets, built on first use
     double* Ys = nullptr;            // [ld / 16][strip rows][16], row-sum operand order (forces, log-weights forward)
     double* Ys1 = nullptr;           // the same strips in column-sum operand order (log-weights adjoint)

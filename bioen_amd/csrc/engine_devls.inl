@@ -364,6 +364,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             launch_rows_combine(c, rd, true, c->strip_center, true, &gate);
             launch_adj_strip(c, k, c->r_c, av, sv, nblk);
         } else {
+            note(ensure_rowmajor(c));
             launch_fwd_partial(c, k, wv);
             launch_fwd_rows_local(c, k, true);
             note(exchange(c, X_YBAR, (size_t)ybar_payload(c, k, true)));

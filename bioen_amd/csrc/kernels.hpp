@@ -74,7 +74,9 @@ void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   /
 void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);   // sharded: -> X_YBAR segment
 int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
 int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
-void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk);
+void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool plain = false);
+int ensure_rowmajor(bioen_hip_ctx* c);                 // the row-major matrix back from the strip copy (it is freed once that exists)
+int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, double* out);   // -> device out[rows][cols]
 int ensure_strip_copy_colsum(bioen_hip_ctx* c);        // builds ctx->Ys1 (column-sum operand order) on first use
 void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk);
 void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk, bool tposed = false);

@@ -86,10 +86,13 @@ __device__ __forceinline__ size_t strip_pos_colsum(int row, int col) {
     return ((size_t)(w * 8 + (g >> 1)) * 64 + (lq * 16 + col)) * 2 + (g & 1);
 }
 
+// The copies hold the RAW matrix (r03; r02 stored Y - centre): the centring is applied to the operand registers
+// inside the kernels -- the same subtraction, hence the same bits in every product -- so that the strip copies can
+// REPLACE the row-major matrix instead of standing beside it: bioen_hip_ctx_read_ytilde gathers the caller's numbers
+// back out of them bit for bit, and the row-major copy is freed once the row-sum copy exists (ctx.hpp: Y).
 template <bool COLSUM>
 __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__ Y, size_t ld, int mp, int mps, int n,
-                                                      const double* __restrict__ center, double* __restrict__ Ys,
-                                                      int nstrips) {
+                                                      double* __restrict__ Ys, int nstrips) {
     for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
         double* dst = Ys + (size_t)s * mps * kStripCols;
         for (int p = threadIdx.x; p < mps * 8; p += 256) {
@@ -98,13 +101,36 @@ __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__
             if (row < mp) {
                 const size_t col = (size_t)s * kStripCols + part * 2;
                 v = *reinterpret_cast<const d2*>(Y + (size_t)row * ld + col);
-                const double cen = center[row];
-                v.x = col < (size_t)n ? v.x - cen : 0.0;
-                v.y = col + 1 < (size_t)n ? v.y - cen : 0.0;
+                v.x = col < (size_t)n ? v.x : 0.0;
+                v.y = col + 1 < (size_t)n ? v.y : 0.0;
             }
             dst[COLSUM ? strip_pos_colsum(row, part * 2) : strip_pos(row, part * 2)] = v.x;
             dst[COLSUM ? strip_pos_colsum(row, part * 2 + 1) : strip_pos(row, part * 2 + 1)] = v.y;
         }
+    }
+}
+
+// row-sum order copy -> column-sum order copy (the log-weights adjoint's), strip by strip through LDS-free index maps
+__global__ __launch_bounds__(256) void k_restripe(const double* __restrict__ Ys, int mps, double* __restrict__ Ys1,
+                                                  int nstrips) {
+    for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
+        const double* src = Ys + (size_t)s * mps * kStripCols;
+        double* dst = Ys1 + (size_t)s * mps * kStripCols;
+        for (int p = threadIdx.x; p < mps * kStripCols; p += 256) {
+            const int row = p >> 4, col = p & 15;
+            dst[strip_pos_colsum(row, col)] = src[strip_pos(row, col)];
+        }
+    }
+}
+
+// row-sum order copy -> row-major block out[rows][cols] (device), rows [row0, row0 + rows), columns [col0, col0 + cols)
+__global__ __launch_bounds__(256) void k_gather_strips(const double* __restrict__ Ys, int mps, int row0, int rows,
+                                                       size_t col0, int cols, double* __restrict__ out, size_t ldo) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)rows * cols; p += (size_t)gridDim.x * 256) {
+        const int r = (int)(p / cols);
+        const size_t cc = col0 + (p - (size_t)r * cols);
+        out[(size_t)r * ldo + (p - (size_t)r * cols)] =
+            Ys[(cc / kStripCols) * (size_t)mps * kStripCols + strip_pos(row0 + r, (int)(cc % kStripCols))];
     }
 }
 
@@ -118,7 +144,8 @@ __device__ __forceinline__ void strip_chunk_offsets(int mps, int rsrc, int (&off
 }
 
 struct StripArgs {
-    const double* Ys;       // strip-major centred copy
+    const double* Ys;       // strip-major copy (raw matrix)
+    const double* center;   // mp values subtracted from the rows on the way into the products (a zero vector: none)
     int mps;                // rows of a strip (multiple of 16)
     int mp;                 // rows of the operands u_c / outputs
     int nstrips;
@@ -156,6 +183,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     double* red = ul + (size_t)lrows * 8;           // [wave][problem 8][column 16]: the waves' partial column sums
     double* tv = red + nwaves * 128;                // v[problem 8][column 16]: e | t of the strip
     double* scale = tv + 128;
+    double* cl = scale + 16;                        // centre[row]
     const int rbase = wave * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
@@ -165,6 +193,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
     }
     for (int i = t; i < 128; i += blockDim.x) tv[i] = 0.0;         // problems k >= K of a quad stay zero
+    for (int i = t; i < lrows; i += blockDim.x) cl[i] = i < q.mp ? q.center[i] : 0.0;
     if (t < 8) scale[t] = 1.0;
 
     // P3 accumulators: row block h (16 rows), problem quad kq: lane 16 i + 4 blk + j holds
@@ -235,10 +264,12 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #pragma unroll
             for (int i = 0; i < kWaveRows / 8; ++i) {
                 const int h = i >> 1, qp = i & 1;
-                a3[2 * qp][h] = pre[i].x;
-                a3[2 * qp + 1][h] = pre[i].y;
-                img[h * 256 + (((8 * qp + lq) ^ sw3) ^ (h & 1))] = pre[i].x;
-                img[h * 256 + (((8 * qp + 4 + lq) ^ sw3) ^ (h & 1))] = pre[i].y;
+                const double ch = cl[rsrc + 16 * h + lr];
+                const double vx = pre[i].x - ch, vy = pre[i].y - ch;              // the centring (r02: stored in the copy)
+                a3[2 * qp][h] = vx;
+                a3[2 * qp + 1][h] = vy;
+                img[h * 256 + (((8 * qp + lq) ^ sw3) ^ (h & 1))] = vx;
+                img[h * 256 + (((8 * qp + 4 + lq) ^ sw3) ^ (h & 1))] = vy;
             }
         }
         // wave-private slice of the tile: the wave's own program order is the synchronisation
@@ -465,6 +496,12 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     for (int k = 1; k < K; ++k)
         if (pk == k) vk = v.p[k];
     d2 pre[kWaveRows / 8];
+    double cen[kWaveRows / 16];                                    // centre of the lane's row in each of its four row blocks
+#pragma unroll
+    for (int h = 0; h < kWaveRows / 16; ++h) {
+        const int row = rsrc + 16 * h + (lane & 15);
+        cen[h] = row < q.mp ? q.center[row] : 0.0;
+    }
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
     int choff[kWaveRows / 8];
     strip_chunk_offsets(q.mps, rsrc, choff);
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 #pragma unroll
             for (int h = 0; h < kWaveRows / 16; ++h) {
                 const d2 y = pre[2 * h + (qq >> 1)];
-                const double a = (qq & 1) ? y.y : y.x;
+                const double a = ((qq & 1) ? y.y : y.x) - cen[h];      // the centring (r02: stored in the copy)
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
                     acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
@@ -536,7 +573,8 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
     const int nwaves = blockDim.x >> 6;
     const int lrows = q.wps * kWaveRows;                          // the table holds 64 rows per wave of a slot
     double* ul = lds;                                             // u[row][8], zero beyond K and mp
-    double* red = ul + (size_t)lrows * 8;                         // [parity][wave][problem 8][column 16]
+    double* cl = ul + (size_t)lrows * 8;                          // centre[row] (16 per lane in registers would spill at K = 8)
+    double* red = cl + lrows;                                     // [parity][wave][problem 8][column 16]
     const int sub = wave / q.wps, rw = wave - sub * q.wps;
     const int rbase = rw * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;                   // the idle second wave of a 64-row strip re-reads the first one's rows
@@ -546,6 +584,7 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
         const int row = i >> 3, k = i & 7;
         ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
     }
+    for (int i = t; i < lrows; i += blockDim.x) cl[i] = i < q.mp ? q.center[i] : 0.0;
     const bool p2 = t < q.spb * kStripCols * K;                   // slot t / 16 K, problem (t % 16 K) / 16, column t % 16
     const int psub = p2 ? t / (kStripCols * K) : 0;
     const int pk = p2 ? (t - psub * kStripCols * K) >> 4 : 0, pc = t & 15;
@@ -573,6 +612,7 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
     fetch(sw < q.nstrips ? sw : base);
     __syncthreads();                                              // ul in place
     const double* pu = ul + (size_t)(rbase + lq) * 8 + lj;
+    const double* pc_ = cl + (rsrc + lq);                         // the centre of row group g: pc_[4 g]
     const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
     for (int par = 0; base < q.nstrips; base += stride, sw += stride, sp += stride, par ^= 1) {
         double* redw = red + (size_t)par * nwaves * 128;
@@ -589,7 +629,7 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
                 for (int kq = 0; kq < NK; ++kq) b1[g][kq] = pu[g * 32 + 4 * kq];
 #pragma unroll
             for (int g = 0; g < kWaveRows / 4; ++g) {
-                const double a = (g & 1) ? pre[g >> 1].y : pre[g >> 1].x;
+                const double a = ((g & 1) ? pre[g >> 1].y : pre[g >> 1].x) - pc_[4 * g];   // the centring (r02: stored in the copy)
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
                     d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1[g][kq], d[g & 3][kq], 0, 0, 0);
@@ -629,7 +669,7 @@ static int strip_waves(const bioen_hip_ctx* c) { return (strip_rows(c) + kWaveRo
 static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_waves(c)); }
 static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
     const size_t waves = strip_threads(c) / 64;          // LDS regions hold 64 rows per wave (k_strip)
-    return (waves * kWaveRows * (kStripCols + 8) + waves * 128 + 128 + 16) * sizeof(double);
+    return (waves * kWaveRows * (kStripCols + 8 + 1) + waves * 128 + 128 + 16) * sizeof(double);
 }
 
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
@@ -652,6 +692,68 @@ static int strip_copy_failed(bioen_hip_ctx* c, double* ys, hipError_t e, const c
     return hip_fail(e, what, __FILE__, __LINE__);
 }
 
+// The row-major matrix is the form data ARRIVE in (upload, device-side assembly, generator) and the operand of the
+// streaming kernels (M > 1024, the r01 forces strips for 512 < M <= 1024).  Once the row-sum strip copy exists it is
+// redundant for every other path -- the copy holds the same numbers -- and is freed (bioen_hip_ctx_read_ytilde,
+// bioen_hip_chi_squared and the column-sum copy are served by the strip copy); a later call that needs it gets it back
+// from the strip copy (ensure_rowmajor) and then keeps it.  Footprint of the matrix, M <= 1024: log-weights 2 x (both
+// strip copies), forces method 1 x (M <= 512).
+int ensure_rowmajor(bioen_hip_ctx* c) {
+    if (c->Y) return 0;
+    if (!c->Ys) return BIOEN_HIP_ESTATE;
+    int rc = 0;
+    double* y = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&y), (size_t)c->mp * c->ld * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        hip_fail(e, "hipMalloc (row-major matrix back from the strip copy)", __FILE__, __LINE__);
+        return BIOEN_HIP_ENOMEM;
+    }
+    e = hipMemsetAsync(y, 0, (size_t)c->mp * c->ld * sizeof(double), c->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
+    if (!rc) {
+        const int mps = strip_rows(c);
+        hipLaunchKernelGGL(k_gather_strips, dim3(4096), dim3(256), 0, c->stream, c->Ys, mps, 0, std::min(mps, c->mp),
+                           (size_t)0, (int)c->ld, y, c->ld);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
+    }
+    if (rc) {
+        (void)hipFree(y);
+        return rc;
+    }
+    c->Y = y;
+    c->rowmajor_rebuilt = 1;
+    return 0;
+}
+
+// block of the matrix -> device buffer out[rows][cols], whichever form is resident
+int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, double* out) {
+    if (c->Y) {
+        hipError_t e = hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), c->Y + (size_t)row0 * c->ld + col0,
+                                        c->ld * sizeof(double), (size_t)cols * sizeof(double), (size_t)rows,
+                                        hipMemcpyDeviceToDevice, c->stream);
+        return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpy2DAsync", __FILE__, __LINE__);
+    }
+    if (!c->Ys) return BIOEN_HIP_ESTATE;
+    const size_t total = (size_t)rows * cols;
+    hipLaunchKernelGGL(k_gather_strips, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->Ys, strip_rows(c), row0, rows, col0, cols, out, (size_t)cols);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
+}
+
+static int ensure_zero_center(bioen_hip_ctx* c) {
+    if (c->zero_center) return 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->zero_center), (size_t)c->mp * sizeof(double));
+    if (e != hipSuccess) {
+        c->zero_center = nullptr;
+        return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    }
+    e = hipMemsetAsync(c->zero_center, 0, (size_t)c->mp * sizeof(double), c->stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
+}
+
 int ensure_strip_copy(bioen_hip_ctx* c) {
     if (c->Ys) return 0;
     if (c->strips_unavailable) return BIOEN_HIP_ENOMEM;
@@ -671,11 +773,20 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
         }
         c->strip_center = cen;
     }
+    if (ensure_zero_center(c)) return strip_copy_failed(c, ys, hipErrorOutOfMemory, "zero centre");
     hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
-                       c->n, c->strip_center, ys, nstrips);
+                       c->n, ys, nstrips);
     e = hipGetLastError();
     if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
     c->Ys = ys;
+    // the row-major form has served: every path of this context that still wants it (none for M <= 512; the r01 forces
+    // strips for 512 < M <= 1024) gets it back through ensure_rowmajor.  BIOEN_HIP_KEEP_ROWMAJOR=1 keeps it (A/B).
+    if (!c->keep_rowmajor) {
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipFree(c->Y);
+        if (e != hipSuccess) return hip_fail(e, "release of the row-major matrix", __FILE__, __LINE__);
+        c->Y = nullptr;
+    }
     return 0;
 }
 
@@ -734,11 +845,13 @@ static void fwd_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const Vec8
     }
 }
 
-// partial[(row K + a) nblk + block] of Y' . v_a; the caller adds the centre back (k_rows_combine's `center`)
-void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk) {
+// partial[(row K + a) nblk + block] of Y' . v_a; the caller adds the centre back (k_rows_combine's `center`);
+// plain = true: Y . v_a itself (no centring: bioen_hip_chi_squared takes any w, not only normalised ones)
+void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool plain) {
     TimedLaunch tl(c, 0, K);
     StripArgs q{};
     q.Ys = c->Ys;
+    q.center = plain ? c->zero_center : c->strip_center;
     q.mps = strip_rows(c);
     q.mp = c->mp;
     q.nstrips = (int)(c->ld / kStripCols);
@@ -756,24 +869,23 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk) {
 // adjoint pass of the log-weights method on the column-sum copy (built on first use)
 int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     if (c->Ys1) return 0;
-    int rc = ensure_strip_copy(c);                               // the centre is shared
+    int rc = ensure_strip_copy(c);                               // the centre is shared; the column-sum copy is cut from the row-sum one
     if (rc) return rc;
     const int mps = strip_rows(c);
     const int nstrips = (int)(c->ld / kStripCols);
     double* ys = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
     if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (column-sum strip copy of yTilde)");
-    hipLaunchKernelGGL(k_build_strips<true>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
-                       c->n, c->strip_center, ys, nstrips);
+    hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Ys, mps, ys, nstrips);
     e = hipGetLastError();
-    if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
+    if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_restripe");
     c->Ys1 = ys;
     return 0;
 }
 
 static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c) {
-    const int wps = fa_wps(c), waves = wps * fa_spb(c);          // u table of one slot's rows | two parity buffers of partial sums
-    return ((size_t)wps * kWaveRows * 8 + (size_t)2 * waves * 128) * sizeof(double);
+    const int wps = fa_wps(c), waves = wps * fa_spb(c);          // u table of one slot's rows | their centres | two parity buffers of partial sums
+    return ((size_t)wps * kWaveRows * 9 + (size_t)2 * waves * 128) * sizeof(double);
 }
 
 template <int K, bool NT>
@@ -807,6 +919,7 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
     TimedLaunch tl(c, 1, K);
     StripArgs q{};
     q.Ys = c->Ys1;
+    q.center = c->strip_center;
     q.mps = strip_rows(c);
     q.mp = c->mp;
     q.nstrips = (int)(c->ld / kStripCols);
@@ -826,6 +939,7 @@ template <bool XY>
 static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, const double* u_c) {
     StripArgs q{};
     q.Ys = c->Ys;
+    q.center = c->strip_center;
     q.mps = strip_rows(c);
     q.mp = c->mp;
     q.nstrips = (int)(c->ld / kStripCols);

@@ -293,6 +293,50 @@ def test_last_average_is_that_of_the_returned_point(optimize, linesearch):
             assert np.abs(ctx.last_average()[0] - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-14
 
 
+@pytest.mark.parametrize("M,N", [(37, 1000), (205, 4099), (512, 3000), (600, 2000), (1100, 1500)])
+def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
+    """For M <= 1024 the strip copies hold the raw matrix and take the row-major one's place: 2 x the matrix for the
+    log-weights method, 1 x for the forces method (M <= 512) -- and read_ytilde still hands back the caller's numbers bit
+    for bit, chi_squared still takes ANY w.  A call that needs the row-major form again (the r01 forces strips for
+    512 < M <= 1024, forces_weights' streaming kernels) gets it back from the strip copy."""
+    import bioen_amd
+    rng = np.random.default_rng(M + N)
+    Y = rng.normal(3.0, 2.0, (M, N))
+    YT = Y.dot(rng.dirichlet(np.ones(N))) + 0.1 * rng.standard_normal(M)
+    G = np.zeros(N)
+    w_any = rng.uniform(0.0, 2.0, N)                       # not normalised
+    params = dict(linesearch=2, max_iterations=30, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9, past=10,
+                  max_linesearch=100)
+    unit = M * ((N + 127) // 128 * 128) * 8               # lower bound of one copy
+    with bioen_amd.Context(Y, YT) as ctx:
+        assert ctx.footprint()[0] == {"rowmajor"}
+        assert np.array_equal(ctx.read_ytilde(), Y)
+        chi2_before, yave_before = ctx.chi_squared(w_any)
+        assert np.abs(yave_before - Y.dot(w_any)).max() <= 1e-12 * np.abs(Y.dot(w_any)).max()
+        ctx.opt_lbfgs_logw(G, G, 10.0, params)
+        forms, nbytes = ctx.footprint()
+        if M <= 1024:
+            assert forms == {"strips", "strips_colsum"} and nbytes < 2.2 * unit + (1 << 20)
+        else:
+            assert forms == {"rowmajor"}
+        assert np.array_equal(ctx.read_ytilde(), Y)                                   # the whole matrix, bit for bit
+        assert np.array_equal(ctx.read_ytilde(M // 2, 1, N // 3, 5), Y[M // 2:M // 2 + 1, N // 3:N // 3 + 5])
+        chi2, yave = ctx.chi_squared(w_any)
+        assert np.abs(yave - Y.dot(w_any)).max() <= 1e-12 * np.abs(Y.dot(w_any)).max()
+        assert rel(chi2, 0.5 * np.sum((Y.dot(w_any) - YT) ** 2)) < 1e-12
+        f, g = ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
+        if 512 < M <= 1024:
+            assert "rowmajor" in ctx.footprint()[0]                                   # back for the row-major strip kernels
+        assert np.array_equal(ctx.read_ytilde(), Y)
+    with bioen_amd.Context(Y, YT) as ctx:                                             # a forces-only context
+        ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
+        forms, nbytes = ctx.footprint()
+        assert forms == ({"strips"} if M <= 512 else {"rowmajor"})
+        w = ctx.forces_weights(np.zeros(M), np.full(N, 1.0 / N))                      # streaming kernels: row-major again
+        assert np.abs(w - 1.0 / N).max() < 1e-18 + 1e-12 / N
+        assert np.array_equal(ctx.read_ytilde(), Y)
+
+
 @pytest.mark.parametrize("M", [23, 600, 1100])
 def test_last_average_after_forces_calls(optimize, M):
     """forces_fdf / opt_lbfgs_forces -> last_average hands out yTilde . w at the point the call ended on, on all three
