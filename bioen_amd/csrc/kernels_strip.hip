@@ -53,6 +53,9 @@
 #ifndef STRIP_DIAG
 #define STRIP_DIAG 0      // diagnostic builds: 1 = no MFMAs, 2 = no matrix loads
 #endif
+#ifndef STRIP_PRECENTERED
+#define STRIP_PRECENTERED 0   // diagnostic builds: 1 = the r02 layout (copies hold Y - centre, no subtraction in the kernels;
+#endif                        // read_ytilde is then off by the centre): A/B of what the in-kernel centring costs
 
 namespace bioen {
 
@@ -92,7 +95,8 @@ __device__ __forceinline__ size_t strip_pos_colsum(int row, int col) {
 // back out of them bit for bit, and the row-major copy is freed once the row-sum copy exists (ctx.hpp: Y).
 template <bool COLSUM>
 __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__ Y, size_t ld, int mp, int mps, int n,
-                                                      double* __restrict__ Ys, int nstrips) {
+                                                      double* __restrict__ Ys, int nstrips,
+                                                      const double* __restrict__ center_diag) {
     for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
         double* dst = Ys + (size_t)s * mps * kStripCols;
         for (int p = threadIdx.x; p < mps * 8; p += 256) {
@@ -103,6 +107,10 @@ __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__
                 v = *reinterpret_cast<const d2*>(Y + (size_t)row * ld + col);
                 v.x = col < (size_t)n ? v.x : 0.0;
                 v.y = col + 1 < (size_t)n ? v.y : 0.0;
+#if STRIP_PRECENTERED
+                if (col < (size_t)n) v.x -= center_diag[row];
+                if (col + 1 < (size_t)n) v.y -= center_diag[row];
+#endif
             }
             dst[COLSUM ? strip_pos_colsum(row, part * 2) : strip_pos(row, part * 2)] = v.x;
             dst[COLSUM ? strip_pos_colsum(row, part * 2 + 1) : strip_pos(row, part * 2 + 1)] = v.y;
@@ -165,7 +173,7 @@ struct StripArgs {
 // one-hot operands, tools/mfma_f64_4x4_probe.hip): lane l = 16 kk + 4 blk + r holds A_blk[i = r][kk],
 // B_blk[kk][j = r]; the result lane 16 i + 4 blk + j holds D_blk[i][j].  Unlike the 16x16x4 form nothing is
 // padded: K <= 4 problems take one instruction per operand fetch, K <= 8 two, at 32 FLOP/clk/SIMD either way.
-template <int K, bool NT, bool XY>
+template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH>
 __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
     constexpr int NK = (K + 3) / 4;                 // problem quads
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -232,9 +240,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 
     // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
     d2 preA[kWaveRows / 8];
-#if STRIP_DEPTH == 2
-    d2 preB[kWaveRows / 8];
-#endif
+    d2 preB[DEPTH == 2 ? kWaveRows / 8 : 1];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
     int choff[kWaveRows / 8];                                                   // chunk -> chunk actually loaded (wave-uniform)
     strip_chunk_offsets(q.mps, rsrc, choff);
@@ -265,7 +271,11 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             for (int i = 0; i < kWaveRows / 8; ++i) {
                 const int h = i >> 1, qp = i & 1;
                 const double ch = cl[rsrc + 16 * h + lr];
+#if STRIP_PRECENTERED
+                const double vx = pre[i].x, vy = pre[i].y;
+#else
                 const double vx = pre[i].x - ch, vy = pre[i].y - ch;              // the centring (r02: stored in the copy)
+#endif
                 a3[2 * qp][h] = vx;
                 a3[2 * qp + 1][h] = vy;
                 img[h * 256 + (((8 * qp + lq) ^ sw3) ^ (h & 1))] = vx;
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        fetch(s + STRIP_DEPTH * G < q.nstrips ? s + STRIP_DEPTH * G : s, pre);    // unconditional, see k_strip_adj
+        fetch(s + DEPTH * G < q.nstrips ? s + DEPTH * G : s, pre);    // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
         {
@@ -404,19 +414,19 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     };
     int s = blockIdx.x;
     fetch(s, preA);                                                // grid <= strips: every block has a first strip
-#if STRIP_DEPTH == 2
-    fetch(s + G < q.nstrips ? s + G : s, preB);
-    __syncthreads();                                              // ul / tv / scale initialised
-    // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
-    for (; s + G < q.nstrips; s += 2 * G) {
-        one_strip(s, preA, 0);
-        one_strip(s + G, preB, 1);
+    if constexpr (DEPTH == 2) {
+        fetch(s + G < q.nstrips ? s + G : s, preB);
+        __syncthreads();                                          // ul / tv / scale initialised
+        // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
+        for (; s + G < q.nstrips; s += 2 * G) {
+            one_strip(s, preA, 0);
+            one_strip(s + G, preB, 1);
+        }
+        if (s < q.nstrips) one_strip(s, preA, 0);
+    } else {
+        __syncthreads();
+        for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
     }
-    if (s < q.nstrips) one_strip(s, preA, 0);
-#else
-    __syncthreads();
-    for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
-#endif
 #if STRIP_DIAG & 4
     if (q.stamps && lane == 0)
         for (int i = 0; i < 8; ++i) q.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + i] = tacc[i];
@@ -532,7 +542,11 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 #pragma unroll
             for (int h = 0; h < kWaveRows / 16; ++h) {
                 const d2 y = pre[2 * h + (qq >> 1)];
+#if STRIP_PRECENTERED
+                const double a = (qq & 1) ? y.y : y.x;
+#else
                 const double a = ((qq & 1) ? y.y : y.x) - cen[h];      // the centring (r02: stored in the copy)
+#endif
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
                     acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
@@ -629,7 +643,11 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
                 for (int kq = 0; kq < NK; ++kq) b1[g][kq] = pu[g * 32 + 4 * kq];
 #pragma unroll
             for (int g = 0; g < kWaveRows / 4; ++g) {
+#if STRIP_PRECENTERED
+                const double a = (g & 1) ? pre[g >> 1].y : pre[g >> 1].x;
+#else
                 const double a = ((g & 1) ? pre[g >> 1].y : pre[g >> 1].x) - pc_[4 * g];   // the centring (r02: stored in the copy)
+#endif
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
                     d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1[g][kq], d[g & 3][kq], 0, 0, 0);
@@ -775,7 +793,7 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     }
     if (ensure_zero_center(c)) return strip_copy_failed(c, ys, hipErrorOutOfMemory, "zero centre");
     hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
-                       c->n, ys, nstrips);
+                       c->n, ys, nstrips, c->strip_center);
     e = hipGetLastError();
     if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
     c->Ys = ys;
@@ -790,15 +808,28 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     return 0;
 }
 
-template <int K, bool NT, bool XY>
-static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+template <int K, bool NT, bool XY, int DEPTH>
+static void strip_launch_kd(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
     static bool attr_done = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip<K, NT, XY>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip<K, NT, XY, DEPTH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY>), dim3(q.nblk), block, lds, q, fr);
+    BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY, DEPTH>), dim3(q.nblk), block, lds, q, fr);
+}
+
+// strips in flight per wave: two register sets, except where the second one does not fit (K > 4, pass 1: the
+// compiler spilled; experiment knob BIOEN_HIP_STRIP_DEPTH5)
+template <int K, bool NT, bool XY>
+static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+    static int depth5 = -1;
+    if (depth5 < 0) {
+        const char* e = std::getenv("BIOEN_HIP_STRIP_DEPTH5");
+        depth5 = e ? std::atoi(e) : 2;
+    }
+    if (K > 4 && depth5 == 1) strip_launch_kd<K, NT, XY, 1>(c, q, fr, block, lds);
+    else strip_launch_kd<K, NT, XY, 2>(c, q, fr, block, lds);
 }
 
 template <bool NT, bool XY>
