@@ -63,7 +63,7 @@ enum ScalarSlot : int {
     S_YSH,                         // [kHistory] y.s per history slot
     S_ALPHA = S_YSH + kHistory,    // [kHistory]
     S_INV = S_ALPHA + kHistory,    // w_j = e_j * S_INV on this rank (deferred softmax normalisation)
-    S_B0,                          // sum_i center_i r_i   (strip passes on the centred copy: the adjoint's constant)
+    S_B0,                          // sum_i center_i r_i   (strip passes with centred operands: the adjoint's constant)
     S_UY,                          // sum_i ybar_raw_i r_i
     S_COUNT
 };
@@ -161,7 +161,8 @@ struct bioen_hip_ctx {
     int keep_rowmajor = 0;     // BIOEN_HIP_KEEP_ROWMAJOR=1: never free it (A/B)
     int rowmajor_rebuilt = 0;  // it was freed and has been re-created since
     double* zero_center = nullptr;   // mp zeros: "no centring" for the strip kernels (bioen_hip_chi_squared)
-    // forces method, M <= 1024 (kernels_strip.hip): strip-major copy centred on the targets, built on first use
+    // M <= 1024 (kernels_strip.hip): strip-major copies of the RAW matrix, built on first use; the kernels centre the
+    // operands on strip_center on the fly
     double* Ys = nullptr;            // [ld / 16][strip rows][16], row-sum operand order (forces, log-weights forward)
     double* Ys1 = nullptr;           // the same strips in column-sum operand order (log-weights adjoint)
     double* strip_center = nullptr;  // mp: YTilde at the time of the copy

@@ -8,17 +8,19 @@
 // stream at 6.8 TB/s).  The forces evaluation needs whole COLUMNS (x_j = sum_i Y_ij f_i) and whole ROWS
 // (ybar_i = sum_j Y_ij e_j) of the same data in one pass, i.e. a block must hold all rows of a few
 // columns: 128-byte row segments 8 MB apart in the row-major matrix, which reach 4.9 TB/s at best (r01).
-// So the forces method gets its own copy, built on first use:
-//     Ys[strip s][row][c ^ swz(row)] = Y[row][16 s + c] - center[row]
+// So the matrix passes for M <= 1024 read strip-major copies, built on first use:
+//     Ys[strip s][row][c ^ swz(row)] = Y[row][16 s + c]          (raw numbers; rows padded to 16)
 // * strip-major: the 16 columns x all rows a block works on are ONE contiguous chunk (64 KB at
 //   M = 512) -- every wave-load is a contiguous KiB, as in the streaming kernels;
-// * centred on center = YTilde (the targets, identical on every rank of a sharded context).  The
-//   softmax is invariant under x_j -> x_j + const, ybar_i = center_i + sum_j Y'_ij w_j, the adjoint picks
-//   up the constant B0 = sum_i center_i r_i, and the reference's centred gradient sum becomes
+// * the kernels subtract center = YTilde (the targets, identical on every rank of a sharded context) from every
+//   operand on its way from the load registers into the products: Y' = Y - center.  The softmax is invariant under
+//   x_j -> x_j + const, ybar_i = center_i + sum_j Y'_ij w_j, the adjoint picks up the constant
+//   B0 = sum_i center_i r_i, and the reference's centred gradient sum becomes
 //       sum_j (Y_ij - ybar_i) t_j  =  sum_j Y'_ij t_j  -  (ybar_i - center_i) sum_j t_j
 //   with BOTH terms at the scale of the data's spread instead of its offset: the plain matrix product
 //   the matrix cores compute loses nothing to cancellation, and no per-problem centring is needed
-//   inside the product;
+//   inside the product.  (r02 stored Y' in the copies; the raw copies of r03 give the same operands -- the same
+//   subtraction, a register later -- and let the copies REPLACE the row-major matrix: read_ytilde is exact from them.)
 // * the XOR swizzle (columns permuted by bits 1..4 of the row) makes the LDS image of a strip -- a plain
 //   copy, 16 doubles per row, no padding -- conflict-free for both operand fetch patterns below.
 //
@@ -669,7 +671,11 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
             if (colsum == 1.2345e300) outk[(size_t)sp * kStripCols + pc] = colsum + shift;
 #else
             // streamed past the L2 (no write-allocate): a plain store here cost 3 % of the pass -- the 8 K bytes per
-            // column are 0.8 % of the traffic, without any store the pass runs at the forward pass's time
+            // column are 0.8 % of the traffic, without any store the pass runs at the forward pass's time.  (r03, tried
+            // and dropped: contiguous runs of strips per block with the outputs staged in LDS and written as KiB runs --
+            // which strip a block takes changes no bit here.  One run per block: 1 % SLOWER at N = 1e6 x M = 1024, the
+            // blocks' reads no longer sweep the HBM channels together; runs of 8 strips dealt round-robin: +0.2..0.7 %,
+            // within the noise, and the uneven last run costs as much.)
             __builtin_nontemporal_store(colsum + shift, outk + (size_t)sp * kStripCols + pc);
 #endif
         }

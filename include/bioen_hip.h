@@ -228,10 +228,12 @@ int bioen_hip_opt_lbfgs_forces_batch(bioen_hip_ctx* ctx, int ntheta, const doubl
  * off_i + sc_i (yTilde . w)_i (sum w = 1 assumed, as everywhere in BioEn), while yave stays the RAW product
  * of the resident matrix -- the quantity a nuisance refit needs; bioen_hip_last_average hands out both. */
 int bioen_hip_chi_squared(bioen_hip_ctx* ctx, const double* w, double* yave, double* chi2);
-/* Averages left on the device by the most recent SINGLE-problem call (bioen_hip_chi_squared, *_fdf,
- * bioen_hip_opt_lbfgs_logw, bioen_hip_opt_gsl_logw): yraw[m] = yTilde . w of the resident matrix at the
- * point that call ended on, yeff[m] = off + sc * yraw.  Either may be NULL.  2 m doubles cross PCIe -- a
- * refit between two optimizations (analyze/procedure.py:82-83) never moves the N weights. */
+/* Averages left on the device by the most recent SINGLE-problem call (bioen_hip_chi_squared, bioen_hip_logw_fdf,
+ * bioen_hip_forces_fdf, bioen_hip_opt_lbfgs_logw, bioen_hip_opt_lbfgs_forces, bioen_hip_opt_gsl_logw):
+ * yraw[m] = yTilde . w of the resident matrix at the point that call ended on, yeff[m] = off + sc * yraw.  Either
+ * may be NULL.  2 m doubles cross PCIe -- a refit between two optimizations (analyze/procedure.py:82-83) never moves
+ * the N weights.  After a multi-problem call (*_batch with more than one problem) there is no single point to report:
+ * BIOEN_HIP_ESTATE until the next single-problem call. */
 int bioen_hip_last_average(bioen_hip_ctx* ctx, double* yraw, double* yeff);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------- */
