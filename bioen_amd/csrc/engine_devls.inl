@@ -141,6 +141,9 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     if (const char* e = std::getenv("BIOEN_HIP_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(e)));
     int next = 0, active = 0;
     std::deque<DevFlight> inflight;
+    std::vector<int> start_order(ntheta);            // ascending theta: the slow problems first
+    for (int i = 0; i < ntheta; ++i) start_order[i] = i;
+    std::stable_sort(start_order.begin(), start_order.end(), [&](int x, int y) { return thetas[x] < thetas[y]; });
 
     auto start_problem = [&](int s) {
         settle(s);                                   // the previous tenant's results have left
@@ -151,15 +154,16 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         st.d[0] = sl.d;
         st.gram[0] = sl.gram;
         st.tab = tab;
+        const int id = start_order[next];
         if (shared_start) {
             st.g0[0] = c->g0;
         } else {                                     // staged in the slot's adjoint buffer (scratch between rounds)
-            note(upload_n(c, sl.a, g0_host + (size_t)next * g0_stride));
+            note(upload_n(c, sl.a, g0_host + (size_t)id * g0_stride));
             st.g0[0] = sl.a;
         }
         launch_dev_start(c, st, cfg);
         occupied[s] = true;
-        prob[s] = next;
+        prob[s] = id;
         initial_round[s] = c->dev_round + 1;         // the next round enqueued
         t0[s] = std::chrono::steady_clock::now();
         if (shadow_owner[s] >= 0) release_round[s] = c->dev_round + 1;

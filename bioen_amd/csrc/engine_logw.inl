@@ -21,6 +21,8 @@ struct LogwBatchEngine {
     bool verbose;
     int rc = 0;
     bool speculate = true;
+    int max_shadows = 2;                             // shadow evaluations per round at most (BIOEN_HIP_HOST_SHADOWS): both
+                                                     // steps of the slowest problem (r02: every idle slot)
     long long spec_launched = 0, spec_used = 0;      // shadow evaluations issued / adopted
 
     // Deliveries: the optimum and the weights of a finished problem (2 N doubles into the caller's pageable arrays,
@@ -40,6 +42,7 @@ struct LogwBatchEngine {
         : c(ctx), cfg(config), verbose(verb) {
         const char* e = std::getenv("BIOEN_HIP_SPECULATE");
         speculate = !(e && e[0] == '0');
+        if (const char* m = std::getenv("BIOEN_HIP_HOST_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(m)));
         const char* d = std::getenv("BIOEN_HIP_DELIVERY");
         async_delivery = c->world == 1 && !(d && d[0] == '0');
     }
@@ -254,6 +257,19 @@ struct LogwBatchEngine {
         if (device_engine_applies())
             return run_device(ntheta, thetas, g0_host, g0_stride, G_host, max_batch, results, w_opt, infos);
         int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
+        // Problems start in ascending theta (the slow ones first: the series ends with its slowest member).  A series
+        // that fills the batch exactly leaves no slot to speculate in until its first member finishes -- and a line
+        // search rejects most in its first iterations (the headline's slowest theta: 19 of 39 rejected trials in the
+        // first 13 rounds).  Such a series keeps two slots back for shadows of the slowest problem from the first
+        // round on; the two fastest thetas wait for the first slots to come free (they need a fraction of the rounds).
+        std::vector<int> start_order(ntheta);
+        for (int i = 0; i < ntheta; ++i) start_order[i] = i;
+        std::stable_sort(start_order.begin(), start_order.end(), [&](int x, int y) { return thetas[x] < thetas[y]; });
+        const bool backtracking = cfg.linesearch >= 1 && cfg.linesearch <= 3;
+        if (speculate && backtracking && max_shadows >= 2 && kb == kMaxBatch && ntheta <= kMaxBatch) {
+            const char* e = std::getenv("BIOEN_HIP_RESERVE");
+            kb -= e ? std::max(0, std::min(4, std::atoi(e))) : 2;
+        }
         for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, true));
         if (rc) return rc;
         note(upload_n(c, c->fixed, G_host));
@@ -283,6 +299,8 @@ struct LogwBatchEngine {
             }
         }
 
+        const bool dbg = std::getenv("BIOEN_HIP_SPEC_DEBUG") != nullptr;
+        std::vector<int> dbg_rej(ntheta, 0), dbg_noslot(ntheta, 0), dbg_miss(ntheta, 0);
         BatchProblem slots[kMaxBatch];
         std::vector<LbfgsMachine> machines;
         machines.reserve(ntheta);
@@ -293,16 +311,17 @@ struct LogwBatchEngine {
         auto start_problem = [&](int s) {
             BatchProblem& p = slots[s];
             p = BatchProblem();
-            p.id = next;
-            p.theta = thetas[next];
-            p.machine = &machines[next];
+            const int id = start_order[next];
+            p.id = id;
+            p.theta = thetas[id];
+            p.machine = &machines[id];
             p.t0 = std::chrono::steady_clock::now();
             ProblemSlot& sl = c->slot[s];
             settle(s);                               // the previous tenant's results have left
             if (shared_start)
                 note(hipMemcpyAsync(sl.xp, c->g0, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "copy g0");
             else
-                note(upload_n(c, sl.xp, g0_host + (size_t)next * g0_stride));
+                note(upload_n(c, sl.xp, g0_host + (size_t)id * g0_stride));
             note(hipMemsetAsync(sl.d, 0, c->ld * sizeof(double), c->stream), "memset d");
             note(hipMemsetAsync(sl.gram, 0, kGramStride * sizeof(double), c->stream), "memset gram");
             // the Gram sweep multiplies with every history buffer, live or not: leftovers of an earlier
@@ -388,17 +407,40 @@ struct LogwBatchEngine {
                 int free_slots[kMaxBatch], nfree = 0;
                 for (int s = 0; s < nslots; ++s)
                     if ((s >= kb || !occupied[s]) && !slot_busy(s)) free_slots[nfree++] = s;
-                for (int pass = 0; pass < 2 && nfree > 0; ++pass)            // first everybody's stp/2, then 2.1 stp
-                    for (int a = 0; a < k && nfree > 0; ++a) {
-                        BatchProblem& p = slots[list[a]];
-                        double cand[2];
-                        if (p.initial || pass >= p.machine->speculative_steps(cand)) continue;
+                // Who gets the idle slots: the series ends when its SLOWEST member does, so a saved evaluation shortens it
+                // only on that member's path -- the smallest theta in every series measured (r03; r02 dealt stp / 2 to
+                // everybody first and reached the straggler last: 22 of its 45 rejected trials saved at the headline).
+                // Owners in ascending theta, both steps each, while slots last.
+                int order[kMaxBatch];
+                for (int a = 0; a < k; ++a) order[a] = a;
+                std::sort(order, order + k, [&](int x, int y) { return th[x] < th[y]; });
+                for (int i = 0; i < k && nfree > 0 && nshadow < max_shadows; ++i) {
+                    const int a = order[i];
+                    BatchProblem& p = slots[list[a]];
+                    // The steps the search can ask for after this trial -- formed exactly as report_backtracking forms
+                    // them (lbfgs.c:686-727): stp * 0.5 | stp * 2.1 -- and, should slots remain, the ones a rejected
+                    // successor would ask for.  (Measured at the headline, r03: the two first-level steps for the slowest
+                    // theta catch every first rejection, 29 of its 45 extra evaluations; second-level shadows, or a
+                    // "the search keeps going the same way" guess for the second slot, save no further round.)
+                    double c1[2], cand[4];
+                    int nc = p.initial ? 0 : p.machine->speculative_steps(c1);
+                    for (int i2 = 0; i2 < nc; ++i2) cand[i2] = c1[i2];
+                    if (nc == 2) {
+                        cand[2] = c1[0] * 0.5;
+                        cand[3] = c1[1] * 2.1;
+                        nc = 4;
+                    } else if (nc == 1) {
+                        cand[1] = c1[0] * 0.5;
+                        nc = 2;
+                    }
+                    for (int pass = 0; pass < nc && nfree > 0 && nshadow < max_shadows; ++pass) {
                         note(alloc_slot(c, free_slots[nfree - 1], false));
                         shadow_owner[nshadow] = a;
                         shadow_slot[nshadow] = free_slots[--nfree];
                         shadow_stp[nshadow] = cand[pass];
                         ++nshadow;
                     }
+                }
             }
             Round r = make_round(c, list, k, stp, th);
             for (int q = 0; q < nshadow; ++q) {
@@ -454,28 +496,44 @@ struct LogwBatchEngine {
                 } else {
                     TrialResult t{h[S_F], h[S_DG], h[S_GG], h[S_XX], h[S_DGINIT]};
                     act = p.machine->on_trial(t);
-                    if (act.kind == LbfgsMachine::TRIAL) {
-                        // rejected: is the step it asks for next among this round's shadows?
-                        for (int q = 0; q < nshadow; ++q) {
-                            if (shadow_owner[q] != a || shadow_stp[q] != p.machine->trial_step()) continue;
-                            ProblemSlot& sh = c->slot[shadow_slot[q]];
-                            std::swap(sl.x, sh.x);           // the shadow's point, gradient, e and adjoint become the trial's
-                            std::swap(sl.g, sh.g);
-                            std::swap(sl.w, sh.w);
-                            std::swap(sl.a, sh.a);
-                            double* hs = c->host_scal + (size_t)shadow_slot[q] * kScalStride;
-                            double* ho = c->host_scal + (size_t)s * kScalStride;
-                            for (const auto& rg : kEvalScal) {
-                                note(hipMemcpyAsync(sl.scal + rg[0], sh.scal + rg[0], rg[1] * sizeof(double),
-                                                    hipMemcpyDeviceToDevice, c->stream), "adopt scalars");
-                                std::memcpy(ho + rg[0], hs + rg[0], rg[1] * sizeof(double));
-                            }
-                            ++spec_used;
-                            column = k + q;
-                            TrialResult t2{ho[S_F], ho[S_DG], ho[S_GG], ho[S_XX], ho[S_DGINIT]};
-                            act = p.machine->on_trial(t2);
-                            break;
+                    if (act.kind == LbfgsMachine::TRIAL && dbg) {
+                        int mine = 0, hit = 0;
+                        for (int q = 0; q < nshadow; ++q)
+                            if (shadow_owner[q] == a) { ++mine; hit += shadow_stp[q] == p.machine->trial_step(); }
+                        ++dbg_rej[p.id];
+                        if (!mine) ++dbg_noslot[p.id]; else if (!hit) ++dbg_miss[p.id];
+                    }
+                    // rejected: is the step it asks for next among this round's shadows?  An adopted evaluation may be
+                    // rejected in its turn: its successor may be there too (second-level shadows)
+                    bool used[kMaxBatch] = {};
+                    double prev = 0.0;
+                    while (act.kind == LbfgsMachine::TRIAL) {
+                        prev = p.machine->trial_step();
+                        int q = 0;
+                        for (; q < nshadow; ++q)
+                            if (shadow_owner[q] == a && !used[q] && shadow_stp[q] == prev) break;
+                        if (q == nshadow) break;
+                        used[q] = true;
+                        ProblemSlot& sh = c->slot[shadow_slot[q]];
+                        std::swap(sl.x, sh.x);           // the shadow's point, gradient, e and adjoint become the trial's
+                        std::swap(sl.g, sh.g);
+                        std::swap(sl.w, sh.w);
+                        std::swap(sl.a, sh.a);
+                        double* hs = c->host_scal + (size_t)shadow_slot[q] * kScalStride;
+                        double* ho = c->host_scal + (size_t)s * kScalStride;
+                        for (const auto& rg : kEvalScal) {
+                            note(hipMemcpyAsync(sl.scal + rg[0], sh.scal + rg[0], rg[1] * sizeof(double),
+                                                hipMemcpyDeviceToDevice, c->stream), "adopt scalars");
+                            // (the shadow keeps the owner's former values: a second adoption must not read them back)
+                            double tmp[8];
+                            std::memcpy(tmp, ho + rg[0], rg[1] * sizeof(double));
+                            std::memcpy(ho + rg[0], hs + rg[0], rg[1] * sizeof(double));
+                            std::memcpy(hs + rg[0], tmp, rg[1] * sizeof(double));
                         }
+                        ++spec_used;
+                        column = k + q;
+                        TrialResult t2{ho[S_F], ho[S_DG], ho[S_GG], ho[S_XX], ho[S_DGINIT]};
+                        act = p.machine->on_trial(t2);
                     }
                     if (act.kind == LbfgsMachine::ACCEPT) {
                         p.need_direction = true;
@@ -497,6 +555,10 @@ struct LogwBatchEngine {
         for (int s = 0; s < kMaxBatch; ++s) settle(s);
         c->spec_launched += spec_launched;
         c->spec_used += spec_used;
+        if (dbg)
+            for (int i = 0; i < ntheta; ++i)
+                std::fprintf(stderr, "spec debug: theta %g: %d rejected trials, %d without a shadow slot, %d with shadows but none matching\n",
+                             thetas[i], dbg_rej[i], dbg_noslot[i], dbg_miss[i]);
         if (verbose && spec_launched)
             std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n",
                         spec_launched, spec_used);
