@@ -183,6 +183,43 @@ __device__ __forceinline__ double xmax_local(const Xch& x, int a, int q, double*
     return block_max(s, sh);
 }
 
+// The 39 Gram sums of one evaluation finished by ONE block of four waves (few partials per sum: npl * world <= 256):
+// wave w forms the sums w, w + 4, ..., lane l adding the partials l, l + 64, ... of each in turn, then the lanes' shares
+// meet in wave_sum's pair order.  r03: all loads of a wave in flight at once and ONE batched butterfly for its ten sums
+// (wave_multi_reduce: 15 shuffles instead of 60 dependent ones -- 8.7 k of the decision kernel's 33 k cycles were
+// spent here); every sum is formed from the same terms in the same order as before.
+__device__ __forceinline__ void fused_gram_dots(const Xch& xi, int a, double* dots /* LDS [kGramDots] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
+    static_assert(kPerWave <= 16, "one 16-value butterfly per wave");
+    double acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    for (int r = 0; r < xi.world; ++r)
+        for (int k0 = 0; k0 < xi.npl; k0 += 256) {
+            double v[4][kPerWave];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 64 * j + lane;
+#pragma unroll
+                for (int u = 0; u < kPerWave; ++u) {
+                    const int c = wave + u * kWaves;
+                    v[j][u] = (k < xi.npl && c < kGramDots)
+                                  ? xi.base[(size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl + k] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + 64 * j + lane < xi.npl) {
+#pragma unroll
+                    for (int u = 0; u < kPerWave; ++u) acc[u] += v[j][u];
+                }
+        }
+    wave_multi_reduce<16>(acc, lane);          // lane l now holds the total of value l >> 2
+    const int u = lane >> 2, c = wave + u * kWaves;
+    if ((lane & 3) == 0 && u < kPerWave && c < kGramDots) dots[c] = acc[0];
+}
+
 // The scalar part of the Gram-form direction (kernels_logw.hip: k_gram_solve; kernels_devls.hip: k_dev_decide), run by
 // ONE thread: the 39 finished sums `dots` update rows / columns s_e, y_e, g of the 13 x 13 Gram matrix (G in HBM, Gs
 // its LDS image), then the two-loop recursion (lbfgs.c:571-598) runs on 13 coefficients over {S_0..5, Y_0..5, g};
@@ -195,49 +232,73 @@ __device__ __forceinline__ void gram_solve_thread0(double* G, double* Gs, const 
         Gs[ry * kBasis + c] = Gs[c * kBasis + ry] = dots[kBasis + c];
     }
     for (int c = 0; c < kBasis; ++c) Gs[rg * kBasis + c] = Gs[c * kBasis + rg] = dots[2 * kBasis + c];
-    for (int c = 0; c < kBasis; ++c) {        // the three rows/columns that changed go back to HBM
-        G[rs * kBasis + c] = G[c * kBasis + rs] = Gs[rs * kBasis + c];
-        G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
-        G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
-    }
-    // q = -g as coefficients over {S, Y, g}.  The coefficients stay in registers (an LDS array put a store -> load
-    // round trip into every step of the two dependent chains); slot numbers are run-time values, so the one entry a
-    // step changes is picked by comparison.  Same operations in the same order as before.
+    if (G != Gs)                              // (the decision kernel updates the LDS image in place and writes it back whole:
+        for (int c = 0; c < kBasis; ++c) {    //  as a self-copy these 39 dependent load -> store pairs cost one lane 4 k cycles)
+            G[rs * kBasis + c] = G[c * kBasis + rs] = Gs[rs * kBasis + c];     // the three rows/columns that changed go back to HBM
+            G[ry * kBasis + c] = G[c * kBasis + ry] = Gs[ry * kBasis + c];
+            G[rg * kBasis + c] = G[c * kBasis + rg] = Gs[rg * kBasis + c];
+        }
+    // q = -g as coefficients over {S, Y, g}.  The coefficients stay in registers; slot numbers are run-time values, so
+    // the one entry a step changes is picked by comparison.  r03: the rows a loop needs are fetched from LDS up front,
+    // all at once (the lane used to wait for an LDS round trip, an integer modulo and thirteen selects in every one of
+    // the up to twelve dependent steps: 12.5 k cycles of the decision kernel's 33 k), the per-step quotients stay in
+    // registers.  Same operations on the same numbers in the same order as before.
     double cf[kBasis];
 #pragma unroll
     for (int c = 0; c < kBasis; ++c) cf[c] = c == rg ? -1.0 : 0.0;
-    for (int b = 0; b < bound; ++b) {         // first loop, newest -> oldest
-        const int i = (e + kHistory - b) % kHistory;
-        double row[kBasis];
+    int idx[kHistory];                       // ring order, newest -> oldest: (e + kHistory - b) % kHistory
 #pragma unroll
-        for (int c = 0; c < kBasis; ++c) row[c] = Gs[i * kBasis + c];
-        const double diag = Gs[(kHistory + i) * kBasis + i];
-        double sq = 0.0;
+    for (int b = 0; b < kHistory; ++b) {
+        idx[b] = e - b;
+        if (idx[b] < 0) idx[b] += kHistory;
+    }
+    double R[kHistory][kBasis], D[kHistory], A[kHistory];
 #pragma unroll
-        for (int c = 0; c < kBasis; ++c) sq = fma(cf[c], row[c], sq);
-        const double al = sq / diag;
-        alpha[i] = al;
+    for (int b = 0; b < kHistory; ++b) {
+        D[b] = 1.0;
+        A[b] = 0.0;
 #pragma unroll
-        for (int c = 0; c < kBasis; ++c)
-            if (c == kHistory + i) cf[c] -= al;
+        for (int c = 0; c < kBasis; ++c) R[b][c] = 0.0;
+        if (b < bound) {
+#pragma unroll
+            for (int c = 0; c < kBasis; ++c) R[b][c] = Gs[idx[b] * kBasis + c];
+            D[b] = Gs[(kHistory + idx[b]) * kBasis + idx[b]];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < kHistory; ++b) {      // first loop, newest -> oldest
+        if (b < bound) {
+            double sq = 0.0;
+#pragma unroll
+            for (int c = 0; c < kBasis; ++c) sq = fma(cf[c], R[b][c], sq);
+            const double al = sq / D[b];
+            A[b] = al;
+            alpha[idx[b]] = al;
+#pragma unroll
+            for (int c = kHistory; c < 2 * kHistory; ++c)
+                if (c == kHistory + idx[b]) cf[c] -= al;
+        }
     }
     const double scale = Gs[ry * kBasis + rs] / Gs[ry * kBasis + ry];   // ys / yy of the newest pair
 #pragma unroll
     for (int c = 0; c < kBasis; ++c) cf[c] *= scale;
-    for (int b = bound - 1; b >= 0; --b) {    // second loop, oldest -> newest
-        const int i = (e + kHistory - b) % kHistory;
-        double row[kBasis];
 #pragma unroll
-        for (int c = 0; c < kBasis; ++c) row[c] = Gs[(kHistory + i) * kBasis + c];
-        const double diag = Gs[(kHistory + i) * kBasis + i];
-        const double al = alpha[i];
-        double yq = 0.0;
+    for (int b = 0; b < kHistory; ++b)
+        if (b < bound) {
 #pragma unroll
-        for (int c = 0; c < kBasis; ++c) yq = fma(cf[c], row[c], yq);
-        const double beta = yq / diag;
+            for (int c = 0; c < kBasis; ++c) R[b][c] = Gs[(kHistory + idx[b]) * kBasis + c];
+        }
 #pragma unroll
-        for (int c = 0; c < kBasis; ++c)
-            if (c == i) cf[c] += al - beta;
+    for (int b = kHistory - 1; b >= 0; --b) {    // second loop, oldest -> newest
+        if (b < bound) {
+            double yq = 0.0;
+#pragma unroll
+            for (int c = 0; c < kBasis; ++c) yq = fma(cf[c], R[b][c], yq);
+            const double beta = yq / D[b];
+#pragma unroll
+            for (int c = 0; c < kHistory; ++c)
+                if (c == idx[b]) cf[c] += A[b] - beta;
+        }
     }
     double dg = 0.0;
 #pragma unroll

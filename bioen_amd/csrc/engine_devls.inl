@@ -41,7 +41,7 @@ bool LogwBatchEngine::device_engine_applies() const {
 int LogwBatchEngine::ensure_device_state() {
     if (!c->dev_tab) {
         void* p = nullptr;
-        const size_t bytes = (size_t)kMaxBatch * sizeof(DevSlot) + 64;
+        const size_t bytes = (size_t)kMaxBatch * sizeof(DevSlot) + 64 + 16 * sizeof(long long);   // counters | diagnostic stamps
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return hip_fail(e, "hipMalloc (role table)", __FILE__, __LINE__);
         BIOEN_HIP_CHECK(hipMemsetAsync(p, 0, bytes, c->stream));
@@ -429,6 +429,14 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         unsigned long long used = 0;
         note(hipMemcpy(&used, spec_dev, sizeof used, hipMemcpyDeviceToHost), "spec");
         spec_used += (long long)used;
+    }
+    if (std::getenv("BIOEN_HIP_DECIDE_STAMPS")) {     // diagnostic builds (-DDECIDE_STAMPS): phase cycles of k_dev_decide, block 0
+        long long st[8] = {};
+        (void)hipMemcpy(st, reinterpret_cast<long long*>(spec_dev) + 8, sizeof st, hipMemcpyDeviceToHost);
+        if (st[0] > 0)
+            std::fprintf(stderr, "k_dev_decide stamps (100 MHz ticks per call): loads+sums %.1f, gram dots %.1f, decision %.1f, solve %.1f, publish %.1f over %lld calls\n",
+                         (double)st[1] / st[0], (double)st[2] / st[0], (double)st[3] / st[0], (double)st[4] / st[0], (double)st[5] / st[0], st[0]);
+        (void)hipMemset(reinterpret_cast<long long*>(spec_dev) + 8, 0, sizeof st);
     }
     c->spec_launched += spec_launched;
     c->spec_used += spec_used;

@@ -456,29 +456,7 @@ __device__ __forceinline__ void dev_gram_dots(const DevRound& r, const Xch& xm, 
     if (MODE == 2) {
         for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = dev_ranks_sum(xm, pos, i);
     } else if (MODE == 0) {
-        // as k_gram_solve<true>: a wave's sums side by side, every sum formed in the same order
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
-        double acc[kPerWave];
-#pragma unroll
-        for (int u = 0; u < kPerWave; ++u) acc[u] = 0.0;
-        for (int rk = 0; rk < xm.world; ++rk)
-            for (int k = lane; k < xm.npl; k += 64) {
-                double v[kPerWave];
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) {
-                    const int c = wave + u * kWaves;
-                    v[u] = c < kGramDots ? xm.base[(size_t)rk * xm.payload + (size_t)(pos * kGramDots + c) * xm.npl + k] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) acc[u] += v[u];
-            }
-#pragma unroll
-        for (int u = 0; u < kPerWave; ++u) {
-            const int c = wave + u * kWaves;
-            const double t = wave_sum(acc[u]);
-            if (lane == 0 && c < kGramDots) dots[c] = t;
-        }
+        fused_gram_dots(xm, pos, dots);          // as k_gram_solve<true>
     } else {
         const double* Gq = r.gram[pos];
         for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = Gq[kGramSums + i];
@@ -505,6 +483,14 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
     DevSlot& T = *reinterpret_cast<DevSlot*>(Tw);
     double* scg = r.scal[a];
     double* G = r.gram[a];
+#ifdef DECIDE_STAMPS
+    long long st_[8];
+    int sti_ = 0;
+#define DSTAMP() { if (threadIdx.x == 0 && a == 0 && sti_ < 8) st_[sti_++] = __builtin_amdgcn_s_memtime(); }
+#else
+#define DSTAMP()
+#endif
+    DSTAMP()
     // ---- everything the decision may need, fetched side by side ----
     for (int i = threadIdx.x; i < kSlotWords; i += kBlock) Tw[i] = reinterpret_cast<const unsigned long long*>(Tg)[i];
     if (threadIdx.x < kScalStride) scs[threadIdx.x] = scg[threadIdx.x];
@@ -517,9 +503,11 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
     } else {
         dev_three_sums(xg, a, sh3, sums);     // (two barriers: Tw, scs, Gs are in place after it)
     }
+    DSTAMP()                                                                     // 1: loads + three sums
     const int status = T.status;
     const bool alive = dev_alive(status);
     if (alive && status == DS_RUNNING) dev_gram_dots<MODE>(r, xm, a, dots);      // block-uniform
+    DSTAMP()                                                                     // 2: gram dots
     int kind = ACT_DONE, evalpos = a;
     bool dirty = false;
     if (alive) {
@@ -555,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
             ctl[0] = act.kind; ctl[1] = adopt; ctl[2] = act.end; ctl[3] = act.bound; ctl[4] = act.code; ctl[5] = act.keep_trial;
             ctl[6] = 0;
         }
+        DSTAMP()                                                                 // 3: decision
         __syncthreads();
         const int adopt = ctl[1];
         if (adopt >= 0) {                      // block-uniform, rare: the shadow's sums are fetched now
@@ -617,6 +606,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
             }
             T.m.pf = Tg->pf;                  // back to the entry's own array
         }
+        DSTAMP()                                                                 // 4: solve
         dirty = true;
     }
     // ---- the record, built in LDS ----
@@ -646,6 +636,14 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
         if (threadIdx.x == 0)
             __hip_atomic_store(flags + a, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    DSTAMP()                                                                     // 5: record, write-back, publish
+#ifdef DECIDE_STAMPS
+    if (threadIdx.x == 0 && a == 0) {
+        long long* out = reinterpret_cast<long long*>(spec) + 8;
+        for (int i = 1; i < sti_; ++i) out[i] += st_[i] - st_[i - 1];
+        out[0] += 1;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -412,30 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
     double* G = q.gram[a];
     for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
     if (FUSED) {
-        // a wave's sums side by side: their loads are all in flight together (one after the other, each sum waited
-        // for its own loads: 10 round trips to L2 in a row); every sum is still formed in the same order
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
-        double acc[kPerWave];
-#pragma unroll
-        for (int u = 0; u < kPerWave; ++u) acc[u] = 0.0;
-        for (int r = 0; r < xi.world; ++r)
-            for (int k = lane; k < xi.npl; k += 64) {
-                double v[kPerWave];
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) {
-                    const int c = wave + u * kWaves;
-                    v[u] = c < kGramDots ? xi.base[(size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl + k] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) acc[u] += v[u];
-            }
-#pragma unroll
-        for (int u = 0; u < kPerWave; ++u) {
-            const int c = wave + u * kWaves;
-            const double t = wave_sum(acc[u]);
-            if (lane == 0 && c < kGramDots) dots[c] = t;
-        }
+        fused_gram_dots(xi, a, dots);
     } else {
         for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = G[kGramSums + i];
     }

@@ -480,6 +480,10 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 // block B is partial set B spb + sub and takes the strips set + it * (sets): the assignment, and therefore every
 // bit of the result, is that of one block per set.  A 64-row strip keeps a second, idle wave per slot (the 16 K
 // threads that stage e need up to two waves): it re-reads the first one's rows and stores nothing.
+// One register set (one strip in flight per wave, 128 KB per CU).  r03 tried two (110-126 VGPRs, no spill, loop
+// unrolled by two as in k_strip): 2418-2443 vs 2432-2438 us of matrix kernels per headline round, 84.7 vs 82 us at
+// N = 1e5 x M = 256 -- no gain: the ~7 TB/s these passes reach is the memory system's rate for this stream, not a
+// shortage of bytes in flight.
 template <int K, bool NT>
 __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     constexpr int NK = (K + 3) / 4;
