@@ -63,7 +63,7 @@ int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 // tsum = true (strip passes on the centred copy): gm = sum of partials - ybar_c * T, T = sum of the blocks' P_KL shares
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);
-// forces evaluation in TWO matrix passes over LDS-resident column strips (M <= 512, unsharded):
+// forces evaluation in TWO matrix passes over LDS-resident column strips (M <= 1024):
 //   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
 constexpr int kFusedBlocks = 1024;

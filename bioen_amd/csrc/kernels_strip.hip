@@ -1,4 +1,4 @@
-// Forces method, M <= 512: the whole evaluation in TWO passes over a strip-major copy of yTilde, with both
+// Forces method, M <= 1024 (k_strip: M <= 512; k_strip2: 512 < M <= 1024): the whole evaluation in TWO passes over a strip-major copy of yTilde, with both
 // products of each pass on the FP64 matrix cores (v_mfma_f64_4x4x4_4b_f64).
 //
 // Reference: _get_weights_from_forces (c_bioen_kernels_forces.c:111-224), _bioen_log_posterior_forces
@@ -468,6 +468,278 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     }
 }
 
+// ---- the same two passes for 512 < M <= 1024 (r03; until then the r01 kernels on the row-major matrix: 4.8 TB/s at K = 1,
+// spilling at K = 8).  Sixteen waves of 64 rows would leave 128 registers per wave and need a 128-KB image beside the
+// 64-KB operand table; instead EIGHT waves own 128 rows each (256 registers, as k_strip): a wave keeps its 16 KB of
+// the strip in registers as the row-sum operands (a3) and passes it through its 8-KB slice of the LDS image in two
+// halves of 64 rows for the column sums (P1 over the first half, rewrite, P1 over the second half, one chain of
+// accumulators).  One register set in flight (the prefetch is issued as soon as a3 holds the strip): 8 waves x 16 KB =
+// the 128 KB per CU the other strip kernels keep in flight.  Everything else -- operand maps, swizzle, P2, P3, the
+// straight-line rules about vmcnt -- is k_strip's; kept as a kernel of its own so that the tuned M <= 512 code does not
+// move by an instruction.
+#ifndef STRIP2_GB2
+#define STRIP2_GB2 2
+#endif
+template <int K, bool NT, bool XY>
+__global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) {
+    constexpr int RH = 2;                           // 64-row halves per wave
+    constexpr int WR = 64 * RH;                     // rows per wave
+    constexpr int NK = (K + 3) / 4;                 // problem quads
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int lrows = nwaves * WR;
+    double* tile = lds;                              // [wave][64 rows][16]: one half of a wave's rows at a time
+    double* ul = tile + (size_t)nwaves * 64 * kStripCols;  // u[row][8]: forces | residuals, zero beyond K and mp
+    double* red = ul + (size_t)lrows * 8;           // [wave][problem 8][column 16]: the waves' partial column sums
+    double* tv = red + nwaves * 128;                // v[problem 8][column 16]: e | t of the strip
+    double* scale = tv + 128;
+    double* cl = scale + 16;                        // centre[row]
+    const int rbase = wave * WR;
+    const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
+    const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
+
+    for (int i = t; i < lrows * 8; i += blockDim.x) {
+        const int row = i >> 3, k = i & 7;
+        ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
+    }
+    for (int i = t; i < 128; i += blockDim.x) tv[i] = 0.0;         // problems k >= K of a quad stay zero
+    for (int i = t; i < lrows; i += blockDim.x) cl[i] = i < q.mp ? q.center[i] : 0.0;
+    if (t < 8) scale[t] = 1.0;
+
+    // P3 accumulators: row block h (16 rows), problem quad kq: lane 16 i + 4 blk + j holds
+    // row rbase + 16 h + 4 blk + i, problem 4 kq + j
+    double acc[WR / 16][NK];
+#pragma unroll
+    for (int h = 0; h < WR / 16; ++h)
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) acc[h][kq] = 0.0;
+
+    // P2 state (threads t < 16 K: problem k = t / 16, column c = t % 16 -- a problem's 16 columns sit in one
+    // 16-lane group, so the strip's maximum needs no LDS and no barrier)
+    const bool p2 = t < kStripCols * K;
+    const int pk = p2 ? t >> 4 : 0, pc = t & 15;
+    double m_run = -DBL_MAX, zacc = 0.0, pxacc = 0.0;             // xy: running maximum, sum e, sum e x | bt: zacc = sum t
+    double logs = 0.0, theta = 0.0, b0 = 0.0;
+    // per-lane choice among the K kernel arguments by comparison (indexing the argument block with a lane value is
+    // a vector load whose pending state forces vmcnt(0) -- a drain of the prefetch -- wherever the pointer is used)
+    double* ak = fr.a[0];
+    double* sck = fr.scal[0];
+    double* pak = fr.part[0];
+    double thk = fr.theta[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (pk == k) {
+            ak = fr.a[k];
+            sck = fr.scal[k];
+            pak = fr.part[k];
+            thk = fr.theta[k];
+        }
+    if (!XY && p2) {
+        logs = sck[S_LOGS];
+        b0 = sck[S_B0];
+        theta = thk;
+    }
+
+    // the wave's 16 KB of the next strip travel in registers
+    d2 pre[WR / 8];
+    const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
+    int choff[WR / 8];                                                          // chunk -> chunk actually loaded (wave-uniform)
+    {
+        const int nh = min(WR / 16, (q.mps - rsrc) / 16);                       // row blocks of this wave's slice
+#pragma unroll
+        for (int i = 0; i < WR / 8; ++i) choff[i] = __builtin_amdgcn_readfirstlane(((i >> 1) < nh ? i : (i & 1)) * 128);
+    }
+    auto fetch = [&](int strip) {
+        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+#pragma unroll
+        for (int i = 0; i < WR / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+    };
+    const int G = gridDim.x;
+    auto one_strip = [&](int s) {
+        // the strip's centred values: the row-sum operands of P3, and the source of the LDS image below
+        double a3[4][WR / 16];
+        {
+#pragma unroll
+            for (int i = 0; i < WR / 8; ++i) {
+                const int h = i >> 1, qp = i & 1;
+                const double ch = cl[rsrc + 16 * h + lr];
+                a3[2 * qp][h] = pre[i].x - ch;                                    // the centring
+                a3[2 * qp + 1][h] = pre[i].y - ch;
+            }
+        }
+        // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
+        // prefetch would wait for the whole strip after next
+        const size_t col = (size_t)s * kStripCols + pc;
+        double w0v = 0.0, xv = 0.0;
+        if (p2) {
+            w0v = q.w0[col];
+            if (!XY) xv = ak[col];
+        }
+        fetch(s + G < q.nstrips ? s + G : s);      // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
+        // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k], half by half through the LDS image ----
+        {
+            // four chains over the row groups (the result latency is 3 issues) for EVERY K: a problem's sums must not
+            // depend on the width of its batch
+            double d[4][NK];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) d[ch][kq] = 0.0;
+            const int sw3 = strip_swz(lr);          // row 16 h + lr of the half: only bit 0 of its swizzle depends on h
+            double* img = tile + (size_t)(wave * 64 + lr) * kStripCols;
+            const double* p1 = tile + (size_t)(wave * 64 + lq) * kStripCols;
+#pragma unroll
+            for (int half = 0; half < RH; ++half) {
+                // registers -> image (row-major, swizzled: the same 16 rows x 2 columns per 32 lanes as a row-sum operand
+                // fetch: conflict-free); the wave's own program order is the synchronisation of its private slice
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int hl = 0; hl < 4; ++hl)
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        img[hl * 256 + (((8 * qp + lq) ^ sw3) ^ (hl & 1))] = a3[2 * qp][4 * half + hl];
+                        img[hl * 256 + (((8 * qp + 4 + lq) ^ sw3) ^ (hl & 1))] = a3[2 * qp + 1][4 * half + hl];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
+                const double* pu = ul + (size_t)(rbase + 64 * half + lq) * 8 + lj;
+                // operand batches that fit beside a3 and the prefetch (K > 4, batches of 4 | 2 | 1: 27-31 | 7-12 | 8-9 registers
+                // spilled; pass 1 / pass 2 at N = 1e6 x M = 1024, K = 8: 1.66 / 1.45 | 1.50 / 1.39 | 1.51 / 1.41 ms)
+                constexpr int GB = NK > 1 ? STRIP2_GB2 : 8, NB = 16 / GB;
+#pragma unroll
+                for (int hb = 0; hb < NB; ++hb) {
+                    double a1[GB], b1[GB][NK];
+#pragma unroll
+                    for (int gg = 0; gg < GB; ++gg) {
+                        const int g = hb * GB + gg;
+                        a1[gg] = p1[g * 64 + (lr ^ (((((lq >> 1) + 2 * g) & 7) << 1) ^ ((g >> 2) & 1)))];
+#pragma unroll
+                        for (int kq = 0; kq < NK; ++kq) b1[gg][kq] = pu[g * 32 + 4 * kq];
+                    }
+#pragma unroll
+                    for (int gg = 0; gg < GB; ++gg)
+#pragma unroll
+                        for (int kq = 0; kq < NK; ++kq)
+                            d[(hb * GB + gg) & 3][kq] =
+                                __builtin_amdgcn_mfma_f64_4x4x4f64(a1[gg], b1[gg][kq], d[(hb * GB + gg) & 3][kq], 0, 0, 0);
+                }
+            }
+            // result lane 16 i + 4 blk + j: column c = 4 blk + i, problem 4 kq + j
+            const int c = 4 * ((lane >> 2) & 3) + lq;
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq)
+                red[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
+        }
+        __syncthreads();
+        // ---- P2 ----
+        if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
+            double colsum = 0.0;
+            if (p2) {
+                const int nown = (q.mps + WR - 1) / WR;
+                for (int wv = 0; wv < nown; ++wv) colsum += red[wv * 128 + pk * 16 + pc];
+            }
+            if (XY) {
+                const bool valid = p2 && col < (size_t)q.n;
+                if (p2) __builtin_nontemporal_store(valid ? colsum : 0.0, ak + col);   // streamed, see k_strip_adj (plain: +3..5 %)
+                double smax = valid ? colsum : -DBL_MAX;          // the strip's maximum: over the 16 lanes of the problem
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
+                const double m_new = fmax(m_run, smax);
+                // the running maximum rarely moves after the first strips: exp(0) = 1 exactly, skip it wave-wide
+                double sc = 1.0;
+                if (__any(m_new != m_run)) sc = exp(m_run - m_new);   // 0 the first time
+                const double e = valid ? w0v * exp(colsum - m_new) : 0.0;
+                zacc = fma(zacc, sc, e);
+                pxacc = fma(pxacc, sc, valid ? e * colsum : 0.0);
+                m_run = m_new;
+                if (p2) {
+                    if (pc == 0) scale[pk] = sc;
+                    tv[pk * 16 + pc] = e;
+                }
+            } else if (p2) {
+                const double lrat = xv - logs;                    // log(w / w0)
+                const double wv = w0v * exp(lrat);
+                double dd = 1.0;
+                if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += lrat;  // c_bioen_kernels_forces.c:320-328
+                const double tval = (dd * theta + (colsum + b0)) * wv;
+                tv[pk * 16 + pc] = tval;
+                zacc += tval;
+            }
+        }
+        __syncthreads();
+        // ---- P3: acc[row][k] (+)= sum_c Y'[row][c] v[c][k] ----
+        // A: lane (kk = lq, blk, i) = Y'[r0 + 4 blk + i = r0 + lr][c = 4 qq + lq]; B: lane (kk, blk, j) = v[4 qq + lq][4 kq + j]
+        {
+            if (XY) {
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) {
+                    const double sc = scale[4 * kq + lj];
+#pragma unroll
+                    for (int h = 0; h < WR / 16; ++h) acc[h][kq] *= sc;
+                }
+            }
+            double bv[4][NK];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tv[(4 * kq + lj) * 16 + 4 * qq + lq];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int h = 0; h < WR / 16; ++h)
+#pragma unroll
+                    for (int kq = 0; kq < NK; ++kq)
+                        acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3[qq][h], bv[qq][kq], acc[h][kq], 0, 0, 0);
+        }
+        // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
+        // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
+    };
+    int s = blockIdx.x;
+    fetch(s);                                                      // grid <= strips: every block has a first strip
+    __syncthreads();                                              // ul / tv / scale / cl initialised
+    for (; s < q.nstrips; s += G) one_strip(s);
+    {
+        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
+        const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
+#pragma unroll
+        for (int h = 0; h < WR / 16; ++h)
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const int row = rr + 16 * h, k = 4 * kq + lj;
+                // transposed: a block's sums are one run; rows between the strip's last row block and mp exist only in
+                // the M-vectors: their sums are zero (the wave computed a redirected row block's there)
+                if (row < q.mp && k < K)
+                    q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
+            }
+    }
+    // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
+    {
+        double z = zacc, px = pxacc;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            z += __shfl_xor(z, o, 64);
+            px += __shfl_xor(px, o, 64);
+        }
+        if (p2 && pc == 0) {
+            double* pa = pak;
+            if (XY) {
+                pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;
+                pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
+                pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = px;
+            } else {
+                pa[(size_t)P_KL * kMaxPartials + blockIdx.x] = z;        // this block's share of sum_j t_j
+            }
+        }
+    }
+}
+
 // ---- log-weights forward pass on the strip copy: partial[set mp K + row K + k] = sum_{j in the set's strips} Y'[row][j] e_k[j]
 // (A4, c_bioen_common.c:70-108; replaces k_fwd_partial for M <= 1024).  The copy is stored in the operand
 // order of this product, so the matrix goes HBM -> registers -> matrix cores: no LDS image, no shuffles, and the
@@ -694,14 +966,25 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
 // straight-line code and every sum is formed from the same terms in the same order as before.
 static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->m, 16); }
 static int strip_waves(const bioen_hip_ctx* c) { return (strip_rows(c) + kWaveRows - 1) / kWaveRows; }
-static int strip_threads(const bioen_hip_ctx* c) { return 64 * std::max(2, strip_waves(c)); }
+// forces kernels: k_strip (a wave owns 64 rows) for M <= 512, k_strip2 (128 rows per wave) for 512 < M <= 1024
+static bool strip_tall(const bioen_hip_ctx* c) { return c->mp > 512; }
+static int strip_threads(const bioen_hip_ctx* c) {
+    return 64 * std::max(2, strip_tall(c) ? (strip_rows(c) + 2 * kWaveRows - 1) / (2 * kWaveRows) : strip_waves(c));
+}
 static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
-    const size_t waves = strip_threads(c) / 64;          // LDS regions hold 64 rows per wave (k_strip)
-    return (waves * kWaveRows * (kStripCols + 8 + 1) + waves * 128 + 128 + 16) * sizeof(double);
+    const size_t waves = strip_threads(c) / 64;
+    if (strip_tall(c))      // image: 64 rows per wave (one half at a time); operand table and centres: 128 rows per wave
+        return (waves * kWaveRows * kStripCols + waves * 2 * kWaveRows * (8 + 1) + waves * 128 + 128 + 16) * sizeof(double);
+    return (waves * kWaveRows * (kStripCols + 8 + 1) + waves * 128 + 128 + 16) * sizeof(double);   // 64 rows per wave
 }
 
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
-    if (c->mp > 512 || c->strips_unavailable) return 0;
+    static int tall_off = -1;                          // BIOEN_HIP_STRIP_TALL=0: the r01 kernels for 512 < M <= 1024 (A/B)
+    if (tall_off < 0) {
+        const char* e = std::getenv("BIOEN_HIP_STRIP_TALL");
+        tall_off = (e && std::atoi(e) == 0) ? 1 : 0;
+    }
+    if (c->mp > 1024 || (c->mp > 512 && tall_off) || c->strips_unavailable) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
     // blocks per CU: LDS (160 KiB) and the waves per SIMD the kernel's register budget admits
     const int by_lds = (int)((size_t)160 * 1024 / strip_lds_bytes(c));
@@ -721,11 +1004,11 @@ static int strip_copy_failed(bioen_hip_ctx* c, double* ys, hipError_t e, const c
 }
 
 // The row-major matrix is the form data ARRIVE in (upload, device-side assembly, generator) and the operand of the
-// streaming kernels (M > 1024, the r01 forces strips for 512 < M <= 1024).  Once the row-sum strip copy exists it is
+// streaming kernels (M > 1024).  Once the row-sum strip copy exists it is
 // redundant for every other path -- the copy holds the same numbers -- and is freed (bioen_hip_ctx_read_ytilde,
 // bioen_hip_chi_squared and the column-sum copy are served by the strip copy); a later call that needs it gets it back
 // from the strip copy (ensure_rowmajor) and then keeps it.  Footprint of the matrix, M <= 1024: log-weights 2 x (both
-// strip copies), forces method 1 x (M <= 512).
+// strip copies), forces method 1 x.
 int ensure_rowmajor(bioen_hip_ctx* c) {
     if (c->Y) return 0;
     if (!c->Ys) return BIOEN_HIP_ESTATE;
@@ -807,8 +1090,8 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     e = hipGetLastError();
     if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
     c->Ys = ys;
-    // the row-major form has served: every path of this context that still wants it (none for M <= 512; the r01 forces
-    // strips for 512 < M <= 1024) gets it back through ensure_rowmajor.  BIOEN_HIP_KEEP_ROWMAJOR=1 keeps it (A/B).
+    // the row-major form has served: every path of this context that still wants it (forces_weights' streaming
+    // kernels, the r01 kernels of an A/B run) gets it back through ensure_rowmajor.  BIOEN_HIP_KEEP_ROWMAJOR=1 keeps it (A/B).
     if (!c->keep_rowmajor) {
         e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = hipFree(c->Y);
@@ -842,8 +1125,32 @@ static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRou
     else strip_launch_kd<K, NT, XY, 2>(c, q, fr, block, lds);
 }
 
+template <int K, bool NT, bool XY>
+static void strip2_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY>), dim3(q.nblk), block, lds, q, fr);
+}
+
 template <bool NT, bool XY>
 static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+    if (strip_tall(c)) {
+        switch (fr.n) {
+            case 1: strip2_launch_k<1, NT, XY>(c, q, fr, block, lds); break;
+            case 2: strip2_launch_k<2, NT, XY>(c, q, fr, block, lds); break;
+            case 3: strip2_launch_k<3, NT, XY>(c, q, fr, block, lds); break;
+            case 4: strip2_launch_k<4, NT, XY>(c, q, fr, block, lds); break;
+            case 5: strip2_launch_k<5, NT, XY>(c, q, fr, block, lds); break;
+            case 6: strip2_launch_k<6, NT, XY>(c, q, fr, block, lds); break;
+            case 7: strip2_launch_k<7, NT, XY>(c, q, fr, block, lds); break;
+            default: strip2_launch_k<8, NT, XY>(c, q, fr, block, lds); break;
+        }
+        return;
+    }
     switch (fr.n) {
         case 1: strip_launch_k<1, NT, XY>(c, q, fr, block, lds); break;
         case 2: strip_launch_k<2, NT, XY>(c, q, fr, block, lds); break;

@@ -296,9 +296,9 @@ def test_last_average_is_that_of_the_returned_point(optimize, linesearch):
 @pytest.mark.parametrize("M,N", [(37, 1000), (205, 4099), (512, 3000), (600, 2000), (1100, 1500)])
 def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
     """For M <= 1024 the strip copies hold the raw matrix and take the row-major one's place: 2 x the matrix for the
-    log-weights method, 1 x for the forces method (M <= 512) -- and read_ytilde still hands back the caller's numbers bit
-    for bit, chi_squared still takes ANY w.  A call that needs the row-major form again (the r01 forces strips for
-    512 < M <= 1024, forces_weights' streaming kernels) gets it back from the strip copy."""
+    log-weights method, 1 x for the forces method -- and read_ytilde still hands back the caller's numbers bit for bit,
+    chi_squared still takes ANY w.  A call that needs the row-major form again (forces_weights' streaming kernels) gets
+    it back from the strip copy."""
     import bioen_amd
     rng = np.random.default_rng(M + N)
     Y = rng.normal(3.0, 2.0, (M, N))
@@ -325,13 +325,13 @@ def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
         assert np.abs(yave - Y.dot(w_any)).max() <= 1e-12 * np.abs(Y.dot(w_any)).max()
         assert rel(chi2, 0.5 * np.sum((Y.dot(w_any) - YT) ** 2)) < 1e-12
         f, g = ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
-        if 512 < M <= 1024:
-            assert "rowmajor" in ctx.footprint()[0]                                   # back for the row-major strip kernels
+        if M <= 1024:
+            assert ctx.footprint()[0] == {"strips", "strips_colsum"}                  # the forces passes read the same copy
         assert np.array_equal(ctx.read_ytilde(), Y)
     with bioen_amd.Context(Y, YT) as ctx:                                             # a forces-only context
         ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
         forms, nbytes = ctx.footprint()
-        assert forms == ({"strips"} if M <= 512 else {"rowmajor"})
+        assert forms == ({"strips"} if M <= 1024 else {"rowmajor"})
         w = ctx.forces_weights(np.zeros(M), np.full(N, 1.0 / N))                      # streaming kernels: row-major again
         assert np.abs(w - 1.0 / N).max() < 1e-18 + 1e-12 / N
         assert np.array_equal(ctx.read_ytilde(), Y)
@@ -340,8 +340,8 @@ def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
 @pytest.mark.parametrize("M", [23, 600, 1100])
 def test_last_average_after_forces_calls(optimize, M):
     """forces_fdf / opt_lbfgs_forces -> last_average hands out yTilde . w at the point the call ended on, on all three
-    matrix-pass families (M <= 512: strip passes on the centred copy, which keep ybar - centre on the device; M <= 1024:
-    the row-major strip kernels; beyond: streaming passes).  After a multi-problem call there is nothing to hand out."""
+    matrix-pass families (M <= 512 and 512 < M <= 1024: the two strip kernels on the raw copy, which keep ybar - centre on
+    the device; beyond: streaming passes).  After a multi-problem call there is nothing to hand out."""
     import bioen_amd
     rng = np.random.default_rng(11)
     N = 900

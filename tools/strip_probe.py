@@ -19,7 +19,7 @@ out = {"N": N, "M": M, "old": os.environ.get("BIOEN_HIP_STRIP_OLD", "0"), "K": {
 with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
     f1, g1 = ctx.forces_fdf_batch(forces[:1], w0, thetas[:1])          # builds the strip copy, warms up
     ref = [ctx.forces_fdf_batch(forces[k:k + 1], w0, thetas[k:k + 1]) for k in range(8)]
-    for K in (1, 2, 4, 6, 8):
+    for K in [int(k) for k in os.environ.get("KS", "1,2,4,6,8").split(",")]:
         ctx.forces_fdf_batch(forces[:K], w0, thetas[:K])
         ctx.kernel_stats_enable(True); ctx.kernel_stats_reset(); ctx.synchronize()
         t0 = time.perf_counter()
