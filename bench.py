@@ -61,6 +61,22 @@ def synthetic_targets(M, seed=SEED):
     return YTrue, sig_sim, sig_exp, YTilde
 
 
+def survey_inputs(M, N, seed=SEED):
+    """SURVEY 8(d)'s synthetic inputs to the letter: ONE PCG64 stream -- YTrue, then the matrix ROW by ROW, then the
+    targets (after forces.py:19-68) -- so that iteration counts can be set beside the survey's orientation runs
+    (theta = 10 at N = 1e5 x M = 256: 409 iterations on 8 threads, 388 on one).  The device generator of
+    Context.synthetic draws the same distribution from a counter-based stream; this is the host form of it."""
+    rng = np.random.default_rng(seed)
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp = 0.1 * YTrue
+    sig_sim = 0.5 * YTrue
+    yTilde = np.empty((M, N))
+    for i in range(M):
+        yTilde[i, :] = rng.normal(YTrue[i], sig_sim[i], N) / sig_exp[i]
+    YTilde = rng.normal(YTrue, sig_exp) / sig_exp
+    return yTilde, YTilde
+
+
 def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
     """Time the CPU path on a bounded sample of the SAME matrix (a column block read back
     from HBM): the reference's own C + liblbfgs code when oracle/_ref travelled here
@@ -222,11 +238,12 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
     if not R.available():
         return None
     N, M = 100000, 256
-    YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M, seed)
+    yT, YTilde = survey_inputs(M, N, seed)
     cores = cpus.usable_cpus()
     out = {"workload": "log-weights theta series, N=%d x M=%d, %d thetas, cold starts, yaml-default liblbfgs" % (N, M, len(thetas)),
+           "inputs": "SURVEY 8(d) to the letter: numpy default_rng(%d), row-wise normals, uploaded from the host" % seed,
            "cores": cores}
-    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=seed) as ctx:
+    with bioen_amd.Context(yT, YTilde) as ctx:
         from bioen_amd import sweep
         G = np.zeros(N)
         sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)                       # warm-up
@@ -236,7 +253,8 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
         ctx.synchronize()
         out["gpu_sweep_s"] = time.perf_counter() - t0
         out["gpu_iterations"] = int(sum(r["iterations"] for r in res))
-        yT = np.ascontiguousarray(ctx.read_ytilde())
+        out["gpu_iterations_per_theta"] = [int(r["iterations"]) for r in res]
+        out["survey_iterations_theta10"] = {"8 threads": 409, "1 thread": 388}            # BASELINE.md 2 (orientation runs)
     yTT = np.ascontiguousarray(yT.T)
     R.set_fast_openmp_flag(1)
     R.omp_set_num_threads(cores)
