@@ -349,7 +349,7 @@ def test_ala5_shape_forces_series_against_the_reference_binary():
             assert rel(i.fmin, fmin_c) < 1e-6, (theta, i.fmin, fmin_c)
 
 
-@pytest.mark.parametrize("M,N", [(256, 100000), (512, 50000), (96, 30000)])
+@pytest.mark.parametrize("M,N", [(256, 100000), (512, 50000), (96, 30000), (1024, 20000), (600, 30000)])   # k_strip | k_strip2
 def test_configs1_forces_converged_against_the_reference_binary(M, N):
     """The same size through the forces method: the reference's _opt_lbfgs_forces and the device's lock-step batch,
     both with epsilon = 1e-9, delta = 0, past = 0.  Both end at the rounding floor of the line search (-998) or on
@@ -376,11 +376,12 @@ def test_configs1_forces_converged_against_the_reference_binary(M, N):
         assert np.abs(w[k] - w_ref).max() <= 1e-5 * w_ref.max(), (theta, np.abs(w[k] - w_ref).max() / w_ref.max())
 
 
-@pytest.mark.parametrize("M,N", [(256, 100000), (1024, 20000), (512, 50000), (205, 50000), (1056, 12000)])
+@pytest.mark.parametrize("M,N", [(256, 100000), (1024, 20000), (512, 50000), (205, 50000), (600, 30000), (1056, 12000)])
 def test_objective_and_gradient_against_the_reference_binary(M, N):
     """One evaluation of both methods at random points with a non-uniform prior, device against the reference's C
     functions (_bioen_log_posterior_*, _grad_bioen_log_posterior_*): every matrix-pass variant (strip kernels with 4, 8,
-    16 waves per strip and padded rows; streaming kernels at M = 1056) at sizes the golden fixtures do not reach."""
+    16 waves per strip and padded rows, the forces kernels with 64 and with 128 rows per wave; streaming kernels at
+    M = 1056) at sizes the golden fixtures do not reach."""
     import bioen_amd
     from oracle import ref_binding as R
     from oracle import cpus

@@ -47,7 +47,7 @@ for prior, M, N, eps in [("uniform", 256, 100000, 1e-9), ("random", 256, 100000,
             prior, M, N, eps, th, code, infos[k].lbfgs_code, abs(infos[k].fmin - fmin_ref) / abs(fmin_ref),
             np.abs(w[k] - w_ref).max() / w_ref.max(), infos[k].iterations))
     sys.stdout.flush()
-for M, N in [(256, 100000), (512, 50000), (96, 30000)]:
+for M, N in [(256, 100000), (512, 50000), (96, 30000), (1024, 20000), (600, 30000)]:
     thetas = [316.0, 100.0, 31.6]
     YTrue, sig_sim, sig_exp, YTilde = _targets(M)
     w0 = np.full(N, 1.0 / N)
