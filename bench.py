@@ -51,6 +51,56 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def pmc_kernel_means(directory, counter):
+    """rocprofv3 --pmc <counter> output -> {kernel base name: (mean counter value per launch, launches)}"""
+    import collections, csv, glob
+    files = glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for f in files[:1]:
+        with open(f) as fp:
+            for r in csv.DictReader(fp):
+                if r["Counter_Name"] == counter:
+                    name = r["Kernel_Name"].replace("void ", "").replace("bioen::", "").split("(")[0].split("<")[0]
+                    agg[name].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def under_profiler():
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+
+
+def live_traffic(method, M, N, kernel):
+    """HBM bytes per launch of `kernel` (base name), measured NOW on this box: tools/pmc_pass.py as a child process under
+    `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (the two counters cannot share a pass), converted
+    with the gfx950 corrections of MI355X_MICROARCH.md (both in KiB; FETCH_SIZE counts a wide coalesced read stream at
+    half its bytes).  None (with the reason) when rocprofv3 is absent, fails, or this process is itself being profiled."""
+    import shutil, subprocess, tempfile
+    if under_profiler():
+        return None, "bench.py itself runs under rocprofv3"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        return None, "rocprofv3 not found"
+    vals, launches = {}, 0
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bioen_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", "python3",
+                                os.path.join(ROOT, "tools", "pmc_pass.py"), method, str(M), str(N)],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s: exit %d: %s" % (ctr, p.returncode, (p.stderr or "")[-300:])
+            means = pmc_kernel_means(d, ctr)
+            if kernel not in means:
+                return None, "no %s launch in the %s pass" % (kernel, ctr)
+            vals[ctr], launches = means[kernel]
+        except Exception as e:
+            return None, repr(e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024, "live: rocprofv3 --pmc passes inside this run (%d launches)" % launches
+
+
 def synthetic_targets(M, seed=SEED):
     """Per-observable vectors of the SURVEY 8(d) recipe (after forces.py:19-68)."""
     rng = np.random.default_rng(seed)
@@ -496,6 +546,8 @@ def main():
     ap.add_argument("--no-ala5", action="store_true", help="skip the ala5-shaped forces series (BASELINE.md's only reference timing)")
     ap.add_argument("--cpu-cols", type=int, default=524288, help="columns of the matrix the CPU baseline runs on")
     ap.add_argument("--cpu-iters", type=int, default=120, help="L-BFGS iterations the CPU baseline is capped at")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the live rocprofv3 --pmc passes for roofline.traffic (falls back to profiles/traffic.json)")
     ap.add_argument("--no-cpu-fullsize", action="store_true",
                     help="skip the reference run on the FULL headline matrix (two cheapest thetas, ~1 minute)")
     args = ap.parse_args()
@@ -632,7 +684,7 @@ def main():
             alg = mat_bytes + avg_k * (8.0 * n_rank + 8.0 * M)
             strip = M <= 1024 and not os.environ.get("BIOEN_HIP_FWD_STREAM") == "1"     # kernels_strip.hip serves M <= 1024
             if forces_mode:      # timer slots of launch_forces_xy ("adjoint") / _bt ("forward")
-                kname = "k_strip<K, nt, %s>" % ("true" if name == "adjoint" else "false") if M <= 1024 else \
+                kname = "%s<K, nt, %s>" % ("k_strip" if M <= 512 else "k_strip2", "true" if name == "adjoint" else "false") if M <= 1024 else \
                         ("k_adj + k_fwd_partial" if name == "adjoint" else "k_fwd_partial")
             else:
                 kname = ("k_strip_fwd" if strip else "k_fwd_partial") if name == "forward" else \
@@ -655,7 +707,9 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernels": kern}
+                    "traffic": traffic, "kernels": kern,
+                    "traffic_source": "profiles/traffic.json (builder's rocprofv3 --pmc passes of these kernel sources)"
+                                      if traffic is not None else None}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -705,6 +759,21 @@ def main():
                     cpu["single_thread"] = cpu["matched_sweep"].pop("single_thread")
             except Exception as e:
                 cpu["matched_sweep"] = {"error": repr(e)}
+
+        if world == 1 and not args.no_pmc and M <= 1024:
+            # roofline.traffic from counters read on THIS box, in this run (the committed profiles/traffic.json stays the
+            # fallback): child processes, after every context of this one is closed
+            ctx.close()
+            base = roofline["kernel"].split("<")[0]
+            t_live, src = live_traffic(args.method, M, N, base)
+            if t_live is not None:
+                roofline["traffic"], roofline["traffic_source"] = t_live, src
+            else:
+                roofline["traffic_live_error"] = src
+            if forces and "roofline" in forces:
+                t_live, src = live_traffic("forces", 512, 1000000, "k_strip")
+                if t_live is not None:
+                    forces["roofline"]["traffic"], forces["roofline"]["traffic_source"] = t_live, src
 
         line = {
             "metric": "L-BFGS iterations/sec x (N structures * M observables), %s theta sweep"

@@ -10,6 +10,8 @@ from bench import synthetic_targets, LBFGS_DEFAULTS, SEED
 
 sizes = [tuple(int(v) for v in s.split(":")) for s in os.environ.get("SIZES", "256:100000,1024:125000,64:20000").split(",")]
 thetas = np.logspace(3, -0.5, 8)
+if os.environ.get("THETAS"):                       # e.g. THETAS=10 for a K = 1 series
+    thetas = np.array([float(v) for v in os.environ["THETAS"].split(",")])
 for (M, N) in sizes:
     YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED) as ctx:
