@@ -711,6 +711,14 @@ def main():
                     "traffic_source": "profiles/traffic.json (builder's rocprofv3 --pmc passes of these kernel sources)"
                                       if traffic is not None else None}
 
+        try:      # what this box's memory system gives a plain read-only stream over the same copy of the matrix
+            ceil_gbs, ceil_bytes = ctx.read_probe(reps=10)
+            roofline["read_ceiling"] = {"GB/s": ceil_gbs, "bytes_per_pass": ceil_bytes, "frac_of_peak": ceil_gbs / HBM_PEAK_GBS,
+                                        "kernel": "k_read_probe: wide nontemporal loads and an add, no LDS, no matrix cores",
+                                        "achieved_over_ceiling": roofline["achieved"] / ceil_gbs}
+        except Exception as e:
+            roofline["read_ceiling"] = {"error": repr(e)}
+
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:

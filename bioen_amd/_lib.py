@@ -111,6 +111,7 @@ _SIGNATURES = {
     "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
     "bioen_hip_comm_allgather": (C.c_int, [ctx_p, dp, C.c_size_t, dp]),
     "bioen_hip_exchange_probe": (C.c_int, [ctx_p, C.c_size_t, C.c_int, dp]),
+    "bioen_hip_read_probe": (C.c_int, [ctx_p, C.c_int, C.c_int, dp, C.POINTER(C.c_longlong)]),
     "bioen_hip_comm_destroy": (C.c_int, [ctx_p]),
 }
 
@@ -610,6 +611,13 @@ class Context(object):
         us = C.c_double(0.0)
         check(lib().bioen_hip_exchange_probe(self._h, int(count), int(reps), C.byref(us)))
         return us.value
+
+    def read_probe(self, reps=10, form=0):
+        """-> (GB/s of a plain read-only stream over the resident matrix, its bytes): the box's measured read ceiling.
+        form: 0 = whichever is resident, 1 = row-major, 2 = row-sum strips, 4 = column-sum strips"""
+        gbs, nbytes = C.c_double(0.0), C.c_longlong(0)
+        check(lib().bioen_hip_read_probe(self._h, int(form), int(reps), C.byref(gbs), C.byref(nbytes)))
+        return gbs.value, nbytes.value
 
     def comm_destroy(self):
         check(lib().bioen_hip_comm_destroy(self._h))

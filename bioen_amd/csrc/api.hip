@@ -1333,6 +1333,38 @@ int bioen_hip_exchange_probe(bioen_hip_ctx* c, size_t count, int reps, double* u
     return 0;
 }
 
+int bioen_hip_read_probe(bioen_hip_ctx* c, int form, int reps, double* gbytes_per_s, long long* bytes) {
+    if (!c || !gbytes_per_s || reps <= 0) return fail(BIOEN_HIP_EINVAL, "bad argument");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    // form: 0 = whichever is resident (strip copy first), 1 = row-major, 2 = row-sum strips, 4 = column-sum strips
+    const double* src = form == 1 ? c->Y : form == 2 ? c->Ys : form == 4 ? c->Ys1 : (c->Ys ? c->Ys : c->Y);
+    if (!src) return fail(BIOEN_HIP_ESTATE, "that form of the matrix is not resident");
+    const size_t doubles = src == c->Y ? (size_t)c->mp * c->ld : (size_t)(c->ld / 16) * ((size_t)(c->m + 15) / 16 * 16) * 16;
+    double* sink = nullptr;
+    BIOEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sink), 256 * sizeof(double)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.f;
+    if (e == hipSuccess) {
+        launch_read_probe(c, src, doubles, sink);                 // warm-up (TLB, clocks)
+        launch_read_probe(c, src, doubles, sink);
+        e = hipEventRecord(e0, c->stream);
+        for (int i = 0; i < reps; ++i) launch_read_probe(c, src, doubles, sink);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return hip_fail(e, "read probe", __FILE__, __LINE__);
+    *gbytes_per_s = (double)doubles * 8.0 * reps / (ms * 1e-3) / 1e9;
+    if (bytes) *bytes = (long long)(doubles * 8);
+    return 0;
+}
+
 int bioen_hip_comm_destroy(bioen_hip_ctx* c) {
     if (!c) return 0;
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->comm));

@@ -67,6 +67,7 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const stru
 //   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
 constexpr int kFusedBlocks = 1024;
+void launch_read_probe(bioen_hip_ctx* c, const double* p, size_t doubles, double* out);   // bench: measured read ceiling
 int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);

@@ -159,6 +159,37 @@ __global__ __launch_bounds__(kBlock) void k_generate(double* __restrict__ Y, siz
 }
 
 
+// ---- measured read ceiling (bench.py: roofline.read_ceiling): the resident copy of the matrix streamed ONCE by the
+// plainest kernel that can -- 16 waves per CU, eight independent 16-byte nontemporal loads per lane in flight, an add per
+// value, one store per block -- i.e. what the memory system delivers to a read-only stream of these bytes on this box.
+// The matrix kernels are judged against the 8 TB/s spec peak; this number says how much of the gap is the chip's.
+__global__ __launch_bounds__(1024) void k_read_probe(const double* __restrict__ p, size_t n2, double* out) {
+    // a wave reads 8 KB contiguous per trip (eight 1-KB loads), the waves of the grid side by side: the access pattern of
+    // the strip kernels (a wave's 64 rows of a strip are one 8-KB run)
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t base = wave * 512;
+    for (; base + 512 <= n2; base += nwaves * 512) {
+        d2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ldg2<true>(p + 2 * (base + u * 64 + lane));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += v[u].x + v[u].y;
+    }
+    for (size_t i = base + lane; i < n2 && base < n2; i += 64) {      // the last, partial run
+        const d2 v = ldg2<true>(p + 2 * i);
+        acc[0] += v.x + v.y;
+    }
+    double t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    t = wave_sum(t);
+    if (lane == 0 && t == 123.456) out[blockIdx.x] = t;      // keeps the loads; never true for real data
+}
+
+void launch_read_probe(bioen_hip_ctx* c, const double* p, size_t doubles, double* out) {
+    hipLaunchKernelGGL(k_read_probe, dim3(256), dim3(1024), 0, c->stream, p, doubles / 2, out);
+}
+
 // ---- level-1 algebra (multimin) -------------------------------------------------------------
 void launch_vaxpy(bioen_hip_ctx* c, double a, const double* x, double* y) {
     hipLaunchKernelGGL(k_vaxpy, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, y, (int)(c->ld / 2));

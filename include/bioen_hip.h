@@ -322,6 +322,12 @@ int bioen_hip_comm_allgather(bioen_hip_ctx* ctx, const double* send, size_t coun
  * context, back to back on the context's stream: lets the host decide whether splitting the
  * structures beats dealing thetas for a given problem size */
 int bioen_hip_exchange_probe(bioen_hip_ctx* ctx, size_t count, int reps, double* usec_per_exchange);
+
+/* Measurement aid (bench.py: roofline.read_ceiling): streams the resident form of the matrix `reps` times with a plain
+ * read-only kernel (wide nontemporal loads, no LDS, no matrix cores) and reports the rate -- what this box's memory
+ * system delivers to a read stream of exactly the bytes the matrix passes read.  form: 0 = whichever form is resident
+ * (strip copy first), 1 / 2 / 4 = the form of that bioen_hip_ctx_footprint bit.  No reference counterpart. */
+int bioen_hip_read_probe(bioen_hip_ctx* ctx, int form, int reps, double* gbytes_per_s, long long* bytes);
 int bioen_hip_comm_destroy(bioen_hip_ctx* ctx);
 
 #ifdef __cplusplus

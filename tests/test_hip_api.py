@@ -453,3 +453,18 @@ def test_find_optimum_series_equals_find_optimum_per_theta(optimize):
     with pytest.raises(RuntimeError):
         optimize.log_weights.find_optimum_series(d["GInit"], d["G"], d["y"], d["yTilde"], YT, thetas,
                                                  optimize.minimize.Parameters("scipy"))
+
+
+def test_read_probe_streams_the_resident_matrix(optimize):
+    """bench.py's measured read ceiling: a plain read-only pass over whichever form of the matrix is resident."""
+    import bioen_amd
+    rng = np.random.default_rng(3)
+    M, N = 300, 40000
+    Y = rng.standard_normal((M, N))
+    with bioen_amd.Context(Y, Y.mean(axis=1)) as ctx:
+        gbs, nbytes = ctx.read_probe(reps=3)
+        assert nbytes == ctx.footprint()[1] and gbs > 50.0                  # row-major form
+        ctx.logw_fdf(np.zeros(N), np.zeros(N), 1.0)                          # builds the strip copies, frees the row-major one
+        gbs2, nbytes2 = ctx.read_probe(reps=3)
+        assert nbytes2 == (N + 127) // 128 * 128 * 304 * 8 and gbs2 > 50.0   # one strip copy: rows padded to 16
+        assert np.array_equal(ctx.read_ytilde(), Y)
