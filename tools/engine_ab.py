@@ -13,6 +13,7 @@ VARIANTS = {
     "device-nospec": {"BIOEN_HIP_SPECULATE": "0"},
     "device-eager": {"BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOWS": "8"},
     "device-noqueue": {"BIOEN_HIP_QUEUE": "0"},
+    "device-queue2": {"BIOEN_HIP_QUEUE": "2"},
     "host": {"BIOEN_HIP_DEVICE_LS": "0"},
     "host-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
 }
