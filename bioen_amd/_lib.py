@@ -579,7 +579,7 @@ class Context(object):
         return out
 
     def speculation_stats(self):
-        """(issued, adopted): speculative line-search evaluations of the log-weights batch engine so far"""
+        """(issued, adopted): speculative line-search evaluations of the batch engines (both methods) so far"""
         a, b = C.c_longlong(0), C.c_longlong(0)
         check(lib().bioen_hip_speculation_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value

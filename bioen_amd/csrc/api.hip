@@ -1086,7 +1086,8 @@ int bioen_hip_opt_lbfgs_forces(bioen_hip_ctx* c, const double* forces0, const do
                                const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                                double* result, double* w_opt, bioen_opt_result* info) {
     if (!info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    return bioen_hip_opt_lbfgs_forces_batch(c, 1, &theta, forces0, 0, w0, config, visual, 1, result, w_opt, info);
+    // one problem; the batch width left over serves its line search's speculative trials (engine_forces.inl)
+    return bioen_hip_opt_lbfgs_forces_batch(c, 1, &theta, forces0, 0, w0, config, visual, kMaxBatch, result, w_opt, info);
 }
 
 // ---- shared ---------------------------------------------------------------------------

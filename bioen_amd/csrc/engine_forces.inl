@@ -12,6 +12,8 @@ struct ForcesProblem {
     std::vector<double> x, xp, g, gp, d;
     std::vector<double> S[kHistory], Y[kHistory];
     double ys[kHistory] = {}, alpha[kHistory] = {};
+    int last_dir = 0, prev_dir = 0;     // the running line search's last two moves: -1 step decreased, +1 increased, 0 none yet
+    std::string moves;                  // BIOEN_HIP_SPEC_DEBUG: the running search's moves ('d' | 'i'; upper case = adopted shadow; '|' = a new round)
     std::chrono::steady_clock::time_point t0;
 
     static double dot(const std::vector<double>& a, const std::vector<double>& b) {
@@ -113,7 +115,20 @@ struct ForcesBatchEngine {
             return 0;
         }
         const int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
-        for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, false));
+        // Speculative line-search trials (r03; the log-weights engines have had them since r02): a backtracking search
+        // moves its step by fixed factors (x 0.5 after a failed decrease test, x 2.1 after a failed curvature test,
+        // lbfgs.c:686-727), so the steps it may ask for next are known before the trial returns.  Batch slots without
+        // a problem evaluate them alongside the trial -- the matrix passes are shared, a column more costs little --
+        // and a rejected trial finds its successor (and that one's successor ...) already evaluated.  The decisions,
+        // their order and every number they see are those of the serial search: results do not change by a bit
+        // (tests: BIOEN_HIP_SPECULATE=0 against the default).  A warm-started series at small N (the ala5 protocol:
+        // 5.7 evaluations per iteration) is where this pays; on big matrices a wider batch costs real time and only
+        // searches that have shown a rejection rate get shadows.
+        bool spec = cfg.linesearch >= 1 && cfg.linesearch <= 3;
+        if (const char* e = std::getenv("BIOEN_HIP_SPECULATE")) spec = spec && std::atoi(e) != 0;
+        const int nslots = spec ? std::min(std::max(max_batch, 1), kMaxBatch) : kb;      // max_batch bounds the batch WIDTH
+        const bool big = 2.0 * c->mp * (double)c->ld * sizeof(double) > 1e9;             // a column more is not free there
+        for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, false));
         if (rc) return rc;
         note(upload_n(c, c->fixed, w0_host));
 
@@ -164,6 +179,17 @@ struct ForcesBatchEngine {
             --active;
         };
 
+        struct Shadow {
+            int owner;                  // slot of the problem it works for
+            int slot;                   // free batch slot that evaluates it
+            double stp;                 // formed as report_backtracking would form it: parent * 0.5 | parent * 2.1
+            int col;                    // column of the round
+            std::vector<double> x;
+        };
+        std::vector<Shadow> shadows;
+        long long issued = 0, adopted = 0;
+        const bool dbg = std::getenv("BIOEN_HIP_SPEC_DEBUG") != nullptr;
+
         for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
         while (active > 0 && !rc) {
             int list[kMaxBatch];
@@ -184,9 +210,89 @@ struct ForcesBatchEngine {
                 th[k] = p.theta;
                 ++k;
             }
+            const int nown = k;
+            // ---- shadows: the free slots go round the searching problems, each taking the next step of its candidate
+            // order -- the chain of the search's last move first (a run of halvings is the common case), the other
+            // move and the mixed step (x 0.5 x 2.1, the same number either way round) behind it
+            shadows.clear();
+            if (spec && nown < nslots) {
+                int freeslot[kMaxBatch], nfree = 0;
+                for (int s = 0; s < nslots; ++s)
+                    if (s >= kb || !occupied[s]) freeslot[nfree++] = s;
+                struct Plan { int owner; double cand[kMaxBatch]; int n, taken; bool keen; };
+                Plan plan[kMaxBatch];
+                int nplan = 0;
+                for (int a = 0; a < nown; ++a) {
+                    ForcesProblem& p = probs[list[a]];
+                    if (p.initial) continue;
+                    const long long ev = p.machine->evaluations(), it = p.machine->iterations();
+                    Plan& q = plan[nplan++];
+                    q.owner = list[a];
+                    // big matrices: the strip passes take the same time for 1..4 columns (0.60 ms at N = 1e6 x M = 512)
+                    // and 25 % more for 8: a search gets more than a free column only if a quarter of the problem's
+                    // trials have been rejected so far
+                    q.keen = !big || (ev >= 16 && (ev - it) * 4 >= ev);
+                    q.n = q.taken = 0;
+                    const double stp = p.machine->trial_step();
+                    const bool wolfe = cfg.linesearch >= 2;
+                    // The main chain follows the search's habit -- a run of one move goes on (halvings from a step far
+                    // too long: the first search of a warm start), two different moves in a row alternate (a search
+                    // caught between the decrease and the curvature test: x 0.5, x 2.1, x 0.5 ... until max_linesearch)
+                    // -- six steps deep; the other move at its first node takes the slot left.
+                    auto other = [](char mv) { return mv == 'd' ? 'i' : 'd'; };
+                    auto apply = [](double v, char mv) { return mv == 'd' ? v * 0.5 : v * 2.1; };
+                    char h1 = p.last_dir == 0 ? 0 : (p.last_dir < 0 ? 'd' : 'i'), h2 = p.prev_dir == 0 ? 0 : (p.prev_dir < 0 ? 'd' : 'i');
+                    double v = stp, node[1] = {stp};
+                    char nodemove[1] = {'d'};
+                    for (int depth = 0; depth < (wolfe ? 6 : kMaxBatch - 1); ++depth) {
+                        char mv = 'd';
+                        if (wolfe && h1) mv = (h2 && h1 != h2) ? other(h1) : h1;
+                        if (depth < 1) {
+                            node[depth] = v;
+                            nodemove[depth] = mv;
+                        }
+                        v = apply(v, mv);
+                        if (q.n < kMaxBatch - 1) q.cand[q.n++] = v;
+                        h2 = h1;
+                        h1 = mv;
+                    }
+                    if (wolfe) {
+                        // order: chain[0], the other move at the first node, chain[1..5]
+                        const double s0 = apply(node[0], other(nodemove[0]));
+                        double ordered[kMaxBatch] = {q.cand[0], s0, q.cand[1], q.cand[2], q.cand[3], q.cand[4], q.cand[5]};
+                        q.n = 7;
+                        for (int i = 0; i < q.n; ++i) q.cand[i] = ordered[i];
+                    }
+                }
+                while (nfree > 0 && nplan > 0) {
+                    bool any = false;
+                    for (int q = 0; q < nplan && nfree > 0; ++q) {
+                        Plan& pl = plan[q];
+                        if (pl.taken >= pl.n || (!pl.keen && k >= 4)) continue;
+                        const double stp = pl.cand[pl.taken++];
+                        any = true;
+                        if (!(stp >= kMinStep && stp <= kMaxStep)) continue;        // the search would end there (lbfgs.c:718-725)
+                        ForcesProblem& p = probs[pl.owner];
+                        Shadow sh;
+                        sh.owner = pl.owner;
+                        sh.slot = freeslot[--nfree];
+                        sh.stp = stp;
+                        sh.col = k;
+                        sh.x.resize(m);
+                        for (int i = 0; i < m; ++i) sh.x[i] = p.xp[i] + stp * p.d[i];
+                        shadows.push_back(std::move(sh));
+                        list[k] = shadows.back().slot;
+                        th[k] = p.theta;
+                        ++k;
+                    }
+                    if (!any) break;
+                }
+                for (const Shadow& sh : shadows) pts[sh.col] = sh.x.data();           // after the vector stopped growing
+                issued += (long long)shadows.size();
+            }
             evaluate(list, k, pts, th, true);
             if (rc) break;
-            for (int a = 0; a < k; ++a) {
+            for (int a = 0; a < nown; ++a) {
                 const int s = list[a];
                 ForcesProblem& p = probs[s];
                 const double f = c->host_scal[(size_t)s * kScalStride + S_F];
@@ -198,12 +304,43 @@ struct ForcesBatchEngine {
                     if (act.kind != LbfgsMachine::DONE) {
                         for (int i = 0; i < m; ++i) p.d[i] = -p.gp[i];
                         p.initial = false;
+                        p.last_dir = p.prev_dir = 0;
                     }
                 } else {
+                    double tried = p.machine->trial_step();
+                    if (dbg) p.moves += '|';
                     TrialResult t{f, ForcesProblem::dot(p.g, p.d), ForcesProblem::dot(p.g, p.g),
                                   ForcesProblem::dot(p.x, p.x), ForcesProblem::dot(p.gp, p.d)};
                     act = p.machine->on_trial(t);
-                    if (act.kind == LbfgsMachine::ACCEPT) p.accept(act.end, act.bound);
+                    // the search asks for another step: if a shadow of this round sat exactly there, its values ARE that
+                    // trial's -- feed them in, and so on down the chain
+                    while (act.kind == LbfgsMachine::TRIAL) {
+                        const double want = p.machine->trial_step();
+                        p.prev_dir = p.last_dir;
+                        p.last_dir = want < tried ? -1 : 1;
+                        if (dbg) p.moves += p.last_dir < 0 ? 'd' : 'i';
+                        const Shadow* hit = nullptr;
+                        for (const Shadow& sh : shadows)
+                            if (sh.owner == s && sh.stp == want) { hit = &sh; break; }
+                        if (!hit) break;
+                        if (dbg) p.moves.back() = (char)std::toupper(p.moves.back());
+                        ++adopted;
+                        tried = want;
+                        p.x = hit->x;
+                        for (int i = 0; i < m; ++i) p.g[i] = gm_h[(size_t)i * k + hit->col];
+                        const double fs = c->host_scal[(size_t)hit->slot * kScalStride + S_F];
+                        TrialResult ts{fs, ForcesProblem::dot(p.g, p.d), ForcesProblem::dot(p.g, p.g),
+                                       ForcesProblem::dot(p.x, p.x), ForcesProblem::dot(p.gp, p.d)};
+                        act = p.machine->on_trial(ts);
+                    }
+                    if (act.kind == LbfgsMachine::ACCEPT) {
+                        p.accept(act.end, act.bound);
+                        p.last_dir = p.prev_dir = 0;
+                    }
+                    if (dbg && act.kind != LbfgsMachine::TRIAL) {
+                        std::fprintf(stderr, "theta %g search %s %s\n", p.theta, p.moves.c_str(), act.kind == LbfgsMachine::ACCEPT ? "accepted" : "done");
+                        p.moves.clear();
+                    }
                 }
                 if (act.kind == LbfgsMachine::DONE) {
                     finish_problem(s, act.code, act.keep_trial && !p.initial);
@@ -211,6 +348,10 @@ struct ForcesBatchEngine {
                 }
             }
         }
+        c->spec_launched += issued;
+        c->spec_used += adopted;
+        if (verbose && issued)
+            std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n", issued, adopted);
         note(hipStreamSynchronize(c->stream), "sync");
         return rc;
     }

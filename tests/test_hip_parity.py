@@ -570,3 +570,33 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
     for tag, other in runs.items():
         for ls in ("2", "3", "1", "0"):
             assert on[ls] == other[ls], (tag, ls)
+
+
+@pytest.mark.parametrize("name", ["synth_forces_M30xN1000.npz", "synth_forces_M96xN3000.npz"])
+def test_forces_speculative_line_search_changes_no_bit(hip, name, monkeypatch):
+    """The forces engine evaluates the steps a backtracking search may ask for next (the chain of halvings first) in batch
+    slots without a problem; an adopted shadow's numbers ARE that trial's.  Off (BIOEN_HIP_SPECULATE=0) and on: optimum,
+    weights, fmin, iteration and evaluation counts, status identical to the last bit -- single runs (seven free slots), a
+    warm-started chain (the ala5 protocol, where searches are long) and lock-step batches with fewer problems than slots."""
+    d = load_golden(name)
+    w0 = d["w0"] / d["w0"].sum()
+    M = d["yTilde"].shape[0]
+    thetas = [1e4, 300.0, 20.0, 2.0, 0.4]
+    runs = {}
+    for tag in ("on", "off"):
+        monkeypatch.setenv("BIOEN_HIP_SPECULATE", "1" if tag == "on" else "0")
+        out = []
+        with hip.Context(d["yTilde"], d["YTilde"]) as ctx:
+            for ls in (2, 3, 1, 0):
+                params = dict(LBFGS_DEFAULTS, linesearch=ls)
+                f = np.zeros(M)
+                for th in thetas:                                      # warm-started chain of single runs
+                    f, w, info = ctx.opt_lbfgs_forces(f, w0, th, params)
+                    out.append((f.tobytes(), w.tobytes(), info.fmin, info.iterations, info.evaluations, info.lbfgs_code))
+                res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, params, max_batch=8)   # 5 problems, 8 slots
+                out.append((res.tobytes(), w.tobytes(), [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in infos]))
+            stats = ctx.speculation_stats()
+        runs[tag] = (out, stats)
+    assert tuple(runs["off"][1]) == (0, 0)
+    assert runs["on"][1][0] > 0 and runs["on"][1][1] > 0, runs["on"][1]          # issued, and some adopted
+    assert runs["on"][0] == runs["off"][0]
