@@ -127,6 +127,7 @@ struct ForcesBatchEngine {
         bool spec = cfg.linesearch >= 1 && cfg.linesearch <= 3;
         if (const char* e = std::getenv("BIOEN_HIP_SPECULATE")) spec = spec && std::atoi(e) != 0;
         const int nslots = spec ? std::min(std::max(max_batch, 1), kMaxBatch) : kb;      // max_batch bounds the batch WIDTH
+        const bool reuse_wanted = !std::getenv("BIOEN_HIP_FORCES_REEVALUATE");     // A/B: evaluate the returned point again, as until r03
         const bool big = 2.0 * c->mp * (double)c->ld * sizeof(double) > 1e9;             // a column more is not free there
         for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, false));
         if (rc) return rc;
@@ -150,7 +151,10 @@ struct ForcesBatchEngine {
             ++active;
             ++next;
         };
-        auto finish_problem = [&](int s, int code, bool keep_trial) {
+        // evalslot >= 0: the returned point is the one slot `evalslot` (column evalcol of the last round) has just
+        // evaluated -- its scalars are on the host, x_j and the normalisation still in the slot: the weights come from
+        // one N-vector kernel instead of another evaluation (the strip passes; elsewhere the point is evaluated again)
+        auto finish_problem = [&](int s, int code, bool keep_trial, int evalslot, int evalcol) {
             ForcesProblem& p = probs[s];
             bioen_opt_result& info = infos[p.id];
             info.lbfgs_code = code;
@@ -160,14 +164,25 @@ struct ForcesBatchEngine {
             const std::vector<double>& res = keep_trial ? p.x : p.xp;
             std::memcpy(results + (size_t)p.id * m, res.data(), (size_t)m * sizeof(double));
             // weights, chi^2 and KL at the returned forces (forces.py:535-548 recomputes them too)
-            const int one[1] = {s};
-            const double* pt[1] = {res.data()};
-            evaluate(one, 1, pt, &p.theta, false);
-            const double* h = c->host_scal + (size_t)s * kScalStride;
+            int ws = s;
+            if (evalslot >= 0 && reuse_wanted && c->Ys && !c->strip_old && forces_fused_blocks(c) > 0) {   // the last round ran the strip passes
+                ws = evalslot;
+                c->last_pos = evalcol;                    // bioen_hip_last_average: the column of that round's ybar_c
+                if (w_opt) {
+                    const int one[1] = {ws};
+                    launch_forces_w_from_x(c, make_forces_round(c, one, 1, &p.theta));
+                    note(check_launch());
+                }
+            } else {
+                const int one[1] = {s};
+                const double* pt[1] = {res.data()};
+                evaluate(one, 1, pt, &p.theta, false);
+            }
+            const double* h = c->host_scal + (size_t)ws * kScalStride;
             info.chi2 = 0.5 * h[S_CHI];
             info.kl = h[S_KL];
             if (w_opt) {
-                note(download_n(c, w_opt + (size_t)p.id * c->n_global, c->slot[s].w));   // gathers the ranks' blocks
+                note(download_n(c, w_opt + (size_t)p.id * c->n_global, c->slot[ws].w));   // gathers the ranks' blocks
                 note(hipStreamSynchronize(c->stream), "sync");
             }
             info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - p.t0).count();
@@ -299,6 +314,7 @@ struct ForcesBatchEngine {
                 std::vector<double>& grad = p.initial ? p.gp : p.g;
                 for (int i = 0; i < m; ++i) grad[i] = gm_h[(size_t)i * k + a];
                 LbfgsMachine::Action act;
+                int evalslot = s, evalcol = a;
                 if (p.initial) {
                     act = p.machine->on_initial(f, ForcesProblem::dot(p.gp, p.gp), ForcesProblem::dot(p.xp, p.xp));
                     if (act.kind != LbfgsMachine::DONE) {
@@ -326,6 +342,8 @@ struct ForcesBatchEngine {
                         if (dbg) p.moves.back() = (char)std::toupper(p.moves.back());
                         ++adopted;
                         tried = want;
+                        evalslot = hit->slot;
+                        evalcol = hit->col;
                         p.x = hit->x;
                         for (int i = 0; i < m; ++i) p.g[i] = gm_h[(size_t)i * k + hit->col];
                         const double fs = c->host_scal[(size_t)hit->slot * kScalStride + S_F];
@@ -343,7 +361,9 @@ struct ForcesBatchEngine {
                     }
                 }
                 if (act.kind == LbfgsMachine::DONE) {
-                    finish_problem(s, act.code, act.keep_trial && !p.initial);
+                    // the point handed out was evaluated in THIS round if it is the trial (keep_trial) or the start
+                    const bool fresh = p.initial || act.keep_trial;
+                    finish_problem(s, act.code, act.keep_trial && !p.initial, fresh ? evalslot : -1, evalcol);
                     if (next < ntheta && !rc) start_problem(s);
                 }
             }

@@ -91,9 +91,10 @@ def test_forces_series_through_rccl_stage_exchanges_is_bitwise_the_plain_run():
         res1, wb, info1 = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, LBFGS_DEFAULTS, max_batch=3)
         ff1, fg1 = ctx.forces_fdf(res0[0], w0, thetas[0])
         n_rccl, n_host = ctx.exchange_counts()
+        adopted = ctx.speculation_stats()[1]          # evaluations that cost no round of their own (shadows in free slots)
     finally:
         ctx.close()
-    assert n_host == 0 and n_rccl >= 2 * max(i.evaluations for i in info1)
+    assert n_host == 0 and n_rccl >= 2 * (max(i.evaluations for i in info1) - adopted)
     assert np.array_equal(res0, res1) and np.array_equal(wa, wb)
     assert ff0 == ff1 and np.array_equal(fg0, fg1)
     for a, b in zip(info0, info1):
