@@ -439,10 +439,11 @@ def deer_record(bioen_amd, seed):
         ctx.synchronize()
         dt = time.perf_counter() - t0
     its = int(sum(sum(x["iterations"] for x in r["trace"]) for r in res))
+    evs = int(sum(sum(x["evaluations"] for x in r["trace"]) for r in res))
     return {"workload": "DEER rotamer refinement, N=%d x M=%d (trace exp-370-292, Fresnel kernel), thetas %s, %d optimise/refit "
                         "iterations each (cold-started weights, modulation depth carried over), yaml-default liblbfgs, "
                         "modulation depth refitted on the resident matrix" % (N, M, thetas, iterations),
-            "seconds": dt, "iterations": its, "value": its * float(N) * M / dt, "unit": "iter*N*M/s",
+            "seconds": dt, "iterations": its, "evaluations": evs, "value": its * float(N) * M / dt, "unit": "iter*N*M/s",
             "refits": len(thetas) * iterations, "moddepth_start": m0, "input_synthesis_s": t_inputs,
             "moddepth_fit": [r["scales"][0] for r in res], "fmin": [r["fmin"] for r in res],
             "chi2": [r["chi2"] for r in res]}

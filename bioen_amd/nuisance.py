@@ -63,7 +63,7 @@ def series(ctx, thetas, G, g_init, lbfgs_params, YTilde, groups=None, row_offset
                 raise RuntimeError("nuisance.series, liblbfgs return code: %d" % info.lbfgs_code)
             yraw, _ = ctx.last_average()             # raw Y . w at the optimum: already on the device, 8 m bytes back
             trace.append({"scales": list(scales), "fmin": info.fmin, "chi2": info.chi2,
-                          "iterations": info.iterations})
+                          "iterations": info.iterations, "evaluations": info.evaluations})
             scales = refit_scales(yraw, YTilde, row_offset, groups)
         out.append({"theta": float(theta), "w": w, "g": g, "fmin": info.fmin, "chi2": info.chi2, "S": -info.kl,
                     "scales": list(scales), "trace": trace})
