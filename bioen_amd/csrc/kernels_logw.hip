@@ -112,15 +112,36 @@ __global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
 }
 
 // log s0 = log sum exp(G): constant per problem, computed once (the reference recomputes it
-// at every evaluation, c_bioen_kernels_logw.c:122).  One block; every problem of the round
-// gets the value.
-__global__ __launch_bounds__(kBlock) void k_logsumexp1(const double* __restrict__ G, int n, Round r) {
+// at every evaluation, c_bioen_kernels_logw.c:122).  Two stages (until r03 one block walked the whole vector: 1.2 ms
+// at N = 1e6, 0.6 ms per run of a K = 1 series at N = 5e5): every block of the N-vector grid leaves {max, sum of
+// exp(G - max)} of its share, one block merges them in block order -- a fixed order, and for a uniform prior
+// (G = 0: every term is exactly 1, the sums are integers) the same bits as any other order.
+__global__ __launch_bounds__(kBlock) void k_logsumexp_part(const double* __restrict__ G, int n, double* __restrict__ part) {
     __shared__ double sh[kWaves];
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int j0 = blockIdx.x * per, j1 = min(n, j0 + per);
     double mx = -DBL_MAX;
-    for (int j = threadIdx.x; j < n; j += kBlock) mx = fmax(mx, G[j]);
+    for (int j = j0 + threadIdx.x; j < j1; j += kBlock) mx = fmax(mx, G[j]);
     mx = block_max(mx, sh);
     double s = 0.0;
-    for (int j = threadIdx.x; j < n; j += kBlock) s += exp(G[j] - mx);
+    for (int j = j0 + threadIdx.x; j < j1; j += kBlock) s += exp(G[j] - mx);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = mx;
+        part[2 * blockIdx.x + 1] = s;          // 0 for a block without elements
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_logsumexp_merge(const double* __restrict__ part, int nblk, Round r) {
+    __shared__ double sh[kWaves];
+    double mx = -DBL_MAX;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) mx = fmax(mx, part[2 * b]);
+    mx = block_max(mx, sh);
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) {
+        const double sb = part[2 * b + 1];
+        if (sb > 0.0) s += sb * exp(part[2 * b] - mx);
+    }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) {
         const double v = mx + log(s);
@@ -475,7 +496,12 @@ void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
 }
 
 void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logsumexp1, dim3(1), dim3(kBlock), 0, c->stream, c->fixed, c->n, r);
+    // the per-block pairs go through the X_GRAD stage's buffer (3 K values per block: room for 2), idle before a run's
+    // first evaluation; nothing is exchanged -- unsharded contexts only (sharded ones take the host's value)
+    const int g = vec_grid(c);
+    double* part = c->xbuf[X_GRAD];
+    hipLaunchKernelGGL(k_logsumexp_part, dim3(g), dim3(kBlock), 0, c->stream, c->fixed, c->n, part);
+    hipLaunchKernelGGL(k_logsumexp_merge, dim3(1), dim3(kBlock), 0, c->stream, part, g, r);
 }
 
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
