@@ -30,6 +30,7 @@ SIZES=1024:125000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv
 python tools/trace_gaps.py $OUT/small2/small_kernel_trace.csv > $OUT/small_round_1024x125000.txt
 timeout -k 10 300 python tools/ref_margins.py > $OUT/parity_margins.md 2> $OUT/parity_margins.err
 REPS=30 timeout -k 10 200 python tools/strip_probe.py > $OUT/forces_strip_probe.json 2>/dev/null
+FORCES_M=1024 REPS=30 timeout -k 10 200 python tools/strip_probe.py > $OUT/forces_strip_probe_M1024.json 2>/dev/null
 echo "timelines done"
 rm -f $OUT/*/*_kernel_trace.csv $OUT/*/*_counter_collection.csv     # tens of MB; the summaries are what is kept
 tail -1 $OUT/bench_N1.json | cut -c1-400
