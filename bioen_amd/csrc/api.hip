@@ -785,6 +785,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->live) hipHostFree(c->live);
     if (c->live2) hipHostFree(c->live2);
+    if (c->live_f) hipHostFree(c->live_f);
     if (c->dev_tab) hipFree(c->dev_tab);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->host_m) hipHostFree(c->host_m);

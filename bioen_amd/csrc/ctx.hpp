@@ -207,6 +207,8 @@ struct bioen_hip_ctx {
     // slot straight into this host-mapped page and then the round number into its flag; the host spins on the flags
     // instead of queueing a copy and sleeping on the stream (saves the copy kernel and the wake-up, ~15 us a round).
     double* live = nullptr;                        // pinned, coherent: kMaxBatch * kScalStride values | kMaxBatch flags
+    double* live_f = nullptr;                      // forces engine, pinned, coherent: gradients mp x kMaxBatch | scalars kMaxBatch x kScalStride | 1 flag
+    unsigned long long forces_round = 0;           // last round number published there
     unsigned long long live_seq = 0;               // last round number handed out
     unsigned long long live_round = 0;             // != 0: the next launch_finish_eval publishes under this number
     int live_off = 0;                              // BIOEN_HIP_LIVE=0: copy + stream synchronisation as before (A/B)

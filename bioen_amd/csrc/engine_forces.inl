@@ -77,6 +77,45 @@ struct ForcesBatchEngine {
                  "hipHostMalloc");
         um_h = c->host_m;
         gm_h = c->host_m ? c->host_m + cnt : nullptr;
+        // results published by a kernel into a coherent host page (see k_forces_publish); BIOEN_HIP_FORCES_LIVE=0 or a
+        // failed allocation: the two device-to-host copies + stream synchronisation of r02
+        const char* e = std::getenv("BIOEN_HIP_FORCES_LIVE");
+        live = !(e && e[0] == '0') && !c->live_off;
+        if (live && !c->live_f) {
+            const size_t n = cnt + (size_t)kMaxBatch * kScalStride + 8;
+            if (hipHostMalloc(reinterpret_cast<void**>(&c->live_f), n * sizeof(double),
+                              hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+                (void)hipGetLastError();
+                c->live_f = nullptr;
+                live = false;
+            } else {
+                std::memset(c->live_f, 0, n * sizeof(double));
+            }
+        }
+    }
+    bool live = false;
+
+    // wait for round `round` of k_forces_publish; the stream is polled now and then so that a failed launch ends the
+    // wait with its error instead of hanging the caller
+    int await_page(unsigned long long round) {
+        const size_t scal_at = (size_t)c->mp * kMaxBatch;
+        const volatile unsigned long long* flag =
+            reinterpret_cast<const volatile unsigned long long*>(c->live_f + scal_at + (size_t)kMaxBatch * kScalStride);
+        unsigned spins = 0;
+        while (*flag != round) {
+            if ((++spins & 0xfffu) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) {
+                    if (*flag == round) break;
+                    return fail(BIOEN_HIP_ESTATE, "round finished without publishing its results");
+                }
+                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        std::memcpy(c->host_scal, c->live_f + scal_at, (size_t)kMaxBatch * kScalStride * sizeof(double));
+        return 0;
     }
 
     void note(int e) { if (e && !rc) rc = e; }
@@ -94,6 +133,14 @@ struct ForcesBatchEngine {
         const ForcesRound fr = make_forces_round(c, slots, k, thetas);
         const Round r = make_round(c, slots, k, nullptr, thetas);
         note(enqueue_forces_eval(c, fr, r, with_grad));
+        if (live && !rc) {
+            const unsigned long long round = ++c->forces_round;
+            launch_forces_publish(c, with_grad ? c->mp * k : 0, round);
+            note(check_launch());
+            if (!rc) note(await_page(round));
+            gm_h = c->live_f;                       // compact [row * k + problem], as c->gm
+            return;
+        }
         if (with_grad)
             note(hipMemcpyAsync(gm_h, c->gm, (size_t)c->mp * k * sizeof(double), hipMemcpyDeviceToHost, c->stream),
                  "gradient D2H");

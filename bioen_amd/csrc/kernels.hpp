@@ -68,6 +68,8 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const stru
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
 constexpr int kFusedBlocks = 1024;
 void launch_read_probe(bioen_hip_ctx* c, const double* p, size_t doubles, double* out);   // bench: measured read ceiling
+// forces engine: the round's gradients and scalars straight into the host's page, then the round number into its flag
+void launch_forces_publish(bioen_hip_ctx* c, int ngrad, unsigned long long round);
 int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);

@@ -472,4 +472,27 @@ void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r) {
 }
 
 
+// ---- the round's results to the host without a copy engine and without a stream synchronisation (r03) -------------
+// page = [gradients, compact mp x k | scalars of all slots | flag]: one block copies both arrays into the host-mapped,
+// coherent page, every thread fences its own stores, the last instruction publishes the round number.  The host spins
+// on the flag (ForcesBatchEngine::evaluate): a round used to end with two device-to-host copies and
+// hipStreamSynchronize.
+__global__ __launch_bounds__(kBlock) void k_forces_publish(const double* __restrict__ gm, int ngrad,
+                                                           const double* __restrict__ scal, int nscal,
+                                                           double* __restrict__ page, int scal_at,
+                                                           unsigned long long* __restrict__ flag, unsigned long long round) {
+    for (int i = threadIdx.x; i < ngrad; i += kBlock) page[i] = gm[i];
+    for (int i = threadIdx.x; i < nscal; i += kBlock) page[scal_at + i] = scal[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_forces_publish(bioen_hip_ctx* c, int ngrad, unsigned long long round) {
+    const int scal_at = c->mp * kMaxBatch;
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->live_f + scal_at + kMaxBatch * kScalStride);
+    hipLaunchKernelGGL(k_forces_publish, dim3(1), dim3(kBlock), 0, c->stream, c->gm, ngrad, c->scal, kMaxBatch * kScalStride,
+                       c->live_f, scal_at, flag, round);
+}
+
 }  // namespace bioen
