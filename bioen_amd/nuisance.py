@@ -53,12 +53,14 @@ def series(ctx, thetas, G, g_init, lbfgs_params, YTilde, groups=None, row_offset
     out = []
     for theta in thetas:
         trace = []
-        for _ in range(int(iterations)):
+        for it in range(int(iterations)):
             row_scale = np.ones(m)
             for s, ix in zip(scales, groups):
                 row_scale[ix] = s
             ctx.set_affine(row_offset, row_scale)
-            g, w, info = ctx.opt_lbfgs_logw(g_init, G, float(theta), lbfgs_params, verbose=verbose)
+            # the refit needs Y . w only (last_average: 8 m bytes); the N weights travel once per theta
+            g, w, info = ctx.opt_lbfgs_logw(g_init, G, float(theta), lbfgs_params, verbose=verbose,
+                                            want_weights=(it == int(iterations) - 1))
             if info.lbfgs_code not in accept_codes:
                 raise RuntimeError("nuisance.series, liblbfgs return code: %d" % info.lbfgs_code)
             yraw, _ = ctx.last_average()             # raw Y . w at the optimum: already on the device, 8 m bytes back
