@@ -675,7 +675,9 @@ def main():
         # algorithmic bytes of ONE launch serving K thetas: the matrix once, plus per theta one
         # N-vector and one M-vector in, one out (matrix bytes are shared by the batch)
         n_rank = ctx.n_local if nshard else N            # columns streamed by one launch on rank 0
-        mat_bytes = float(M) * n_rank * 8
+        # M > 1024 (log-weights): one launch per row panel of <= 1024 rows, each streaming its share of the matrix
+        panels = 1 if (M <= 1024 or forces_mode or os.environ.get("BIOEN_HIP_PANELS") == "0") else (M + 1023) // 1024
+        mat_bytes = float(M) * n_rank * 8 / panels
         kern = {}
         for name in ("forward", "adjoint"):
             s = stats[name]
@@ -683,7 +685,7 @@ def main():
             avg_ms = s["total_ms"] / launches
             avg_k = s["problem_passes"] / launches
             alg = mat_bytes + avg_k * (8.0 * n_rank + 8.0 * M)
-            strip = M <= 1024 and not os.environ.get("BIOEN_HIP_FWD_STREAM") == "1"     # kernels_strip.hip serves M <= 1024
+            strip = (M <= 1024 or panels > 1) and not os.environ.get("BIOEN_HIP_FWD_STREAM") == "1"     # kernels_strip.hip
             if forces_mode:      # timer slots of launch_forces_xy ("adjoint") / _bt ("forward")
                 kname = "%s<K, nt, %s>" % ("k_strip" if M <= 512 else "k_strip2", "true" if name == "adjoint" else "false") if M <= 1024 else \
                         ("k_adj + k_fwd_partial" if name == "adjoint" else "k_fwd_partial")

@@ -159,6 +159,8 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
         c->keep_rowmajor = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_FWD_STREAM");       // A/B: the streaming forward kernel on the row-major matrix
         c->fwd_stream = (e && e[0] == '1') ? 1 : 0;
+        e = std::getenv("BIOEN_HIP_PANELS");           // A/B: M > 1024 on the r01 streaming kernels instead of row panels
+        c->panel_off = (e && e[0] == '0') ? 1 : 0;
     }
 
     int rc = 0;
@@ -392,7 +394,7 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
         if (rc) nblk = 0;
     }
     if (nblk > 0) {
-        // M <= 1024: matrix pass 1 streams the strip-major centred copy straight into the matrix cores
+        // matrix pass 1 streams the strip-major copy (M > 1024: row panel by row panel) straight into the matrix cores
         // (kernels_strip.hip: k_strip_fwd) -- the same time for every batch width; the centre returns in
         // k_rows_combine, which leaves the RAW ybar in ybar_c for the centred adjoint below
         launch_fwd_strip(c, r.n, w, nblk);
@@ -785,6 +787,10 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->live) hipHostFree(c->live);
     if (c->live2) hipHostFree(c->live2);
+    for (int p = 0; p < bioen_hip_ctx::kMaxPanels; ++p) {
+        if (c->Yp[p]) hipFree(c->Yp[p]);
+        if (c->Y1p[p]) hipFree(c->Y1p[p]);
+    }
     if (c->live_f) hipHostFree(c->live_f);
     if (c->dev_tab) hipFree(c->dev_tab);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -844,6 +850,13 @@ int bioen_hip_ctx_footprint(const bioen_hip_ctx* c, int* forms, long long* bytes
     if (c->Y) { f |= 1; b += rowmajor; }
     if (c->Ys) { f |= 2; b += strips; }
     if (c->Ys1) { f |= 4; b += strips; }
+    for (int p = 0; p < bioen_hip_ctx::kMaxPanels; ++p) {        // M > 1024: row panels of <= 1024 rows, both orders
+        const long long rows = std::min(1024, c->m - p * 1024);
+        if (rows <= 0) break;
+        const long long panel = (long long)(c->ld / 16) * ((rows + 15) / 16 * 16) * 16 * 8;
+        if (c->Yp[p]) { f |= 2; b += panel; }
+        if (c->Y1p[p]) { f |= 4; b += panel; }
+    }
     if (forms) *forms = f;
     if (bytes) *bytes = b;
     return 0;
@@ -1106,11 +1119,12 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     Vec8 v{};
     v.p[0] = s0.w;
     int nblk = fwd_strip_blocks(c);
+    if (c->mp > 1024 && !c->Yp[0]) nblk = 0;      // row panels are built for the optimizer's passes, not for one product
     if (nblk > 0 && (rc = ensure_strip_copy(c))) {
         if (!c->strips_unavailable) return rc;
         nblk = 0;
     }
-    if (nblk > 0) {            // M <= 1024: the strip copy, uncentred (any w, not only normalised ones)
+    if (nblk > 0) {            // the strip copy, uncentred (any w, not only normalised ones)
         launch_fwd_strip(c, 1, v, nblk, true);
         launch_fwd_rows_local(c, 1, false, nblk, true);
     } else {

@@ -157,7 +157,8 @@ struct bioen_hip_ctx {
     hipStream_t copy_stream = nullptr;   // results of finished problems leave on this one (engine_logw.inl: deliveries)
 
     double* Y = nullptr;       // mp x ld, row-major: the form data arrive in; M <= 1024: freed once the strip copy Ys
-                               // exists (kernels_strip.hip: ensure_strip_copy), back on demand (ensure_rowmajor)
+                               // exists (kernels_strip.hip: ensure_strip_copy), back on demand (ensure_rowmajor);
+                               // M > 1024: stays (source of the row panels, operand of the forces method's passes)
     int keep_rowmajor = 0;     // BIOEN_HIP_KEEP_ROWMAJOR=1: never free it (A/B)
     int rowmajor_rebuilt = 0;  // it was freed and has been re-created since
     double* zero_center = nullptr;   // mp zeros: "no centring" for the strip kernels (bioen_hip_chi_squared)
@@ -166,6 +167,12 @@ struct bioen_hip_ctx {
     double* Ys = nullptr;            // [ld / 16][strip rows][16], row-sum operand order (forces, log-weights forward)
     double* Ys1 = nullptr;           // the same strips in column-sum operand order (log-weights adjoint)
     double* strip_center = nullptr;  // mp: YTilde at the time of the copy
+    // M > 1024 (r03): the log-weights passes run the same kernels over PANELS of <= 1024 rows, each with its own pair
+    // of strip copies; the row-major matrix stays (forces method, read-back and chi^2 use it): 3 x the matrix resident
+    static constexpr int kMaxPanels = 16;
+    double* Yp[kMaxPanels] = {};     // row-sum order copy of rows [1024 p, 1024 (p + 1))
+    double* Y1p[kMaxPanels] = {};    // column-sum order copy
+    int panel_off = 0;               // BIOEN_HIP_PANELS=0: the r01 streaming kernels for M > 1024 (A/B)
     double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
     int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)
     int strip_old = 0;               // BIOEN_HIP_STRIP_OLD=1: the r01 strip kernels on the row-major matrix (A/B)

@@ -8,7 +8,8 @@
 // stream at 6.8 TB/s).  The forces evaluation needs whole COLUMNS (x_j = sum_i Y_ij f_i) and whole ROWS
 // (ybar_i = sum_j Y_ij e_j) of the same data in one pass, i.e. a block must hold all rows of a few
 // columns: 128-byte row segments 8 MB apart in the row-major matrix, which reach 4.9 TB/s at best (r01).
-// So the matrix passes for M <= 1024 read strip-major copies, built on first use:
+// So the matrix passes for M <= 1024 (log-weights: any M, over row panels of <= 1024 rows) read strip-major copies,
+// built on first use:
 //     Ys[strip s][row][c ^ swz(row)] = Y[row][16 s + c]          (raw numbers; rows padded to 16)
 // * strip-major: the 16 columns x all rows a block works on are ONE contiguous chunk (64 KB at
 //   M = 512) -- every wave-load is a contiguous KiB, as in the streaming kernels;
@@ -166,6 +167,8 @@ struct StripArgs {
     const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
     const double* w0;
     double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
+    int pstride;            // k_strip_fwd: rows of the partial layout (= mp; a row panel of a taller matrix: the matrix's)
+    int accumulate;         // k_strip_adj: add to the outputs of the panels before this one instead of starting at `shift`
     long long* stamps;      // diagnostic builds (STRIP_DIAG & 4): per wave 8 phase-cycle sums
 };
 
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
                 if (set < q.nblk && row < q.mp && k < K)     // transposed: a set's sums are one run; rows beyond the strip: zero
-                    q.partial[(size_t)set * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
+                    q.partial[(size_t)set * q.pstride * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
             }
     }
 }
@@ -952,7 +955,9 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
             // which strip a block takes changes no bit here.  One run per block: 1 % SLOWER at N = 1e6 x M = 1024, the
             // blocks' reads no longer sweep the HBM channels together; runs of 8 strips dealt round-robin: +0.2..0.7 %,
             // within the noise, and the uneven last run costs as much.)
-            __builtin_nontemporal_store(colsum + shift, outk + (size_t)sp * kStripCols + pc);
+            // (a row panel behind the first one of a matrix taller than 1024 rows continues its predecessors' sums)
+            const double start = q.accumulate ? outk[(size_t)sp * kStripCols + pc] : shift;
+            __builtin_nontemporal_store(colsum + start, outk + (size_t)sp * kStripCols + pc);
 #endif
         }
     }
@@ -965,6 +970,18 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
 // row block (cache hits, multiplied with zero operands or never stored), so that every wave runs the same
 // straight-line code and every sum is formed from the same terms in the same order as before.
 static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->m, 16); }
+// Matrices taller than 1024 rows (r03): the log-weights passes run over row PANELS of <= 1024 rows -- the same two
+// kernels once per panel, the forward pass writing its panel's rows of the partial sums, the adjoint pass continuing
+// the column sums of the panels before it.  Until r03 that range ran the r01 streaming kernels (K = 8 forward pass 1.28 x
+// its K = 1 time).  The panels are cut from the row-major matrix, which stays resident (the forces method for M > 1024,
+// read-back and chi^2 use it).
+constexpr int kPanelRows = 1024;
+static int panel_count(const bioen_hip_ctx* c) { return c->mp <= kPanelRows ? 1 : (c->m + kPanelRows - 1) / kPanelRows; }
+static int panel_m(const bioen_hip_ctx* c, int p) { return c->mp <= kPanelRows ? c->m : std::min(kPanelRows, c->m - p * kPanelRows); }   // valid rows
+static int panel_mp(const bioen_hip_ctx* c, int p) { return c->mp <= kPanelRows ? c->mp : std::min(kPanelRows, c->mp - p * kPanelRows); } // operand rows
+static int panel_mps(const bioen_hip_ctx* c, int p) { return (int)round_up((size_t)panel_m(c, p), 16); }                                  // strip rows
+static bool paneled(const bioen_hip_ctx* c) { return c->mp > kPanelRows; }
+
 static int strip_waves(const bioen_hip_ctx* c) { return (strip_rows(c) + kWaveRows - 1) / kWaveRows; }
 // forces kernels: k_strip (a wave owns 64 rows) for M <= 512, k_strip2 (128 rows per wave) for 512 < M <= 1024
 static bool strip_tall(const bioen_hip_ctx* c) { return c->mp > 512; }
@@ -1065,7 +1082,47 @@ static int ensure_zero_center(bioen_hip_ctx* c) {
     return e == hipSuccess ? 0 : hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
 }
 
+static int ensure_center(bioen_hip_ctx* c) {
+    if (c->strip_center) return 0;
+    double* cen = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&cen), (size_t)c->mp * sizeof(double));
+    if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (strip centre)");
+    e = hipMemcpyAsync(cen, c->YT, (size_t)c->mp * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(cen);
+        return strip_copy_failed(c, nullptr, e, "hipMemcpyAsync (strip centre)");
+    }
+    c->strip_center = cen;
+    return 0;
+}
+
 int ensure_strip_copy(bioen_hip_ctx* c) {
+    if (paneled(c)) {                                   // row panels of a matrix taller than 1024 rows; Y stays
+        if (c->Yp[0]) return 0;
+        if (c->strips_unavailable || !c->Y) return BIOEN_HIP_ENOMEM;
+        int rc = ensure_center(c);
+        if (rc) return rc;
+        if (ensure_zero_center(c)) return strip_copy_failed(c, nullptr, hipErrorOutOfMemory, "zero centre");
+        const int nstrips = (int)(c->ld / kStripCols);
+        double* made[bioen_hip_ctx::kMaxPanels] = {};
+        for (int p = 0; p < panel_count(c); ++p) {
+            const int mps = panel_mps(c, p);
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&made[p]), (size_t)nstrips * mps * kStripCols * sizeof(double));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream,
+                                   c->Y + (size_t)p * kPanelRows * c->ld, c->ld, panel_mp(c, p), mps, c->n, made[p], nstrips,
+                                   c->strip_center + (size_t)p * kPanelRows);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) {
+                for (int q = 0; q <= p; ++q)
+                    if (made[q]) (void)hipFree(made[q]);
+                return strip_copy_failed(c, nullptr, e, "strip copies of the row panels");
+            }
+        }
+        for (int p = 0; p < panel_count(c); ++p) c->Yp[p] = made[p];
+        return 0;
+    }
     if (c->Ys) return 0;
     if (c->strips_unavailable) return BIOEN_HIP_ENOMEM;
     const int mps = strip_rows(c);
@@ -1164,14 +1221,16 @@ static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
 }
 
 // geometry of the 16-wave kernels (k_strip_fwd / k_strip_adj): waves per strip slot, slots per block
-static int fa_wps(const bioen_hip_ctx* c) { return std::max(2, strip_waves(c)); }
-static int fa_spb(const bioen_hip_ctx* c) { return std::max(1, std::min(16 / fa_wps(c), 4)); }
+static int fa_wps_rows(int mps) { return std::max(2, (mps + kWaveRows - 1) / kWaveRows); }
+static int fa_spb_rows(int mps) { return std::max(1, std::min(16 / fa_wps_rows(mps), 4)); }
+static int fa_spb(const bioen_hip_ctx* c) { return fa_spb_rows(paneled(c) ? kPanelRows : strip_rows(c)); }
 
-// forward pass of the log-weights method on the strip copy (all K <= 8; M <= 1024): the number of partial sets
+// forward pass of the log-weights method on the strip copy (all K <= 8): the number of partial sets
 int fwd_strip_blocks(const bioen_hip_ctx* c) {
-    if (c->mp > 1024 || c->fwd_stream || c->strips_unavailable) return 0;
+    if (c->fwd_stream || c->strips_unavailable) return 0;
+    if (paneled(c) && (c->panel_off || panel_count(c) > bioen_hip_ctx::kMaxPanels)) return 0;
     const int nstrips = (int)(c->ld / kStripCols);
-    return std::min(256 * fa_spb(c), nstrips);
+    return std::min(256 * fa_spb(c), nstrips);         // paneled: every panel uses the sets of a full 1024-row panel
 }
 
 template <int K, bool NT>
@@ -1196,26 +1255,54 @@ static void fwd_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const Vec8
 // partial[(row K + a) nblk + block] of Y' . v_a; the caller adds the centre back (k_rows_combine's `center`);
 // plain = true: Y . v_a itself (no centring: bioen_hip_chi_squared takes any w, not only normalised ones)
 void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool plain) {
-    TimedLaunch tl(c, 0, K);
-    StripArgs q{};
-    q.Ys = c->Ys;
-    q.center = plain ? c->zero_center : c->strip_center;
-    q.mps = strip_rows(c);
-    q.mp = c->mp;
-    q.nstrips = (int)(c->ld / kStripCols);
-    q.n = c->n;
-    q.K = K;
-    q.nblk = nblk;
-    q.partial = c->fwd_partial;
-    q.wps = fa_wps(c);
-    q.spb = fa_spb(c);
-    const dim3 block(64 * q.wps * q.spb);
-    if (c->nontemporal) fwd_strip_launch_nt<true>(c, q, v, block);
-    else fwd_strip_launch_nt<false>(c, q, v, block);
+    const double* center = plain ? c->zero_center : c->strip_center;
+    for (int p = 0; p < panel_count(c); ++p) {
+        TimedLaunch tl(c, 0, K);
+        const int row0 = p * kPanelRows;
+        StripArgs q{};
+        q.Ys = paneled(c) ? c->Yp[p] : c->Ys;
+        q.center = center + row0;
+        q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+        q.mp = panel_mp(c, p);
+        q.nstrips = (int)(c->ld / kStripCols);
+        q.n = c->n;
+        q.K = K;
+        q.nblk = nblk;
+        q.partial = c->fwd_partial + (size_t)row0 * K;
+        q.pstride = c->mp;
+        q.wps = fa_wps_rows(q.mps);
+        q.spb = fa_spb(c);                               // the sets are those of the context's geometry in every panel
+        if (q.wps * q.spb > 16) q.wps = 16 / q.spb;     // (cannot happen: a shorter last panel needs fewer waves per slot)
+        const dim3 block(64 * q.wps * q.spb);
+        if (c->nontemporal) fwd_strip_launch_nt<true>(c, q, v, block);
+        else fwd_strip_launch_nt<false>(c, q, v, block);
+    }
 }
 
 // adjoint pass of the log-weights method on the column-sum copy (built on first use)
 int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
+    if (paneled(c)) {
+        if (c->Y1p[0]) return 0;
+        int rc = ensure_strip_copy(c);
+        if (rc) return rc;
+        const int nstrips = (int)(c->ld / kStripCols);
+        double* made[bioen_hip_ctx::kMaxPanels] = {};
+        for (int p = 0; p < panel_count(c); ++p) {
+            const int mps = panel_mps(c, p);
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&made[p]), (size_t)nstrips * mps * kStripCols * sizeof(double));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Yp[p], mps, made[p], nstrips);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) {
+                for (int q = 0; q <= p; ++q)
+                    if (made[q]) (void)hipFree(made[q]);
+                return strip_copy_failed(c, nullptr, e, "column-sum strip copies of the row panels");
+            }
+        }
+        for (int p = 0; p < panel_count(c); ++p) c->Y1p[p] = made[p];
+        return 0;
+    }
     if (c->Ys1) return 0;
     int rc = ensure_strip_copy(c);                               // the centre is shared; the column-sum copy is cut from the row-sum one
     if (rc) return rc;
@@ -1231,8 +1318,8 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     return 0;
 }
 
-static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c) {
-    const int wps = fa_wps(c), waves = wps * fa_spb(c);          // u table of one slot's rows | their centres | two parity buffers of partial sums
+static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c, int wps) {
+    const int waves = wps * fa_spb(c);          // u table of one slot's rows | their centres | two parity buffers of partial sums
     return ((size_t)wps * kWaveRows * 9 + (size_t)2 * waves * 128) * sizeof(double);
 }
 
@@ -1264,23 +1351,27 @@ static void adj_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const MVec
 // out_a[j] = sum_i u_c[i K + a] (Y_ij - ybar_c[i K + a]) with the RAW ybar in ybar_c; needs S_B0 / S_UY of this
 // round in the problems' scalars (k_rows_combine with the strip centre)
 void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk) {
-    TimedLaunch tl(c, 1, K);
-    StripArgs q{};
-    q.Ys = c->Ys1;
-    q.center = c->strip_center;
-    q.mps = strip_rows(c);
-    q.mp = c->mp;
-    q.nstrips = (int)(c->ld / kStripCols);
-    q.n = c->n;
-    q.K = K;
-    q.nblk = nblk;
-    q.u_c = u_c;
-    q.wps = fa_wps(c);
-    q.spb = fa_spb(c);
-    const dim3 block(64 * q.wps * q.spb);
-    const size_t lds = adj_strip_lds_bytes(c);
-    if (c->nontemporal) adj_strip_launch_nt<true>(c, q, out, scal, block, lds);
-    else adj_strip_launch_nt<false>(c, q, out, scal, block, lds);
+    for (int p = 0; p < panel_count(c); ++p) {
+        TimedLaunch tl(c, 1, K);
+        const int row0 = p * kPanelRows;
+        StripArgs q{};
+        q.Ys = paneled(c) ? c->Y1p[p] : c->Ys1;
+        q.center = c->strip_center + row0;
+        q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+        q.mp = panel_mp(c, p);
+        q.nstrips = (int)(c->ld / kStripCols);
+        q.n = c->n;
+        q.K = K;
+        q.nblk = nblk;
+        q.u_c = u_c + (size_t)row0 * K;
+        q.accumulate = p > 0;
+        q.wps = fa_wps_rows(q.mps);
+        q.spb = fa_spb(c);
+        const dim3 block(64 * q.wps * q.spb);
+        const size_t lds = adj_strip_lds_bytes(c, q.wps);
+        if (c->nontemporal) adj_strip_launch_nt<true>(c, q, out, scal, block, lds);
+        else adj_strip_launch_nt<false>(c, q, out, scal, block, lds);
+    }
 }
 
 template <bool XY>

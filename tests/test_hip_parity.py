@@ -297,7 +297,10 @@ def test_bitwise_reproducible(hip):
 # beyond 1024 rows the four streaming passes take over)
 @pytest.mark.parametrize("M,N", [(1, 1), (1, 2), (3, 127), (31, 128), (32, 129), (33, 255), (65, 257), (7, 1000),
                                  (255, 300), (257, 2049), (500, 1500), (512, 4100), (513, 700), (1000, 900),
-                                 (1024, 1100), (1025, 300)])
+                                 (1024, 1100), (1025, 300),
+                                 # beyond 1024 rows the log-weights passes run over row panels of <= 1024 rows (a 1-row
+                                 # panel, two full ones, a ragged third)
+                                 (1040, 129), (2048, 200), (2100, 333)])
 def test_ragged_shapes_vs_oracle(hip, M, N):
     from oracle import oracle_binding as O
     rng = np.random.default_rng(1000 * M + N)
@@ -600,3 +603,43 @@ def test_forces_speculative_line_search_changes_no_bit(hip, name, monkeypatch):
     assert tuple(runs["off"][1]) == (0, 0)
     assert runs["on"][1][0] > 0 and runs["on"][1][1] > 0, runs["on"][1]          # issued, and some adopted
     assert runs["on"][0] == runs["off"][0]
+
+
+@pytest.mark.parametrize("M,N", [(1300, 700), (2050, 400)])
+def test_logw_lbfgs_over_row_panels_vs_oracle(hip, M, N, monkeypatch):
+    """Matrices taller than 1024 rows: the log-weights matrix passes run the strip kernels once per panel of <= 1024 rows
+    (forward: the panel's rows of the partial sums; adjoint: the column sums continue across panels).  A converged L-BFGS
+    series through that path against the oracle (1e-6 / 1e-5), batched == single and device == host engine bit for bit,
+    and objective/gradient against the r01 streaming kernels (BIOEN_HIP_PANELS=0) to rounding."""
+    from oracle import oracle_binding as O
+    rng = np.random.default_rng(M + N)
+    yTilde = rng.normal(5.0, 2.0, (M, N))
+    YTilde = yTilde.dot(rng.dirichlet(np.ones(N))) + 0.05 * rng.standard_normal(M)
+    w0 = rng.dirichlet(np.ones(N) * 3.0)
+    G = np.log(w0)
+    g0 = G + 0.2 * rng.standard_normal(N)
+    thetas = [30.0, 3.0]
+    with hip.Context(yTilde, YTilde) as ctx:
+        f_p, grad_p = ctx.logw_fdf(g0, G, 3.0)
+        assert ctx.footprint()[0] == {"rowmajor", "strips", "strips_colsum"}
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, g0, G, LBFGS_CONV)
+        monkeypatch.setenv("BIOEN_HIP_DEVICE_LS", "0")
+        res_h, w_h, infos_h = ctx.opt_lbfgs_logw_batch(thetas, g0, G, LBFGS_CONV)
+        monkeypatch.delenv("BIOEN_HIP_DEVICE_LS")
+        for k, th in enumerate(thetas):
+            gs, ws, info = ctx.opt_lbfgs_logw(g0, G, th, LBFGS_CONV)
+            assert infos[k].fmin == info.fmin == infos_h[k].fmin
+            assert np.array_equal(res[k], gs) and np.array_equal(w[k], ws) and np.array_equal(res[k], res_h[k])
+            g_o, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_logw(g0, G, yTilde, YTilde, th, LBFGS_CONV)
+            assert rel(info.fmin, fmin_o) < 1e-6
+            w_o = O.logw_weights(g_o)[0]
+            assert np.abs(ws - w_o).max() <= 1e-5 * w_o.max()
+        assert np.array_equal(ctx.read_ytilde(), yTilde)
+    monkeypatch.setenv("BIOEN_HIP_PANELS", "0")
+    with hip.Context(yTilde, YTilde) as ctx:
+        f_s, grad_s = ctx.logw_fdf(g0, G, 3.0)
+        assert ctx.footprint()[0] == {"rowmajor"}
+    f_o, grad_o, _ = O.logw_fdf(g0, G, yTilde, YTilde, 3.0)
+    assert rel(f_p, f_s) < 1e-13 and rel(f_p, f_o) < F_RTOL
+    assert np.abs(grad_p - grad_s).max() <= 1e-11 * np.abs(grad_s).max()
+    assert np.abs(grad_p - grad_o).max() <= G_RTOL * np.abs(grad_o).max() + 1e-14 * np.abs(yTilde).max() * (abs(f_o) + 1)
