@@ -449,12 +449,16 @@ static ForcesRound make_forces_round(bioen_hip_ctx* c, const int* slots, int k, 
     return r;
 }
 
-static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {
+static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr, int panel_sets = 0) {
     MVec8 out{};
     for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
-    const int rc = ensure_rowmajor(c);        // streaming kernels: the row-major matrix (back from the strip copy if it was freed)
-    if (rc) return rc;
-    launch_adj(c, fr.n, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
+    if (panel_sets > 0) {                     // M > 1024, row panels: the column sums on the strip kernel, uncentred
+        launch_adj_strip(c, fr.n, c->um, out, MVec8{}, panel_sets, true);
+    } else {
+        const int rc = ensure_rowmajor(c);    // streaming kernels: the row-major matrix (back from the strip copy if it was freed)
+        if (rc) return rc;
+        launch_adj(c, fr.n, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
+    }
     launch_forces_max(c, fr);
     launch_forces_exp(c, fr);
     launch_forces_norm(c, fr);                // w ; KL partials
@@ -520,21 +524,47 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         return 0;
     }
     if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "forces on a sharded context need M <= 1024 (strip passes)");
-    if ((rc = enqueue_forces_weights(c, fr))) return rc;
+    // M > 1024: four passes.  r03: on the strip kernels over row panels of <= 1024 rows (kernels_strip.hip) -- the two
+    // column-sum passes uncentred, the two row-sum passes centred on the targets as in the two-pass path, T = sum_j t_j
+    // taken off in the gradient's reduction -- with the r01 streaming kernels as the fallback (BIOEN_HIP_PANELS=0, or
+    // no memory for the panel copies)
+    int psets = strip_panels(c) ? fwd_strip_blocks(c) : 0;
+    if (psets > 0) {
+        rc = ensure_strip_copy(c);
+        if (!rc) rc = ensure_strip_copy_colsum(c);
+        if (rc && !c->strips_unavailable) return rc;
+        if (rc) psets = 0;
+    }
+    if ((rc = enqueue_forces_weights(c, fr, psets))) return rc;
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
-    launch_fwd_partial(c, fr.n, v);           // F2: ybar                         [matrix pass 2]
-    launch_fwd_rows_local(c, fr.n, false);
-    launch_rows_combine(c, r, false);
+    if (psets > 0) {
+        launch_fwd_strip(c, fr.n, v, psets);                       // F2: ybar - centre        [matrix pass 2]
+        launch_fwd_rows_local(c, fr.n, false, psets, true);
+        launch_rows_combine(c, r, false, c->strip_center, false);  //     ybar_c = ybar - centre; r, chi^2 from the raw averages
+        c->last_centered = true;
+    } else {
+        launch_fwd_partial(c, fr.n, v);       // F2: ybar                         [matrix pass 2]
+        launch_fwd_rows_local(c, fr.n, false);
+        launch_rows_combine(c, r, false);
+    }
     launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
         MVec8 out{};
         for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
-        launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
-        launch_forces_t(c, fr);               //     t_j
-        for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
-        launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
-        launch_fwd_rows_forces_grad(c, fr.n, c->fwd_ctiles);
+        if (psets > 0) {
+            launch_adj_strip(c, fr.n, c->r_c, out, MVec8{}, psets, true);   // F3: b = yTilde^T r  [matrix pass 3]
+            launch_forces_t(c, fr, psets);                                  //     t_j and T = sum_j t_j
+            for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
+            launch_fwd_strip(c, fr.n, v, psets);                            //     sum_j (yTilde_ij - c_i) t_j   [matrix pass 4]
+            launch_fwd_rows_forces_grad(c, fr.n, psets, &fr, true);         //     ... - (ybar_i - c_i) T
+        } else {
+            launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
+            launch_forces_t(c, fr);               //     t_j
+            for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
+            launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
+            launch_fwd_rows_forces_grad(c, fr.n, c->fwd_ctiles);
+        }
     }
     return 0;
 }

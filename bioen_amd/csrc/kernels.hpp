@@ -70,6 +70,7 @@ constexpr int kFusedBlocks = 1024;
 void launch_read_probe(bioen_hip_ctx* c, const double* p, size_t doubles, double* out);   // bench: measured read ceiling
 // forces engine: the round's gradients and scalars straight into the host's page, then the round number into its flag
 void launch_forces_publish(bioen_hip_ctx* c, int ngrad, unsigned long long round);
+bool strip_panels(const bioen_hip_ctx* c);             // M > 1024: the strip kernels run over row panels
 int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
@@ -81,7 +82,7 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
 int ensure_rowmajor(bioen_hip_ctx* c);                 // the row-major matrix back from the strip copy (it is freed once that exists)
 int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, double* out);   // -> device out[rows][cols]
 int ensure_strip_copy_colsum(bioen_hip_ctx* c);        // builds ctx->Ys1 (column-sum operand order) on first use
-void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk);
+void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk, bool plain = false);
 void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk, bool tposed = false);
 int forces_fused_blocks_old(const bioen_hip_ctx* c);   // r01 strip kernels (A/B only)
 void launch_forces_xy_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
@@ -113,7 +114,7 @@ struct ForcesRound {
 void launch_forces_max(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_exp(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r);
-void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r);
+void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r, int tsum_sets = 0);   // tsum_sets > 0: also T = sum_j t_j -> P_KL share 0 of that many (the rest zero)
 void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r);
 
 // ---- assembly of yTilde = sim / sigma on the device ----------------------------------------

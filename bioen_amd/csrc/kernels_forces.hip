@@ -54,18 +54,39 @@ __global__ __launch_bounds__(kBlock) void k_forces_norm(ForcesRound r, const dou
 }
 
 // t_j = (theta (1 + log w_j - log w0_j) + b_j) w_j     (c_bioen_kernels_forces.c:320-328)
-__global__ __launch_bounds__(kBlock) void k_forces_t(ForcesRound r, const double* __restrict__ w0, int n) {
+// tpart != nullptr: the block's share of T = sum_j t_j as well (row panels, M > 1024: the last matrix pass forms
+// sum_j (Y_ij - c_i) t_j and the gradient takes (ybar_i - c_i) T off, as the strip passes do)
+__global__ __launch_bounds__(kBlock) void k_forces_t(ForcesRound r, const double* __restrict__ w0, int n, double* __restrict__ tpart) {
+    __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     const double* __restrict__ w = r.w[a];
     const double* __restrict__ b = r.a[a];
     double* __restrict__ t = r.t[a];
     const double theta = r.theta[a];
+    double s = 0.0;
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
         const double wv = w[j], w0v = w0[j];
         double dd = 1.0;
         if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += log(wv) - log(w0v);
-        t[j] = (dd * theta + b[j]) * wv;
+        const double tv = (dd * theta + b[j]) * wv;
+        t[j] = tv;
+        s += tv;
     }
+    if (tpart) {
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) tpart[(size_t)a * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// the blocks' shares in block order -> share 0 of the `sets` P_KL shares k_fwd_rows_forces_grad_t totals; the others zero
+__global__ __launch_bounds__(kBlock) void k_forces_tsum(const double* __restrict__ tpart, int nblk, ForcesRound r, int sets) {
+    __shared__ double sh[kWaves];
+    const int a = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += kBlock) s += tpart[(size_t)a * nblk + b];
+    s = block_sum(s, sh);
+    double* share = r.part[a] + (size_t)P_KL * kMaxPartials;
+    for (int b = threadIdx.x; b < sets; b += kBlock) share[b] = b == 0 ? s : 0.0;
 }
 
 // ------------------------------------------------------------------------------
@@ -463,8 +484,16 @@ void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r) {
                        vec_grid(c));
 }
 
-void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r) {
-    hipLaunchKernelGGL(k_forces_t, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n);
+void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r, int tsum_sets) {
+    if (tsum_sets > 0) {
+        const int g = vec_grid(c);
+        double* tpart = c->xbuf[X_GRAM];            // kGramDots values per block and problem: room for one; idle in the forces method
+        hipLaunchKernelGGL(k_forces_t, dim3(g, r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n, tpart);
+        hipLaunchKernelGGL(k_forces_tsum, dim3(r.n), dim3(kBlock), 0, c->stream, tpart, g, r, tsum_sets);
+        return;
+    }
+    hipLaunchKernelGGL(k_forces_t, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                       static_cast<double*>(nullptr));
 }
 
 void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r) {

@@ -168,7 +168,7 @@ struct StripArgs {
     const double* w0;
     double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
     int pstride;            // k_strip_fwd: rows of the partial layout (= mp; a row panel of a taller matrix: the matrix's)
-    int accumulate;         // k_strip_adj: add to the outputs of the panels before this one instead of starting at `shift`
+    int accumulate;         // k_strip_adj: 0 = start at `shift`, 1 = add to the outputs of the panels before this one, 2 = start at 0
     long long* stamps;      // diagnostic builds (STRIP_DIAG & 4): per wave 8 phase-cycle sums
 };
 
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
             outk = out.p[k];
             sck = scal.p[k];
         }
-    if (p2) shift = sck[S_B0] - sck[S_UY];
+    if (p2 && q.accumulate == 0) shift = sck[S_B0] - sck[S_UY];
     d2 pre[kWaveRows / 8];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
     int choff[kWaveRows / 8];
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
             // blocks' reads no longer sweep the HBM channels together; runs of 8 strips dealt round-robin: +0.2..0.7 %,
             // within the noise, and the uneven last run costs as much.)
             // (a row panel behind the first one of a matrix taller than 1024 rows continues its predecessors' sums)
-            const double start = q.accumulate ? outk[(size_t)sp * kStripCols + pc] : shift;
+            const double start = q.accumulate == 1 ? outk[(size_t)sp * kStripCols + pc] : shift;     // (2: shift stayed 0)
             __builtin_nontemporal_store(colsum + start, outk + (size_t)sp * kStripCols + pc);
 #endif
         }
@@ -981,6 +981,7 @@ static int panel_m(const bioen_hip_ctx* c, int p) { return c->mp <= kPanelRows ?
 static int panel_mp(const bioen_hip_ctx* c, int p) { return c->mp <= kPanelRows ? c->mp : std::min(kPanelRows, c->mp - p * kPanelRows); } // operand rows
 static int panel_mps(const bioen_hip_ctx* c, int p) { return (int)round_up((size_t)panel_m(c, p), 16); }                                  // strip rows
 static bool paneled(const bioen_hip_ctx* c) { return c->mp > kPanelRows; }
+bool strip_panels(const bioen_hip_ctx* c) { return paneled(c); }
 
 static int strip_waves(const bioen_hip_ctx* c) { return (strip_rows(c) + kWaveRows - 1) / kWaveRows; }
 // forces kernels: k_strip (a wave owns 64 rows) for M <= 512, k_strip2 (128 rows per wave) for 512 < M <= 1024
@@ -1350,13 +1351,13 @@ static void adj_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const MVec
 
 // out_a[j] = sum_i u_c[i K + a] (Y_ij - ybar_c[i K + a]) with the RAW ybar in ybar_c; needs S_B0 / S_UY of this
 // round in the problems' scalars (k_rows_combine with the strip centre)
-void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk) {
+void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk, bool plain) {
     for (int p = 0; p < panel_count(c); ++p) {
         TimedLaunch tl(c, 1, K);
         const int row0 = p * kPanelRows;
         StripArgs q{};
         q.Ys = paneled(c) ? c->Y1p[p] : c->Ys1;
-        q.center = c->strip_center + row0;
+        q.center = (plain ? c->zero_center : c->strip_center) + row0;      // plain: out = Y^T u itself (forces method, M > 1024)
         q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
         q.mp = panel_mp(c, p);
         q.nstrips = (int)(c->ld / kStripCols);
@@ -1364,7 +1365,7 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
         q.K = K;
         q.nblk = nblk;
         q.u_c = u_c + (size_t)row0 * K;
-        q.accumulate = p > 0;
+        q.accumulate = p > 0 ? 1 : (plain ? 2 : 0);
         q.wps = fa_wps_rows(q.mps);
         q.spb = fa_spb(c);
         const dim3 block(64 * q.wps * q.spb);

@@ -328,12 +328,13 @@ def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
         if M <= 1024:
             assert ctx.footprint()[0] == {"strips", "strips_colsum"}                  # the forces passes read the same copy
         else:
-            assert "rowmajor" in ctx.footprint()[0]                                   # forces beyond 1024 rows: streaming passes
+            assert ctx.footprint()[0] == {"rowmajor", "strips", "strips_colsum"}      # forces beyond 1024 rows: the same panels
         assert np.array_equal(ctx.read_ytilde(), Y)
     with bioen_amd.Context(Y, YT) as ctx:                                             # a forces-only context
         ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
         forms, nbytes = ctx.footprint()
-        assert forms == ({"strips"} if M <= 1024 else {"rowmajor"})
+        # M > 1024: both orders of the row panels beside the row-major matrix (the forces method's four passes)
+        assert forms == ({"strips"} if M <= 1024 else {"rowmajor", "strips", "strips_colsum"})
         w = ctx.forces_weights(np.zeros(M), np.full(N, 1.0 / N))                      # streaming kernels: row-major again
         assert np.abs(w - 1.0 / N).max() < 1e-18 + 1e-12 / N
         assert np.array_equal(ctx.read_ytilde(), Y)

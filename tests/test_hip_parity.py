@@ -619,9 +619,12 @@ def test_logw_lbfgs_over_row_panels_vs_oracle(hip, M, N, monkeypatch):
     G = np.log(w0)
     g0 = G + 0.2 * rng.standard_normal(N)
     thetas = [30.0, 3.0]
+    forces = 0.01 * rng.standard_normal(M)
     with hip.Context(yTilde, YTilde) as ctx:
         f_p, grad_p = ctx.logw_fdf(g0, G, 3.0)
         assert ctx.footprint()[0] == {"rowmajor", "strips", "strips_colsum"}
+        ff_p, fg_p = ctx.forces_fdf(forces, w0, 3.0)                    # the forces method's four passes over the same panels
+        yraw_p, _ = ctx.last_average()
         res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, g0, G, LBFGS_CONV)
         monkeypatch.setenv("BIOEN_HIP_DEVICE_LS", "0")
         res_h, w_h, infos_h = ctx.opt_lbfgs_logw_batch(thetas, g0, G, LBFGS_CONV)
@@ -639,6 +642,13 @@ def test_logw_lbfgs_over_row_panels_vs_oracle(hip, M, N, monkeypatch):
     with hip.Context(yTilde, YTilde) as ctx:
         f_s, grad_s = ctx.logw_fdf(g0, G, 3.0)
         assert ctx.footprint()[0] == {"rowmajor"}
+        ff_s, fg_s = ctx.forces_fdf(forces, w0, 3.0)
+        yraw_s, _ = ctx.last_average()
+    ff_o, fg_o, fw_o = O.forces_fdf(forces, w0, yTilde, YTilde, 3.0)
+    assert rel(ff_p, ff_s) < 1e-13 and rel(ff_p, ff_o) < F_RTOL
+    assert np.abs(fg_p - fg_s).max() <= 1e-10 * np.abs(fg_s).max() + 1e-13 * np.abs(yTilde).max() * (abs(ff_o) + 1)
+    assert np.abs(fg_p - fg_o).max() <= 1e-9 * np.abs(fg_o).max() + 1e-13 * np.abs(yTilde).max() * (abs(ff_o) + 1)
+    assert np.abs(yraw_p - yraw_s).max() <= 1e-12 * np.abs(yraw_s).max() and np.abs(yraw_p - yTilde.dot(fw_o)).max() < 1e-11
     f_o, grad_o, _ = O.logw_fdf(g0, G, yTilde, YTilde, 3.0)
     assert rel(f_p, f_s) < 1e-13 and rel(f_p, f_o) < F_RTOL
     assert np.abs(grad_p - grad_s).max() <= 1e-11 * np.abs(grad_s).max()
