@@ -1383,9 +1383,13 @@ int bioen_hip_read_probe(bioen_hip_ctx* c, int form, int reps, double* gbytes_pe
     if (!c || !gbytes_per_s || reps <= 0) return fail(BIOEN_HIP_EINVAL, "bad argument");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     // form: 0 = whichever is resident (strip copy first), 1 = row-major, 2 = row-sum strips, 4 = column-sum strips
-    const double* src = form == 1 ? c->Y : form == 2 ? c->Ys : form == 4 ? c->Ys1 : (c->Ys ? c->Ys : c->Y);
+    // (matrices taller than 1024 rows keep their strip copies as row panels: the first panel stands for the form)
+    const double* ys = c->Ys ? c->Ys : c->Yp[0];
+    const double* ys1 = c->Ys1 ? c->Ys1 : c->Y1p[0];
+    const double* src = form == 1 ? c->Y : form == 2 ? ys : form == 4 ? ys1 : (ys ? ys : c->Y);
     if (!src) return fail(BIOEN_HIP_ESTATE, "that form of the matrix is not resident");
-    const size_t doubles = src == c->Y ? (size_t)c->mp * c->ld : (size_t)(c->ld / 16) * ((size_t)(c->m + 15) / 16 * 16) * 16;
+    const size_t strip_rows_ = (size_t)(std::min(c->m, 1024) + 15) / 16 * 16;
+    const size_t doubles = src == c->Y ? (size_t)c->mp * c->ld : (size_t)(c->ld / 16) * strip_rows_ * 16;
     double* sink = nullptr;
     BIOEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sink), 256 * sizeof(double)));
     hipEvent_t e0 = nullptr, e1 = nullptr;

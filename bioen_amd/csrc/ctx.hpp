@@ -158,7 +158,7 @@ struct bioen_hip_ctx {
 
     double* Y = nullptr;       // mp x ld, row-major: the form data arrive in; M <= 1024: freed once the strip copy Ys
                                // exists (kernels_strip.hip: ensure_strip_copy), back on demand (ensure_rowmajor);
-                               // M > 1024: stays (source of the row panels, read-back, the streaming fallback)
+                               // (M > 1024: the copies are row panels, Yp / Y1p)
     int keep_rowmajor = 0;     // BIOEN_HIP_KEEP_ROWMAJOR=1: never free it (A/B)
     int rowmajor_rebuilt = 0;  // it was freed and has been re-created since
     double* zero_center = nullptr;   // mp zeros: "no centring" for the strip kernels (bioen_hip_chi_squared)
@@ -168,8 +168,7 @@ struct bioen_hip_ctx {
     double* Ys1 = nullptr;           // the same strips in column-sum operand order (log-weights adjoint)
     double* strip_center = nullptr;  // mp: YTilde at the time of the copy
     // M > 1024 (r03): the matrix passes of both methods run the same kernels over PANELS of <= 1024 rows, each with its
-    // own pair of strip copies; the row-major matrix stays (source of the panels, read-back, chi^2, fallback kernels):
-    // 3 x the matrix resident
+    // own pair of strip copies; the row-major matrix is freed once the row-sum panels exist, as for M <= 1024
     static constexpr int kMaxPanels = 16;
     double* Yp[kMaxPanels] = {};     // row-sum order copy of rows [1024 p, 1024 (p + 1))
     double* Y1p[kMaxPanels] = {};    // column-sum order copy

@@ -970,11 +970,11 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
 // row block (cache hits, multiplied with zero operands or never stored), so that every wave runs the same
 // straight-line code and every sum is formed from the same terms in the same order as before.
 static int strip_rows(const bioen_hip_ctx* c) { return (int)round_up((size_t)c->m, 16); }
-// Matrices taller than 1024 rows (r03): the log-weights passes run over row PANELS of <= 1024 rows -- the same two
+// Matrices taller than 1024 rows (r03): the matrix passes run over row PANELS of <= 1024 rows -- the same two
 // kernels once per panel, the forward pass writing its panel's rows of the partial sums, the adjoint pass continuing
 // the column sums of the panels before it.  Until r03 that range ran the r01 streaming kernels (K = 8 forward pass 1.28 x
-// its K = 1 time).  The panels are cut from the row-major matrix, which stays resident (the forces method for M > 1024,
-// read-back and chi^2 use it).
+// its K = 1 time).  The panels are cut from the row-major matrix, which is freed once they exist (read-back and the
+// fallback kernels gather it back from them: gather_block / ensure_rowmajor).
 constexpr int kPanelRows = 1024;
 static int panel_count(const bioen_hip_ctx* c) { return c->mp <= kPanelRows ? 1 : (c->m + kPanelRows - 1) / kPanelRows; }
 static int panel_m(const bioen_hip_ctx* c, int p) { return c->mp <= kPanelRows ? c->m : std::min(kPanelRows, c->m - p * kPanelRows); }   // valid rows
@@ -1029,7 +1029,7 @@ static int strip_copy_failed(bioen_hip_ctx* c, double* ys, hipError_t e, const c
 // strip copies), forces method 1 x.
 int ensure_rowmajor(bioen_hip_ctx* c) {
     if (c->Y) return 0;
-    if (!c->Ys) return BIOEN_HIP_ESTATE;
+    if (!c->Ys && !(paneled(c) && c->Yp[0])) return BIOEN_HIP_ESTATE;
     int rc = 0;
     double* y = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&y), (size_t)c->mp * c->ld * sizeof(double));
@@ -1040,10 +1040,11 @@ int ensure_rowmajor(bioen_hip_ctx* c) {
     }
     e = hipMemsetAsync(y, 0, (size_t)c->mp * c->ld * sizeof(double), c->stream);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
-    if (!rc) {
-        const int mps = strip_rows(c);
-        hipLaunchKernelGGL(k_gather_strips, dim3(4096), dim3(256), 0, c->stream, c->Ys, mps, 0, std::min(mps, c->mp),
-                           (size_t)0, (int)c->ld, y, c->ld);
+    for (int p = 0; p < panel_count(c) && !rc; ++p) {
+        const int mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+        const double* src = paneled(c) ? c->Yp[p] : c->Ys;
+        hipLaunchKernelGGL(k_gather_strips, dim3(4096), dim3(256), 0, c->stream, src, mps, 0, std::min(mps, panel_mp(c, p)),
+                           (size_t)0, (int)c->ld, y + (size_t)p * kPanelRows * c->ld, c->ld);
         e = hipGetLastError();
         if (e != hipSuccess) rc = hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
     }
@@ -1063,6 +1064,19 @@ int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, do
                                         c->ld * sizeof(double), (size_t)cols * sizeof(double), (size_t)rows,
                                         hipMemcpyDeviceToDevice, c->stream);
         return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpy2DAsync", __FILE__, __LINE__);
+    }
+    if (paneled(c)) {                                   // the rows of [row0, row0 + rows) panel by panel
+        if (!c->Yp[0]) return BIOEN_HIP_ESTATE;
+        for (int p = row0 / kPanelRows; p < panel_count(c) && p * kPanelRows < row0 + rows; ++p) {
+            const int lo = std::max(row0, p * kPanelRows), hi = std::min(row0 + rows, (p + 1) * kPanelRows);
+            const size_t total = (size_t)(hi - lo) * cols;
+            hipLaunchKernelGGL(k_gather_strips, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                               c->stream, c->Yp[p], panel_mps(c, p), lo - p * kPanelRows, hi - lo, col0, cols,
+                               out + (size_t)(lo - row0) * cols, (size_t)cols);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
+        }
+        return 0;
     }
     if (!c->Ys) return BIOEN_HIP_ESTATE;
     const size_t total = (size_t)rows * cols;
@@ -1100,7 +1114,8 @@ static int ensure_center(bioen_hip_ctx* c) {
 int ensure_strip_copy(bioen_hip_ctx* c) {
     if (paneled(c)) {                                   // row panels of a matrix taller than 1024 rows; Y stays
         if (c->Yp[0]) return 0;
-        if (c->strips_unavailable || !c->Y) return BIOEN_HIP_ENOMEM;
+        if (c->strips_unavailable) return BIOEN_HIP_ENOMEM;
+        if (!c->Y) return BIOEN_HIP_ESTATE;
         int rc = ensure_center(c);
         if (rc) return rc;
         if (ensure_zero_center(c)) return strip_copy_failed(c, nullptr, hipErrorOutOfMemory, "zero centre");
@@ -1122,6 +1137,12 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
             }
         }
         for (int p = 0; p < panel_count(c); ++p) c->Yp[p] = made[p];
+        if (!c->keep_rowmajor) {                        // the panels hold the same numbers: the row-major form has served
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipFree(c->Y);
+            if (e != hipSuccess) return hip_fail(e, "release of the row-major matrix", __FILE__, __LINE__);
+            c->Y = nullptr;
+        }
         return 0;
     }
     if (c->Ys) return 0;

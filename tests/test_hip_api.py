@@ -317,24 +317,21 @@ def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
         forms, nbytes = ctx.footprint()
         if M <= 1024:
             assert forms == {"strips", "strips_colsum"} and nbytes < 2.2 * unit + (1 << 20)
-        else:                                                  # row panels of <= 1024 rows beside the row-major matrix
-            assert forms == {"rowmajor", "strips", "strips_colsum"} and nbytes < 3.3 * unit + (1 << 20)
+        else:                                                  # row panels of <= 1024 rows, both orders: 2 x as well
+            assert forms == {"strips", "strips_colsum"} and nbytes < 2.2 * unit + (1 << 20)
         assert np.array_equal(ctx.read_ytilde(), Y)                                   # the whole matrix, bit for bit
         assert np.array_equal(ctx.read_ytilde(M // 2, 1, N // 3, 5), Y[M // 2:M // 2 + 1, N // 3:N // 3 + 5])
         chi2, yave = ctx.chi_squared(w_any)
         assert np.abs(yave - Y.dot(w_any)).max() <= 1e-12 * np.abs(Y.dot(w_any)).max()
         assert rel(chi2, 0.5 * np.sum((Y.dot(w_any) - YT) ** 2)) < 1e-12
         f, g = ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
-        if M <= 1024:
-            assert ctx.footprint()[0] == {"strips", "strips_colsum"}                  # the forces passes read the same copy
-        else:
-            assert ctx.footprint()[0] == {"rowmajor", "strips", "strips_colsum"}      # forces beyond 1024 rows: the same panels
+        assert ctx.footprint()[0] == {"strips", "strips_colsum"}                      # the forces passes read the same copies
         assert np.array_equal(ctx.read_ytilde(), Y)
     with bioen_amd.Context(Y, YT) as ctx:                                             # a forces-only context
         ctx.forces_fdf(1e-3 * rng.standard_normal(M), np.full(N, 1.0 / N), 5.0)
         forms, nbytes = ctx.footprint()
-        # M > 1024: both orders of the row panels beside the row-major matrix (the forces method's four passes)
-        assert forms == ({"strips"} if M <= 1024 else {"rowmajor", "strips", "strips_colsum"})
+        # M > 1024: both orders of the row panels (the forces method's four passes: column sums and row sums)
+        assert forms == ({"strips"} if M <= 1024 else {"strips", "strips_colsum"})
         w = ctx.forces_weights(np.zeros(M), np.full(N, 1.0 / N))                      # streaming kernels: row-major again
         assert np.abs(w - 1.0 / N).max() < 1e-18 + 1e-12 / N
         assert np.array_equal(ctx.read_ytilde(), Y)

@@ -622,7 +622,7 @@ def test_logw_lbfgs_over_row_panels_vs_oracle(hip, M, N, monkeypatch):
     forces = 0.01 * rng.standard_normal(M)
     with hip.Context(yTilde, YTilde) as ctx:
         f_p, grad_p = ctx.logw_fdf(g0, G, 3.0)
-        assert ctx.footprint()[0] == {"rowmajor", "strips", "strips_colsum"}
+        assert ctx.footprint()[0] == {"strips", "strips_colsum"}            # the panels have taken the row-major matrix's place
         ff_p, fg_p = ctx.forces_fdf(forces, w0, 3.0)                    # the forces method's four passes over the same panels
         yraw_p, _ = ctx.last_average()
         res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, g0, G, LBFGS_CONV)
