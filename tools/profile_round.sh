@@ -31,6 +31,8 @@ python tools/trace_gaps.py $OUT/small2/small_kernel_trace.csv > $OUT/small_round
 timeout -k 10 300 python tools/ref_margins.py > $OUT/parity_margins.md 2> $OUT/parity_margins.err
 REPS=30 timeout -k 10 200 python tools/strip_probe.py > $OUT/forces_strip_probe.json 2>/dev/null
 FORCES_M=1024 REPS=30 timeout -k 10 200 python tools/strip_probe.py > $OUT/forces_strip_probe_M1024.json 2>/dev/null
+# matrices taller than 1024 rows: the strip kernels over row panels against the r01 streaming kernels (log-weights sweep)
+(SIZES=2048:500000,1536:300000 timeout -k 10 200 python tools/small_timeline.py; echo "-- BIOEN_HIP_PANELS=0 (r01 streaming kernels):"; BIOEN_HIP_PANELS=0 SIZES=2048:500000,1536:300000 timeout -k 10 200 python tools/small_timeline.py) > $OUT/panels.txt 2>&1
 echo "timelines done"
 rm -f $OUT/*/*_kernel_trace.csv $OUT/*/*_counter_collection.csv     # tens of MB; the summaries are what is kept
 tail -1 $OUT/bench_N1.json | cut -c1-400
