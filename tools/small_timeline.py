@@ -28,7 +28,8 @@ for (M, N) in sizes:
         ctx.synchronize()
         ks = ctx.kernel_stats()
         ctx.kernel_stats_enable(False)
-        rounds = ks["forward"]["launches"]
+        panels = (M + 1023) // 1024 if (M > 1024 and os.environ.get("BIOEN_HIP_PANELS") != "0") else 1
+        rounds = ks["forward"]["launches"] // panels       # beyond 1024 rows a pass is one launch per row panel
         mat = ks["forward"]["total_ms"] + ks["adjoint"]["total_ms"]
         print("M=%d N=%d: sweep %.4f s, %d iterations, %d rounds -> %.1f us/round, matrix kernels %.1f us/round (%.0f %%)" % (
             M, N, dt, sum(r["iterations"] for r in res), rounds, 1e6 * dt / rounds, 1e3 * mat / rounds, 100 * mat / (1e3 * dt)))
