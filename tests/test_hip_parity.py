@@ -653,3 +653,29 @@ def test_logw_lbfgs_over_row_panels_vs_oracle(hip, M, N, monkeypatch):
     assert rel(f_p, f_s) < 1e-13 and rel(f_p, f_o) < F_RTOL
     assert np.abs(grad_p - grad_s).max() <= 1e-11 * np.abs(grad_s).max()
     assert np.abs(grad_p - grad_o).max() <= G_RTOL * np.abs(grad_o).max() + 1e-14 * np.abs(yTilde).max() * (abs(f_o) + 1)
+
+
+def test_forces_speculation_on_random_problems_changes_no_bit(hip, monkeypatch):
+    """Twenty random small problems (shapes, priors, theta ladders, all three backtracking searches, odd batch widths):
+    the forces engine with and without speculative chains -- every number identical."""
+    rng = np.random.default_rng(2026)
+    cases = []
+    for _ in range(20):
+        M, N = int(rng.integers(3, 90)), int(rng.integers(40, 700))
+        Y = rng.normal(4.0, 2.0, (M, N))
+        YT = Y.dot(rng.dirichlet(np.ones(N))) + 0.1 * rng.standard_normal(M)
+        w0 = rng.dirichlet(np.ones(N) * 2.0)
+        thetas = list(10.0 ** rng.uniform(-1, 4, int(rng.integers(1, 7))))
+        cases.append((Y, YT, w0, thetas, int(rng.integers(1, 4)), int(rng.integers(1, 9)), 0.02 * rng.standard_normal(M)))
+    outs = {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("BIOEN_HIP_SPECULATE", tag)
+        res_all = []
+        for Y, YT, w0, thetas, ls, mb, f0 in cases:
+            params = dict(LBFGS_DEFAULTS, linesearch=ls, max_iterations=300)
+            with hip.Context(Y, YT) as ctx:
+                res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params, max_batch=mb)
+                res_all.append((res.tobytes(), w.tobytes(),
+                                [(i.fmin, i.chi2, i.kl, i.iterations, i.evaluations, i.lbfgs_code) for i in infos]))
+        outs[tag] = res_all
+    assert outs["1"] == outs["0"]
