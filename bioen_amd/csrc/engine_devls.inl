@@ -88,8 +88,22 @@ int LogwBatchEngine::await_flight(const DevFlight& f) {
 int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride,
                                 const double* G_host, int max_batch, double* results, double* w_opt,
                                 bioen_opt_result* infos) {
-    const int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
+    int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
     const bool can_speculate = speculate && cfg.linesearch >= 1 && cfg.linesearch <= 3;
+    // Shadow policy.  Unsharded contexts take this engine only at sizes where a shadow costs more than it saves (table
+    // in DESIGN 6a): none.  SHARDED contexts (a rank's share of a big matrix) pay two all-gathers per round on top of
+    // the kernels, and a shadow's N-vector work is an eighth of the unsharded one: there the host engine's policy applies
+    // -- two slots kept back from a series that would fill the batch, both steps of the slowest thetas evaluated from
+    // the first search on (engine_logw.inl: 435 -> 406 rounds at the headline).
+    const bool sharded = c->world > 1;
+    double shadow_rate = sharded ? 0.0 : 0.08;
+    int min_evals = sharded ? 0 : 24, max_shadows = sharded ? 2 : 0, reserve = sharded ? 2 : 0;
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOW_RATE")) shadow_rate = std::atof(e);
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOW_MINEV")) min_evals = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(e)));
+    if (const char* e = std::getenv("BIOEN_HIP_DEV_RESERVE")) reserve = std::max(0, std::min(4, std::atoi(e)));
+    if (can_speculate && cfg.linesearch >= 2 && max_shadows >= 2 && reserve > 0 && kb == kMaxBatch && ntheta <= kMaxBatch)
+        kb -= reserve;
     const int nslots = can_speculate ? kMaxBatch : kb;
     for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, s < kb));   // history + spare pair: owners only
     note(ensure_device_state());
@@ -132,13 +146,8 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     unsigned long long release_round[kMaxBatch] = {};      // ... the round in which they lost their owner
     for (int s = 0; s < kMaxBatch; ++s) { prob[s] = -1; shadow_owner[s] = -1; shadow_cand[s] = 0; }
     int seen_ev[kMaxBatch] = {}, seen_dec[kMaxBatch] = {}, seen_inc[kMaxBatch] = {};   // from the newest record of each owner
-    double shadow_rate = 0.08;
-    if (const char* e = std::getenv("BIOEN_HIP_SHADOW_RATE")) shadow_rate = std::atof(e);
-    // default: no shadows -- at the sizes this engine takes by default they cost more than they save (table above);
-    // BIOEN_HIP_SHADOWS=n lets up to n idle slots shadow (tests run the adoption paths that way)
-    int max_positions = kMaxBatch, max_shadows = 0;
+    int max_positions = kMaxBatch;
     if (const char* e = std::getenv("BIOEN_HIP_SHADOW_MAXPOS")) max_positions = std::max(1, std::min((int)kMaxBatch, std::atoi(e)));
-    if (const char* e = std::getenv("BIOEN_HIP_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(e)));
     int next = 0, active = 0;
     std::deque<DevFlight> inflight;
     std::vector<int> start_order(ntheta);            // ascending theta: the slow problems first
@@ -264,7 +273,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             for (int s = 0; s < kb; ++s) {
                 if (!occupied[s] || initial_round[s] >= round) continue;
                 const int rejected = seen_dec[s] + seen_inc[s];
-                if (seen_ev[s] < 24 || rejected < shadow_rate * seen_ev[s]) continue;
+                if (seen_ev[s] < min_evals || rejected < shadow_rate * seen_ev[s]) continue;
                 order[no++] = s;
             }
             std::sort(order, order + no, [&](int x, int y) { return thetas[prob[x]] < thetas[prob[y]]; });

@@ -28,6 +28,22 @@ def main():
     w, logs = ctx.logw_weights(g)
     f, grad = ctx.logw_fdf(g, d["G"], d["theta"])
     res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    spec = ctx.speculation_stats()                 # sharded contexts shadow the slowest thetas' line searches by default
+    os.environ["BIOEN_HIP_SHADOWS"] = "0"          # ... and must land on the same bits without
+    res_ns, wopt_ns, infos_ns = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    del os.environ["BIOEN_HIP_SHADOWS"]
+    same_without = bool(np.array_equal(res, res_ns) and np.array_equal(wopt, wopt_ns) and
+                        [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in infos] ==
+                        [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in infos_ns])
+    # a series that fills the batch: two slots are kept back for the shadows (the headline's shape at 8 GPUs)
+    th8 = [300.0, 100.0, 30.0, 10.0, 3.0, 1.0, 0.3, 0.1]
+    r8, w8, i8 = ctx.opt_lbfgs_logw_batch(th8, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=8)
+    os.environ["BIOEN_HIP_SHADOWS"] = "0"
+    r8n, w8n, i8n = ctx.opt_lbfgs_logw_batch(th8, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=8)
+    del os.environ["BIOEN_HIP_SHADOWS"]
+    same_without = same_without and bool(np.array_equal(r8, r8n) and np.array_equal(w8, w8n) and
+                                         [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in i8] ==
+                                         [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in i8n])
     # the converged run the reference's golden pins (tests/golden: lbfgs_conv_*)
     gconv, wconv, iconv = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_CONV)
     chi2, yave = ctx.chi_squared(w)
@@ -54,6 +70,7 @@ def main():
              ff=ff, fgrad=fgrad, fres=fres, fw=fw, ffmin=np.array([i.fmin for i in finfos]),
              fiters=np.array([i.iterations for i in finfos]), fcodes=np.array([i.lbfgs_code for i in finfos]),
              fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]),
+             spec=np.array(spec), same_without=same_without,
              wconv=wconv, fminconv=iconv.fmin, codeconv=iconv.lbfgs_code,
              fwconv=fwconv, ffminconv=ficonv.fmin, fcodeconv=ficonv.lbfgs_code)
     comm.close()

@@ -14,6 +14,9 @@ VARIANTS = {
     "device-eager": {"BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOWS": "8"},
     "device-noqueue": {"BIOEN_HIP_QUEUE": "0"},
     "device-queue2": {"BIOEN_HIP_QUEUE": "2"},
+    # the policy of sharded contexts (two slots kept back, both steps of the slowest thetas from the first search on), on one GPU
+    "device-reserve": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "2"},
+    "device-shadows0": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "0"},
     "host": {"BIOEN_HIP_DEVICE_LS": "0"},
     "host-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
 }
