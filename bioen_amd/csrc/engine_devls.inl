@@ -90,14 +90,15 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
                                 bioen_opt_result* infos) {
     int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
     const bool can_speculate = speculate && cfg.linesearch >= 1 && cfg.linesearch <= 3;
-    // Shadow policy.  Unsharded contexts take this engine only at sizes where a shadow costs more than it saves (table
-    // in DESIGN 6a): none.  SHARDED contexts (a rank's share of a big matrix) pay two all-gathers per round on top of
-    // the kernels, and a shadow's N-vector work is an eighth of the unsharded one: there the host engine's policy applies
-    // -- two slots kept back from a series that would fill the batch, both steps of the slowest thetas evaluated from
-    // the first search on (engine_logw.inl: 435 -> 406 rounds at the headline).
-    const bool sharded = c->world > 1;
-    double shadow_rate = sharded ? 0.0 : 0.08;
-    int min_evals = sharded ? 0 : 24, max_shadows = sharded ? 2 : 0, reserve = sharded ? 2 : 0;
+    // Shadow policy: none by default.  Unsharded contexts take this engine only at sizes where a shadow costs more than
+    // it saves (table in DESIGN 6a).  On SHARDED contexts a shadow's N-vector work is small, and the host engine's policy
+    // (two slots kept back from a series that would fill the batch, both steps of the slowest thetas from the first
+    // search on: BIOEN_HIP_SHADOWS=2 BIOEN_HIP_SHADOW_RATE=0 BIOEN_HIP_SHADOW_MINEV=0 BIOEN_HIP_DEV_RESERVE=2) takes the
+    // headline from 436 to 407 rounds -- but a round with shadows carries a THIRD all-gather (the late Gram products of
+    // an adopted and accepted shadow, below), which costs more than 6.7 % of a round unless an all-gather takes less
+    // than ~13 us.  Off until the shadows sweep their Gram products in the main pass.
+    double shadow_rate = 0.08;
+    int min_evals = 24, max_shadows = 0, reserve = 0;
     if (const char* e = std::getenv("BIOEN_HIP_SHADOW_RATE")) shadow_rate = std::atof(e);
     if (const char* e = std::getenv("BIOEN_HIP_SHADOW_MINEV")) min_evals = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BIOEN_HIP_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(e)));
