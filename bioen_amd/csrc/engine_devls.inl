@@ -90,15 +90,18 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
                                 bioen_opt_result* infos) {
     int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
     const bool can_speculate = speculate && cfg.linesearch >= 1 && cfg.linesearch <= 3;
-    // Shadow policy: none by default.  Unsharded contexts take this engine only at sizes where a shadow costs more than
-    // it saves (table in DESIGN 6a).  On SHARDED contexts a shadow's N-vector work is small, and the host engine's policy
-    // (two slots kept back from a series that would fill the batch, both steps of the slowest thetas from the first
-    // search on: BIOEN_HIP_SHADOWS=2 BIOEN_HIP_SHADOW_RATE=0 BIOEN_HIP_SHADOW_MINEV=0 BIOEN_HIP_DEV_RESERVE=2) takes the
-    // headline from 436 to 407 rounds -- but a round with shadows carries a THIRD all-gather (the late Gram products of
-    // an adopted and accepted shadow, below), which costs more than 6.7 % of a round unless an all-gather takes less
-    // than ~13 us.  Off until the shadows sweep their Gram products in the main pass.
-    double shadow_rate = 0.08;
-    int min_evals = 24, max_shadows = 0, reserve = 0;
+    // Shadow policy.  Unsharded contexts take this engine only at sizes where a shadow costs more than it saves (table
+    // in DESIGN 6a): none.  SHARDED contexts pay two all-gathers per round on top of the kernels, and a shadow's
+    // N-vector work is a fraction of the unsharded one: there the host engine's policy applies -- two slots kept back
+    // from a series that would fill the batch, both steps of the slowest thetas' searches evaluated from the first round
+    // on (436 -> 407 rounds at the headline) -- with the shadows sweeping their own (s, y) pair and its products in the
+    // main pass (`sgram`): the late Gram pass of an adopted and accepted shadow would be a third all-gather per round,
+    // more than the rounds saved are worth.
+    bool sgram = c->world > 1;
+    if (const char* e = std::getenv("BIOEN_HIP_SHADOW_GRAM")) sgram = std::atoi(e) != 0;      // one-GPU tests of the sharded form
+    const bool sharded_policy = c->world > 1;
+    double shadow_rate = sharded_policy ? 0.0 : 0.08;
+    int min_evals = sharded_policy ? 0 : 24, max_shadows = sharded_policy ? 2 : 0, reserve = sharded_policy ? 2 : 0;
     if (const char* e = std::getenv("BIOEN_HIP_SHADOW_RATE")) shadow_rate = std::atof(e);
     if (const char* e = std::getenv("BIOEN_HIP_SHADOW_MINEV")) min_evals = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("BIOEN_HIP_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(e)));
@@ -106,7 +109,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     if (can_speculate && cfg.linesearch >= 2 && max_shadows >= 2 && reserve > 0 && kb == kMaxBatch && ntheta <= kMaxBatch)
         kb -= reserve;
     const int nslots = can_speculate ? kMaxBatch : kb;
-    for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, s < kb));   // history + spare pair: owners only
+    for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, s < kb || sgram));   // history: owners; spare pair: owners (shadows too when they sweep their own)
     note(ensure_device_state());
     if (rc) return rc;
     note(upload_n(c, c->fixed, G_host));
@@ -329,6 +332,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
                 }
         }
         r.n = k;
+        r.sgram = sgram ? 1 : 0;
         Vec8 wv{};
         MVec8 av{}, sv{};
         Round rd{};
@@ -394,7 +398,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));
         }
         launch_dev_decide(c, r, cfg, round);
-        if (r.n > r.nown) {                         // a round with shadows: one of them may have been adopted and accepted
+        if (r.n > r.nown && !sgram) {               // a round with shadows: one of them may have been adopted and accepted
             launch_dev_late_gram(c, r);
             if (c->world > 1) note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
             else note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));

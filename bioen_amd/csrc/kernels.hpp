@@ -238,6 +238,8 @@ struct DevRound {                     // a round as the kernels see it (by value
     double* a[kMaxBatch];             //   adjoint output
     double* scal[kMaxBatch];          //   scalar slot
     DevSlot* tab;                     // ctx->dev_tab
+    int sgram;                        // shadows sweep their own (s, y) pair and its 39 products in the main pass (sharded
+                                      // contexts: no late Gram pass, no third all-gather); they own a spare pair then
 };
 
 struct DevStart {                     // (re)start of problems: by value to k_dev_start

@@ -254,8 +254,9 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
     const double Pp = r.scal[a][S_P];
     const double inv = r.scal[a][S_INV];      // w = e * inv
     // the evaluation of the start point has no pair to form; a shadow's is formed only if it is adopted AND accepted
-    // (k_dev_late_gram): 14 vector passes per shadow and round for a pair that is used once in ten rounds
-    const bool gram = ost == DS_RUNNING && r.cand[a] == 0;
+    // (k_dev_late_gram): 14 vector passes per shadow and round for a pair that is used once in ten rounds -- unless the
+    // round says otherwise (r.sgram: sharded contexts, where those passes are short and the late pass costs an all-gather)
+    const bool gram = ost == DS_RUNNING && (r.cand[a] == 0 || r.sgram);
     const int e = T.m.end;                    // history slot the pair would take
     const double* __restrict__ xo_ = T.xp;
     const double* __restrict__ go = T.gp;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_gram_reduce(DevRound r, Xch xi) 
     __shared__ double sh[kWaves];
     const int c = blockIdx.x, a = blockIdx.y;
     int ost;
-    if (!dev_pos_live(r, a, &ost) || ost != DS_RUNNING || r.cand[a] != 0) return;
+    if (!dev_pos_live(r, a, &ost) || ost != DS_RUNNING || (r.cand[a] != 0 && !r.sgram)) return;
     const double v = xsum<kGramDots>(xi, a, c, sh);
     if (threadIdx.x == 0) r.gram[a][kGramSums + c] = v;
 }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_rank_reduce(DevRound r, Xch xg, 
     if (!dev_pos_live(r, a, &ost)) return;
     double v = 0.0;
     if (c < kGramDots) {
-        if (ost == DS_RUNNING && r.cand[a] == 0) v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
+        if (ost == DS_RUNNING && (r.cand[a] == 0 || r.sgram)) v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
     } else {
         v = xsum_rank<3>(xg, xg.rank, a, c - kGramDots, sh);
     }
@@ -553,11 +554,16 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
             } else {
                 dev_three_sums(xg, adopt, sh3, sums);
             }
+            if (r.sgram) dev_gram_dots<MODE>(r, xm, adopt, dots);     // the shadow swept its own pair: its 39 products
             if (threadIdx.x == 0) {
                 DevSlot* Q = r.tab + r.slot[adopt];           // the shadow's entry (nobody else touches it in this kernel)
                 double* t;
                 t = T.x; T.x = Q->x; Q->x = t;                 // the shadow's point and gradient become the trial's
                 t = T.g; T.g = Q->g; Q->g = t;
+                if (r.sgram) {                                 // ... and its pending (s, y) pair the problem's
+                    t = T.Ssp; T.Ssp = Q->Ssp; Q->Ssp = t;
+                    t = T.Ysp; T.Ysp = Q->Ysp; Q->Ysp = t;
+                }
                 const double* qs = r.scal[adopt];
                 // the evaluation-owned entries of a slot's scalars (the rest -- y.s, alpha, gp.d -- belongs to the problem)
                 for (int i = S_F; i < S_F + 4; ++i) scs[i] = qs[i];
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
         if (threadIdx.x == 0) {
             if (kind == ACT_ACCEPT) {
                 const int e = ctl[2];
-                if (evalpos == a) {
+                if (evalpos == a || r.sgram) {
                     // the LDS image is also the destination of the update (a single lane's ~90 stores to HBM would
                     // sit in front of the publishing fence): the block writes it back below
                     gram_solve_thread0(Gs, Gs, dots, alpha, e, ctl[3], scs);

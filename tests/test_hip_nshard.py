@@ -46,7 +46,7 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
         assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
 
-    # the sharded engine's speculative trials (opt-in: two slots' worth for the slowest thetas) ran, were adopted, and changed no bit
+    # the sharded engine's speculative trials (two slots' worth for the slowest thetas) ran, were adopted, and changed no bit
     for r in range(world):
         assert bool(z[r]["same_without"]) and z[r]["spec"][0] > 0 and z[r]["spec"][1] > 0, (r, z[r]["spec"])
 

@@ -548,6 +548,10 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
     code = _SPEC_SNIPPET % dict(root=ROOT, tests=os.path.join(ROOT, "tests"), name=name, mb=mb)
     variants = {"default": {}, "nospec": {"BIOEN_HIP_SPECULATE": "0"}, "nodelivery": {"BIOEN_HIP_DELIVERY": "0"},
                 "device": {"BIOEN_HIP_DEVICE_LS": "1"}, "device-shadows": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0.02"},
+                # the sharded contexts' form of it on one GPU: shadows sweep their own (s, y) pair (no late Gram pass), from
+                # the first search on, two slots kept back from a series that fills the batch
+                "device-sgram": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0",
+                                 "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "2", "BIOEN_HIP_SHADOW_GRAM": "1"},
                 # the helper thread's timing decides which slots are free for shadows: without speculation AND
                 # without it the schedule is the plainest one
                 "plain": {"BIOEN_HIP_SPECULATE": "0", "BIOEN_HIP_DELIVERY": "0"},
@@ -568,7 +572,7 @@ def test_speculative_line_search_changes_no_bit(hip, name, mb):
     on = runs["default"]
     for tag in ("nospec", "plain", "hostls-nospec", "default", "device"):
         assert runs[tag]["stats"] == [0, 0], tag
-    for tag in ("hostls", "noqueue", "eager"):
+    for tag in ("hostls", "noqueue", "eager", "device-sgram"):
         assert runs[tag]["stats"][0] > 0 and runs[tag]["stats"][1] > 0, (tag, runs[tag]["stats"])   # issued and adopted
     for tag, other in runs.items():
         for ls in ("2", "3", "1", "0"):
