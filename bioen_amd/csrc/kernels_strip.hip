@@ -555,11 +555,16 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
 #pragma unroll
         for (int i = 0; i < WR / 8; ++i) choff[i] = __builtin_amdgcn_readfirstlane(((i >> 1) < nh ? i : (i & 1)) * 128);
     }
-    auto fetch = [&](int strip) {
+    auto fetch_part = [&](int strip, int lo, int hi) {
         const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < WR / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+        for (int i = 0; i < WR / 8; ++i)
+            if (i >= lo && i < hi) pre[i] = ldg2<NT>(src + choff[i]);
     };
+    auto fetch = [&](int strip) { fetch_part(strip, 0, WR / 8); };
+    // K > 4: the operand batches of the column-sum product do not fit beside a3 AND the whole prefetch (7-12 registers
+    // spilled per strip); the second half of the prefetch is issued behind that product instead
+    constexpr int SPLIT = NK > 1 ? WR / 16 : WR / 8;
     const int G = gridDim.x;
     auto one_strip = [&](int s) {
         // the strip's centred values: the row-sum operands of P3, and the source of the LDS image below
@@ -581,7 +586,8 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        fetch(s + G < q.nstrips ? s + G : s);      // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
+        const int nxt = s + G < q.nstrips ? s + G : s;
+        fetch_part(nxt, 0, SPLIT);                 // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k], half by half through the LDS image ----
         {
             // four chains over the row groups (the result latency is 3 issues) for EVERY K: a problem's sums must not
@@ -613,8 +619,9 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
                 const double* pu = ul + (size_t)(rbase + 64 * half + lq) * 8 + lj;
-                // operand batches that fit beside a3 and the prefetch (K > 4, batches of 4 | 2 | 1: 27-31 | 7-12 | 8-9 registers
-                // spilled; pass 1 / pass 2 at N = 1e6 x M = 1024, K = 8: 1.66 / 1.45 | 1.50 / 1.39 | 1.51 / 1.41 ms)
+                // operand batches that fit beside a3 and the prefetch (K > 4 with the WHOLE prefetch in flight here, batches of
+                // 4 | 2 | 1: 27-31 | 7-12 | 8-9 registers spilled; pass 1 / pass 2 at N = 1e6 x M = 1024, K = 8: 1.66 / 1.45 |
+                // 1.50 / 1.39 | 1.51 / 1.41 ms; with the prefetch split around this product (SPLIT): none, 1.30 / 1.19 ms)
                 constexpr int GB = NK > 1 ? STRIP2_GB2 : 8, NB = 16 / GB;
 #pragma unroll
                 for (int hb = 0; hb < NB; ++hb) {
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
             for (int kq = 0; kq < NK; ++kq)
                 red[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
         }
+        if (SPLIT < WR / 8) fetch_part(nxt, SPLIT, WR / 8);
         __syncthreads();
         // ---- P2 ----
         if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
