@@ -113,6 +113,14 @@ _SIGNATURES = {
     "bioen_hip_exchange_probe": (C.c_int, [ctx_p, C.c_size_t, C.c_int, dp]),
     "bioen_hip_read_probe": (C.c_int, [ctx_p, C.c_int, C.c_int, dp, C.POINTER(C.c_longlong)]),
     "bioen_hip_comm_destroy": (C.c_int, [ctx_p]),
+    "bioen_hip_p2p_export": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte)]),
+    "bioen_hip_p2p_attach": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte)]),
+    "bioen_hip_p2p_detach": (C.c_int, [ctx_p]),
+    "bioen_hip_exchange_transport": (C.c_int, [ctx_p]),
+    "bioen_hip_exchange_selftest": (C.c_int, [ctx_p, C.c_int, C.POINTER(C.c_longlong)]),
+    "bioen_hip_exchange_counts3": (C.c_int, [ctx_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                             C.POINTER(C.c_longlong)]),
+    "bioen_hip_ctx_set_wait_timeout": (C.c_int, [ctx_p, C.c_double]),
 }
 
 _lib = None
@@ -621,6 +629,50 @@ class Context(object):
 
     def comm_destroy(self):
         check(lib().bioen_hip_comm_destroy(self._h))
+
+    # -- peer-to-peer stage exchange (hipIpc mailboxes, one kernel per all-gather) ------------------
+    def p2p_export(self):
+        """64-byte hipIpc handle of this rank's mailbox (allocated on first call)"""
+        buf = (C.c_ubyte * 64)()
+        check(lib().bioen_hip_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_attach(self, handles):
+        """handles: the `world` mailbox handles in rank order (this rank's own is ignored); None for world = 1"""
+        if handles is None:
+            check(lib().bioen_hip_p2p_attach(self._h, None))
+            return
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) != 64 * self.world:
+            raise ValueError("p2p_attach needs world = %d handles of 64 bytes" % self.world)
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        check(lib().bioen_hip_p2p_attach(self._h, buf))
+
+    def p2p_detach(self):
+        check(lib().bioen_hip_p2p_detach(self._h))
+
+    TRANSPORTS = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
+
+    def exchange_transport(self):
+        """'none' | 'rccl' | 'host' | 'p2p': what the next stage exchange of this context goes through"""
+        return self.TRANSPORTS[lib().bioen_hip_exchange_transport(self._h)]
+
+    def exchange_selftest(self, reps=40):
+        """`reps` back-to-back stage exchanges of varying size with a (rank, exchange, index) pattern, checked on the
+        device; -> number of wrong doubles (0 = the active transport delivers)"""
+        bad = C.c_longlong(0)
+        check(lib().bioen_hip_exchange_selftest(self._h, int(reps), C.byref(bad)))
+        return bad.value
+
+    def exchange_counts3(self):
+        """(RCCL, host callback, peer-to-peer): stage all-gathers executed on this context so far"""
+        a, b, c3 = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        check(lib().bioen_hip_exchange_counts3(self._h, C.byref(a), C.byref(b), C.byref(c3)))
+        return a.value, b.value, c3.value
+
+    def set_wait_timeout(self, seconds):
+        """bound (s) of every wait on a round or a peer; past it the call fails instead of hanging"""
+        check(lib().bioen_hip_ctx_set_wait_timeout(self._h, float(seconds)))
 
     def comm_allgather(self, send, nranks):
         send = as_f64(send).ravel()

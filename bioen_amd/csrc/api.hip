@@ -152,6 +152,10 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     // stream yTilde with non-temporal loads once it no longer fits the 256 MiB Infinity Cache
     c->nontemporal = (size_t)c->mp * c->ld * sizeof(double) > (size_t)192 * 1024 * 1024;
     if (const char* e = std::getenv("BIOEN_HIP_FORCE_EXCHANGE")) c->force_exchange = (e[0] == '1') ? 1 : 0;
+    if (const char* e = std::getenv("BIOEN_HIP_WAIT_TIMEOUT")) {      // seconds; bound of every wait on a round or an exchange
+        const double v = std::atof(e);
+        if (v > 0.0) c->wait_timeout_s = v;
+    }
     {
         const char* e = std::getenv("BIOEN_HIP_STRIP_OLD");
         c->strip_old = (e && e[0] == '1') ? 1 : 0;
@@ -238,18 +242,107 @@ static int upload_n(bioen_hip_ctx* c, double* dst, const double* src) {
 }
 
 static int rccl_allgather_inplace(bioen_hip_ctx* c, double* base, size_t count);   // defined with the RCCL glue
+static int rccl_async_error(bioen_hip_ctx* c);      // != 0: the communicator reports a failure (last_error set)
+static void rccl_abort(bioen_hip_ctx* c);           // ncclCommAbort: kernels of a collective a dead peer left hanging return
+
+// What went wrong asynchronously on this context's transports since the last look: the error word of the peer-to-peer
+// exchange kernels (kernels_p2p.hip) and the RCCL communicator's own.  0 = nothing.
+static int transport_error(bioen_hip_ctx* c) {
+    if (c->p2p_err) {
+        const unsigned long long w = __atomic_load_n(c->p2p_err, __ATOMIC_ACQUIRE);
+        if (w) {
+            static const char* const why[] = {"?", "timed out waiting for", "received an ABORT flag from", "an earlier exchange failed; peer"};
+            char buf[256];
+            std::snprintf(buf, sizeof buf, "peer-to-peer exchange %llu (stage %d): %s rank %d (BIOEN_HIP_WAIT_TIMEOUT = %g s)",
+                          w & 0xffffffffffull, (int)((w >> 52) & 0xff), why[std::min<unsigned long long>(3, w >> 60)],
+                          (int)((w >> 40) & 0xfff), c->wait_timeout_s);
+            c->failed = 1;
+            return fail(BIOEN_HIP_ERCCL, buf);
+        }
+    }
+    if (c->comm) {
+        const int rc = rccl_async_error(c);
+        if (rc) {
+            c->failed = 1;
+            return rc;
+        }
+    }
+    return 0;
+}
+
+// A bounded host wait on a word a kernel publishes (the live pages of the engines).  tick() is called once per look at
+// the word: it spins politely (pause, later yield), and every 4096 looks asks the stream (a failed launch ends the wait
+// with its error), the transports (above) and the clock: past c->wait_timeout_s the wait fails with BIOEN_HIP_ERCCL
+// on a context that exchanges (a peer is gone: the communicator is aborted so that its kernel returns) and BIOEN_HIP_EHIP
+// otherwise -- never a hang.
+struct BoundedWait {
+    bioen_hip_ctx* c;
+    const char* what;
+    unsigned spins = 0;
+    bool armed = false;
+    std::chrono::steady_clock::time_point deadline;
+    BoundedWait(bioen_hip_ctx* ctx, const char* w) : c(ctx), what(w) {}
+    // published(): re-reads the word; -> 0 keep waiting, 1 it is there, < 0 failure
+    template <class Pred>
+    int tick(Pred published) {
+        ++spins;
+        if ((spins & 0xfffu) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (published()) return 1;
+                const int te = transport_error(c);
+                if (te) return te;
+                return fail(BIOEN_HIP_ESTATE, "round finished without publishing its results");
+            }
+            if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            const int te = transport_error(c);
+            if (te) return te;
+            const auto now = std::chrono::steady_clock::now();
+            if (!armed) {
+                armed = true;
+                deadline = now + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                     std::chrono::duration<double>(c->wait_timeout_s + (c->p2p_on ? 2.0 : 0.0)));
+            } else if (now > deadline) {
+                char buf[200];
+                std::snprintf(buf, sizeof buf, "timed out after %g s waiting for %s (BIOEN_HIP_WAIT_TIMEOUT)",
+                              c->wait_timeout_s, what);
+                c->failed = 1;
+                const bool exchanging = c->world > 1 || c->comm || c->exchange_cb || c->p2p_on;
+                if (c->comm) rccl_abort(c);
+                return fail(exchanging ? BIOEN_HIP_ERCCL : BIOEN_HIP_EHIP, buf);
+            }
+        }
+        if (spins < 20000u) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
+        } else {
+            std::this_thread::yield();
+        }
+        return 0;
+    }
+};
 
 // One in-place all-gather of an exchange stage ([world][payload] doubles).  world == 1: nothing.
 // world == 1 with force_exchange (bioen_hip_ctx_set_force_exchange / BIOEN_HIP_FORCE_EXCHANGE=1) and a communicator
 // or callback in place: the one-rank all-gather is executed all the same -- a copy of the rank's segment onto
 // itself, same bits -- so the stage path can run under test on a single GPU.
 static bool exchanges_forced(const bioen_hip_ctx* c) {
-    return c->world == 1 && c->force_exchange && (c->comm || c->exchange_cb);
+    return c->world == 1 && c->force_exchange && (c->comm || c->exchange_cb || c->p2p_on);
 }
 
 static int exchange(bioen_hip_ctx* c, int stage, size_t payload) {
     if (c->world == 1 && !exchanges_forced(c)) return 0;
+    if (c->failed) return fail(BIOEN_HIP_ESTATE, "an earlier exchange on this context failed; destroy it");
     double* base = c->xbuf[stage];
+    if (c->p2p_on) {          // stores into the peers' mailboxes + flags, one kernel (kernels_p2p.hip)
+        if (payload > c->p2p_cap) return fail(BIOEN_HIP_EINVAL, "exchange payload exceeds the mailbox slot");
+        ++c->n_p2p_exchanges;
+        launch_p2p_exchange(c, stage, payload);
+        return 0;
+    }
     if (c->comm) {
         ++c->n_rccl_exchanges;
         return rccl_allgather_inplace(c, base, payload);
@@ -302,7 +395,7 @@ static int read_scalars(bioen_hip_ctx* c, int nslots = 1) {
     BIOEN_HIP_CHECK(hipMemcpyAsync(c->host_scal, c->scal, (size_t)nslots * kScalStride * sizeof(double),
                                    hipMemcpyDeviceToHost, c->stream));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return 0;
+    return transport_error(c);      // scalars behind a failed exchange are not results
 }
 
 // The scalars of a round whose last kernel published them live (k_finish_eval): wait for the n flags to reach the
@@ -311,18 +404,12 @@ static int read_scalars(bioen_hip_ctx* c, int nslots = 1) {
 static int await_live(bioen_hip_ctx* c, unsigned long long round, const int* slots, int n) {
     const volatile unsigned long long* flag =
         reinterpret_cast<const volatile unsigned long long*>(c->live + (size_t)kMaxBatch * kScalStride);
+    BoundedWait w(c, "a round's scalars (log-weights engine)");
     for (int a = 0; a < n; ++a) {
-        unsigned spins = 0;
         while (flag[a] != round) {
-            if ((++spins & 0xfffu) == 0) {
-                const hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess) {
-                    if (flag[a] == round) break;
-                    return fail(BIOEN_HIP_ESTATE, "round finished without publishing its scalars");
-                }
-                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
-            }
-            __builtin_ia32_pause();
+            const int t = w.tick([&] { return flag[a] == round; });
+            if (t < 0) return t;
+            if (t > 0) break;
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -790,7 +877,19 @@ int bioen_hip_ctx_shard(const bioen_hip_ctx* c, int* rank, int* world, long long
 int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
+    if (c->stream && c->comm) {      // a collective a dead peer left hanging must not hang the destructor: bounded, then abort
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(c->failed ? 0.0 : c->wait_timeout_s);
+        while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() > deadline) {
+                c->failed = 1;
+                rccl_abort(c);
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
     if (c->stream) hipStreamSynchronize(c->stream);
+    bioen_hip_p2p_detach(c);
     bioen_hip_comm_destroy(c);
     resolve_timers(c);
     for (auto& p : c->timer.pool) {
@@ -1257,6 +1356,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                         // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -1279,6 +1380,8 @@ int load_rccl() {
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
+    g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return fail(BIOEN_HIP_ERCCL, "librccl.so lacks a required symbol");
     g_rccl.h = h;
@@ -1301,6 +1404,27 @@ static int rccl_allgather_inplace(bioen_hip_ctx* c, double* base, size_t count) 
                                       static_cast<ncclComm_t>(c->comm), c->stream);
     if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather");
     return 0;
+}
+
+// the communicator's asynchronous state (a peer that died, a transport error): polled from the bounded waits
+static int rccl_async_error(bioen_hip_ctx* c) {
+    if (!c->comm || !g_rccl.CommGetAsyncError) return 0;
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t r = g_rccl.CommGetAsyncError(static_cast<ncclComm_t>(c->comm), &st);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclCommGetAsyncError");
+    if (st != ncclSuccess && st != ncclInProgress) {
+        const int rc = rccl_fail(st, "RCCL communicator (asynchronous error)");
+        rccl_abort(c);
+        return rc;
+    }
+    return 0;
+}
+
+static void rccl_abort(bioen_hip_ctx* c) {
+    if (!c->comm) return;
+    if (g_rccl.CommAbort) g_rccl.CommAbort(static_cast<ncclComm_t>(c->comm));    // frees the communicator as well
+    else if (g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->comm));
+    c->comm = nullptr;
 }
 }  // namespace bioen
 
@@ -1375,8 +1499,37 @@ int bioen_hip_exchange_probe(bioen_hip_ctx* c, size_t count, int reps, double* u
     for (int i = 0; i < reps && !rc; ++i) rc = exchange(c, X_YBAR, count);
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if ((rc = transport_error(c))) return rc;
     *usec_per_exchange = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
     return 0;
+}
+
+int bioen_hip_exchange_selftest(bioen_hip_ctx* c, int reps, long long* mismatches) {
+    if (!c || !mismatches || reps <= 0) return fail(BIOEN_HIP_EINVAL, "bad argument");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    unsigned long long* bad = nullptr;
+    BIOEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bad), sizeof *bad));
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof *bad, c->stream);
+    int rc = e == hipSuccess ? 0 : hip_fail(e, "memset", __FILE__, __LINE__);
+    // payloads of every shape the stages use: odd and even counts, a few doubles to the whole slot, back to back
+    const size_t cap = c->xcap[X_YBAR];
+    const size_t sizes[] = {1, 2, 3, 42, 169, 336, 1027, cap / 2, cap > 1 ? cap - 1 : 1, cap};
+    for (int rep = 0; rep < reps && !rc; ++rep) {
+        const size_t payload = std::max<size_t>(1, std::min(cap, sizes[rep % (sizeof sizes / sizeof *sizes)]));
+        launch_xch_fill(c, X_YBAR, (int)payload, rep);
+        rc = exchange(c, X_YBAR, payload);
+        if (!rc) launch_xch_check(c, X_YBAR, (int)payload, rep, bad);
+    }
+    unsigned long long h = 0;
+    if (!rc) {
+        e = hipMemcpyAsync(&h, bad, sizeof h, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "exchange self-test", __FILE__, __LINE__);
+    }
+    if (!rc) rc = transport_error(c);
+    (void)hipFree(bad);
+    *mismatches = (long long)h;
+    return rc;
 }
 
 int bioen_hip_read_probe(bioen_hip_ctx* c, int form, int reps, double* gbytes_per_s, long long* bytes) {
@@ -1415,8 +1568,144 @@ int bioen_hip_read_probe(bioen_hip_ctx* c, int form, int reps, double* gbytes_pe
     return 0;
 }
 
+
+// ---- peer-to-peer stage exchange (kernels_p2p.hip) ------------------------------------------------------------
+int bioen_hip_p2p_export(bioen_hip_ctx* c, unsigned char handle[64]) {
+    if (!c || !handle) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    if (c->p2p_on) return fail(BIOEN_HIP_ESTATE, "peer-to-peer exchange already attached");
+    if (!c->p2p_box) {
+        size_t cap = 0;
+        for (int st = 0; st < X_COUNT; ++st) cap = std::max(cap, c->xcap[st]);
+        cap = round_up(cap, 2);
+        const size_t doubles = p2p_mailbox_doubles(c->world, cap);
+        void* p = nullptr;
+        // uncached: a polling wave must see what a peer's store put into this GPU's memory, not a line its L2 kept
+        hipError_t e = hipExtMallocWithFlags(&p, doubles * sizeof(double), hipDeviceMallocUncached);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipExtMallocWithFlags(&p, doubles * sizeof(double), hipDeviceMallocFinegrained);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            hip_fail(e, "hipExtMallocWithFlags (mailbox)", __FILE__, __LINE__);
+            return BIOEN_HIP_ENOMEM;
+        }
+        c->p2p_box = static_cast<double*>(p);
+        c->p2p_cap = cap;
+        c->p2p_bytes = doubles * sizeof(double);
+        BIOEN_HIP_CHECK(hipMemsetAsync(c->p2p_box, 0, c->p2p_bytes, c->stream));
+        BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    hipIpcMemHandle_t h;
+    BIOEN_HIP_CHECK(hipIpcGetMemHandle(&h, c->p2p_box));
+    std::memcpy(handle, &h, 64);
+    return 0;
+}
+
+int bioen_hip_p2p_detach(bioen_hip_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    c->p2p_on = 0;
+    if (c->p2p_err && __atomic_load_n(c->p2p_err, __ATOMIC_ACQUIRE) && !c->comm)
+        c->failed = 0;      // the failure was this transport's; the stream has drained and the transport goes: usable again
+    for (int r = 0; r < 128; ++r)
+        if (c->p2p_mapped[r]) {
+            hipIpcCloseMemHandle(c->p2p_mapped[r]);
+            c->p2p_mapped[r] = nullptr;
+        }
+    if (c->p2p_peers) hipFree(c->p2p_peers);
+    c->p2p_peers = nullptr;
+    if (c->p2p_box) hipFree(c->p2p_box);
+    c->p2p_box = nullptr;
+    if (c->p2p_err) hipHostFree(c->p2p_err);
+    c->p2p_err = nullptr;
+    if (c->p2p_dev_err) hipFree(c->p2p_dev_err);
+    c->p2p_dev_err = nullptr;
+    c->p2p_seq = 0;
+    (void)hipGetLastError();
+    return 0;
+}
+
+int bioen_hip_p2p_attach(bioen_hip_ctx* c, const unsigned char* handles) {
+    if (!c || (!handles && c->world > 1)) return fail(BIOEN_HIP_EINVAL, "NULL argument");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    if (c->p2p_on) return fail(BIOEN_HIP_ESTATE, "peer-to-peer exchange already attached");
+    if (!c->p2p_box) return fail(BIOEN_HIP_ESTATE, "bioen_hip_p2p_export first");
+    std::vector<double*> peers((size_t)c->world, nullptr);
+    int rc = 0;
+    for (int r = 0; r < c->world && !rc; ++r) {
+        if (r == c->rank) {
+            peers[r] = c->p2p_box;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "hipIpcOpenMemHandle of rank %d's mailbox failed: %s", r, hipGetErrorString(e));
+            rc = fail(BIOEN_HIP_ERCCL, buf);
+            break;
+        }
+        c->p2p_mapped[r] = p;
+        peers[r] = static_cast<double*>(p);
+    }
+    if (!rc && !c->p2p_err) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->p2p_err), 64, hipHostMallocCoherent | hipHostMallocMapped);
+        if (e == hipSuccess) {
+            std::memset(c->p2p_err, 0, 64);
+            e = hipMalloc(reinterpret_cast<void**>(&c->p2p_dev_err), 64);
+        }
+        if (e == hipSuccess) e = hipMemset(c->p2p_dev_err, 0, 64);
+        if (e != hipSuccess) rc = hip_fail(e, "error words of the peer-to-peer exchange", __FILE__, __LINE__);
+    }
+    if (!rc) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->p2p_peers), (size_t)c->world * sizeof(double*));
+        if (e == hipSuccess)
+            e = hipMemcpy(c->p2p_peers, peers.data(), (size_t)c->world * sizeof(double*), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "peer table", __FILE__, __LINE__);
+    }
+    if (rc) {
+        const std::string keep = g_last_error;
+        bioen_hip_p2p_detach(c);
+        g_last_error = keep;
+        return rc;
+    }
+    c->p2p_seq = 0;
+    c->p2p_on = 1;
+    return 0;
+}
+
+int bioen_hip_exchange_transport(const bioen_hip_ctx* c) {
+    if (!c) return -1;
+    if (c->p2p_on) return 3;
+    if (c->comm) return 1;
+    if (c->exchange_cb) return 2;
+    return 0;
+}
+
+int bioen_hip_exchange_counts3(const bioen_hip_ctx* c, long long* rccl, long long* host_staged, long long* p2p) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    if (rccl) *rccl = c->n_rccl_exchanges;
+    if (host_staged) *host_staged = c->n_host_exchanges;
+    if (p2p) *p2p = c->n_p2p_exchanges;
+    return 0;
+}
+
+int bioen_hip_ctx_set_wait_timeout(bioen_hip_ctx* c, double seconds) {
+    if (!c || !(seconds > 0.0)) return fail(BIOEN_HIP_EINVAL, "bad argument");
+    c->wait_timeout_s = seconds;
+    return 0;
+}
+
 int bioen_hip_comm_destroy(bioen_hip_ctx* c) {
     if (!c) return 0;
+    if (c->comm && c->failed) rccl_abort(c);      // a destroy would wait for peers that may be gone
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(c->comm));
     c->comm = nullptr;
     if (c->comm_buf) hipFree(c->comm_buf);

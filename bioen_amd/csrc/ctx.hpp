@@ -153,6 +153,24 @@ struct bioen_hip_ctx {
     int force_exchange = 0;              // world == 1: run the stage exchanges all the same (through the communicator or the
                                          // callback, if there is one) -- puts the RCCL stage path under single-GPU tests
     long long n_rccl_exchanges = 0, n_host_exchanges = 0;   // stage all-gathers executed so far, by transport
+    long long n_p2p_exchanges = 0;
+    // Peer-to-peer stage exchange (r04; kernels_p2p.hip): every rank owns a MAILBOX in its HBM -- two halves (by the
+    // parity of the exchange number) of `world` slots of p2p_cap doubles, behind 2 x world flags -- which every peer
+    // maps through hipIpc.  One small kernel per exchange: block p stores this rank's segment into peer p's mailbox,
+    // releases the exchange number into p's flag for this rank (system scope), waits for p's flag in its OWN mailbox and
+    // copies p's segment into the stage buffer.  No collective launch, no host.  A wait is bounded (wait_timeout_s): on
+    // expiry the kernel records the failure in p2p_err / p2p_dev_err and every later exchange publishes an ABORT flag.
+    double* p2p_box = nullptr;               // this rank's mailbox (uncached / fine-grained device memory)
+    size_t p2p_cap = 0;                      // doubles per slot
+    size_t p2p_bytes = 0;
+    double** p2p_peers = nullptr;            // device array [world]: every rank's mailbox as mapped here ([rank] = p2p_box)
+    void* p2p_mapped[128] = {};              // what hipIpcOpenMemHandle returned per peer (closed by p2p_detach)
+    unsigned long long p2p_seq = 0;          // exchanges issued so far
+    int p2p_on = 0;                          // attached: exchange() uses this transport
+    unsigned long long* p2p_err = nullptr;   // host-mapped: first failure of an exchange kernel (0 = none)
+    unsigned long long* p2p_dev_err = nullptr;   // the same word in device memory (read by the later kernels)
+    double wait_timeout_s = 60.0;            // BIOEN_HIP_WAIT_TIMEOUT: bound of every host and device wait on a round
+    int failed = 0;                          // a wait expired or a transport failed: every later call returns at once
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // results of finished problems leave on this one (engine_logw.inl: deliveries)
 

@@ -67,18 +67,12 @@ int LogwBatchEngine::await_flight(const DevFlight& f) {
     const volatile unsigned long long* flag =
         reinterpret_cast<const volatile unsigned long long*>(c->live2 + (size_t)kLiveRing * kMaxBatch * kLiveRec) +
         (size_t)pg * kMaxBatch;
+    BoundedWait w(c, "a round's decisions (device-resident engine)");
     for (int a = 0; a < f.nown; ++a) {
-        unsigned spins = 0;
         while (flag[a] != f.round) {
-            if ((++spins & 0xfffu) == 0) {
-                const hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess) {
-                    if (flag[a] == f.round) break;
-                    return fail(BIOEN_HIP_ESTATE, "round finished without publishing its decisions");
-                }
-                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
-            }
-            __builtin_ia32_pause();
+            const int t = w.tick([&] { return flag[a] == f.round; });
+            if (t < 0) return t;
+            if (t > 0) break;
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);

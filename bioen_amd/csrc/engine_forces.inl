@@ -101,17 +101,11 @@ struct ForcesBatchEngine {
         const size_t scal_at = (size_t)c->mp * kMaxBatch;
         const volatile unsigned long long* flag =
             reinterpret_cast<const volatile unsigned long long*>(c->live_f + scal_at + (size_t)kMaxBatch * kScalStride);
-        unsigned spins = 0;
+        BoundedWait w(c, "a round's results (forces engine)");
         while (*flag != round) {
-            if ((++spins & 0xfffu) == 0) {
-                const hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess) {
-                    if (*flag == round) break;
-                    return fail(BIOEN_HIP_ESTATE, "round finished without publishing its results");
-                }
-                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
-            }
-            __builtin_ia32_pause();
+            const int t = w.tick([&] { return *flag == round; });
+            if (t < 0) return t;
+            if (t > 0) break;
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         std::memcpy(c->host_scal, c->live_f + scal_at, (size_t)kMaxBatch * kScalStride * sizeof(double));

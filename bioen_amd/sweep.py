@@ -308,6 +308,40 @@ def init_rccl(ctx, comm):
     return True
 
 
+def init_p2p(ctx, comm, selftest=40):
+    """Attach the peer-to-peer stage exchange of a structure-sharded `ctx` (one rank per process): every rank exports the
+    hipIpc handle of its mailbox, the control plane all-gathers the 64-byte handles, every rank maps its peers.  Ranks
+    agree on the outcome: if any rank cannot export, map or pass the self-test, ALL detach and the function returns
+    False (the caller falls back to RCCL / the host-staged path)."""
+    if comm.world == 1:
+        return False
+    handle, err = None, None
+    try:
+        handle = ctx.p2p_export()
+    except BioenHipError as e:
+        err = str(e)
+    got = comm.allgather_object((handle, err))
+    ok = all(h is not None for h, _ in got)
+    if ok:
+        try:
+            ctx.p2p_attach([h for h, _ in got])
+        except BioenHipError:
+            ok = False
+    ok = all(comm.allgather_object(ok))
+    if ok and selftest:
+        try:
+            ok = ctx.exchange_selftest(selftest) == 0
+        except BioenHipError:
+            ok = False
+        ok = all(comm.allgather_object(ok))
+    if not ok:
+        try:
+            ctx.p2p_detach()
+        except BioenHipError:
+            pass
+    return ok
+
+
 # ------------------------------------------------------------------------------------
 # the sweep
 # ------------------------------------------------------------------------------------

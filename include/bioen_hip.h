@@ -331,6 +331,34 @@ int bioen_hip_exchange_probe(bioen_hip_ctx* ctx, size_t count, int reps, double*
 int bioen_hip_read_probe(bioen_hip_ctx* ctx, int form, int reps, double* gbytes_per_s, long long* bytes);
 int bioen_hip_comm_destroy(bioen_hip_ctx* ctx);
 
+/* ---- peer-to-peer stage exchange (r04): a third transport for the stage all-gathers of structure-sharded contexts,
+ *      beside RCCL (bioen_hip_comm_init) and the host callback.  Every rank owns a mailbox in its HBM; the peers map
+ *      it through hipIpc (xGMI between GPUs; between processes sharing ONE GPU too, which is how the single-GPU test
+ *      box runs it) and an exchange is one small kernel on the context's stream: stores of this rank's segment into
+ *      every peer's mailbox, a system-scope flag per peer, a bounded wait for the peers' flags -- no collective launch
+ *      and no host.  No reference counterpart (bioen/analyze/procedure.py:62-63 is a serial loop in one process).
+ *        1. every rank: bioen_hip_p2p_export(ctx, handle)           -- allocates the mailbox, returns its 64-byte hipIpc handle
+ *        2. the host side all-gathers the handles (bioen_amd.sweep: SocketComm)
+ *        3. every rank: bioen_hip_p2p_attach(ctx, handles[world][64]) -- maps the peers; from now on the exchanges of this
+ *           context use this transport (it takes precedence over a communicator / callback that is also set)
+ *      bioen_hip_p2p_detach unmaps and frees (also done by bioen_hip_ctx_destroy).  world = 1 with
+ *      bioen_hip_ctx_set_force_exchange: attach(ctx, NULL) runs the (empty) exchange kernels all the same. */
+int bioen_hip_p2p_export(bioen_hip_ctx* ctx, unsigned char handle[64]);
+int bioen_hip_p2p_attach(bioen_hip_ctx* ctx, const unsigned char* handles);
+int bioen_hip_p2p_detach(bioen_hip_ctx* ctx);
+/* which transport the next stage exchange would use: 0 none (unsharded), 1 RCCL, 2 host callback, 3 peer-to-peer */
+int bioen_hip_exchange_transport(const bioen_hip_ctx* ctx);
+/* Self-test of whichever transport is active (sharded context, or world = 1 with forced exchanges): `reps` stage
+ * exchanges of varying size queued back to back, each rank's segment a pattern of (rank, exchange, index), every segment
+ * checked on the device after each exchange.  *mismatches = wrong doubles seen (0 = the transport delivers). */
+int bioen_hip_exchange_selftest(bioen_hip_ctx* ctx, int reps, long long* mismatches);
+int bioen_hip_exchange_counts3(const bioen_hip_ctx* ctx, long long* rccl, long long* host_staged, long long* p2p);
+/* Every wait of the library on a round's results or on a peer is bounded: after `seconds` (default 60, environment
+ * BIOEN_HIP_WAIT_TIMEOUT) without the awaited word the call returns BIOEN_HIP_ERCCL (a context that exchanges: a peer
+ * is gone; an RCCL communicator is aborted with ncclCommAbort so that its kernel returns) or BIOEN_HIP_EHIP, with
+ * bioen_hip_last_error() naming what was awaited.  The context is unusable afterwards (BIOEN_HIP_ESTATE): destroy it. */
+int bioen_hip_ctx_set_wait_timeout(bioen_hip_ctx* ctx, double seconds);
+
 #ifdef __cplusplus
 }
 #endif

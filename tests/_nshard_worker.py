@@ -1,6 +1,8 @@
 """Worker of tests/test_hip_nshard.py: one rank of a structure-sharded (column-sharded) run.
 All ranks share the single GPU of the test box, so the cross-rank all-gathers go through the
-host-staged exchange hook (SocketComm); on a real multi-GPU node the same code path uses RCCL."""
+host-staged exchange hook (SocketComm) or -- BIOEN_TEST_TRANSPORT=p2p -- through the peer-to-peer
+mailboxes (hipIpc works between processes on one GPU); on a real multi-GPU node the same code path
+uses the mailboxes over xGMI, or RCCL."""
 import os
 import sys
 
@@ -23,8 +25,18 @@ def main():
     rng = np.random.default_rng(99)
     g = d["GInit"].ravel() + 0.2 * rng.standard_normal(d["GInit"].size)
 
+    transport = os.environ.get("BIOEN_TEST_TRANSPORT", "host")
+
+    def attach(c):
+        if transport == "p2p":
+            assert sweep.init_p2p(c, comm), "the peer-to-peer exchange did not attach"
+            assert c.exchange_transport() == "p2p"
+        else:
+            c.set_exchange(comm)
+            assert c.exchange_transport() == "host"
+
     ctx = bioen_amd.Context(d["yTilde"], d["YTilde"], device=0, rank=comm.rank, world=comm.world)
-    ctx.set_exchange(comm)
+    attach(ctx)
     w, logs = ctx.logw_weights(g)
     f, grad = ctx.logw_fdf(g, d["G"], d["theta"])
     res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
@@ -54,12 +66,14 @@ def main():
     chi2, yave = ctx.chi_squared(w)
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
+    counts = ctx.exchange_counts3()
+    probe_us = ctx.exchange_probe(count=64 * 8, reps=200)
     ctx.close()
 
     # forces method on a sharded context (strip passes: 2 all-gathers per evaluation)
     fd = load_golden("synth_forces_M96xN3000.npz")
     fctx = bioen_amd.Context(fd["yTilde"], fd["YTilde"], device=0, rank=comm.rank, world=comm.world)
-    fctx.set_exchange(comm)
+    attach(fctx)
     f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
     ff, fgrad = fctx.forces_fdf(f0, fd["w0"], 10.0)
     fthetas = [100.0, 10.0, 1000.0]
@@ -75,7 +89,7 @@ def main():
              ff=ff, fgrad=fgrad, fres=fres, fw=fw, ffmin=np.array([i.fmin for i in finfos]),
              fiters=np.array([i.iterations for i in finfos]), fcodes=np.array([i.lbfgs_code for i in finfos]),
              fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]),
-             spec=np.array(spec), same_without=same_without,
+             spec=np.array(spec), same_without=same_without, counts=np.array(counts), probe_us=probe_us,
              wconv=wconv, fminconv=iconv.fmin, codeconv=iconv.lbfgs_code,
              fwconv=fwconv, ffminconv=ficonv.fmin, fcodeconv=ficonv.lbfgs_code)
     comm.close()

@@ -25,19 +25,53 @@ def free_port():
     return p
 
 
+def run_ranks(tmp_path, world, transport):
+    port = free_port()
+    procs = []
+    out = tmp_path / transport
+    out.mkdir()
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="nshard%d" % os.getpid(),
+                   BIOEN_TEST_TRANSPORT=transport, BIOEN_HIP_WAIT_TIMEOUT="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, str(out / "rank%d.npz")], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            assert p.wait(timeout=280) == 0
+    finally:
+        for p in procs:                 # a failed rank must not leave the others waiting on the GPU
+            if p.poll() is None:
+                p.kill()
+    return [np.load(str(out / ("rank%d.npz" % r))) for r in range(world)]
+
+
+RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
+               "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.timeout(600)
+def test_peer_to_peer_exchange_equals_host_staged_bitwise(tmp_path, world):
+    """The stage all-gathers through the hipIpc mailboxes (one kernel per exchange, no host) deliver the same bytes as
+    the host-staged path: every result of the sharded worker -- evaluations, five- and eight-theta series with and
+    without shadows, converged runs, both methods -- is identical to the last bit, on every rank."""
+    zh = run_ranks(tmp_path, world, "host")
+    zp = run_ranks(tmp_path, world, "p2p")
+    for r in range(world):
+        for key in RESULT_KEYS:
+            assert np.array_equal(zh[r][key], zp[r][key]), (key, r)
+        rccl, host, p2p = (int(v) for v in zp[r]["counts"])
+        assert p2p > 100 and rccl == 0 and host == 0, (r, zp[r]["counts"])
+        assert int(zh[r]["counts"][1]) > 100 and int(zh[r]["counts"][2]) == 0
+    print("exchange latency, %d ranks on one GPU: p2p %.1f us, host-staged %.1f us"
+          % (world, float(zp[0]["probe_us"]), float(zh[0]["probe_us"])))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.timeout(300)
 def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     import bioen_amd
-    port = free_port()
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="nshard%d" % os.getpid())
-        procs.append(subprocess.Popen([sys.executable, WORKER, str(tmp_path / "rank%d.npz")], env=env, cwd=ROOT))
-    for p in procs:
-        assert p.wait(timeout=280) == 0
-    z = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    z = run_ranks(tmp_path, world, "p2p")
 
     # (a) every rank holds identical (gathered) results
     for r in range(1, world):

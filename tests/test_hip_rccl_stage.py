@@ -137,3 +137,24 @@ def test_host_callback_exchange_on_one_rank_is_bitwise_too():
         r1, w1, i1 = ctx.opt_lbfgs_logw(g0, d["G"], 20.0, LBFGS_DEFAULTS)
         assert ctx.exchange_counts()[1] == OneRank.calls > 2 * i1.iterations
     assert np.array_equal(r0, r1) and np.array_equal(w0, w1) and i0.fmin == i1.fmin
+
+
+def test_peer_to_peer_transport_on_one_rank_is_bitwise_too():
+    """the third transport of the stage path with nobody to exchange with: the (empty) exchange kernels are launched at
+    every stage, the self-test runs, nothing moves by a bit"""
+    import bioen_amd
+    d, g0 = _problem()
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as plain:
+        r0, w0, i0 = plain.opt_lbfgs_logw(g0, d["G"], 20.0, LBFGS_DEFAULTS)
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
+        assert ctx.exchange_transport() == "none"
+        assert len(ctx.p2p_export()) == 64
+        ctx.p2p_attach(None)
+        ctx.set_force_exchange(True)
+        assert ctx.exchange_transport() == "p2p"
+        assert ctx.exchange_selftest(20) == 0
+        r1, w1, i1 = ctx.opt_lbfgs_logw(g0, d["G"], 20.0, LBFGS_DEFAULTS)
+        assert ctx.exchange_counts3()[2] > 2 * i1.iterations and ctx.exchange_counts3()[:2] == (0, 0)
+        ctx.p2p_detach()
+        assert ctx.exchange_transport() == "none"
+    assert np.array_equal(r0, r1) and np.array_equal(w0, w1) and i0.fmin == i1.fmin
