@@ -540,6 +540,9 @@ def main():
     ap.add_argument("--shard", choices=("auto", "structures", "thetas"), default="auto",
                     help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal "
                          "thetas; auto = structures when the measured all-gather latency makes it the faster one")
+    ap.add_argument("--transport", choices=("auto", "p2p", "rccl", "host"), default="auto",
+                    help="stage exchanges of a structure-sharded run: peer-to-peer mailboxes (hipIpc over xGMI, one kernel "
+                         "per all-gather), RCCL all-gathers, or host-staged; auto = the faster of p2p / rccl as measured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forces", action="store_true", help="skip the forces-method record (configs[4])")
     ap.add_argument("--no-matched", action="store_true", help="skip the matched CPU/GPU sweep at configs[1] size")
@@ -572,12 +575,15 @@ def main():
     ndev = bioen_amd.device_count()
     if ndev < 1:
         raise SystemExit("bench.py: no MI355X visible to HIP -- this benchmark has no CPU path")
+    xinfo = {}     # what the stage exchanges of the sharded context go through, and what each transport measured
+
     def build(nshard):
         """context + communicator for one of the two decompositions"""
         ctx = bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED,
                                           device=local_rank % ndev, rank=rank if nshard else 0,
                                           world=world if nshard else 1)
         gather, rccl = "none", False
+        xinfo.clear()
         if world > 1:
             try:
                 with stdout_to_stderr():
@@ -590,8 +596,38 @@ def main():
                 rccl = False
                 gather = "tcp-allgather (RCCL init failed on some rank)"
                 ctx.comm_destroy()
-            if nshard and not rccl:
-                ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
+            if nshard:
+                count = M * min(8, len(thetas))
+
+                def probe():          # slowest rank's view; inf where the transport does not work
+                    try:
+                        t = ctx.exchange_probe(count=count, reps=40)
+                    except bioen_amd.BioenHipError as e:
+                        xinfo.setdefault("probe_errors", []).append(str(e))
+                        t = float("inf")
+                    return max(comm.allgather_object(t))
+                if rccl and args.transport in ("auto", "rccl"):
+                    xinfo["rccl_us"] = probe()
+                p2p = False
+                if args.transport in ("auto", "p2p"):
+                    p2p = sweep.init_p2p(ctx, comm)          # agreed between the ranks; self-tested
+                    xinfo["p2p_attached"] = p2p
+                    if p2p:
+                        xinfo["p2p_us"] = probe()
+                        if args.transport == "auto" and xinfo.get("rccl_us", float("inf")) < xinfo["p2p_us"]:
+                            ctx.p2p_detach()                 # RCCL is the faster one on this node
+                            p2p = False
+                if not p2p and not (rccl and args.transport in ("auto", "rccl")):
+                    if rccl:
+                        ctx.comm_destroy()
+                        rccl = False
+                    ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
+                    xinfo["host_us"] = probe()
+                xinfo["transport"] = ctx.exchange_transport()
+                xinfo["exchange_us"] = xinfo.get({"p2p": "p2p_us", "rccl": "rccl_us", "host": "host_us"}[xinfo["transport"]])
+                for k in list(xinfo):
+                    if isinstance(xinfo[k], float) and not np.isfinite(xinfo[k]):
+                        xinfo[k] = None
         return ctx, gather, rccl
 
     decision = None
@@ -601,21 +637,23 @@ def main():
         # Splitting the structures pays when the per-pass saving beats the 3 small all-gathers a
         # round then needs (ybar + softmax totals, gradient dots, Gram update) plus launch
         # overhead; decided with margin:  t_pass * (1 - 1/world)  vs  5 * t_exchange + 0.15 ms.
-        try:
-            t_mine, probe_error = ctx.exchange_probe(count=M * min(8, len(thetas)), reps=40), None
-        except bioen_amd.BioenHipError as e:      # an exchange that does not work anywhere: deal thetas everywhere
-            t_mine, probe_error = float("inf"), str(e)
-        t_ex = max(comm.allgather_object(t_mine))
+        t_ex = xinfo.get("exchange_us")            # measured by build(): the chosen transport, slowest rank
+        probe_error = "; ".join(xinfo.get("probe_errors", [])) or None
+        if t_ex is None:                           # an exchange that does not work anywhere: deal thetas everywhere
+            t_ex = float("inf")
         t_pass_us = 2.0 * M * float(N) * 8 / 6.4e12 * 1e6
         gain_us = t_pass_us * (1.0 - 1.0 / world)
         cost_us = (3.0 * t_ex + 100.0) if forces_mode else (4.0 * t_ex + 150.0)   # 2 exchanges per round, with margin
-        decision = {"exchange_us": t_ex if np.isfinite(t_ex) else None, "pass_saving_us": gain_us,
+        decision = {"exchange_us": t_ex if np.isfinite(t_ex) else None, "transport": xinfo.get("transport"),
+                    "pass_saving_us": gain_us,
                     "exchange_cost_us": cost_us if np.isfinite(cost_us) else None,
                     "chosen": "structures" if gain_us > cost_us else "thetas", "probe_error": probe_error}
         if gain_us <= cost_us:
             ctx.close()
             nshard = False
+            xsaved = dict(xinfo)
             ctx, gather, rccl = build(False)
+            xinfo.update(xsaved, transport=None)   # keep what was measured; nothing is exchanged when thetas are dealt
 
     G = np.zeros(N)          # w0 = 1/N  =>  G = 0 ; GInit = G
     g0 = np.zeros(N)
@@ -647,7 +685,9 @@ def main():
         else:
             ctx.close()
             nshard = False
+            xsaved = dict(xinfo)
             ctx, gather, rccl = build(False)
+            xinfo.update(xsaved, transport=None)
             decision = dict(decision or {}, chosen="thetas", fallback="structure-sharded sweep failed: %s" % why)
     for _ in range(max(args.warmup - warm_done, 0)):
         results = step()
@@ -657,9 +697,21 @@ def main():
     comm.barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        results = step()
-    ctx.synchronize()
+    try:
+        for _ in range(args.steps):
+            results = step()
+        ctx.synchronize()
+    except bioen_amd.BioenHipError as e:
+        # a transport that failed inside the timed region (a rank gone, a wait past BIOEN_HIP_WAIT_TIMEOUT): every rank
+        # gets here through the bounded waits; say so in ONE line and leave with a non-zero status -- nothing is retried
+        # in a process whose GPU work has failed
+        if rank == 0:
+            print(json.dumps({"metric": "L-BFGS iterations/sec x (N structures * M observables), theta sweep", "value": None,
+                              "unit": "iter*N*M/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "error": str(e), "config": {"exchange_transport": xinfo.get("transport"),
+                                                          "sharding_fallback": True}}))
+            sys.stdout.flush()
+        sys.exit(4)
     comm.barrier()
     dt = comm.max(time.perf_counter() - t0)
     stats = ctx.kernel_stats()
@@ -809,9 +861,12 @@ def main():
                        if nshard else ("theta round-robin over %d rank(s)" % world), "gather": gather,
                        "max_batch": args.max_batch, "shard_decision": decision,
                        "rccl_ranks": world if rccl else (0 if world > 1 else None),
-                       "exchange_us": (decision or {}).get("exchange_us"),
+                       "exchange_transport": xinfo.get("transport") if nshard else None,
+                       "exchange_us": xinfo.get("exchange_us") if xinfo else (decision or {}).get("exchange_us"),
+                       "exchange_us_by_transport": {k[:-3]: xinfo[k] for k in ("p2p_us", "rccl_us", "host_us") if k in xinfo},
                        "decomposition": ("structures" if nshard else "thetas") if world > 1 else "single GPU",
-                       "sharding_fallback": bool(world > 1 and ((decision or {}).get("fallback") or not rccl))},
+                       "sharding_fallback": bool(world > 1 and ((decision or {}).get("fallback") or
+                                                                not (nshard and xinfo.get("transport") in ("p2p", "rccl"))))},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "forces": forces,
@@ -829,12 +884,12 @@ def main():
 
     # --shard structures was asked for explicitly: a run that ended on anything but RCCL-backed structure sharding has
     # not measured what was asked -- the line above says so (sharding_fallback), the exit status too
-    failed = world > 1 and args.shard == "structures" and not (nshard and rccl)
+    failed = world > 1 and args.shard == "structures" and not (nshard and xinfo.get("transport") in ("p2p", "rccl"))
     ctx.close()
     comm.close()
     if failed:
-        print("bench.py: --shard structures requested, but the run fell back (RCCL ranks: %s, decomposition: %s)"
-              % (world if rccl else 0, "structures" if nshard else "thetas"), file=sys.stderr)
+        print("bench.py: --shard structures requested, but the run fell back (transport: %s, decomposition: %s)"
+              % (xinfo.get("transport"), "structures" if nshard else "thetas"), file=sys.stderr)
         sys.exit(3)
 
 
