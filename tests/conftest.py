@@ -52,6 +52,27 @@ LBFGS_CONV = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iteration
 LBFGS_CONVMT = dict(LBFGS_CONV, linesearch=0)
 
 
+def require_reference():
+    """-> oracle.ref_binding, the ctypes binding of the reference's own C path (oracle/_ref/libbioen_ref.so, git-ignored,
+    built from /root/reference by oracle/Makefile in the build container; it travels to the GPU box with the repository).
+    Where a GPU is present its absence is a FAILURE: the parity evidence against the reference binary must not turn
+    into skips silently.  Only the GPU-less build container without /root/reference may skip."""
+    from oracle import ref_binding
+    if ref_binding.available():
+        return ref_binding
+    gpu = False
+    try:
+        import bioen_amd
+        gpu = bioen_amd.device_count() > 0
+    except Exception:
+        gpu = False
+    msg = ("oracle/_ref/libbioen_ref.so is missing (build it with `make -C oracle` where /root/reference exists; "
+           "it is git-ignored but NOT gpurun-ignored and must travel with the repository)")
+    if gpu:
+        pytest.fail(msg + " -- on a box with a GPU this is a failure, not a skip")
+    pytest.skip(msg)
+
+
 @pytest.fixture(scope="session")
 def have_ref():
     from oracle import ref_binding

@@ -12,6 +12,8 @@ device results are checked through size-independent properties instead --
 import numpy as np
 import pytest
 
+from conftest import require_reference
+
 pytestmark = pytest.mark.gpu
 
 LBFGS_DEFAULTS = dict(linesearch=2, max_iterations=5000, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9,
@@ -257,10 +259,8 @@ def test_configs1_converged_against_the_reference_binary(prior, M, N):
     log-posterior, 1e-5 max(w) on the weights -- at a size no golden fixture reaches.  Three thetas the reference
     converges on in seconds; the device solves them as one lock-step batch."""
     import bioen_amd
-    from oracle import ref_binding as R
     from oracle import cpus
-    if not R.available():
-        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    R = require_reference()             # absent on a GPU box = failure, not skip (conftest.py)
     conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
     thetas = [316.0, 100.0, 31.6] if (M, N) == (256, 100000) else [316.0, 100.0]
     YTrue, sig_sim, sig_exp, YTilde = _targets(M)
@@ -319,10 +319,8 @@ def test_ala5_shape_forces_series_against_the_reference_binary():
     warm-started from the previous optimum as run_theta_series does -- on synthetic data, against the reference's
     _opt_lbfgs_forces fed the same chain: 1e-6 on the negative log-posterior, 1e-5 max(w) on the weights, as they stand."""
     import bioen_amd
-    from oracle import ref_binding as R
     from oracle import cpus
-    if not R.available():
-        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    R = require_reference()             # absent on a GPU box = failure, not skip (conftest.py)
     from bench import ALA5_LBFGS
     N, M = 50001, 28
     thetas = np.logspace(5, -1, 80)[::8]
@@ -355,10 +353,8 @@ def test_configs1_forces_converged_against_the_reference_binary(M, N):
     both with epsilon = 1e-9, delta = 0, past = 0.  Both end at the rounding floor of the line search (-998) or on
     the gradient test; 1e-6 on the negative log-posterior and 1e-5 max(w) on the weights, as they stand."""
     import bioen_amd
-    from oracle import ref_binding as R
     from oracle import cpus
-    if not R.available():
-        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    R = require_reference()             # absent on a GPU box = failure, not skip (conftest.py)
     conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=200000)
     thetas = [316.0, 100.0, 31.6]
     YTrue, sig_sim, sig_exp, YTilde = _targets(M)
@@ -383,10 +379,8 @@ def test_objective_and_gradient_against_the_reference_binary(M, N):
     16 waves per strip and padded rows, the forces kernels with 64 and with 128 rows per wave; streaming kernels at
     M = 1056) at sizes the golden fixtures do not reach."""
     import bioen_amd
-    from oracle import ref_binding as R
     from oracle import cpus
-    if not R.available():
-        pytest.skip("oracle/_ref/libbioen_ref.so not built")
+    R = require_reference()             # absent on a GPU box = failure, not skip (conftest.py)
     YTrue, sig_sim, sig_exp, YTilde = _targets(M)
     rng = np.random.default_rng(7 + M)
     G = np.log(rng.gamma(2.0, 1.0, N))
