@@ -85,7 +85,10 @@ def live_traffic(method, M, N, kernel):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bioen_pmc_", dir="/tmp")
         try:
-            p = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", "python3",
+            # the program after `--` is THIS interpreter's ELF binary, resolved: a PATH lookup could land on a shim or a
+            # launcher script, and any such hop is an exec after the profiler's preloaded library has touched the GPU
+            p = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                os.path.realpath(sys.executable),
                                 os.path.join(ROOT, "tools", "pmc_pass.py"), method, str(M), str(N)],
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             if p.returncode != 0:
@@ -309,14 +312,31 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
     R.set_fast_openmp_flag(1)
     R.omp_set_num_threads(cores)
     R.logw_f(G, G, yT, YTilde, 10.0)                                                     # thread pool up
-    cpu_s, rel, codes = 0.0, [], []
+    cpu_s, rel, signed, codes, fref = 0.0, [], [], [], []
     for th, r in zip(thetas, res):
         gopt, fmin, code, dt = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, th, LBFGS_DEFAULTS)
         cpu_s += dt
         codes.append(code)
+        fref.append(fmin)
         rel.append(abs(r["fmin"] - fmin) / abs(fmin))
+        signed.append((r["fmin"] - fmin) / abs(fmin))       # > 0: the device stopped ABOVE the reference's minimum
     out.update({"cpu_sweep_s": cpu_s, "cpu_codes": codes, "speedup": cpu_s / out["gpu_sweep_s"],
-                "fmin_rel_diff_per_theta": rel, "fmin_rel_diff_max": max(rel)})
+                "fmin_rel_diff_per_theta": rel, "fmin_rel_diff_max": max(rel),
+                "fmin_signed_rel_diff_per_theta": signed})
+    # The yardstick for those differences: the REFERENCE against itself.  At yaml defaults both codes stop on the plateau
+    # test (delta = 1e-6 over 10 iterations), and where exactly depends on the rounding of the sums: the same binary, the
+    # same inputs, serial sums (fast_openmp = 0) instead of OpenMP reductions.
+    R.set_fast_openmp_flag(0)
+    spread, spread_s = [], 0.0
+    for th, f1 in zip(thetas, fref):
+        _, f0, code0, dt = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, th, LBFGS_DEFAULTS)
+        spread_s += dt
+        spread.append((f0 - f1) / abs(f1))
+    R.set_fast_openmp_flag(1)
+    out["reference_self_spread_per_theta"] = spread
+    out["reference_self_spread"] = ("fmin(fast_openmp=0) - fmin(fast_openmp=1) over |fmin|, the reference's own binary on the "
+                                    "same inputs with %d threads (second sweep: %.1f s)" % (cores, spread_s))
+    out["device_within_reference_spread"] = [bool(abs(a) <= max(abs(b), 1e-9)) for a, b in zip(signed, spread)]
     # 1 thread: theta = 10 capped at budget_iters_1t iterations (-997 = cap reached)
     R.omp_set_num_threads(1)
     capped = dict(LBFGS_DEFAULTS, max_iterations=budget_iters_1t)
@@ -329,7 +349,7 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
     return out
 
 
-def forces_record(bioen_amd, thetas, seed, max_batch):
+def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True):
     """BASELINE configs[4] on one GPU: forces method, N = 1e6 x M = 512, the theta series as ONE lock-step
     batch (cold starts, yaml-default liblbfgs).  Not part of `value`; reported beside it."""
     N, M = 1000000, 512
@@ -346,6 +366,12 @@ def forces_record(bioen_amd, thetas, seed, max_batch):
         ctx.synchronize()
         dt = time.perf_counter() - t0
         st = ctx.kernel_stats()
+        cpu = None
+        if with_cpu:     # the reference's _opt_lbfgs_forces (c_bioen_kernels_forces.c:574-662) on a column block of THIS matrix
+            try:
+                cpu = cpu_baseline_forces(ctx, M, N, YTilde, 10.0, 262144, 40)
+            except Exception as e:
+                cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
     its = int(sum(i.iterations for i in infos))
     kern = {}
     for name, which in (("xy", "adjoint"), ("bt", "forward")):       # timer slots of launch_forces_xy / _bt
@@ -362,6 +388,8 @@ def forces_record(bioen_amd, thetas, seed, max_batch):
                         % (N, M, len(thetas)),
             "value": its * float(N) * M / dt, "unit": "iter*N*M/s", "ms_per_step": 1e3 * dt, "iterations": its,
             "evaluations": int(sum(i.evaluations for i in infos)),
+            "cpu_baseline": cpu,
+            "speedup_vs_cpu": (its * float(N) * M / dt) / cpu["value"] if cpu and cpu.get("value") else None,
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
                          "traffic": None, "kernels": kern},
@@ -794,7 +822,7 @@ def main():
         if world == 1 and not args.no_forces and not forces_mode:
             ctx.close()              # 8 GB back before the second workload (closed again below: idempotent)
             try:
-                forces = forces_record(bioen_amd, thetas, SEED, args.max_batch)
+                forces = forces_record(bioen_amd, thetas, SEED, args.max_batch, with_cpu=not args.no_cpu_baseline)
                 tj_f = None
                 if os.path.isfile(tpath):
                     with open(tpath) as fp:
@@ -853,8 +881,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%s theta sweep, N=%d structures x M=%d observables, %d thetas "
-                                   "logspace(3,-0.5), cold starts, liblbfgs yaml defaults"
-                                   % ("forces-method" if forces_mode else "log-weights", N, M, len(thetas)),
+                                   "logspace(3,-0.5), cold starts, liblbfgs yaml defaults; yTilde = SURVEY 8(d)'s recipe "
+                                   "(row-wise normals around YTrue, sig_sim = 0.5 YTrue, sig_exp = 0.1 YTrue) drawn by a "
+                                   "device counter-based normal stream in HBM (k_generate: SplitMix64 + Box-Muller, seed %d), "
+                                   "not numpy's PCG64 stream -- iteration counts are specific to this generator "
+                                   "(cpu_baseline.matched_sweep runs numpy's stream to the letter)"
+                                   % ("forces-method" if forces_mode else "log-weights", N, M, len(thetas), SEED),
                        "method": args.method,
                        "N": N, "M": M, "thetas": [float(t) for t in thetas], "lbfgs": LBFGS_DEFAULTS,
                        "sharding": ("structures (columns) split over %d rank(s), all thetas batched on every rank" % world)

@@ -4,15 +4,19 @@
 # record is left out of them so that only the two headline sizes launch the strip kernels), then the default
 # bench unprofiled with those traffic figures in place.  usage: tools/profile_round.sh <tag>
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+# the program after `--` must be the interpreter's ELF binary itself (no shim, no `#!/usr/bin/env` hop: the profiler's
+# preloaded library has initialised the GPU by then, and an exec after that is forbidden on this pool)
+PY=$(readlink -f "$(command -v python3)")
+head -c 4 "$PY" | grep -q ELF || { echo "profile_round.sh: $PY is not an ELF binary" >&2; exit 2; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $PY bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 echo "stats done"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- python3 bench.py --no-cpu-baseline --no-deer --no-ala5 --warmup 0 > $OUT/fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- $PY bench.py --no-cpu-baseline --no-deer --no-ala5 --warmup 0 > $OUT/fetch.log 2>&1
 echo "fetch done"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- python3 bench.py --no-cpu-baseline --no-deer --no-ala5 --warmup 0 > $OUT/write.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- $PY bench.py --no-cpu-baseline --no-deer --no-ala5 --warmup 0 > $OUT/write.log 2>&1
 echo "write done"
 mkdir -p $OUT/profiles
 cp profiles/traffic.json $OUT/profiles/ 2>/dev/null || true
@@ -24,9 +28,9 @@ timeout -k 10 600 python bench.py > $OUT/bench_N1.json 2> $OUT/bench_N1.err
 echo "bench done"
 # the launch-bound regime: wall time per lock-step round (both engines, one process, interleaved) and the per-kernel split
 REPS=4 SIZES=256:100000,1024:125000,205:500000,64:20000,28:50001 VARIANTS=device,host,host-nospec timeout -k 10 300 python tools/engine_ab.py > $OUT/engine_ab.txt 2>&1
-SIZES=256:100000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/small -o small -- python3 tools/small_timeline.py > $OUT/small.log 2>&1
+SIZES=256:100000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/small -o small -- $PY tools/small_timeline.py > $OUT/small.log 2>&1
 python tools/trace_gaps.py $OUT/small/small_kernel_trace.csv > $OUT/small_round_256x100000.txt
-SIZES=1024:125000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/small2 -o small -- python3 tools/small_timeline.py >> $OUT/small.log 2>&1
+SIZES=1024:125000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/small2 -o small -- $PY tools/small_timeline.py >> $OUT/small.log 2>&1
 python tools/trace_gaps.py $OUT/small2/small_kernel_trace.csv > $OUT/small_round_1024x125000.txt
 timeout -k 10 300 python tools/ref_margins.py > $OUT/parity_margins.md 2> $OUT/parity_margins.err
 REPS=30 timeout -k 10 200 python tools/strip_probe.py > $OUT/forces_strip_probe.json 2>/dev/null
