@@ -51,9 +51,10 @@ int LogwBatchEngine::ensure_device_state() {
         const size_t cnt = (size_t)kLiveRing * kMaxBatch * (kLiveRec + 1);
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->live2), cnt * sizeof(double),
                                      hipHostMallocCoherent | hipHostMallocMapped);
-        if (e != hipSuccess) {
+        if (e != hipSuccess) {       // no coherent host page to publish into: the host-driven engine serves this context
             (void)hipGetLastError();
             c->live2 = nullptr;
+            c->live_off = 1;
             return BIOEN_HIP_ENOMEM;
         }
         std::memset(c->live2, 0, cnt * sizeof(double));
@@ -102,9 +103,10 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     if (const char* e = std::getenv("BIOEN_HIP_DEV_RESERVE")) reserve = std::max(0, std::min(4, std::atoi(e)));
     if (can_speculate && cfg.linesearch >= 2 && max_shadows >= 2 && reserve > 0 && kb == kMaxBatch && ntheta <= kMaxBatch)
         kb -= reserve;
-    const int nslots = can_speculate ? kMaxBatch : kb;
+    // slots: the owners' kb, plus as many as may shadow at a time (none on unsharded contexts by default) -- a slot's
+    // seven N-vectors (and the spare pair of a shadow that sweeps its own) are allocated only if it can be used
+    const int nslots = can_speculate ? std::min((int)kMaxBatch, kb + max_shadows) : kb;
     for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, s < kb || sgram));   // history: owners; spare pair: owners (shadows too when they sweep their own)
-    note(ensure_device_state());
     if (rc) return rc;
     note(upload_n(c, c->fixed, G_host));
     const bool shared_start = (g0_stride == 0) || ntheta == 1;
@@ -180,10 +182,15 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         ++next;
     };
 
-    auto finish_problem = [&](int s, const DevRecord& rec, int column) {
+    auto finish_problem = [&](int s, const DevRecord& rec, int column, int width) {
         ProblemSlot& sl = c->slot[s];
         const double theta = thetas[prob[s]];
-        c->last_pos = column;                        // where this problem's averages sit in ybar_c (bioen_hip_last_average)
+        // where this problem's averages sit in ybar_c (bioen_hip_last_average): column and row pitch of the round that
+        // PUBLISHED the record -- not of a (dead) round queued behind it, whose width enqueue_round has noted since;
+        // that round's gated kernels leave ybar_c as the publishing round wrote it
+        c->last_pos = column;
+        c->last_width = width;
+        c->last_centered = false;
         bioen_opt_result& info = infos[prob[s]];
         info.lbfgs_code = rec.code;
         info.iterations = rec.iterations;
@@ -426,7 +433,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             seen_dec[s] = rec.rej_dec;
             seen_inc[s] = rec.rej_inc;
             if (rec.status != DS_DONE) continue;
-            finish_problem(s, rec, rec.evalpos);
+            finish_problem(s, rec, rec.evalpos, f.n);
             if (next < ntheta && !rc) start_problem(s);
         }
     }

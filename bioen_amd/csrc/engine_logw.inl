@@ -254,8 +254,11 @@ struct LogwBatchEngine {
             }
             return 0;
         }
-        if (device_engine_applies())
-            return run_device(ntheta, thetas, g0_host, g0_stride, G_host, max_batch, results, w_opt, infos);
+        if (device_engine_applies()) {
+            const int e = ensure_device_state();      // a context without a coherent host page falls back to the host-driven engine
+            if (!e) return run_device(ntheta, thetas, g0_host, g0_stride, G_host, max_batch, results, w_opt, infos);
+            if (!c->live_off) return e;
+        }
         int kb = std::max(1, std::min(std::min(max_batch, kMaxBatch), ntheta));
         // Problems start in ascending theta (the slow ones first: the series ends with its slowest member).  A series
         // that fills the batch exactly leaves no slot to speculate in until its first member finishes -- and a line

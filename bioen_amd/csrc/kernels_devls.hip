@@ -34,8 +34,9 @@ namespace bioen {
 
 __device__ __forceinline__ bool dev_alive(int status) { return status == DS_INITIAL || status == DS_RUNNING; }
 
-// behind the kMaxBatch table entries: [0] adopted shadows (64-bit counter), [2] (as int) problems alive
-__device__ __forceinline__ int* dev_alive_word(DevSlot* tab) { return reinterpret_cast<int*>(tab + kMaxBatch) + 2; }
+// (behind the kMaxBatch table entries: [0] adopted shadows, a 64-bit counter.  A round queued ahead of the host in which
+// every problem has meanwhile finished still runs its matrix passes at full cost -- they do not depend on the table; all
+// its N-vector work is gated off by the status words -- once per series.)
 
 // position a of the round takes part: its owner is alive, and a speculative trial needs a line search in progress
 __device__ __forceinline__ bool dev_pos_live(const DevRound& r, int a, int* owner_status) {
@@ -93,7 +94,6 @@ __global__ __launch_bounds__(kBlock) void k_dev_start(DevStart s, bioen_lbfgs_co
         for (int q = threadIdx.x; q < kGramStride; q += kBlock) s.gram[i][q] = 0.0;
         if (threadIdx.x == 0) {
             lb::machine_reset(T.m, cfg, T.pf);
-            atomicAdd(dev_alive_word(s.tab), 1);
             T.status = DS_INITIAL;
             T.combine = 0;
             T.code = 0;
@@ -604,7 +604,6 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
             } else {
                 T.combine = 0;
                 if (kind == ACT_DONE) {
-                    atomicAdd(dev_alive_word(r.tab), -1);     // the matrix passes of a round without live problems return at once
                     T.status = DS_DONE;
                     T.code = ctl[4];
                     T.keep_trial = ctl[5];

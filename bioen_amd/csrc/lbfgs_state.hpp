@@ -18,7 +18,7 @@
 
 #include "../../include/bioen_hip.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BIOEN_HD __host__ __device__
 #else
 #define BIOEN_HD

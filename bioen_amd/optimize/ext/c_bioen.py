@@ -7,9 +7,13 @@ via ctypes.  There is no CPU path in here; a missing library or GPU raises.
 Differences from the reference, on purpose:
 * ``yTilde`` is uploaded once and kept resident in HBM.  Calls that pass the same
   matrix again (scipy's separate f / f' callbacks, a theta series) reuse the
-  device copy instead of re-uploading -- see ``_context_for``.
-* ``caching`` / ``cache_ytilde_transposed`` are accepted and ignored: the adjoint
-  kernel walks the row-major matrix coalesced, no transposed copy exists.
+  device copy instead of re-uploading -- see ``_context_for`` -- as long as the WHOLE host
+  buffer can be re-checked for in-place edits (up to 256 MB); larger matrices are uploaded
+  afresh on every call, exactly the reference's behaviour (fresh pointers per call,
+  c_bioen.pyx:463-478), unless ``BIOEN_HIP_CACHE_LARGE=1`` opts into a sampled check.
+* ``caching`` / ``cache_ytilde_transposed`` are accepted and ignored: both matrix passes stream
+  strip-major copies of the matrix built on the device (``csrc/kernels_strip.hip``); no host-side
+  transposed copy exists.
 * ``bioen_log_posterior_logw`` uses its ``G`` argument.  The reference passes the
   *initial* log-weights ``g`` in the ``G`` slot (c_bioen.pyx:279), which is
   invisible in its tests because every fixture has ``GInit == G``.
@@ -46,10 +50,17 @@ _CACHE_MAX = int(os.environ.get("BIOEN_HIP_CACHE", "2"))
 _FULL_CHECK_BYTES = int(os.environ.get("BIOEN_HIP_CACHE_FULLCHECK_MB", "256")) << 20
 
 
+def _cache_large():
+    return os.environ.get("BIOEN_HIP_CACHE_LARGE", "0") == "1"
+
+
 def _fingerprint(a):
     """Content check of the host matrix.  Up to BIOEN_HIP_CACHE_FULLCHECK_MB (default 256 MB) EVERY element
     enters (sum and sum of squares over the whole buffer: two BLAS-speed passes, far cheaper than the
-    upload they save); beyond that a strided sample of ~4 M elements spread over all rows and columns."""
+    upload they save).  Beyond that size a complete check costs more than the upload it would save (8 GB:
+    ~1.6 s against 0.15-0.26 s), so such matrices are NOT cached at all (`_context_for`) -- unless the caller
+    opts in with BIOEN_HIP_CACHE_LARGE=1 and thereby promises not to edit the matrix in place: then a strided
+    sample of ~4 M elements spread over all rows and columns is all that is checked."""
     flat = a.reshape(-1)
     if flat.nbytes > _FULL_CHECK_BYTES:
         stride = max(1, flat.size // (1 << 22)) | 1          # odd: walks through every column residue
@@ -62,15 +73,17 @@ def _context_for(yTilde, YTilde):
 
     A cached context is reused only for the VERY SAME live host object (identity through a weak
     reference -- a new array that happens to land on a freed address never matches) whose content check
-    still agrees (`_fingerprint`: complete up to 256 MB, so in-place edits such as finite-difference
-    perturbations are seen; sampled beyond).  Anything else is a miss and uploads afresh, which is what the
-    reference does on every call.  BIOEN_HIP_CACHE=0 switches the cache off."""
+    still agrees (`_fingerprint`: every element, so in-place edits such as finite-difference perturbations
+    are seen).  Anything else is a miss and uploads afresh, which is what the reference does on every call
+    (c_bioen.pyx:463-478).  Matrices above 256 MB (BIOEN_HIP_CACHE_FULLCHECK_MB) are never cached -- a
+    complete check would cost more than the upload -- unless BIOEN_HIP_CACHE_LARGE=1 opts into a sampled
+    check.  BIOEN_HIP_CACHE=0 switches the cache off."""
     yT = _lib.as_f64(yTilde)
     if yT.ndim != 2:
         raise ValueError("yTilde must be a 2-D (M x N) array")
     YT = _lib.as_f64(YTilde).ravel()
     weakable = isinstance(yTilde, np.ndarray)              # np.matrix included; lists etc. are never cached
-    if _CACHE_MAX <= 0 or not weakable:
+    if _CACHE_MAX <= 0 or not weakable or (yT.nbytes > _FULL_CHECK_BYTES and not _cache_large()):
         return _lib.Context(yT, YT), False
     key = id(yTilde)
     fp = _fingerprint(yT)

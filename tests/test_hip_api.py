@@ -173,6 +173,42 @@ def test_theta_series_reuses_resident_matrix(optimize):
     assert len(c_bioen._CACHE) == 0
 
 
+def test_large_matrix_is_not_served_from_a_stale_device_copy(optimize, monkeypatch):
+    """Above 256 MB the host matrix cannot be re-checked in full for less than the upload it would save, so such a matrix
+    is uploaded afresh on every call -- the reference's behaviour (fresh pointers per call,
+    /root/reference/bioen/optimize/ext/c_bioen.pyx:463-478): an in-place edit of ONE element between two calls is seen.
+    Only BIOEN_HIP_CACHE_LARGE=1 (the caller's promise not to edit in place) caches such a matrix, on a sampled check."""
+    from bioen_amd.optimize.ext import c_bioen
+    c_bioen.clear_cache()
+    M, N = 64, 525000                        # 268.8 MB
+    rng = np.random.default_rng(11)
+    y = rng.normal(5.0, 1.0, (M, N))
+    assert y.nbytes > 256 << 20
+    YT = rng.normal(5.0, 0.1, (1, M))
+    g = np.zeros((N, 1))
+    monkeypatch.delenv("BIOEN_HIP_CACHE_LARGE", raising=False)
+    f0 = optimize.log_weights.bioen_log_posterior(g.ravel().copy(), g, g, y, YT, 2.0)
+    assert len(c_bioen._CACHE) == 0          # not cached
+    i, j = 17, 262147                        # off every stride a sampled check would visit ...
+    stride = max(1, y.size // (1 << 22)) | 1
+    assert (i * N + j) % stride != 0
+    delta = 1.0e6
+    y[i, j] += delta                         # ... one element, in place
+    f1 = optimize.log_weights.bioen_log_posterior(g.ravel().copy(), g, g, y, YT, 2.0)
+    # closed form of the change: ybar_i moves by delta / N, chi^2 / 2 by r_i d + d^2 / 2
+    r_i = (y[i].sum() - delta) / N - YT[0, i]
+    expect = r_i * (delta / N) + 0.5 * (delta / N) ** 2
+    assert abs((f1 - f0) - expect) <= 1e-9 * abs(expect), (f0, f1, expect)
+    # opt-in: cached on the sampled check (which, by construction, does not see this edit)
+    monkeypatch.setenv("BIOEN_HIP_CACHE_LARGE", "1")
+    f2 = optimize.log_weights.bioen_log_posterior(g.ravel().copy(), g, g, y, YT, 2.0)
+    assert len(c_bioen._CACHE) == 1 and f2 == f1
+    y[i, j] -= delta
+    f3 = optimize.log_weights.bioen_log_posterior(g.ravel().copy(), g, g, y, YT, 2.0)
+    assert f3 == f2                          # the documented price of the opt-in
+    c_bioen.clear_cache()
+
+
 def test_synthetic_generator_statistics_and_large_property_checks(optimize):
     """BASELINE config 2 size (N = 1e5 x M = 256), generated in HBM: the generator follows the
     recipe, the oracle agrees on the downloaded matrix, and size-independent properties hold."""
