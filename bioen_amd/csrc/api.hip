@@ -257,13 +257,15 @@ static int transport_error(bioen_hip_ctx* c) {
                           w & 0xffffffffffull, (int)((w >> 52) & 0xff), why[std::min<unsigned long long>(3, w >> 60)],
                           (int)((w >> 40) & 0xfff), c->wait_timeout_s);
             c->failed = 1;
-            return fail(BIOEN_HIP_ERCCL, buf);
+            if (c->fail_msg.empty()) c->fail_msg = buf;
+            return fail(BIOEN_HIP_ERCCL, c->fail_msg.c_str());
         }
     }
     if (c->comm) {
         const int rc = rccl_async_error(c);
         if (rc) {
             c->failed = 1;
+            if (c->fail_msg.empty()) c->fail_msg = g_last_error;
             return rc;
         }
     }
@@ -307,6 +309,7 @@ struct BoundedWait {
                 std::snprintf(buf, sizeof buf, "timed out after %g s waiting for %s (BIOEN_HIP_WAIT_TIMEOUT)",
                               c->wait_timeout_s, what);
                 c->failed = 1;
+                if (c->fail_msg.empty()) c->fail_msg = buf;
                 const bool exchanging = c->world > 1 || c->comm || c->exchange_cb || c->p2p_on;
                 if (c->comm) rccl_abort(c);
                 return fail(exchanging ? BIOEN_HIP_ERCCL : BIOEN_HIP_EHIP, buf);
@@ -335,7 +338,10 @@ static bool exchanges_forced(const bioen_hip_ctx* c) {
 
 static int exchange(bioen_hip_ctx* c, int stage, size_t payload) {
     if (c->world == 1 && !exchanges_forced(c)) return 0;
-    if (c->failed) return fail(BIOEN_HIP_ESTATE, "an earlier exchange on this context failed; destroy it");
+    if (c->failed) {
+        const std::string m = "this context failed earlier and must be destroyed: " + c->fail_msg;
+        return fail(BIOEN_HIP_ESTATE, m.c_str());
+    }
     double* base = c->xbuf[stage];
     if (c->p2p_on) {          // stores into the peers' mailboxes + flags, one kernel (kernels_p2p.hip)
         if (payload > c->p2p_cap) return fail(BIOEN_HIP_EINVAL, "exchange payload exceeds the mailbox slot");
@@ -363,7 +369,9 @@ static int exchange(bioen_hip_ctx* c, int stage, size_t payload) {
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->exchange_cb(c->exchange_user, c->exchange_host, payload) != 0) {
         c->exchange_error = 1;
-        return fail(BIOEN_HIP_ERCCL, "exchange callback failed");
+        c->failed = 1;
+        if (c->fail_msg.empty()) c->fail_msg = "the host-staged exchange callback failed (a peer gone, or its transport timed out)";
+        return fail(BIOEN_HIP_ERCCL, c->fail_msg.c_str());
     }
     BIOEN_HIP_CHECK(hipMemcpyAsync(base, c->exchange_host, total * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return 0;
@@ -419,12 +427,16 @@ static int await_live(bioen_hip_ctx* c, unsigned long long round, const int* slo
     return 0;
 }
 
-static double host_logsumexp(const double* v, long long n) {
-    double mx = -1.7976931348623157e308;
-    for (long long j = 0; j < n; ++j) mx = std::max(mx, v[j]);
-    double s = 0.0;
-    for (long long j = 0; j < n; ++j) s += std::exp(v[j] - mx);
-    return mx + std::log(s);
+// log sum exp(G) of the prior into scal[S_LOGS0] of the round's problems (A2, c_bioen_kernels_logw.c:29-53, hoisted:
+// once per run).  Sharded contexts (r04): every rank leaves the {max, sum} pairs of its blocks in its segment of the
+// X_GRAD stage, ONE exchange, and every rank merges world x blocks pairs in the same order -- the same value everywhere,
+// without the 5-10 ms a host loop over 1e6 exponentials cost every run.
+static int enqueue_logs0(bioen_hip_ctx* c, const Round& r) {
+    launch_logw_logs0_part(c);
+    const int rc = exchange(c, X_GRAD, 2 * (size_t)vec_grid(c));
+    if (rc) return rc;
+    launch_logw_logs0_merge(c, r);
+    return 0;
 }
 
 static int check_launch() {
@@ -1064,13 +1076,7 @@ int bioen_hip_logw_fdf(bioen_hip_ctx* c, const double* g, const double* G, doubl
     if (grad) BIOEN_HIP_CHECK(hipMemsetAsync(s0.d, 0, c->ld * sizeof(double), c->stream));
     const int one[1] = {0};
     const Round r = make_round(c, one, 1, nullptr, &theta);
-    if (c->world == 1) {
-        launch_logw_logs0(c, r);
-    } else {
-        const double v = host_logsumexp(G, c->n_global);
-        BIOEN_HIP_CHECK(hipMemcpyAsync(s0.scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
-    }
+    if ((rc = enqueue_logs0(c, r))) return rc;
     launch_max(c, r);
     if ((rc = enqueue_logw_eval(c, r, grad != nullptr))) return rc;
     if ((rc = check_launch())) return rc;
@@ -1609,8 +1615,10 @@ int bioen_hip_p2p_detach(bioen_hip_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     c->p2p_on = 0;
-    if (c->p2p_err && __atomic_load_n(c->p2p_err, __ATOMIC_ACQUIRE) && !c->comm)
+    if (c->p2p_err && __atomic_load_n(c->p2p_err, __ATOMIC_ACQUIRE) && !c->comm) {
         c->failed = 0;      // the failure was this transport's; the stream has drained and the transport goes: usable again
+        c->fail_msg.clear();
+    }
     for (int r = 0; r < 128; ++r)
         if (c->p2p_mapped[r]) {
             hipIpcCloseMemHandle(c->p2p_mapped[r]);

@@ -208,7 +208,7 @@ int bioen_hip_opt_gsl_logw(bioen_hip_ctx* c, const double* g0, const double* G, 
     if ((rc = upload_n(c, c->fixed, G))) return rc;
     {
         const int one[1] = {0};
-        launch_logw_logs0(c, make_round(c, one, 1, nullptr, &theta));
+        if (int e0 = enqueue_logs0(c, make_round(c, one, 1, nullptr, &theta))) return e0;
     }
     const multimin::Config cfg{config->step_size, config->tol, config->max_iterations, config->algorithm};
     const multimin::Outcome out = multimin::run(B, cfg);

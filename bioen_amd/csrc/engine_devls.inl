@@ -119,15 +119,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         int all[kMaxBatch];
         for (int s = 0; s < nslots; ++s) all[s] = s;
         const Round r = make_round(c, all, nslots, nullptr, nullptr);
-        if (c->world == 1) {
-            launch_logw_logs0(c, r);
-        } else {   // G is sharded on the device but whole on the host: same value on every rank
-            const double v = host_logsumexp(G_host, c->n_global);
-            for (int s = 0; s < nslots; ++s)
-                note(hipMemcpyAsync(c->slot[s].scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream),
-                     "logs0");
-            note(hipStreamSynchronize(c->stream), "sync");
-        }
+        note(enqueue_logs0(c, r));           // sharded: the ranks' block pairs are exchanged, every rank merges the same numbers
     }
     DevSlot* tab = static_cast<DevSlot*>(c->dev_tab);
     unsigned long long* spec_dev = reinterpret_cast<unsigned long long*>(tab + kMaxBatch);
@@ -221,7 +213,10 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
                 note(hipMemcpyAsync(sl.w, wsrc, c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream), "adopt e");
             launch_scale_w(c, rr);                   // e -> w, only now
         }
-        if (async_delivery) {
+        if (async_delivery && c->world > 1) {
+            deliver_sharded(s, results + (size_t)prob[s] * c->n_global, res,
+                            w_opt ? w_opt + (size_t)prob[s] * c->n_global : nullptr, sl.w);
+        } else if (async_delivery) {
             deliver(s, results + (size_t)prob[s] * c->n_global, res,
                     w_opt ? w_opt + (size_t)prob[s] * c->n_global : nullptr, sl.w);
         } else {

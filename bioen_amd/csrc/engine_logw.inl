@@ -44,10 +44,13 @@ struct LogwBatchEngine {
         speculate = !(e && e[0] == '0');
         if (const char* m = std::getenv("BIOEN_HIP_HOST_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(m)));
         const char* d = std::getenv("BIOEN_HIP_DELIVERY");
-        async_delivery = c->world == 1 && !(d && d[0] == '0');
+        async_delivery = !(d && d[0] == '0');
     }
     ~LogwBatchEngine() {
-        for (int s = 0; s < kMaxBatch; ++s) settle(s);
+        for (int s = 0; s < kMaxBatch; ++s) {
+            settle(s);
+            if (gather[s]) (void)hipFree(gather[s]);
+        }
     }
 
     bool slot_busy(int s) const { return pending[s] && !pending[s]->done.load(std::memory_order_acquire); }
@@ -91,6 +94,71 @@ struct LogwBatchEngine {
             pending[s].reset();
         }
     }
+
+    // The same for a structure-sharded context (r04): every rank returns GLOBAL vectors, so a result is gathered first.
+    // The gather (one X_VEC stage exchange per vector, into a buffer of the slot's own instead of the shared stage
+    // buffer) stays on the compute stream, in the order every rank issues it; the world x 2 copies into the caller's
+    // pageable arrays -- 16 MB per theta at the headline, a millisecond the rounds of the other thetas need not wait
+    // for -- leave on the second stream as above.  The slot's vectors are free as soon as the gather is queued.
+    void deliver_sharded(int s, double* dst_x, const double* src_x, double* dst_w, const double* src_w) {
+        settle(s);
+        const size_t per = c->ld * (size_t)c->world;
+        if (!gather[s]) note(dalloc_zero(&gather[s], 2 * per, c->stream));
+        if (!c->copy_stream) note(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+        if (rc) return;
+        double* const stage = c->xbuf[X_VEC];
+        const double* srcs[2] = {src_x, dst_w ? src_w : nullptr};
+        for (int v = 0; v < 2 && !rc; ++v) {
+            if (!srcs[v]) continue;
+            double* base = gather[s] + (size_t)v * per;
+            note(hipMemcpyAsync(base + (size_t)c->rank * c->ld, srcs[v], c->ld * sizeof(double), hipMemcpyDeviceToDevice,
+                                c->stream), "gather: own segment");
+            c->xbuf[X_VEC] = base;                     // the exchange works in place on the stage buffer it is handed
+            note(exchange(c, X_VEC, c->ld));
+            c->xbuf[X_VEC] = stage;
+        }
+        hipEvent_t ev = nullptr;
+        note(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        if (!rc) note(hipEventRecord(ev, c->stream), "hipEventRecord");
+        if (rc) {
+            if (ev) (void)hipEventDestroy(ev);
+            return;
+        }
+        Delivery* d = new Delivery;
+        pending[s].reset(d);
+        const int dev = c->device, world = c->world;
+        hipStream_t cs = c->copy_stream;
+        const size_t ld = c->ld;
+        const long long n_global = c->n_global;
+        double* const gb = gather[s];
+        auto work = [=]() {
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev, 0);
+            double* dsts[2] = {dst_x, dst_w};
+            for (int v = 0; v < 2 && e == hipSuccess; ++v) {
+                if (!dsts[v]) continue;
+                for (int r = 0; r < world && e == hipSuccess; ++r) {
+                    long long col0, nl, pr;
+                    shard_columns(n_global, r, world, &col0, &nl, &pr);
+                    if (nl > 0)
+                        e = hipMemcpyAsync(dsts[v] + col0, gb + (size_t)v * ld * world + (size_t)r * ld,
+                                           (size_t)nl * sizeof(double), hipMemcpyDeviceToHost, cs);
+                }
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(cs);
+            (void)hipEventDestroy(ev);
+            d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
+            d->done.store(1, std::memory_order_release);
+        };
+        try {
+            d->th = std::thread(work);
+        } catch (...) {
+            work();
+            note(d->rc);
+            pending[s].reset();
+        }
+    }
+    double* gather[kMaxBatch] = {};       // per slot: [2][world][ld] results on their way out (sharded contexts)
 
     void note(int e) { if (e && !rc) rc = e; }
     void note(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = hip_fail(e, what, __FILE__, __LINE__); }
@@ -291,15 +359,7 @@ struct LogwBatchEngine {
             int all[kMaxBatch];
             for (int s = 0; s < nslots; ++s) all[s] = s;
             const Round r = make_round(c, all, nslots, nullptr, nullptr);
-            if (c->world == 1) {
-                launch_logw_logs0(c, r);
-            } else {   // G is sharded on the device but whole on the host: same value on every rank
-                const double v = host_logsumexp(G_host, c->n_global);
-                for (int s = 0; s < nslots; ++s)
-                    note(hipMemcpyAsync(c->slot[s].scal + S_LOGS0, &v, sizeof(double), hipMemcpyHostToDevice, c->stream),
-                         "logs0");
-                note(hipStreamSynchronize(c->stream), "sync");
-            }
+            note(enqueue_logs0(c, r));       // sharded: the ranks' block pairs are exchanged, every rank merges the same numbers
         }
 
         const bool dbg = std::getenv("BIOEN_HIP_SPEC_DEBUG") != nullptr;
@@ -364,7 +424,10 @@ struct LogwBatchEngine {
                 const int one[1] = {s};
                 launch_scale_w(c, make_round(c, one, 1, nullptr, &p.theta));   // e -> w, only now
             }
-            if (async_delivery) {
+            if (async_delivery && c->world > 1) {
+                deliver_sharded(s, results + (size_t)p.id * c->n_global, res,
+                                w_opt ? w_opt + (size_t)p.id * c->n_global : nullptr, sl.w);
+            } else if (async_delivery) {
                 deliver(s, results + (size_t)p.id * c->n_global, res, w_opt ? w_opt + (size_t)p.id * c->n_global : nullptr,
                         sl.w);
             } else {

@@ -102,7 +102,8 @@ void launch_trial(bioen_hip_ctx* c, const Round& r);        // x = xp + stp d ; 
 void launch_max(bioen_hip_ctx* c, const Round& r);          // block maxima of x only
 void launch_logw_exp(bioen_hip_ctx* c, const Round& r);     // e = exp(x - max) -> w ; partial sums
 void launch_logw_norm(bioen_hip_ctx* c, const Round& r);    // w /= S ; log s, P
-void launch_logw_logs0(bioen_hip_ctx* c, const Round& r);   // scal[S_LOGS0] = log sum exp(fixed)
+void launch_logw_logs0_part(bioen_hip_ctx* c);               // {max, sum exp(fixed - max)} per block -> X_GRAD segment of this rank
+void launch_logw_logs0_merge(bioen_hip_ctx* c, const Round& r);   // scal[S_LOGS0] = log sum exp(fixed), all ranks' pairs merged
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r);    // gradient epilogue + g.d, g.g, x.x
 void launch_finish_eval(bioen_hip_ctx* c, const Round& r);  // scal[S_DG], S_GG, S_XX
 void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal);   // scal[S_DGINIT] <- X_DGI

@@ -495,13 +495,15 @@ void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
                        make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
-void launch_logw_logs0(bioen_hip_ctx* c, const Round& r) {
-    // the per-block pairs go through the X_GRAD stage's buffer (3 K values per block: room for 2), idle before a run's
-    // first evaluation; nothing is exchanged -- unsharded contexts only (sharded ones take the host's value)
+// the per-block {max, sum} pairs go into this rank's segment of the X_GRAD stage (3 K values per block: room for 2), idle
+// before a run's first evaluation; sharded contexts exchange the segments between the two launches (api.hip: enqueue_logs0)
+void launch_logw_logs0_part(bioen_hip_ctx* c) {
     const int g = vec_grid(c);
-    double* part = c->xbuf[X_GRAD];
+    double* part = c->xbuf[X_GRAD] + (size_t)c->rank * 2 * g;
     hipLaunchKernelGGL(k_logsumexp_part, dim3(g), dim3(kBlock), 0, c->stream, c->fixed, c->n, part);
-    hipLaunchKernelGGL(k_logsumexp_merge, dim3(1), dim3(kBlock), 0, c->stream, part, g, r);
+}
+void launch_logw_logs0_merge(bioen_hip_ctx* c, const Round& r) {
+    hipLaunchKernelGGL(k_logsumexp_merge, dim3(1), dim3(kBlock), 0, c->stream, c->xbuf[X_GRAD], vec_grid(c) * c->world, r);
 }
 
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
