@@ -17,10 +17,17 @@ VARIANTS = {
     # the policy of sharded contexts (two slots kept back, both steps of the slowest thetas from the first search on), on one GPU
     "device-reserve": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "2"},
     "device-shadows0": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "0"},
+    # ... in the form sharded contexts run it (shadows sweep their own Gram products), and with the stage exchanges of the
+    # sharded round executed through the peer-to-peer transport with ONE rank: the exchange kernels are launched (two per
+    # round) and find nobody to wait for -- the launch share of an exchange, on one GPU
+    "sharded-form": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "2",
+                     "BIOEN_HIP_SHADOW_GRAM": "1"},
+    "sharded-form+p2p1": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "2",
+                          "BIOEN_HIP_SHADOW_GRAM": "1", "_P2P": "1"},
     "host": {"BIOEN_HIP_DEVICE_LS": "0"},
     "host-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
 }
-KEYS = sorted({k for v in VARIANTS.values() for k in v})
+KEYS = sorted({k for v in VARIANTS.values() for k in v if not k.startswith('_')})
 sizes = [tuple(int(v) for v in s.split(":")) for s in os.environ.get("SIZES", "256:100000").split(",")]
 reps = int(os.environ.get("REPS", "3"))
 only = os.environ.get("VARIANTS")
@@ -36,7 +43,12 @@ for (M, N) in sizes:
             for n in names:
                 for k in KEYS:
                     os.environ.pop(k, None)
-                os.environ.update(VARIANTS[n])
+                os.environ.update({k: v for k, v in VARIANTS[n].items() if not k.startswith("_")})
+                p2p = VARIANTS[n].get("_P2P") == "1"
+                if p2p:
+                    ctx.p2p_export()
+                    ctx.p2p_attach(None)
+                    ctx.set_force_exchange(True)
                 ctx.kernel_stats_enable(rep == reps)
                 ctx.kernel_stats_reset()
                 ctx.synchronize()
@@ -44,6 +56,9 @@ for (M, N) in sizes:
                 res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
                 ctx.synchronize()
                 dt = time.perf_counter() - t0
+                if p2p:
+                    ctx.set_force_exchange(False)
+                    ctx.p2p_detach()
                 if rep == reps:
                     rounds[n] = ctx.kernel_stats()["forward"]["launches"]
                 elif rep > 0 or reps == 1:
