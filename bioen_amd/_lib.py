@@ -75,6 +75,7 @@ _SIGNATURES = {
     "bioen_hip_ctx_set_ytilde_target": (C.c_int, [ctx_p, dp]),
     "bioen_hip_ctx_set_affine": (C.c_int, [ctx_p, dp, dp]),
     "bioen_hip_ctx_set_direction_mode": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_ctx_set_storage": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_synchronize": (C.c_int, [ctx_p]),
     "bioen_hip_logw_weights": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_logw_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
@@ -408,6 +409,14 @@ class Context(object):
         'gram' (see include/bioen_hip.h: bioen_hip_ctx_set_direction_mode)."""
         code = {"auto": 0, "twoloop": 1, "gram": 2}[mode]
         check(lib().bioen_hip_ctx_set_direction_mode(self._h, code))
+
+    STORAGE_FORMATS = {"f64": 0, "split": 1, "fp32": 2}
+
+    def set_storage(self, fmt):
+        """EXPERIMENT (opt-in, never the default): the log-weights matrix passes stream the centred matrix as
+        'split' (fp32 + bf16 residual, 6 bytes per element, 2^-33 relative) or 'fp32' (4 bytes) instead of 'f64';
+        reassembled to FP64 in registers, all sums FP64.  M <= 1024, log-weights method only."""
+        check(lib().bioen_hip_ctx_set_storage(self._h, self.STORAGE_FORMATS[fmt]))
 
     def synchronize(self):
         check(lib().bioen_hip_synchronize(self._h))

@@ -932,6 +932,8 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
         if (c->Yp[p]) hipFree(c->Yp[p]);
         if (c->Y1p[p]) hipFree(c->Y1p[p]);
     }
+    if (c->Yr) hipFree(c->Yr);
+    if (c->Yr1) hipFree(c->Yr1);
     if (c->live_f) hipHostFree(c->live_f);
     if (c->dev_tab) hipFree(c->dev_tab);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -1030,6 +1032,15 @@ int bioen_hip_ctx_set_affine(bioen_hip_ctx* c, const double* row_offset, const d
     return 0;
 }
 
+int bioen_hip_ctx_set_storage(bioen_hip_ctx* c, int format) {
+    if (!c || format < 0 || format > 2) return fail(BIOEN_HIP_EINVAL, "format must be 0 (FP64), 1 (fp32 + bf16 split) or 2 (fp32)");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    if (format != 0 && c->mp > 1024) return fail(BIOEN_HIP_ESTATE, "the reduced-storage experiment serves M <= 1024");
+    const int rc = set_storage_format(c, format);
+    if (rc == BIOEN_HIP_ESTATE) return fail(rc, "no form of the matrix to build the copies from");
+    return rc;
+}
+
 int bioen_hip_ctx_set_direction_mode(bioen_hip_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) return fail(BIOEN_HIP_EINVAL, "mode must be 0 (auto), 1 (two-loop) or 2 (Gram form)");
     c->direction_mode = mode;
@@ -1122,6 +1133,7 @@ static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
     if (c->world != 1 && !(strip_path_ok && (forces_fused_blocks(c) > 0 || forces_fused_blocks_old(c) > 0)))
         return fail(BIOEN_HIP_ESTATE, "not available on this structure-sharded context");
     if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
+    if (c->storage) return fail(BIOEN_HIP_ESTATE, "the reduced-storage experiment covers the log-weights passes only");
     return 0;
 }
 
@@ -1255,6 +1267,7 @@ int bioen_hip_chi_squared(bioen_hip_ctx* c, const double* w, double* yave, doubl
     v.p[0] = s0.w;
     int nblk = fwd_strip_blocks(c);
     if (c->mp > 1024 && !c->Yp[0]) nblk = 0;      // row panels are built for the optimizer's passes, not for one product
+    if (c->storage) nblk = 0;                     // reduced-storage experiment: its copies are pre-centred; the FP64 matrix serves
     if (nblk > 0 && (rc = ensure_strip_copy(c))) {
         if (!c->strips_unavailable) return rc;
         nblk = 0;

@@ -186,6 +186,11 @@ struct bioen_hip_ctx {
     double* Ys = nullptr;            // [ld / 16][strip rows][16], row-sum operand order (forces, log-weights forward)
     double* Ys1 = nullptr;           // the same strips in column-sum operand order (log-weights adjoint)
     double* strip_center = nullptr;  // mp: YTilde at the time of the copy
+    // reduced-byte storage EXPERIMENT (kernels_strip.hip; bioen_hip_ctx_set_storage): the log-weights passes stream
+    // CENTRED copies of 6 (fp32 + bf16 residual) or 4 (fp32) bytes per element; the row-major FP64 matrix stays resident
+    int storage = 0;                 // 0 FP64 (default, the graded path) | 1 fp32 + bf16 split | 2 fp32
+    void* Yr = nullptr;              // row-sum operand order
+    void* Yr1 = nullptr;             // column-sum operand order
     // M > 1024 (r03): the matrix passes of both methods run the same kernels over PANELS of <= 1024 rows, each with its
     // own pair of strip copies; the row-major matrix is freed once the row-sum panels exist, as for M <= 1024
     static constexpr int kMaxPanels = 16;

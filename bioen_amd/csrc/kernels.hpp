@@ -83,6 +83,7 @@ void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
 void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);   // sharded: -> X_YBAR segment
 int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
+int set_storage_format(bioen_hip_ctx* c, int fmt);     // reduced-byte storage experiment of the log-weights passes (0 = FP64)
 int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
 void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool plain = false);
 int ensure_rowmajor(bioen_hip_ctx* c);                 // the row-major matrix back from the strip copy (it is freed once that exists)

@@ -154,8 +154,72 @@ __device__ __forceinline__ void strip_chunk_offsets(int mps, int rsrc, int (&off
     for (int i = 0; i < kWaveRows / 8; ++i) off[i] = __builtin_amdgcn_readfirstlane(((i >> 1) < nh ? i : (i & 1)) * 128);
 }
 
+// ---- reduced-byte storage EXPERIMENT (r04; SURVEY 7 "treat FP32/BF16-split as an experiment", 8 f4; never the default,
+// never the headline): the log-weights matrix passes can stream copies that hold the CENTRED operand Y' = Y - centre as
+//   STORE 1: fp32 high part + bf16 residual (6 bytes per element, |error| <= 2^-33 |Y'|), reassembled in FP64 registers,
+//   STORE 2: fp32 (4 bytes, 2^-25 |Y'|),
+// in the same operand orders.  A wave's 64-row slice of a strip (rows padded to 64 here) is one contiguous run: four
+// 1-KiB loads of the high parts -- load u, lane l: {chunk 2u .x, .y, chunk 2u+1 .x, .y} of the FP64 layout above -- and,
+// STORE 1, two 1-KiB loads of the residuals behind them -- load v, lane l, word w: chunk 4v + w, .x in the low half,
+// .y in the high half.  Every load is 16 bytes per lane as in the FP64 stream; measured, tools/split_read_probe.hip:
+// 6.87 TB/s for the 6-byte stream reassembled to FP64 = 1.31 x the elements per second of the 8-byte stream, 2.0 x for fp32.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+template <int STORE>
+__host__ __device__ constexpr int reduced_slice_bytes() { return STORE == 1 ? 6144 : 4096; }
+
+template <bool NT, class T>
+__device__ __forceinline__ T ldg16(const void* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+    return *reinterpret_cast<const T*>(p);
+}
+// element (.x | .y) of chunk i of the wave's slice, back in FP64
+template <int STORE>
+__device__ __forceinline__ double reduced_elem(const f4 (&hi)[4], const u4 (&lo)[2], int i, int xy) {
+    const f4 h = hi[i >> 1];
+    const int e = (i & 1) * 2 + xy;
+    double d = (double)(e == 0 ? h.x : e == 1 ? h.y : e == 2 ? h.z : h.w);
+    if (STORE == 1) {
+        const u4 l = lo[i >> 2];
+        const int wsel = i & 3;
+        const unsigned w = wsel == 0 ? l.x : wsel == 1 ? l.y : wsel == 2 ? l.z : l.w;
+        d += (double)__uint_as_float(xy ? (w & 0xffff0000u) : (w << 16));
+    }
+    return d;
+}
+
+// row-major matrix -> reduced strip copy (centred); COLSUM selects the operand order (strip_pos / strip_pos_colsum)
+template <bool COLSUM, int STORE>
+__global__ __launch_bounds__(256) void k_build_strips_reduced(const double* __restrict__ Y, size_t ld, int mp, int mps64, int n,
+                                                              unsigned char* __restrict__ out, int nstrips,
+                                                              const double* __restrict__ center) {
+    constexpr int SB = reduced_slice_bytes<STORE>();
+    const size_t strip_bytes = (size_t)(mps64 / kWaveRows) * SB;
+    for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
+        unsigned char* dst = out + (size_t)s * strip_bytes;
+        for (int p = threadIdx.x; p < mps64 * kStripCols; p += 256) {
+            const int row = p >> 4, cc = p & 15;
+            const size_t col = (size_t)s * kStripCols + cc;
+            double v = 0.0;
+            if (row < mp && col < (size_t)n) v = Y[(size_t)row * ld + col] - center[row];
+            const size_t pos = COLSUM ? strip_pos_colsum(row, cc) : strip_pos(row, cc);     // ((wave 8 + chunk) 64 + lane) 2 + xy
+            const int xy = (int)(pos & 1), lane = (int)((pos >> 1) & 63), chunk = (int)((pos >> 7) & 7), w = (int)(pos >> 10);
+            unsigned char* sl = dst + (size_t)w * SB;
+            const float hi = (float)v;
+            reinterpret_cast<float*>(sl)[((chunk >> 1) * 64 + lane) * 4 + (chunk & 1) * 2 + xy] = hi;
+            if (STORE == 1) {
+                const float r = (float)(v - (double)hi);
+                unsigned b = __float_as_uint(r);
+                b += 0x7fffu + ((b >> 16) & 1u);                        // bf16, round to nearest even
+                reinterpret_cast<unsigned short*>(sl + 4096)[(((chunk >> 2) * 64 + lane) * 4 + (chunk & 3)) * 2 + xy] =
+                    (unsigned short)(b >> 16);
+            }
+        }
+    }
+}
+
 struct StripArgs {
-    const double* Ys;       // strip-major copy (raw matrix)
+    const double* Ys;       // strip-major copy (raw matrix; the reduced formats: bytes, centred)
     const double* center;   // mp values subtracted from the rows on the way into the products (a zero vector: none)
     int mps;                // rows of a strip (multiple of 16)
     int mp;                 // rows of the operands u_c / outputs
@@ -767,7 +831,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
 // unrolled by two as in k_strip): 2418-2443 vs 2432-2438 us of matrix kernels per headline round, 84.7 vs 82 us at
 // N = 1e5 x M = 256 -- no gain: the ~7 TB/s these passes reach is the memory system's rate for this stream, not a
 // shortage of bytes in flight.
-template <int K, bool NT>
+template <int K, bool NT, int STORE = 0>
 __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     constexpr int NK = (K + 3) / 4;
     __shared__ double tv[2][4][8 * kStripCols];                   // [parity][slot][problem][column]
@@ -795,19 +859,33 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     for (int k = 1; k < K; ++k)
         if (pk == k) vk = v.p[k];
     d2 pre[kWaveRows / 8];
+    f4 rhi[4];                                                     // reduced formats (STORE != 0): the wave's slice as it is stored
+    u4 rlo[2];
     double cen[kWaveRows / 16];                                    // centre of the lane's row in each of its four row blocks
 #pragma unroll
     for (int h = 0; h < kWaveRows / 16; ++h) {
         const int row = rsrc + 16 * h + (lane & 15);
-        cen[h] = row < q.mp ? q.center[row] : 0.0;
+        cen[h] = (STORE == 0 && row < q.mp) ? q.center[row] : 0.0;     // the reduced copies hold the centred operand
     }
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
     int choff[kWaveRows / 8];
     strip_chunk_offsets(q.mps, rsrc, choff);
     auto fetch = [&](int strip) {
-        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+        if constexpr (STORE == 0) {
+            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+            for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+        } else {
+            constexpr int SB = reduced_slice_bytes<STORE>();
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(q.Ys) +
+                                       ((size_t)strip * (q.mps / kWaveRows) + (size_t)(rsrc / kWaveRows)) * SB + (size_t)lane * 16;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rhi[u] = ldg16<NT, f4>(src + u * 1024);
+            if constexpr (STORE == 1) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) rlo[u] = ldg16<NT, u4>(src + 4096 + u * 1024);
+            }
+        }
     };
     int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
     int sw = base + sub;                                           // this wave's strip (a slot beyond the last strip works on
@@ -830,12 +908,17 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
         for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
             for (int h = 0; h < kWaveRows / 16; ++h) {
-                const d2 y = pre[2 * h + (qq >> 1)];
+                double a;
+                if constexpr (STORE == 0) {
+                    const d2 y = pre[2 * h + (qq >> 1)];
 #if STRIP_PRECENTERED
-                const double a = (qq & 1) ? y.y : y.x;
+                    a = (qq & 1) ? y.y : y.x;
 #else
-                const double a = ((qq & 1) ? y.y : y.x) - cen[h];      // the centring (r02: stored in the copy)
+                    a = ((qq & 1) ? y.y : y.x) - cen[h];               // the centring (r02: stored in the copy)
 #endif
+                } else {
+                    a = reduced_elem<STORE>(rhi, rlo, 2 * h + (qq >> 1), qq & 1);
+                }
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
                     acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
@@ -866,7 +949,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 // geometry as in the forward pass; u = r (compact [row K + k]) sits in an LDS table in B-operand reach, the partial
 // column sums of a slot's waves meet in LDS (two buffers by strip parity: one barrier per iteration), 16 K threads per
 // slot add the shift and store.
-template <int K, bool NT>
+template <int K, bool NT, int STORE = 0>
 __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec8 scal) {
     constexpr int NK = (K + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -902,13 +985,27 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
         }
     if (p2 && q.accumulate == 0) shift = sck[S_B0] - sck[S_UY];
     d2 pre[kWaveRows / 8];
+    f4 rhi[4];                                                     // reduced formats (STORE != 0)
+    u4 rlo[2];
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;
     int choff[kWaveRows / 8];
     strip_chunk_offsets(q.mps, rsrc, choff);
     auto fetch = [&](int strip) {
-        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+        if constexpr (STORE == 0) {
+            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+            for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+        } else {
+            constexpr int SB = reduced_slice_bytes<STORE>();
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(q.Ys) +
+                                       ((size_t)strip * (q.mps / kWaveRows) + (size_t)(rsrc / kWaveRows)) * SB + (size_t)lane * 16;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rhi[u] = ldg16<NT, f4>(src + u * 1024);
+            if constexpr (STORE == 1) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) rlo[u] = ldg16<NT, u4>(src + 4096 + u * 1024);
+            }
+        }
     };
     int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
     int sw = base + sub, sp = base + psub;                         // this wave's strip / the strip this thread stores for
@@ -932,11 +1029,16 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
                 for (int kq = 0; kq < NK; ++kq) b1[g][kq] = pu[g * 32 + 4 * kq];
 #pragma unroll
             for (int g = 0; g < kWaveRows / 4; ++g) {
+                double a;
+                if constexpr (STORE == 0) {
 #if STRIP_PRECENTERED
-                const double a = (g & 1) ? pre[g >> 1].y : pre[g >> 1].x;
+                    a = (g & 1) ? pre[g >> 1].y : pre[g >> 1].x;
 #else
-                const double a = ((g & 1) ? pre[g >> 1].y : pre[g >> 1].x) - pc_[4 * g];   // the centring (r02: stored in the copy)
+                    a = ((g & 1) ? pre[g >> 1].y : pre[g >> 1].x) - pc_[4 * g];   // the centring (r02: stored in the copy)
 #endif
+                } else {
+                    a = reduced_elem<STORE>(rhi, rlo, g >> 1, g & 1);
+                }
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
                     d[g & 3][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1[g][kq], d[g & 3][kq], 0, 0, 0);
@@ -1119,7 +1221,64 @@ static int ensure_center(bioen_hip_ctx* c) {
     return 0;
 }
 
+// reduced-byte storage experiment: the centred copies of c->storage's format, both operand orders, from the row-major
+// FP64 matrix (which stays resident: read-back, chi_squared and the forces method keep using it)
+static size_t reduced_copy_bytes(const bioen_hip_ctx* c) {
+    const size_t slices = (size_t)(c->ld / kStripCols) * (round_up((size_t)c->m, kWaveRows) / kWaveRows);
+    return slices * (c->storage == 1 ? reduced_slice_bytes<1>() : reduced_slice_bytes<2>());
+}
+static int ensure_reduced_copy(bioen_hip_ctx* c, bool colsum) {
+    void*& slot = colsum ? c->Yr1 : c->Yr;
+    if (slot) return 0;
+    if (paneled(c)) return BIOEN_HIP_ESTATE;
+    int rc = ensure_rowmajor(c);                        // (gathered back exactly if the FP64 strip copy had replaced it)
+    if (rc) return rc;
+    if ((rc = ensure_center(c))) return rc;
+    if (ensure_zero_center(c)) return BIOEN_HIP_ENOMEM;
+    void* buf = nullptr;
+    hipError_t e = hipMalloc(&buf, reduced_copy_bytes(c));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        hip_fail(e, "hipMalloc (reduced-storage strip copy)", __FILE__, __LINE__);
+        return BIOEN_HIP_ENOMEM;
+    }
+    const int nstrips = (int)(c->ld / kStripCols), mps64 = (int)round_up((size_t)c->m, kWaveRows);
+    const dim3 grid(std::min(nstrips, 4096)), block(256);
+    unsigned char* out = static_cast<unsigned char*>(buf);
+    if (c->storage == 1 && !colsum) hipLaunchKernelGGL((k_build_strips_reduced<false, 1>), grid, block, 0, c->stream, c->Y, c->ld, c->mp, mps64, c->n, out, nstrips, c->strip_center);
+    if (c->storage == 1 && colsum) hipLaunchKernelGGL((k_build_strips_reduced<true, 1>), grid, block, 0, c->stream, c->Y, c->ld, c->mp, mps64, c->n, out, nstrips, c->strip_center);
+    if (c->storage == 2 && !colsum) hipLaunchKernelGGL((k_build_strips_reduced<false, 2>), grid, block, 0, c->stream, c->Y, c->ld, c->mp, mps64, c->n, out, nstrips, c->strip_center);
+    if (c->storage == 2 && colsum) hipLaunchKernelGGL((k_build_strips_reduced<true, 2>), grid, block, 0, c->stream, c->Y, c->ld, c->mp, mps64, c->n, out, nstrips, c->strip_center);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        return hip_fail(e, "k_build_strips_reduced", __FILE__, __LINE__);
+    }
+    slot = buf;
+    return 0;
+}
+
+// bioen_hip_ctx_set_storage: switch the format of the log-weights passes' copies (0 = FP64).  Copies of another format
+// are dropped; the row-major FP64 matrix is made resident again and kept from now on.
+int set_storage_format(bioen_hip_ctx* c, int fmt) {
+    if (fmt == c->storage) return 0;
+    if (fmt != 0 && paneled(c)) return BIOEN_HIP_ESTATE;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    if (fmt != 0) {
+        const int rc = ensure_rowmajor(c);
+        if (rc && !(rc == BIOEN_HIP_ESTATE && c->Y)) return rc;
+        c->keep_rowmajor = 1;
+    }
+    if (c->Yr) (void)hipFree(c->Yr);
+    if (c->Yr1) (void)hipFree(c->Yr1);
+    c->Yr = c->Yr1 = nullptr;
+    c->storage = fmt;
+    return 0;
+}
+
 int ensure_strip_copy(bioen_hip_ctx* c) {
+    if (c->storage) return ensure_reduced_copy(c, false);
     if (paneled(c)) {                                   // row panels of a matrix taller than 1024 rows; Y stays
         if (c->Yp[0]) return 0;
         if (c->strips_unavailable) return BIOEN_HIP_ENOMEM;
@@ -1265,7 +1424,10 @@ int fwd_strip_blocks(const bioen_hip_ctx* c) {
 
 template <int K, bool NT>
 static void fwd_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const Vec8& v, dim3 block) {
-    BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT>), dim3((q.nblk + q.spb - 1) / q.spb), block, 0, q, v);
+    const dim3 grid((q.nblk + q.spb - 1) / q.spb);
+    if (c->storage == 1) { BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT, 1>), grid, block, 0, q, v); }
+    else if (c->storage == 2) { BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT, 2>), grid, block, 0, q, v); }
+    else { BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT>), grid, block, 0, q, v); }
 }
 
 template <bool NT>
@@ -1293,6 +1455,10 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
         q.Ys = paneled(c) ? c->Yp[p] : c->Ys;
         q.center = center + row0;
         q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+        if (c->storage) {                               // reduced-storage experiment: centred copies, rows padded to 64
+            q.Ys = static_cast<const double*>(c->Yr);
+            q.mps = (int)round_up((size_t)c->m, kWaveRows);
+        }
         q.mp = panel_mp(c, p);
         q.nstrips = (int)(c->ld / kStripCols);
         q.n = c->n;
@@ -1311,6 +1477,10 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
 
 // adjoint pass of the log-weights method on the column-sum copy (built on first use)
 int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
+    if (c->storage) {
+        const int rc = ensure_reduced_copy(c, false);
+        return rc ? rc : ensure_reduced_copy(c, true);
+    }
     if (paneled(c)) {
         if (c->Y1p[0]) return 0;
         int rc = ensure_strip_copy(c);
@@ -1361,7 +1531,18 @@ static void adj_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const MVec8
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT>), dim3((q.nblk + q.spb - 1) / q.spb), block, lds, q, out, scal);
+    const dim3 grid((q.nblk + q.spb - 1) / q.spb);
+    if (c->storage == 1) {
+        static bool a1 = false;
+        if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_adj<K, NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+        BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT, 1>), grid, block, lds, q, out, scal);
+    } else if (c->storage == 2) {
+        static bool a2 = false;
+        if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_adj<K, NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
+        BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT, 2>), grid, block, lds, q, out, scal);
+    } else {
+        BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT>), grid, block, lds, q, out, scal);
+    }
 }
 
 template <bool NT>
@@ -1388,6 +1569,10 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
         q.Ys = paneled(c) ? c->Y1p[p] : c->Ys1;
         q.center = (plain ? c->zero_center : c->strip_center) + row0;      // plain: out = Y^T u itself (forces method, M > 1024)
         q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+        if (c->storage) {
+            q.Ys = static_cast<const double*>(c->Yr1);
+            q.mps = (int)round_up((size_t)c->m, kWaveRows);
+        }
         q.mp = panel_mp(c, p);
         q.nstrips = (int)(c->ld / kStripCols);
         q.n = c->n;

@@ -155,6 +155,16 @@ int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
  * long; one value per DEER trace / data set, repeated over its rows).  Log-weights method;
  * chi_squared() returns the raw yTilde . w and the chi^2 of the affine model. */
 int bioen_hip_ctx_set_affine(bioen_hip_ctx* ctx, const double* row_offset, const double* row_scale);
+/* EXPERIMENT, opt-in, never the default and never part of a headline number ("keep FP64 as the graded path;
+ * treat FP32/BF16-split as an experiment"; 8 f4): the two matrix passes of the LOG-WEIGHTS evaluation stream copies
+ * of the centred operand yTilde_ij - YTilde_i held in fewer bytes and reassembled to FP64 in registers in front of the
+ * FP64 matrix-core products (all sums stay FP64):
+ *   format 1: fp32 high part + bf16 residual, 6 bytes per element, |error| <= 2^-33 of the centred element;
+ *   format 2: fp32, 4 bytes, 2^-25;       format 0: back to FP64 (8 bytes, exact).
+ * The FP64 row-major matrix stays resident beside them (read-back, chi_squared).  M <= 1024; the forces method returns
+ * BIOEN_HIP_ESTATE while a reduced format is selected.  No reference counterpart: the reference computes in double
+ * throughout (bioen/optimize/ext/c_bioen_common.c:70-108). */
+int bioen_hip_ctx_set_storage(bioen_hip_ctx* ctx, int format);
 /* How the L-BFGS direction d = -H g is formed on the device.
  *   1  two-loop recursion on the vectors, liblbfgs' order of operations (lbfgs.c:571-598):
  *      13 fused vector sweeps and 13 dependent reductions per direction;
