@@ -24,6 +24,12 @@ VARIANTS = {
                      "BIOEN_HIP_SHADOW_GRAM": "1"},
     "sharded-form+p2p1": {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEV_RESERVE": "2",
                           "BIOEN_HIP_SHADOW_GRAM": "1", "_P2P": "1"},
+    # the device-resident engine FORCED (above 4 GB of matrix traffic per round the default is the host-driven one)
+    "dev1": {"BIOEN_HIP_DEVICE_LS": "1"},
+    "dev1-reserve": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0",
+                     "BIOEN_HIP_DEV_RESERVE": "2"},
+    "dev1-sharded-form": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0",
+                          "BIOEN_HIP_DEV_RESERVE": "2", "BIOEN_HIP_SHADOW_GRAM": "1"},
     "host": {"BIOEN_HIP_DEVICE_LS": "0"},
     "host-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
 }
