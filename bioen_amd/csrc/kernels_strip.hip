@@ -242,9 +242,16 @@ struct StripArgs {
 // one-hot operands, tools/mfma_f64_4x4_probe.hip): lane l = 16 kk + 4 blk + r holds A_blk[i = r][kk],
 // B_blk[kk][j = r]; the result lane 16 i + 4 blk + j holds D_blk[i][j].  Unlike the 16x16x4 form nothing is
 // padded: K <= 4 problems take one instruction per operand fetch, K <= 8 two, at 32 FLOP/clk/SIMD either way.
+// DEPTH: 2 = two register sets in flight (K <= 4), 1 = one; 3 (r04, K > 4) = one register set AND the row-sum product of
+// strip s deferred behind the first barrier of strip s + 1, where it runs beside P2 of that strip on the waves P2 leaves
+// idle: ONE barrier per strip, P3 off the serial chain (the partial-sum, e | t and rescale buffers are doubled by strip
+// parity).  Same operands, same order of every sum: the bits of a problem do not depend on which form served it.
 template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH>
 __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
     constexpr int NK = (K + 3) / 4;                 // problem quads
+    constexpr bool DEFER = DEPTH == 3;
+    constexpr int SETS = DEPTH == 2 ? 2 : 1;        // register sets (strips in flight per wave)
+    constexpr int NBUF = DEFER ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -257,10 +264,10 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     const int lrows = nwaves * kWaveRows;
     double* tile = lds;
     double* ul = tile + (size_t)lrows * kStripCols;  // u[row][8]: forces | residuals, zero beyond K and mp
-    double* red = ul + (size_t)lrows * 8;           // [wave][problem 8][column 16]: the waves' partial column sums
-    double* tv = red + nwaves * 128;                // v[problem 8][column 16]: e | t of the strip
-    double* scale = tv + 128;
-    double* cl = scale + 16;                        // centre[row]
+    double* red = ul + (size_t)lrows * 8;           // [parity][wave][problem 8][column 16]: the waves' partial column sums
+    double* tv = red + NBUF * nwaves * 128;         // [parity] v[problem 8][column 16]: e | t of the strip
+    double* scale = tv + NBUF * 128;
+    double* cl = scale + NBUF * 16;                 // centre[row]
     const int rbase = wave * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         const int row = i >> 3, k = i & 7;
         ul[i] = (row < q.mp && k < K) ? q.u_c[(size_t)row * K + k] : 0.0;
     }
-    for (int i = t; i < 128; i += blockDim.x) tv[i] = 0.0;         // problems k >= K of a quad stay zero
+    for (int i = t; i < NBUF * 128; i += blockDim.x) tv[i] = 0.0;  // problems k >= K of a quad stay zero
     for (int i = t; i < lrows; i += blockDim.x) cl[i] = i < q.mp ? q.center[i] : 0.0;
-    if (t < 8) scale[t] = 1.0;
+    if (t < NBUF * 16) scale[t] = 1.0;
 
     // P3 accumulators: row block h (16 rows), problem quad kq: lane 16 i + 4 blk + j holds
     // row rbase + 16 h + 4 blk + i, problem 4 kq + j
@@ -309,7 +316,8 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 
     // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
     d2 preA[kWaveRows / 8];
-    d2 preB[DEPTH == 2 ? kWaveRows / 8 : 1];
+    d2 preB[SETS == 2 ? kWaveRows / 8 : 1];
+    double a3old[4][kWaveRows / 16];                // DEFER: the row-sum operands of the strip before this one
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
     int choff[kWaveRows / 8];                                                   // chunk -> chunk actually loaded (wave-uniform)
     strip_chunk_offsets(q.mps, rsrc, choff);
@@ -328,7 +336,38 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #else
 #define STAMP(i)
 #endif
-    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par) {
+    // ---- P3: acc[row][k] (+)= sum_c Y'[row][c] v[c][k] ----
+    // A: lane (kk = lq, blk, i) = Y'[r0 + 4 blk + i = r0 + lr][c = 4 qq + lq]; B: lane (kk, blk, j) = v[4 qq + lq][4 kq + j]
+    auto p3 = [&](double (&a3x)[4][kWaveRows / 16], const double* tvp, const double* scp) {
+        if (XY) {
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const double sc = scp[4 * kq + lj];
+#pragma unroll
+                for (int h = 0; h < kWaveRows / 16; ++h) acc[h][kq] *= sc;
+            }
+        }
+#if !(STRIP_DIAG & 1)
+        double bv[4][NK];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tvp[(4 * kq + lj) * 16 + 4 * qq + lq];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq)
+                    acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3x[qq][h], bv[qq][kq], acc[h][kq], 0, 0, 0);
+#else
+        acc[0][0] += a3x[0][0] * tvp[lj * 16];
+#endif
+    };
+    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par, bool first = false) {
+        double* const redp = red + (DEFER ? par * nwaves * 128 : 0);
+        double* const tvp = tv + (DEFER ? par * 128 : 0);
+        double* const scp = scale + (DEFER ? par * 16 : 0);
         // registers -> LDS image (row-major, swizzled) for the column sums; the same 16 rows x 2 columns per
         // 32 lanes as the row-sum operand fetch used to read: conflict-free.  The registers themselves ARE the
         // row-sum operands: kept in a3 until P3 (the prefetch below reuses `pre`).
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        fetch(s + DEPTH * G < q.nstrips ? s + DEPTH * G : s, pre);    // unconditional, see k_strip_adj
+        fetch(s + SETS * G < q.nstrips ? s + SETS * G : s, pre);      // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
         {
@@ -403,7 +442,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #endif
             // result lane 16 i + 4 blk + j: column c = 4 blk + i, problem 4 kq + j
             const int c = 4 * ((lane >> 2) & 3) + lq;
-            double* redw = red;
+            double* redw = redp;
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq)
                 redw[wave * 128 + (4 * kq + lj) * 16 + c] = (d[0][kq] + d[1][kq]) + (d[2][kq] + d[3][kq]);
@@ -416,7 +455,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             double colsum = 0.0;
             if (p2) {
                 const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
-                for (int wv = 0; wv < nown; ++wv) colsum += red[wv * 128 + pk * 16 + pc];
+                for (int wv = 0; wv < nown; ++wv) colsum += redp[wv * 128 + pk * 16 + pc];
             }
             if (XY) {
                 const bool valid = p2 && col < (size_t)q.n;
@@ -433,8 +472,8 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
                 pxacc = fma(pxacc, sc, valid ? e * colsum : 0.0);
                 m_run = m_new;
                 if (p2) {
-                    if (pc == 0) scale[pk] = sc;
-                    tv[pk * 16 + pc] = e;
+                    if (pc == 0) scp[pk] = sc;
+                    tvp[pk * 16 + pc] = e;
                 }
             } else if (p2) {
                 const double lrat = xv - logs;                    // log(w / w0)
@@ -442,40 +481,25 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
                 double dd = 1.0;
                 if (wv >= DBL_MIN && w0v >= DBL_MIN) dd += lrat;  // c_bioen_kernels_forces.c:320-328
                 const double tval = (dd * theta + (colsum + b0)) * wv;
-                tv[pk * 16 + pc] = tval;
+                tvp[pk * 16 + pc] = tval;
                 zacc += tval;
             }
         }
         STAMP(3)    // P2
-        __syncthreads();
-        STAMP(4)    // second barrier
-        // ---- P3: acc[row][k] (+)= sum_c Y'[row][c] v[c][k] ----
-        // A: lane (kk = lq, blk, i) = Y'[r0 + 4 blk + i = r0 + lr][c = 4 qq + lq]; B: lane (kk, blk, j) = v[4 qq + lq][4 kq + j]
-        {
-            if (XY) {
-#pragma unroll
-                for (int kq = 0; kq < NK; ++kq) {
-                    const double sc = scale[4 * kq + lj];
-#pragma unroll
-                    for (int h = 0; h < kWaveRows / 16; ++h) acc[h][kq] *= sc;
-                }
-            }
-#if !(STRIP_DIAG & 1)
-            double bv[4][NK];
+        if constexpr (DEFER) {
+            // no second barrier: the row sums of the strip BEFORE this one run here, beside P2 of this strip (its e | t and
+            // rescale factors sit in the other parity's buffers, complete since the barrier above); this strip's own
+            // row-sum operands wait in a3old for the next turn
+            if (!first) p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                for (int kq = 0; kq < NK; ++kq) bv[qq][kq] = tv[(4 * kq + lj) * 16 + 4 * qq + lq];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-                for (int h = 0; h < kWaveRows / 16; ++h)
-#pragma unroll
-                    for (int kq = 0; kq < NK; ++kq)
-                        acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3[qq][h], bv[qq][kq], acc[h][kq], 0, 0, 0);
-#else
-            acc[0][0] += a3[0][0] * tv[lj * 16];
-#endif
+                for (int h = 0; h < kWaveRows / 16; ++h) a3old[qq][h] = a3[qq][h];
+            STAMP(4)
+        } else {
+            __syncthreads();
+            STAMP(4)    // second barrier
+            p3(a3, tvp, scp);
         }
         STAMP(5)    // P3
         // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
@@ -492,6 +516,13 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             one_strip(s + G, preB, 1);
         }
         if (s < q.nstrips) one_strip(s, preA, 0);
+    } else if constexpr (DEFER) {
+        __syncthreads();
+        int par = 0;
+        one_strip(s, preA, 0, true);                              // (grid <= strips: every block has a first strip)
+        for (s += G, par = 1; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
+        __syncthreads();                                          // the last strip's e | t are in place
+        p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
     } else {
         __syncthreads();
         for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
@@ -1365,10 +1396,15 @@ static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRou
     static int depth5 = -1;
     if (depth5 < 0) {
         const char* e = std::getenv("BIOEN_HIP_STRIP_DEPTH5");
-        depth5 = e ? std::atoi(e) : 2;
+        depth5 = e ? std::atoi(e) : 3;
     }
-    if (K > 4 && depth5 == 1) strip_launch_kd<K, NT, XY, 1>(c, q, fr, block, lds);
-    else strip_launch_kd<K, NT, XY, 2>(c, q, fr, block, lds);
+    // K > 4 (r04): one register set + the row-sum product deferred behind the next strip's barrier (DEPTH 3); the LDS
+    // request carries the doubled partial-sum / e | t / rescale buffers.  BIOEN_HIP_STRIP_DEPTH5=2 / 1: the r03 forms (A/B)
+    if constexpr (K > 4) {
+        if (depth5 == 1) { strip_launch_kd<K, NT, XY, 1>(c, q, fr, block, lds); return; }
+        if (depth5 != 2) { strip_launch_kd<K, NT, XY, 3>(c, q, fr, block, lds + ((block.x / 64) * 128 + 128 + 16) * sizeof(double)); return; }
+    }
+    strip_launch_kd<K, NT, XY, 2>(c, q, fr, block, lds);
 }
 
 template <int K, bool NT, bool XY>
