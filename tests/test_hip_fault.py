@@ -61,7 +61,7 @@ def test_killed_rank_turns_into_an_error_on_the_survivor_host_staged(tmp_path):
 
 @pytest.mark.timeout(300)
 def test_stalled_rank_times_out_peer_to_peer(tmp_path):
-    timeout_s, stall_s = 4.0, 14.0
+    timeout_s, stall_s = 3.0, 10.0
     procs = start(tmp_path, "stall", {"BIOEN_HIP_WAIT_TIMEOUT": str(timeout_s), "BIOEN_TEST_STALL": str(stall_s)})
     try:
         for p in procs:

@@ -25,7 +25,12 @@ def free_port():
     return p
 
 
+_RUNS = {}          # (world, transport) -> results: the peer-to-peer runs serve both tests below
+
+
 def run_ranks(tmp_path, world, transport):
+    if (world, transport) in _RUNS:
+        return _RUNS[(world, transport)]
     port = free_port()
     procs = []
     out = tmp_path / transport
@@ -42,7 +47,8 @@ def run_ranks(tmp_path, world, transport):
         for p in procs:                 # a failed rank must not leave the others waiting on the GPU
             if p.poll() is None:
                 p.kill()
-    return [np.load(str(out / ("rank%d.npz" % r))) for r in range(world)]
+    _RUNS[(world, transport)] = [dict(np.load(str(out / ("rank%d.npz" % r)))) for r in range(world)]
+    return _RUNS[(world, transport)]
 
 
 RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
