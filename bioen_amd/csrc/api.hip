@@ -1133,7 +1133,8 @@ static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
     if (c->world != 1 && !(strip_path_ok && (forces_fused_blocks(c) > 0 || forces_fused_blocks_old(c) > 0)))
         return fail(BIOEN_HIP_ESTATE, "not available on this structure-sharded context");
     if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
-    if (c->storage) return fail(BIOEN_HIP_ESTATE, "the reduced-storage experiment covers the log-weights passes only");
+    if (c->storage && !(strip_path_ok && forces_fused_blocks(c) > 0 && !c->strip_old))
+        return fail(BIOEN_HIP_ESTATE, "the reduced-storage experiment serves the strip passes (M <= 1024) only");
     return 0;
 }
 

@@ -173,9 +173,10 @@ __device__ __forceinline__ T ldg16(const void* p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
     return *reinterpret_cast<const T*>(p);
 }
-// element (.x | .y) of chunk i of the wave's slice, back in FP64
-template <int STORE>
-__device__ __forceinline__ double reduced_elem(const f4 (&hi)[4], const u4 (&lo)[2], int i, int xy) {
+// element (.x | .y) of chunk i of the wave's slice(s), back in FP64; NH loads of high parts (chunks 2u, 2u + 1 in load u),
+// NH / 2 loads of residuals (chunks 4v .. 4v + 3 in load v) -- NH = 4: one 64-row slice, 8: the two slices of 128 rows
+template <int STORE, int NH>
+__device__ __forceinline__ double reduced_elem(const f4 (&hi)[NH], const u4 (&lo)[NH / 2], int i, int xy) {
     const f4 h = hi[i >> 1];
     const int e = (i & 1) * 2 + xy;
     double d = (double)(e == 0 ? h.x : e == 1 ? h.y : e == 2 ? h.z : h.w);
@@ -187,6 +188,13 @@ __device__ __forceinline__ double reduced_elem(const f4 (&hi)[4], const u4 (&lo)
     }
     return d;
 }
+// a wave's strip in flight: FP64 chunks, or the reduced formats' loads (the members a format does not use never exist)
+template <int NCH>
+struct StripRegs {
+    d2 v[NCH];
+    f4 hi[NCH / 2];
+    u4 lo[NCH / 4];
+};
 
 // row-major matrix -> reduced strip copy (centred); COLSUM selects the operand order (strip_pos / strip_pos_colsum)
 template <bool COLSUM, int STORE>
@@ -246,7 +254,7 @@ struct StripArgs {
 // strip s deferred behind the first barrier of strip s + 1, where it runs beside P2 of that strip on the waves P2 leaves
 // idle: ONE barrier per strip, P3 off the serial chain (the partial-sum, e | t and rescale buffers are doubled by strip
 // parity).  Same operands, same order of every sum: the bits of a problem do not depend on which form served it.
-template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH>
+template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH, int STORE = 0>
 __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
     constexpr int NK = (K + 3) / 4;                 // problem quads
     constexpr bool DEFER = DEPTH == 3;
@@ -315,17 +323,30 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     }
 
     // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
-    d2 preA[kWaveRows / 8];
-    d2 preB[SETS == 2 ? kWaveRows / 8 : 1];
+    using Regs = StripRegs<kWaveRows / 8>;
+    Regs preA;
+    Regs preB;                                      // (SETS == 1: never touched)
     double a3old[4][kWaveRows / 16];                // DEFER: the row-sum operands of the strip before this one
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
     int choff[kWaveRows / 8];                                                   // chunk -> chunk actually loaded (wave-uniform)
     strip_chunk_offsets(q.mps, rsrc, choff);
-    auto fetch = [&](int strip, d2 (&pre)[kWaveRows / 8]) {
+    auto fetch = [&](int strip, Regs& pre) {
 #if !(STRIP_DIAG & 2)
-        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+        if constexpr (STORE == 0) {
+            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
+            for (int i = 0; i < kWaveRows / 8; ++i) pre.v[i] = ldg2<NT>(src + choff[i]);
+        } else {                                    // reduced-storage experiment: centred, rows padded to 64
+            constexpr int SB = reduced_slice_bytes<STORE>();
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(q.Ys) +
+                                       ((size_t)strip * (q.mps / kWaveRows) + (size_t)(rsrc / kWaveRows)) * SB + (size_t)lane * 16;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pre.hi[u] = ldg16<NT, f4>(src + u * 1024);
+            if constexpr (STORE == 1) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pre.lo[u] = ldg16<NT, u4>(src + 4096 + u * 1024);
+            }
+        }
 #endif
     };
     const int G = gridDim.x;
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         acc[0][0] += a3x[0][0] * tvp[lj * 16];
 #endif
     };
-    auto one_strip = [&](int s, d2 (&pre)[kWaveRows / 8], int par, bool first = false) {
+    auto one_strip = [&](int s, Regs& pre, int par, bool first = false) {
         double* const redp = red + (DEFER ? par * nwaves * 128 : 0);
         double* const tvp = tv + (DEFER ? par * 128 : 0);
         double* const scp = scale + (DEFER ? par * 16 : 0);
@@ -378,12 +399,18 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #pragma unroll
             for (int i = 0; i < kWaveRows / 8; ++i) {
                 const int h = i >> 1, qp = i & 1;
-                const double ch = cl[rsrc + 16 * h + lr];
+                double vx, vy;
+                if constexpr (STORE == 0) {
+                    const double ch = cl[rsrc + 16 * h + lr];
 #if STRIP_PRECENTERED
-                const double vx = pre[i].x, vy = pre[i].y;
+                    vx = pre.v[i].x, vy = pre.v[i].y;
 #else
-                const double vx = pre[i].x - ch, vy = pre[i].y - ch;              // the centring (r02: stored in the copy)
+                    vx = pre.v[i].x - ch, vy = pre.v[i].y - ch;                   // the centring (r02: stored in the copy)
 #endif
+                } else {
+                    vx = reduced_elem<STORE, 4>(pre.hi, pre.lo, i, 0);
+                    vy = reduced_elem<STORE, 4>(pre.hi, pre.lo, i, 1);
+                }
                 a3[2 * qp][h] = vx;
                 a3[2 * qp + 1][h] = vy;
                 img[h * 256 + (((8 * qp + lq) ^ sw3) ^ (h & 1))] = vx;
@@ -578,7 +605,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #ifndef STRIP2_GB2
 #define STRIP2_GB2 2
 #endif
-template <int K, bool NT, bool XY>
+template <int K, bool NT, bool XY, int STORE = 0>
 __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) {
     constexpr int RH = 2;                           // 64-row halves per wave
     constexpr int WR = 64 * RH;                     // rows per wave
@@ -642,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     }
 
     // the wave's 16 KB of the next strip travel in registers
-    d2 pre[WR / 8];
+    StripRegs<WR / 8> pre;
     const size_t wave_off = (size_t)rsrc * kStripCols + (size_t)lane * 2;      // the wave's slice is contiguous in the copy
     int choff[WR / 8];                                                          // chunk -> chunk actually loaded (wave-uniform)
     {
@@ -651,10 +678,24 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         for (int i = 0; i < WR / 8; ++i) choff[i] = __builtin_amdgcn_readfirstlane(((i >> 1) < nh ? i : (i & 1)) * 128);
     }
     auto fetch_part = [&](int strip, int lo, int hi) {
-        const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+        if constexpr (STORE == 0) {
+            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
 #pragma unroll
-        for (int i = 0; i < WR / 8; ++i)
-            if (i >= lo && i < hi) pre[i] = ldg2<NT>(src + choff[i]);
+            for (int i = 0; i < WR / 8; ++i)
+                if (i >= lo && i < hi) pre.v[i] = ldg2<NT>(src + choff[i]);
+        } else {      // reduced-storage experiment: centred, rows padded to 128 here; a wave's two 64-row slices are adjacent
+            constexpr int SB = reduced_slice_bytes<STORE>();
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(q.Ys) +
+                                       ((size_t)strip * (q.mps / 64) + (size_t)(rsrc / 64)) * SB + (size_t)lane * 16;
+#pragma unroll
+            for (int u = 0; u < WR / 16; ++u)
+                if (2 * u >= lo && 2 * u < hi) pre.hi[u] = ldg16<NT, f4>(src + (u >> 2) * SB + (u & 3) * 1024);
+            if constexpr (STORE == 1) {
+#pragma unroll
+                for (int u = 0; u < WR / 32; ++u)
+                    if (4 * u >= lo && 4 * u < hi) pre.lo[u] = ldg16<NT, u4>(src + (u >> 1) * SB + 4096 + (u & 1) * 1024);
+            }
+        }
     };
     auto fetch = [&](int strip) { fetch_part(strip, 0, WR / 8); };
     // K > 4: the operand batches of the column-sum product do not fit beside a3 AND the whole prefetch (7-12 registers
@@ -668,9 +709,14 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
 #pragma unroll
             for (int i = 0; i < WR / 8; ++i) {
                 const int h = i >> 1, qp = i & 1;
-                const double ch = cl[rsrc + 16 * h + lr];
-                a3[2 * qp][h] = pre[i].x - ch;                                    // the centring
-                a3[2 * qp + 1][h] = pre[i].y - ch;
+                if constexpr (STORE == 0) {
+                    const double ch = cl[rsrc + 16 * h + lr];
+                    a3[2 * qp][h] = pre.v[i].x - ch;                              // the centring
+                    a3[2 * qp + 1][h] = pre.v[i].y - ch;
+                } else {
+                    a3[2 * qp][h] = reduced_elem<STORE, WR / 16>(pre.hi, pre.lo, i, 0);
+                    a3[2 * qp + 1][h] = reduced_elem<STORE, WR / 16>(pre.hi, pre.lo, i, 1);
+                }
             }
         }
         // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
@@ -948,7 +994,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
                     a = ((qq & 1) ? y.y : y.x) - cen[h];               // the centring (r02: stored in the copy)
 #endif
                 } else {
-                    a = reduced_elem<STORE>(rhi, rlo, 2 * h + (qq >> 1), qq & 1);
+                    a = reduced_elem<STORE, 4>(rhi, rlo, 2 * h + (qq >> 1), qq & 1);
                 }
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
@@ -1068,7 +1114,7 @@ __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec
                     a = ((g & 1) ? pre[g >> 1].y : pre[g >> 1].x) - pc_[4 * g];   // the centring (r02: stored in the copy)
 #endif
                 } else {
-                    a = reduced_elem<STORE>(rhi, rlo, g >> 1, g & 1);
+                    a = reduced_elem<STORE, 4>(rhi, rlo, g >> 1, g & 1);
                 }
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq)
@@ -1254,8 +1300,11 @@ static int ensure_center(bioen_hip_ctx* c) {
 
 // reduced-byte storage experiment: the centred copies of c->storage's format, both operand orders, from the row-major
 // FP64 matrix (which stays resident: read-back, chi_squared and the forces method keep using it)
+static int reduced_rows(const bioen_hip_ctx* c) {       // rows of a reduced strip: whole 64-row slices; 512 < M <= 1024: pairs of
+    return (int)round_up((size_t)c->m, c->mp > 512 ? 2 * kWaveRows : kWaveRows);     // them (k_strip2's waves own 128 rows)
+}
 static size_t reduced_copy_bytes(const bioen_hip_ctx* c) {
-    const size_t slices = (size_t)(c->ld / kStripCols) * (round_up((size_t)c->m, kWaveRows) / kWaveRows);
+    const size_t slices = (size_t)(c->ld / kStripCols) * (reduced_rows(c) / kWaveRows);
     return slices * (c->storage == 1 ? reduced_slice_bytes<1>() : reduced_slice_bytes<2>());
 }
 static int ensure_reduced_copy(bioen_hip_ctx* c, bool colsum) {
@@ -1273,7 +1322,7 @@ static int ensure_reduced_copy(bioen_hip_ctx* c, bool colsum) {
         hip_fail(e, "hipMalloc (reduced-storage strip copy)", __FILE__, __LINE__);
         return BIOEN_HIP_ENOMEM;
     }
-    const int nstrips = (int)(c->ld / kStripCols), mps64 = (int)round_up((size_t)c->m, kWaveRows);
+    const int nstrips = (int)(c->ld / kStripCols), mps64 = reduced_rows(c);
     const dim3 grid(std::min(nstrips, 4096)), block(256);
     unsigned char* out = static_cast<unsigned char*>(buf);
     if (c->storage == 1 && !colsum) hipLaunchKernelGGL((k_build_strips_reduced<false, 1>), grid, block, 0, c->stream, c->Y, c->ld, c->mp, mps64, c->n, out, nstrips, c->strip_center);
@@ -1388,6 +1437,17 @@ static void strip_launch_kd(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
     }
     BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY, DEPTH>), dim3(q.nblk), block, lds, q, fr);
 }
+// the same on the reduced-storage copies (experiment)
+template <int K, bool NT, bool XY, int DEPTH, int STORE>
+static void strip_launch_kds(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip<K, NT, XY, DEPTH, STORE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY, DEPTH, STORE>), dim3(q.nblk), block, lds, q, fr);
+}
 
 // strips in flight per wave: two register sets, except where the second one does not fit (K > 4, pass 1: the
 // compiler spilled; experiment knob BIOEN_HIP_STRIP_DEPTH5)
@@ -1400,6 +1460,13 @@ static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRou
     }
     // K > 4 (r04): one register set + the row-sum product deferred behind the next strip's barrier (DEPTH 3); the LDS
     // request carries the doubled partial-sum / e | t / rescale buffers.  BIOEN_HIP_STRIP_DEPTH5=2 / 1: the r03 forms (A/B)
+    if (c->storage) {               // reduced-storage experiment: the default forms only
+        constexpr int D = K > 4 ? 3 : 2;
+        const size_t l2 = lds + (D == 3 ? ((block.x / 64) * 128 + 128 + 16) * sizeof(double) : 0);
+        if (c->storage == 1) strip_launch_kds<K, NT, XY, D, 1>(c, q, fr, block, l2);
+        else strip_launch_kds<K, NT, XY, D, 2>(c, q, fr, block, l2);
+        return;
+    }
     if constexpr (K > 4) {
         if (depth5 == 1) { strip_launch_kd<K, NT, XY, 1>(c, q, fr, block, lds); return; }
         if (depth5 != 2) { strip_launch_kd<K, NT, XY, 3>(c, q, fr, block, lds + ((block.x / 64) * 128 + 128 + 16) * sizeof(double)); return; }
@@ -1414,6 +1481,17 @@ static void strip2_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
+    }
+    if (c->storage) {
+        static bool a1 = false, a2 = false;
+        if (c->storage == 1) {
+            if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+            BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY, 1>), dim3(q.nblk), block, lds, q, fr);
+        } else {
+            if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
+            BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY, 2>), dim3(q.nblk), block, lds, q, fr);
+        }
+        return;
     }
     BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY>), dim3(q.nblk), block, lds, q, fr);
 }
@@ -1493,7 +1571,7 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
         q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
         if (c->storage) {                               // reduced-storage experiment: centred copies, rows padded to 64
             q.Ys = static_cast<const double*>(c->Yr);
-            q.mps = (int)round_up((size_t)c->m, kWaveRows);
+            q.mps = reduced_rows(c);
         }
         q.mp = panel_mp(c, p);
         q.nstrips = (int)(c->ld / kStripCols);
@@ -1607,7 +1685,7 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
         q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
         if (c->storage) {
             q.Ys = static_cast<const double*>(c->Yr1);
-            q.mps = (int)round_up((size_t)c->m, kWaveRows);
+            q.mps = reduced_rows(c);
         }
         q.mp = panel_mp(c, p);
         q.nstrips = (int)(c->ld / kStripCols);
@@ -1631,6 +1709,10 @@ static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, cons
     q.Ys = c->Ys;
     q.center = c->strip_center;
     q.mps = strip_rows(c);
+    if (c->storage) {                                   // reduced-storage experiment: the centred row-sum order copy
+        q.Ys = static_cast<const double*>(c->Yr);
+        q.mps = reduced_rows(c);
+    }
     q.mp = c->mp;
     q.nstrips = (int)(c->ld / kStripCols);
     q.n = c->n;

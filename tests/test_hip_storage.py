@@ -26,7 +26,7 @@ def targets(M, seed=12345):
     return YTrue, sig_sim, sig_exp, rng.normal(YTrue, sig_exp) / sig_exp
 
 
-@pytest.mark.parametrize("M,N", [(64, 3000), (205, 5000), (1024, 4000)])
+@pytest.mark.parametrize("M,N", [(64, 3000), (205, 5000), (600, 3000), (1024, 4000)])
 def test_reduced_formats_perturb_the_evaluation_by_their_rounding_only_and_f64_comes_back_bitwise(M, N):
     import bioen_amd
     YTrue, sig_sim, sig_exp, YTilde = targets(M)
@@ -36,6 +36,9 @@ def test_reduced_formats_perturb_the_evaluation_by_their_rounding_only_and_f64_c
     thetas = [30.0, 3.0, 300.0]
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
         f0, grad0 = ctx.logw_fdf(g, G, 5.0)
+        w0 = rng.dirichlet(np.ones(N) * 2.0)
+        fvec = 1e-3 * rng.standard_normal(M)
+        ff0, fg0 = ctx.forces_fdf(fvec, w0, 5.0)
         r0 = ctx.opt_lbfgs_logw_batch(thetas, g, G, LBFGS_DEFAULTS)
         block0 = ctx.read_ytilde()
         for fmt, tol in (("split", 2.0 ** -30), ("fp32", 2.0 ** -21)):
@@ -50,12 +53,17 @@ def test_reduced_formats_perturb_the_evaluation_by_their_rounding_only_and_f64_c
                 gs, ws, info = ctx.opt_lbfgs_logw(g, G, th, LBFGS_DEFAULTS)
                 assert np.array_equal(gs, ra[0][k]) and info.fmin == ra[2][k].fmin
             assert np.array_equal(ctx.read_ytilde(), block0)       # the FP64 matrix stays what the caller gave
-            with pytest.raises(bioen_amd.BioenHipError):
-                ctx.forces_fdf(np.zeros(M), np.full(N, 1.0 / N), 1.0)
+            # the forces method's strip passes stream the same copy
+            ff1, fg1 = ctx.forces_fdf(fvec, w0, 5.0)
+            assert rel(ff1, ff0) <= tol and np.abs(fg1 - fg0).max() <= 64 * tol * np.abs(fg0).max(), fmt
+            fb, gb = ctx.forces_fdf_batch(np.stack([fvec, 0.5 * fvec, 0.0 * fvec]), w0, np.array([5.0, 50.0, 0.5]))
+            assert fb[0] == ff1 and np.array_equal(gb[0], fg1)     # batched == single within the format
         ctx.set_storage("f64")
         f2, grad2 = ctx.logw_fdf(g, G, 5.0)
         r2 = ctx.opt_lbfgs_logw_batch(thetas, g, G, LBFGS_DEFAULTS)
         assert f2 == f0 and np.array_equal(grad2, grad0)
+        ff2, fg2 = ctx.forces_fdf(fvec, w0, 5.0)
+        assert ff2 == ff0 and np.array_equal(fg2, fg0)
         assert np.array_equal(r2[0], r0[0]) and [i.fmin for i in r2[2]] == [i.fmin for i in r0[2]]
 
 
@@ -88,3 +96,26 @@ def test_split_format_passes_the_unwidened_gate_against_the_reference_binary():
             print("storage %s: fmin within %.2e, weights within %.2e max(w) of the reference binary" % (fmt, worst_f, worst_w))
         assert record["split"][0] < 1e-6 and record["split"][1] <= 1e-5, record
         assert record["fp32"][0] < 1e-4, record                     # recorded, not gated: see DESIGN 9a
+
+
+@pytest.mark.parametrize("M,N", [(512, 50000), (1024, 20000)])
+def test_split_format_forces_method_passes_the_unwidened_gate_against_the_reference_binary(M, N):
+    """the forces method on the 6-byte copies (k_strip / k_strip2), converged, against the reference's _opt_lbfgs_forces"""
+    import bioen_amd
+    from oracle import cpus
+    R = require_reference()
+    thetas = [316.0, 100.0, 31.6]
+    YTrue, sig_sim, sig_exp, YTilde = targets(M)
+    w0 = np.full(N, 1.0 / N)
+    R.set_fast_openmp_flag(0)
+    R.omp_set_num_threads(cpus.usable_cpus())
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        yT = np.ascontiguousarray(ctx.read_ytilde())
+        ctx.set_storage("split")
+        res, w, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, CONV)
+        for k, theta in enumerate(thetas):
+            f_ref, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, yT, YTilde, theta, CONV)
+            assert code_ref in _AT_OPTIMUM and infos[k].lbfgs_code in _AT_OPTIMUM
+            assert rel(infos[k].fmin, fmin_ref) < 1e-6, (theta, infos[k].fmin, fmin_ref)
+            w_ref = np.asarray(R.forces_weights(f_ref, w0, yT)).ravel()
+            assert np.abs(w[k] - w_ref).max() <= 1e-5 * w_ref.max(), (theta, np.abs(w[k] - w_ref).max() / w_ref.max())
