@@ -55,7 +55,11 @@ RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "c
                "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff")
 
 
-@pytest.mark.parametrize("world", [2, 3])
+# BIOEN_TEST_WORLDS="2,3,4": more ranks on the one GPU (the 2000-column fixture shards over at most 4 ranks of 128-column blocks; 4 passes)
+WORLDS = [int(w) for w in os.environ.get("BIOEN_TEST_WORLDS", "2,3").split(",")]
+
+
+@pytest.mark.parametrize("world", WORLDS)
 @pytest.mark.timeout(600)
 def test_peer_to_peer_exchange_equals_host_staged_bitwise(tmp_path, world):
     """The stage all-gathers through the hipIpc mailboxes (one kernel per exchange, no host) deliver the same bytes as
