@@ -387,7 +387,7 @@ class Context(object):
         """(forms, bytes) of the resident copies of the matrix: forms is a set out of {"rowmajor", "strips", "strips_colsum"}"""
         f, b = C.c_int(0), C.c_longlong(0)
         check(lib().bioen_hip_ctx_footprint(self._h, C.byref(f), C.byref(b)))
-        names = {1: "rowmajor", 2: "strips", 4: "strips_colsum"}
+        names = {1: "rowmajor", 2: "strips", 4: "strips_colsum", 8: "reduced"}
         return {names[k] for k in names if f.value & k}, b.value
 
     def set_target(self, YTilde):

@@ -1000,6 +1000,12 @@ int bioen_hip_ctx_footprint(const bioen_hip_ctx* c, int* forms, long long* bytes
         if (c->Yp[p]) { f |= 2; b += panel; }
         if (c->Y1p[p]) { f |= 4; b += panel; }
     }
+    if (c->storage) {            // reduced-storage experiment: centred copies of 6 or 4 bytes per element, rows padded to 64 (128)
+        const long long rows = (long long)round_up((size_t)c->m, c->mp > 512 ? 128 : 64);
+        const long long each = (long long)(c->ld / 16) * (rows / 64) * (c->storage == 1 ? 6144 : 4096);
+        if (c->Yr) { f |= 8; b += each; }
+        if (c->Yr1) { f |= 8; b += each; }
+    }
     if (forms) *forms = f;
     if (bytes) *bytes = b;
     return 0;

@@ -144,6 +144,7 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, 
  * bit 2 the one in column-sum operand order.  For M <= 1024 the strip copies hold the raw numbers and REPLACE the
  * row-major matrix once built: log-weights 2 x the matrix (bits 1 + 2), forces method 1 x (bit 1; beyond 1024 rows,
  * where the copies are kept as row panels of <= 1024 rows, 2 x: both orders). */
+/* (bit 3: copies of the reduced-storage experiment, bioen_hip_ctx_set_storage, beside the FP64 row-major matrix) */
 int bioen_hip_ctx_footprint(const bioen_hip_ctx* ctx, int* forms, long long* bytes);
 int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
 /* Affine observable model: the optimizer sees yTilde_eff[i][j] = row_offset[i] + row_scale[i] * yTilde[i][j]
