@@ -308,7 +308,7 @@ def init_rccl(ctx, comm):
     return True
 
 
-def init_p2p(ctx, comm, selftest=40):
+def init_p2p(ctx, comm, selftest=400):
     """Attach the peer-to-peer stage exchange of a structure-sharded `ctx` (one rank per process): every rank exports the
     hipIpc handle of its mailbox, the control plane all-gathers the 64-byte handles, every rank maps its peers.  Ranks
     agree on the outcome: if any rank cannot export, map or pass the self-test, ALL detach and the function returns
