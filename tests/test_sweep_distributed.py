@@ -145,3 +145,54 @@ def test_socketcomm_refuses_a_peer_without_the_token(tmp_path):
     p1 = subprocess.Popen([sys.executable, "-c", code], env=env1, stdout=subprocess.PIPE, text=True)
     assert p1.wait(timeout=45) == 0 and p0.wait(timeout=45) == 0
     assert p0.stdout.read().strip() == "[0, 1]" and p1.stdout.read().strip() == "[0, 1]"
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("fault", ["none", "export", "attach", "selftest"])
+def test_init_p2p_outcome_is_agreed_between_ranks(tmp_path, fault):
+    """sweep.init_p2p over two real SocketComm ranks with FAKE contexts (no GPU): the handles are all-gathered in rank
+    order, and whenever ONE rank cannot export, map or pass the self-test, BOTH return False and BOTH detach -- a
+    transport half attached would hang the first exchange."""
+    port = free_port()
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+from bioen_amd import sweep, BioenHipError
+fault, out = sys.argv[1], sys.argv[2]
+comm = sweep.SocketComm(timeout=40)
+class Ctx(object):
+    world = 2
+    def __init__(self): self.log = []
+    def p2p_export(self):
+        if fault == "export" and comm.rank == 1: raise BioenHipError("no handle here")
+        return bytes([comm.rank]) * 64
+    def p2p_attach(self, handles):
+        self.log.append(("attach", [h[0] for h in handles]))
+        if fault == "attach" and comm.rank == 0: raise BioenHipError("cannot map")
+    def exchange_selftest(self, reps):
+        self.log.append(("selftest", reps))
+        return 3 if (fault == "selftest" and comm.rank == 1) else 0
+    def p2p_detach(self): self.log.append(("detach",))
+ctx = Ctx()
+ok = sweep.init_p2p(ctx, comm)
+json.dump({"ok": ok, "log": ctx.log}, open(out %% comm.rank, "w"))
+comm.close()
+''' % ROOT
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TORCHELASTIC_RUN_ID="p2pagree%d%s" % (os.getpid(), fault))
+        procs.append(subprocess.Popen([sys.executable, "-c", code, fault, str(tmp_path / "r%d.json")], env=env))
+    for p in procs:
+        assert p.wait(timeout=100) == 0
+    import json
+    recs = [json.load(open(str(tmp_path / ("r%d.json" % r)))) for r in range(2)]
+    assert recs[0]["ok"] == recs[1]["ok"] == (fault == "none")
+    for r in recs:
+        kinds = [e[0] for e in r["log"]]
+        if fault == "none":
+            assert kinds == ["attach", "selftest"] and r["log"][0][1] == [0, 1]      # handles in rank order
+        else:
+            assert kinds[-1] == "detach"                                              # every rank lets go
+            assert ("attach" in kinds) == (fault != "export")
+            assert ("selftest" in kinds) == (fault == "selftest")
