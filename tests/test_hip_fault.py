@@ -74,11 +74,11 @@ def test_stalled_rank_times_out_peer_to_peer(tmp_path):
         assert r0["transport"] == "p2p" and r1["transport"] == "p2p"
         # rank 0: its exchange kernel gave up after the bound, the host wait reported it -- well before rank 1 woke up
         assert r0["error"] and "peer-to-peer exchange" in r0["error"] and "rank 1" in r0["error"], r0
-        assert timeout_s - 0.5 <= r0["t_end"] - r0["t_start"] <= timeout_s + 5.0, r0
+        assert timeout_s - 0.5 <= r0["t_end"] - r0["t_start"] <= timeout_s + 6.5, r0   # kernel bound, host bound = + 2 s, margin
         assert r0["after"] != "usable"
         # rank 1: woke up into a dead exchange and was told so (ABORT flag or its own bounded wait)
         assert r1["error"] and "peer-to-peer exchange" in r1["error"], r1
-        assert r1["t_end"] - r1["t_start"] <= timeout_s + 5.0, r1
+        assert r1["t_end"] - r1["t_start"] <= timeout_s + 6.5, r1
     finally:
         for p in procs:
             if p.poll() is None:
