@@ -328,7 +328,10 @@ struct BoundedWait {
     }
 };
 
-// One in-place all-gather of an exchange stage ([world][payload] doubles).  world == 1: nothing.
+// One in-place all-gather of an exchange stage ([world][payload] doubles).  world == 1: nothing.  Three transports, in
+// this order of precedence: the peer-to-peer mailboxes (kernels_p2p.hip: one kernel, no collective launch, no host), RCCL
+// (ncclAllGather on the context's stream), the host callback (D2H, the caller's all-gather, H2D: processes that share
+// neither).  All three leave the same bytes in the stage buffer.
 // world == 1 with force_exchange (bioen_hip_ctx_set_force_exchange / BIOEN_HIP_FORCE_EXCHANGE=1) and a communicator
 // or callback in place: the one-rank all-gather is executed all the same -- a copy of the rank's segment onto
 // itself, same bits -- so the stage path can run under test on a single GPU.

@@ -1,5 +1,6 @@
-// Host-side launch API of the gfx950 kernels (definitions: kernels_matrix.hip, kernels_logw.hip,
-// kernels_forces.hip, kernels_misc.hip; shared device helpers: device_utils.hpp).
+// Host-side launch API of the gfx950 kernels (definitions: kernels_strip.hip -- the matrix passes for M <= 1024 and, over
+// row panels, beyond --, kernels_matrix.hip, kernels_logw.hip, kernels_forces.hip, kernels_devls.hip, kernels_misc.hip,
+// kernels_p2p.hip -- the peer-to-peer stage exchange; shared device helpers: device_utils.hpp).
 // Every function enqueues on ctx->stream and returns without synchronising.
 //
 // All kernels are batched: a launch serves the K (<= kMaxBatch) problems listed in a
