@@ -256,6 +256,7 @@ static int transport_error(bioen_hip_ctx* c) {
             std::snprintf(buf, sizeof buf, "peer-to-peer exchange %llu (stage %d): %s rank %d (BIOEN_HIP_WAIT_TIMEOUT = %g s)",
                           w & 0xffffffffffull, (int)((w >> 52) & 0xff), why[std::min<unsigned long long>(3, w >> 60)],
                           (int)((w >> 40) & 0xfff), c->wait_timeout_s);
+            if (!c->failed) c->failed_p2p = 1;
             c->failed = 1;
             if (c->fail_msg.empty()) c->fail_msg = buf;
             return fail(BIOEN_HIP_ERCCL, c->fail_msg.c_str());
@@ -1638,8 +1639,9 @@ int bioen_hip_p2p_detach(bioen_hip_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     c->p2p_on = 0;
-    if (c->p2p_err && __atomic_load_n(c->p2p_err, __ATOMIC_ACQUIRE) && !c->comm) {
-        c->failed = 0;      // the failure was this transport's; the stream has drained and the transport goes: usable again
+    if (c->failed_p2p) {     // the failure was this transport's own; the stream has drained and the transport goes: the
+        c->failed = 0;       // context (and an RCCL communicator it may hold) is usable again
+        c->failed_p2p = 0;
         c->fail_msg.clear();
     }
     for (int r = 0; r < 128; ++r)

@@ -171,6 +171,7 @@ struct bioen_hip_ctx {
     unsigned long long* p2p_dev_err = nullptr;   // the same word in device memory (read by the later kernels)
     double wait_timeout_s = 60.0;            // BIOEN_HIP_WAIT_TIMEOUT: bound of every host and device wait on a round
     int failed = 0;                          // a wait expired or a transport failed: every later call returns at once
+    int failed_p2p = 0;                      // ... and it was the peer-to-peer transport's own failure (detaching it clears it)
     std::string fail_msg;                    // ... with what happened first
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // results of finished problems leave on this one (engine_logw.inl: deliveries)
