@@ -79,6 +79,9 @@ def main():
     fthetas = [100.0, 10.0, 1000.0]
     fres, fw, finfos = fctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
     fconv, fwconv, ficonv = fctx.opt_lbfgs_forces(fd["forces_init"], fd["w0"], fd["theta"], LBFGS_CONV)
+    # a batch wider than four: the strip kernel's K > 4 form (row-sum product deferred behind the next strip's barrier)
+    f6res, f6w, f6infos = fctx.opt_lbfgs_forces_batch([300.0, 100.0, 30.0, 10.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
+                                                      LBFGS_DEFAULTS, max_batch=6)
     fctx.close()
     comm.barrier()
     np.savez(out_path % comm.rank, w=w, logs=logs, f=f, grad=grad, res=res, wopt=wopt,
@@ -91,7 +94,8 @@ def main():
              fkl=np.array([i.kl for i in finfos]), fchi2=np.array([i.chi2 for i in finfos]),
              spec=np.array(spec), same_without=same_without, counts=np.array(counts), probe_us=probe_us,
              wconv=wconv, fminconv=iconv.fmin, codeconv=iconv.lbfgs_code,
-             fwconv=fwconv, ffminconv=ficonv.fmin, fcodeconv=ficonv.lbfgs_code)
+             fwconv=fwconv, ffminconv=ficonv.fmin, fcodeconv=ficonv.lbfgs_code,
+             f6res=f6res, f6w=f6w, f6fmin=np.array([i.fmin for i in f6infos]))
     comm.close()
 
 

@@ -52,7 +52,8 @@ def run_ranks(tmp_path, world, transport):
 
 
 RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
-               "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff")
+               "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff",
+               "f6res", "f6w", "f6fmin")
 
 
 # BIOEN_TEST_WORLDS="2,3,4": more ranks on the one GPU (the 2000-column fixture shards over at most 4 ranks of 128-column blocks; 4 passes)
@@ -86,7 +87,8 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     # (a) every rank holds identical (gathered) results
     for r in range(1, world):
         for key in ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
-                    "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv"):
+                    "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv",
+                    "f6res", "f6w", "f6fmin"):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
         assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
 
@@ -148,6 +150,11 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     with bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as ctx:
         ff1, fgrad1 = ctx.forces_fdf(f0, fd["w0"], 10.0)
         fres1, fw1, finfos1 = ctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
+        _, _, f6infos1 = ctx.opt_lbfgs_forces_batch([300.0, 100.0, 30.0, 10.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
+                                                    LBFGS_DEFAULTS, max_batch=6)
+    for i, info in enumerate(f6infos1):          # the six-wide batch (K > 4 strip form) against the single-GPU run
+        assert abs(z[0]["f6fmin"][i] - info.fmin) <= 2e-5 * abs(info.fmin)
+        assert abs(z[0]["f6w"][i].sum() - 1.0) < 1e-12
     assert abs(z[0]["ff"] - ff1) <= 1e-13 * abs(ff1)
     assert np.abs(z[0]["fgrad"] - fgrad1).max() <= 1e-10 * np.abs(fgrad1).max()
     for i, info in enumerate(finfos1):
