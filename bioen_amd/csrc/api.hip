@@ -151,6 +151,8 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     choose_fwd_tiling(c);
     // stream yTilde with non-temporal loads once it no longer fits the 256 MiB Infinity Cache
     c->nontemporal = (size_t)c->mp * c->ld * sizeof(double) > (size_t)192 * 1024 * 1024;
+    if (const char* e = std::getenv("BIOEN_HIP_NVEC_NT")) c->nvec_nt_env = e[0] == '1' ? 1 : 0;
+    c->nvec_nt = c->nvec_nt_env == 1;
     if (const char* e = std::getenv("BIOEN_HIP_FORCE_EXCHANGE")) c->force_exchange = (e[0] == '1') ? 1 : 0;
     if (const char* e = std::getenv("BIOEN_HIP_WAIT_TIMEOUT")) {      // seconds; bound of every wait on a round or an exchange
         const double v = std::atof(e);

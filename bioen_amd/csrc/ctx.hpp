@@ -248,6 +248,9 @@ struct bioen_hip_ctx {
 
     long long spec_launched = 0, spec_used = 0;   // speculative line-search evaluations issued / adopted (engine_logw.inl)
     bool nontemporal = true;         // stream yTilde with nt loads (matrix larger than MALL)
+    bool nvec_nt = false;            // the batch's N-vectors are far larger than the caches: history loads and outputs of the
+                                     // round's N-vector kernels nontemporal (kernels_logw.hip); set per run by the host-driven
+    int nvec_nt_env = -1;            // engine from the batch's working set; BIOEN_HIP_NVEC_NT=0/1 forces it
     bioen::KernelTimer timer;
 
     // RCCL (lazy, dlopen)

@@ -343,6 +343,9 @@ struct LogwBatchEngine {
         }
         for (int s = 0; s < kb; ++s) note(alloc_slot(c, s, true));
         if (rc) return rc;
+        // cache policy of the round's N-vector kernels (kernels_logw.hip): nontemporal history loads and outputs once the
+        // batch's vectors (19 per problem) cannot stay in the 256 MB of Infinity Cache anyway
+        c->nvec_nt = c->nvec_nt_env >= 0 ? c->nvec_nt_env == 1 : (double)c->ld * sizeof(double) * 19.0 * kb > 256.0 * 1024 * 1024;
         note(upload_n(c, c->fixed, G_host));
         const bool shared_start = (g0_stride == 0) || ntheta == 1;
         if (shared_start) {
@@ -628,6 +631,7 @@ struct LogwBatchEngine {
         if (verbose && spec_launched)
             std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n",
                         spec_launched, spec_used);
+        c->nvec_nt = c->nvec_nt_env == 1;          // single evaluations outside a run: the cached policy
         return rc;
     }
 };

@@ -3,10 +3,29 @@
 
 namespace bioen {
 
+// Cache policy of the N-vector streams of the round (r04).  POLICY = true (contexts whose N-vectors are far larger than
+// the caches, ctx->nvec_nt): the L-BFGS history vectors -- read once per kernel, 96 MB per problem at N = 1e6 -- come
+// through nontemporal loads and every output leaves through nontemporal stores, so that neither evicts the operands the
+// NEXT kernel of the round reads again (x, e, a, d, g: left on plain loads).  Values are untouched, so are the bits.
+// Measured at the headline, same box, processes alternating (profiles/r04_nvec_nt_ab.txt): 2755-2758 -> 2726-2728 us per
+// round (-1.1 %); all loads nontemporal as well: 2738-2744; history loads alone: -0.9 %.
+template <bool POLICY>
+__device__ __forceinline__ d2 ld_hist(const double* p) {
+    if (POLICY) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    return *reinterpret_cast<const d2*>(p);
+}
+__device__ __forceinline__ d2 ld_vec(const double* p) { return *reinterpret_cast<const d2*>(p); }
+template <bool POLICY>
+__device__ __forceinline__ void st_vec(double* p, d2 v) {
+    if (POLICY) __builtin_nontemporal_store(v, reinterpret_cast<d2*>(p));
+    else *reinterpret_cast<d2*>(p) = v;
+}
+
 // ------------------------------------------------------------------------------
 // log-weights N-vector kernels (blockIdx.y = position a in the round's batch)
 // ------------------------------------------------------------------------------
 // x = xp + stp * d ; block maxima of x
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_trial(Round r, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
@@ -18,10 +37,10 @@ __global__ __launch_bounds__(kBlock) void k_trial(Round r, int n, Xch xo) {
     const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
-        const d2 dv = *reinterpret_cast<const d2*>(d + j);
-        const d2 pv = *reinterpret_cast<const d2*>(xp + j);
+        const d2 dv = ld_vec(d + j);
+        const d2 pv = ld_vec(xp + j);
         d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
-        *reinterpret_cast<d2*>(x + j) = v;
+        st_vec<POLICY>(x + j, v);
         mx = fmax(mx, v.x);
         if (j + 1 < n) mx = fmax(mx, v.y);
     }
@@ -44,6 +63,7 @@ __global__ __launch_bounds__(kBlock) void k_max(Round r, int n, Xch xo) {
 // m_r is the maximum over THIS rank's structures (its own block maxima need no exchange); it
 // travels with the sums (third array, entry 0) and k_logw_norm rescales by exp(m_r - max_r m_r),
 // which is exactly 1 on a single GPU.
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, Xch xmx,
                                                      Xch xo) {
     __shared__ double sh[kWaves];
@@ -55,12 +75,12 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
-        const d2 xv = *reinterpret_cast<const d2*>(x + j);
-        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
+        const d2 xv = ld_vec(x + j);
+        const d2 Gv = ld_vec(G + j);
         d2 ev;
         ev.x = exp(xv.x - gmax);
         ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
-        *reinterpret_cast<d2*>(e + j) = ev;
+        st_vec<POLICY>(e + j, ev);
         s += ev.x;
         pp = fma(ev.x, xv.x - Gv.x, pp);
         s += ev.y;
@@ -152,6 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_logsumexp_merge(const double* __rest
 // gradient epilogue (c_bioen_kernels_logw.c:207-218):
 //   g_k = w_k [ theta (x_k - G_k - P) + a_k ],  a_k = sum_i r_i (yTilde_ik - ybar_i)  (centred adjoint)
 // plus the three dot products the line search / convergence test needs.
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __restrict__ G, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
@@ -167,17 +188,17 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
-        const d2 xv = *reinterpret_cast<const d2*>(x + j);
-        d2 wv = *reinterpret_cast<const d2*>(w + j);           // pad: e = 0  =>  g = 0
+        const d2 xv = ld_vec(x + j);
+        d2 wv = ld_vec(w + j);                                 // pad: e = 0  =>  g = 0
         wv.x *= inv;
         wv.y *= inv;
-        const d2 Gv = *reinterpret_cast<const d2*>(G + j);
-        const d2 aa = *reinterpret_cast<const d2*>(av + j);
-        const d2 dv = *reinterpret_cast<const d2*>(d + j);
+        const d2 Gv = ld_vec(G + j);
+        const d2 aa = ld_vec(av + j);
+        const d2 dv = ld_vec(d + j);
         d2 gv;
         gv.x = wv.x * (theta * ((xv.x - Gv.x) - P) + aa.x);
         gv.y = wv.y * (theta * ((xv.y - Gv.y) - P) + aa.y);
-        *reinterpret_cast<d2*>(g + j) = gv;
+        st_vec<POLICY>(g + j, gv);
         dg = fma(gv.x, dv.x, dg);
         gg = fma(gv.x, gv.x, gg);
         xx = fma(xv.x, xv.x, xx);
@@ -353,6 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int n, Xch xin, X
 // ------------------------------------------------------------------------------
 // One sweep: s = xnew - xold, y = gnew - gold -> history slot `end`; and the 39 inner products
 // of (s, y, gnew) with the basis B = {S_0..5, Y_0..5, gnew} (S_end = s, Y_end = y).
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
     __shared__ double sh[kWaves][64];
     const int a = blockIdx.y;
@@ -367,19 +389,19 @@ __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
-        const d2 a0 = *reinterpret_cast<const d2*>(xn + j), a1 = *reinterpret_cast<const d2*>(xo_ + j);
-        const d2 gv = *reinterpret_cast<const d2*>(gn + j), g1 = *reinterpret_cast<const d2*>(go + j);
+        const d2 a0 = ld_vec(xn + j), a1 = ld_vec(xo_ + j);
+        const d2 gv = ld_vec(gn + j), g1 = ld_vec(go + j);
         const d2 sv = {a0.x - a1.x, a0.y - a1.y};
         const d2 yv = {gv.x - g1.x, gv.y - g1.y};
         d2 B[kBasis];
 #pragma unroll
         for (int k = 0; k < kHistory; ++k) {
-            B[k] = (k == e) ? sv : *reinterpret_cast<const d2*>(q.S[a][k] + j);
-            B[kHistory + k] = (k == e) ? yv : *reinterpret_cast<const d2*>(q.Y[a][k] + j);
+            B[k] = (k == e) ? sv : ld_hist<POLICY>(q.S[a][k] + j);
+            B[kHistory + k] = (k == e) ? yv : ld_hist<POLICY>(q.Y[a][k] + j);
         }
         B[2 * kHistory] = gv;
-        *reinterpret_cast<d2*>(q.S[a][e] + j) = sv;
-        *reinterpret_cast<d2*>(q.Y[a][e] + j) = yv;
+        st_vec<POLICY>(q.S[a][e] + j, sv);
+        st_vec<POLICY>(q.Y[a][e] + j, yv);
 #pragma unroll
         for (int c = 0; c < kBasis; ++c) {
             acc[c] = fma(sv.x, B[c].x, acc[c]);
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
 }
 
 // d = sum_c coef_c B_c
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_combine(GramArgs q, int n) {
     const int a = blockIdx.y;
     const double* coef = q.gram[a] + kBasis * kBasis;
@@ -454,30 +477,32 @@ __global__ __launch_bounds__(kBlock) void k_combine(GramArgs q, int n) {
     const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
-        const d2 gv = *reinterpret_cast<const d2*>(gn + j);
+        const d2 gv = ld_vec(gn + j);
         d2 dv = {cf[2 * kHistory] * gv.x, cf[2 * kHistory] * gv.y};
 #pragma unroll
         for (int k = 0; k < kHistory; ++k) {
             if (cf[k] != 0.0) {               // unused history slots may hold another problem's leftovers
-                const d2 v = *reinterpret_cast<const d2*>(q.S[a][k] + j);
+                const d2 v = ld_hist<POLICY>(q.S[a][k] + j);
                 dv.x = fma(cf[k], v.x, dv.x);
                 dv.y = fma(cf[k], v.y, dv.y);
             }
             if (cf[kHistory + k] != 0.0) {
-                const d2 v = *reinterpret_cast<const d2*>(q.Y[a][k] + j);
+                const d2 v = ld_hist<POLICY>(q.Y[a][k] + j);
                 dv.x = fma(cf[kHistory + k], v.x, dv.x);
                 dv.y = fma(cf[kHistory + k], v.y, dv.y);
             }
         }
-        *reinterpret_cast<d2*>(d + j) = dv;
+        st_vec<POLICY>(d + j, dv);
     }
 }
 
 
 // ---- log-weights vector kernels -----------------------------------------------------------
 void launch_trial(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_trial, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
-                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_trial<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_trial<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+                            make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_max(bioen_hip_ctx* c, const Round& r) {
@@ -486,8 +511,10 @@ void launch_max(bioen_hip_ctx* c, const Round& r) {
 }
 
 void launch_logw_exp(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
-                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_logw_exp<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_logw_exp<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                            make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
 void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
@@ -507,8 +534,10 @@ void launch_logw_logs0_merge(bioen_hip_ctx* c, const Round& r) {
 }
 
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_grad, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
-                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_logw_grad<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_logw_grad<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                            make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
 }
 
 void launch_finish_eval(bioen_hip_ctx* c, const Round& r) {
@@ -538,8 +567,10 @@ void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step) {
 }
 
 void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
-    hipLaunchKernelGGL(k_gram, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
-                       make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_gram<true>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+                                       make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_gram<false>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+                            make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
 }
 
 static Xch gram_rank_view(const bioen_hip_ctx* c, int k) {      // X_GRAMR: one value per (rank, problem, sum)
@@ -568,7 +599,8 @@ void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
 }
 
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {
-    hipLaunchKernelGGL(k_combine, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+    if (c->nvec_nt) hipLaunchKernelGGL(k_combine<true>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+    else hipLaunchKernelGGL(k_combine<false>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
 }
 
 
