@@ -8,7 +8,8 @@ namespace bioen {
 // through nontemporal loads and every output leaves through nontemporal stores, so that neither evicts the operands the
 // NEXT kernel of the round reads again (x, e, a, d, g: left on plain loads).  Values are untouched, so are the bits.
 // Measured at the headline, same box, processes alternating (profiles/r04_nvec_nt_ab.txt): 2755-2758 -> 2726-2728 us per
-// round (-1.1 %); all loads nontemporal as well: 2738-2744; history loads alone: -0.9 %.
+// round (-1.1 %); all loads nontemporal as well: 2738-2744; history loads alone: -0.9 %; x and d (whose reader is the very
+// next kernel) kept on plain stores: no gain, e as well: +1 %.
 template <bool POLICY>
 __device__ __forceinline__ d2 ld_hist(const double* p) {
     if (POLICY) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
