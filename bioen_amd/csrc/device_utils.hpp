@@ -314,6 +314,25 @@ __device__ __forceinline__ d2 ldg2(const double* p) {
     return *reinterpret_cast<const d2*>(p);
 }
 
+// Cache policy of the N-vector streams of the round (r04).  POLICY = true (contexts whose N-vectors are far larger than
+// the caches, ctx->nvec_nt): the L-BFGS history vectors -- read once per kernel, 96 MB per problem at N = 1e6 -- come
+// through nontemporal loads and every output leaves through nontemporal stores, so that neither evicts the operands the
+// NEXT kernel of the round reads again (x, e, a, d, g: left on plain loads).  Values are untouched, so are the bits.
+// Measured at the headline, same box, processes alternating (profiles/r04_nvec_nt_ab.txt): 2755-2758 -> 2726-2728 us per
+// round (-1.1 %); all loads nontemporal as well: 2738-2744; history loads alone: -0.9 %; x and d (whose reader is the very
+// next kernel) kept on plain stores: no gain, e as well: +1 %.
+template <bool POLICY>
+__device__ __forceinline__ d2 ld_hist(const double* p) {
+    if (POLICY) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    return *reinterpret_cast<const d2*>(p);
+}
+__device__ __forceinline__ d2 ld_vec(const double* p) { return *reinterpret_cast<const d2*>(p); }
+template <bool POLICY>
+__device__ __forceinline__ void st_vec(double* p, d2 v) {
+    if (POLICY) __builtin_nontemporal_store(v, reinterpret_cast<d2*>(p));
+    else *reinterpret_cast<d2*>(p) = v;
+}
+
 constexpr int next_pow2(int v) { return v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : 8)); }
 
 

@@ -108,6 +108,10 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     const int nslots = can_speculate ? std::min((int)kMaxBatch, kb + max_shadows) : kb;
     for (int s = 0; s < nslots; ++s) note(alloc_slot(c, s, s < kb, s < kb || sgram));   // history: owners; spare pair: owners (shadows too when they sweep their own)
     if (rc) return rc;
+    // cache policy of the round's N-vector kernels (device_utils.hpp: ld_hist / st_vec): nontemporal history loads and
+    // outputs once the batch's vectors (21 per problem here) cannot stay in the 256 MB of Infinity Cache anyway -- a rank's
+    // share of the headline at 2 or 4 GPUs; not at 8, not at configs[1], not for a K = 1 chain at N = 5e5
+    c->nvec_nt = c->nvec_nt_env >= 0 ? c->nvec_nt_env == 1 : (double)c->ld * sizeof(double) * 21.0 * nslots > 256.0 * 1024 * 1024;
     note(upload_n(c, c->fixed, G_host));
     const bool shared_start = (g0_stride == 0) || ntheta == 1;
     if (shared_start) {
@@ -453,5 +457,6 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     if (verbose && spec_launched)
         std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n",
                     spec_launched, spec_used);
+    c->nvec_nt = c->nvec_nt_env == 1;
     return rc;
 }

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_start(DevStart s, bioen_lbfgs_co
 // (k_combine: d = sum_c cf_c B_c over {S_0..5, Y_0..5, gp}).  One set of blocks per OWNER: the trial points of its
 // shadows (stp / 2, 2.1 stp) are written in the same sweep from the same d -- a shadow position with blocks of its own
 // would have to form d a second time (it runs beside the owner's blocks, not behind them).
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;                   // owner position
@@ -154,34 +155,34 @@ __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) 
 #pragma unroll
             for (int k = 0; k < kHistory; ++k) {
                 if (cf[k] != 0.0) {               // unused history slots may hold another problem's leftovers
-                    const d2 v = *reinterpret_cast<const d2*>(Sk[k] + j);
+                    const d2 v = ld_hist<POLICY>(Sk[k] + j);
                     dv.x = fma(cf[k], v.x, dv.x);
                     dv.y = fma(cf[k], v.y, dv.y);
                 }
                 if (cf[kHistory + k] != 0.0) {
-                    const d2 v = *reinterpret_cast<const d2*>(Yk[k] + j);
+                    const d2 v = ld_hist<POLICY>(Yk[k] + j);
                     dv.x = fma(cf[kHistory + k], v.x, dv.x);
                     dv.y = fma(cf[kHistory + k], v.y, dv.y);
                 }
             }
-            *reinterpret_cast<d2*>(d + j) = dv;
+            st_vec<POLICY>(d + j, dv);
         } else {
             dv = *reinterpret_cast<const d2*>(d + j);
         }
         const d2 pv = *reinterpret_cast<const d2*>(xp + j);
         const d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
-        *reinterpret_cast<d2*>(x + j) = v;
+        st_vec<POLICY>(x + j, v);
         mx = fmax(mx, v.x);
         if (j + 1 < n) mx = fmax(mx, v.y);
         if (x1) {
             const d2 u = {fma(stp1, dv.x, pv.x), fma(stp1, dv.y, pv.y)};
-            *reinterpret_cast<d2*>(x1 + j) = u;
+            st_vec<POLICY>(x1 + j, u);
             mx1 = fmax(mx1, u.x);
             if (j + 1 < n) mx1 = fmax(mx1, u.y);
         }
         if (x2) {
             const d2 u = {fma(stp2, dv.x, pv.x), fma(stp2, dv.y, pv.y)};
-            *reinterpret_cast<d2*>(x2 + j) = u;
+            st_vec<POLICY>(x2 + j, u);
             mx2 = fmax(mx2, u.x);
             if (j + 1 < n) mx2 = fmax(mx2, u.y);
         }
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) 
 }
 
 // e = exp(x - m) ; partials of sum e and sum e (x - G): k_logw_exp with the trial point taken from the role table
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_dev_exp(DevRound r, const double* __restrict__ G, int n, Xch xmx, Xch xo) {
     __shared__ double sh[kWaves];
     const int a = blockIdx.y;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_exp(DevRound r, const double* __
         d2 ev;
         ev.x = exp(xv.x - gmax);
         ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
-        *reinterpret_cast<d2*>(e + j) = ev;
+        st_vec<POLICY>(e + j, ev);
         s += ev.x;
         pp = fma(ev.x, xv.x - Gv.x, pp);
         s += ev.y;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_exp(DevRound r, const double* __
 // inner products of (s, y, g) with the basis {S_0..5, Y_0..5, g} (slot `end` standing for the new pair) are left as
 // block partials.  A rejected trial wasted the Gram part (13 % of the evaluations of the headline sweep); an accepted
 // one saved a launch and the re-reading of x, xp, g, gp.
+template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const double* __restrict__ G, int n, Xch xg, Xch xm) {
     __shared__ double sh[kWaves];
     __shared__ double shg[kWaves][64];
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
         d2 gv;
         gv.x = wv.x * (theta * ((xv.x - Gv.x) - Pp) + aa.x);
         gv.y = wv.y * (theta * ((xv.y - Gv.y) - Pp) + aa.y);
-        *reinterpret_cast<d2*>(g + j) = gv;
+        st_vec<POLICY>(g + j, gv);
         dg = fma(gv.x, dv.x, dg);
         gg = fma(gv.x, gv.x, gg);
         xx = fma(xv.x, xv.x, xx);
@@ -301,12 +304,12 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
             d2 B[kBasis];
 #pragma unroll
             for (int k = 0; k < kHistory; ++k) {
-                B[k] = (k == e) ? sv : *reinterpret_cast<const d2*>(Sk[k] + j);
-                B[kHistory + k] = (k == e) ? yv : *reinterpret_cast<const d2*>(Yk[k] + j);
+                B[k] = (k == e) ? sv : ld_hist<POLICY>(Sk[k] + j);
+                B[kHistory + k] = (k == e) ? yv : ld_hist<POLICY>(Yk[k] + j);
             }
             B[2 * kHistory] = gv;
-            *reinterpret_cast<d2*>(Ssp + j) = sv;
-            *reinterpret_cast<d2*>(Ysp + j) = yv;
+            st_vec<POLICY>(Ssp + j, sv);
+            st_vec<POLICY>(Ysp + j, yv);
 #pragma unroll
             for (int c = 0; c < kBasis; ++c) {
                 acc[c] = fma(sv.x, B[c].x, acc[c]);
@@ -775,18 +778,24 @@ void launch_dev_start(bioen_hip_ctx* c, const DevStart& s, const bioen_lbfgs_con
 }
 
 void launch_dev_step(bioen_hip_ctx* c, const DevRound& r) {
-    hipLaunchKernelGGL(k_dev_step, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
-                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_step<true>, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
+                                       make_xch(c, X_MAX, r.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_dev_step<false>, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
+                            make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_dev_exp(bioen_hip_ctx* c, const DevRound& r) {
-    hipLaunchKernelGGL(k_dev_exp, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
-                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_exp<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                                       make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_dev_exp<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                            make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
 void launch_dev_grad_gram(bioen_hip_ctx* c, const DevRound& r) {
-    hipLaunchKernelGGL(k_dev_grad_gram, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
-                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)));
+    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_grad_gram<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                                       make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)));
+    else hipLaunchKernelGGL(k_dev_grad_gram<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+                            make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)));
 }
 
 int dev_all_fused(const bioen_hip_ctx* c) { return (long long)vec_grid(c) * c->world <= 256; }
