@@ -200,7 +200,11 @@ int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* ctx, const double* g0, const double*
  * bioen_hip_opt_lbfgs_logw called per theta).  This replaces the serial loop of
  * bioen/analyze/procedure.py:62-83 for cold-started series.
  *   thetas[ntheta]; g0: start log-weights, shared (g0_stride = 0) or per theta (stride >= n);
- *   results[ntheta][n]; w_opt[ntheta][n] or NULL; infos[ntheta]. */
+ *   results[ntheta][n]; w_opt[ntheta][n] or NULL; infos[ntheta].
+ *   max_batch bounds the THETAS in flight.  Columns of the matrix passes that no theta occupies may carry speculative
+ *   line-search trials of the thetas that are in flight (the steps a backtracking search asks for after a rejected trial;
+ *   results are identical with and without them): up to 8 - max_batch on an unsharded context at the headline size, up to
+ *   two on a structure-sharded context -- their N-vectors (seven per column) are allocated only where they can be used. */
 int bioen_hip_opt_lbfgs_logw_batch(bioen_hip_ctx* ctx, int ntheta, const double* thetas,
                                    const double* g0, size_t g0_stride, const double* G,
                                    const bioen_lbfgs_config* config, const bioen_visual_params* visual,
