@@ -404,7 +404,7 @@ def storage_record(ctx, thetas, G, g0, max_batch, base_results, base_stats):
     return out
 
 
-def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True):
+def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=True):
     """BASELINE configs[4] on one GPU: forces method, N = 1e6 x M = 512, the theta series as ONE lock-step
     batch (cold starts, yaml-default liblbfgs).  Not part of `value`; reported beside it."""
     N, M = 1000000, 512
@@ -423,6 +423,8 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True):
         st = ctx.kernel_stats()
         split = None
         try:             # the opt-in storage experiment on this workload too (never the graded number): 6-byte split copies
+            if not with_split:
+                raise RuntimeError("skipped (--no-storage-experiment)")
             ctx.set_storage("split")
             ctx.opt_lbfgs_forces_batch(thetas[:2], f0, w0, dict(LBFGS_DEFAULTS, max_iterations=3), max_batch=max_batch)
             ctx.kernel_stats_enable(True)
@@ -913,7 +915,8 @@ def main():
         if world == 1 and not args.no_forces and not forces_mode:
             ctx.close()              # 8 GB back before the second workload (closed again below: idempotent)
             try:
-                forces = forces_record(bioen_amd, thetas, SEED, args.max_batch, with_cpu=not args.no_cpu_baseline)
+                forces = forces_record(bioen_amd, thetas, SEED, args.max_batch, with_cpu=not args.no_cpu_baseline,
+                                        with_split=not args.no_storage_experiment)
                 tj_f = None
                 if os.path.isfile(tpath):
                     with open(tpath) as fp:
