@@ -1551,6 +1551,12 @@ int bioen_hip_exchange_selftest(bioen_hip_ctx* c, int reps, long long* mismatche
         launch_xch_fill(c, X_YBAR, (int)payload, rep);
         rc = exchange(c, X_YBAR, payload);
         if (!rc) launch_xch_check(c, X_YBAR, (int)payload, rep, bad);
+        if (!rc && c->xcap[X_VEC] && rep % 8 == 7) {       // the result gathers' shape: a whole N-vector share per rank
+            const size_t pv = rep % 16 == 7 ? c->xcap[X_VEC] : std::max<size_t>(1, c->xcap[X_VEC] - 1);
+            launch_xch_fill(c, X_VEC, (int)pv, rep);
+            rc = exchange(c, X_VEC, pv);
+            if (!rc) launch_xch_check(c, X_VEC, (int)pv, rep, bad);
+        }
     }
     unsigned long long h = 0;
     if (!rc) {
@@ -1659,6 +1665,8 @@ int bioen_hip_p2p_detach(bioen_hip_ctx* c) {
     c->p2p_err = nullptr;
     if (c->p2p_dev_err) hipFree(c->p2p_dev_err);
     c->p2p_dev_err = nullptr;
+    if (c->p2p_cnt) hipFree(c->p2p_cnt);
+    c->p2p_cnt = nullptr;
     c->p2p_seq = 0;
     (void)hipGetLastError();
     return 0;
@@ -1697,6 +1705,8 @@ int bioen_hip_p2p_attach(bioen_hip_ctx* c, const unsigned char* handles) {
             e = hipMalloc(reinterpret_cast<void**>(&c->p2p_dev_err), 64);
         }
         if (e == hipSuccess) e = hipMemset(c->p2p_dev_err, 0, 64);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->p2p_cnt), 128 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(c->p2p_cnt, 0, 128 * sizeof(unsigned int));
         if (e != hipSuccess) rc = hip_fail(e, "error words of the peer-to-peer exchange", __FILE__, __LINE__);
     }
     if (!rc) {

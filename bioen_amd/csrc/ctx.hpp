@@ -169,6 +169,7 @@ struct bioen_hip_ctx {
     int p2p_on = 0;                          // attached: exchange() uses this transport
     unsigned long long* p2p_err = nullptr;   // host-mapped: first failure of an exchange kernel (0 = none)
     unsigned long long* p2p_dev_err = nullptr;   // the same word in device memory (read by the later kernels)
+    unsigned int* p2p_cnt = nullptr;         // [world] arrival counters of the multi-block form (large segments)
     double wait_timeout_s = 60.0;            // BIOEN_HIP_WAIT_TIMEOUT: bound of every host and device wait on a round
     int failed = 0;                          // a wait expired or a transport failed: every later call returns at once
     int failed_p2p = 0;                      // ... and it was the peer-to-peer transport's own failure (detaching it clears it)

@@ -21,6 +21,7 @@
 #include "device_utils.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace bioen {
 
@@ -102,6 +103,78 @@ __global__ __launch_bounds__(1024) void k_p2p_exchange(P2PArgs q) {
     }
 }
 
+// The same exchange for LARGE segments (the result gathers: a rank's share of an N-vector, 1 MB at the headline on 8 GPUs,
+// 4 MB on 2): `nsub` blocks per peer, each moving its slice.  The flag for peer p may only go up when ALL of them have
+// stored and fenced: every sub-block counts itself in on a device counter after its fence, the one that completes the count
+// resets it and releases the flag; every sub-block then polls the flag of ITS peer and copies its slice in.  Exchanges are
+// serialised on the stream, so one counter per peer serves them all.
+__global__ __launch_bounds__(1024) void k_p2p_exchange_big(P2PArgs q, unsigned int* cnt) {
+    const int p = blockIdx.x, sub = blockIdx.y, nsub = gridDim.y;
+    if (p == q.rank) return;
+    __shared__ unsigned long long verdict;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = (int)(q.seq & 1ull);
+    // this sub-block's slice, in 16-byte pairs where the payload allows it (it does for every vector gather: ld is even)
+    const bool wide = ((q.payload | (int)(q.cap & 1)) & 1) == 0;
+    const int units = wide ? q.payload / 2 : q.payload;
+    const int per = (units + nsub - 1) / nsub;
+    const int u0 = min(units, sub * per), u1 = min(units, u0 + per);
+    unsigned long long failed_before = 0;
+    if (tid == 0) failed_before = *q.err_dev;
+    {
+        const double* src = q.local + (size_t)q.rank * q.payload;
+        double* dst = q.peers[p] + p2p_data_offset(q.world) + ((size_t)half * q.world + q.rank) * q.cap;
+        if (wide) {
+            for (int i = u0 + tid; i < u1; i += nt) *reinterpret_cast<d2*>(dst + 2 * i) = *reinterpret_cast<const d2*>(src + 2 * i);
+        } else {
+            for (int i = u0 + tid; i < u1; i += nt) dst[i] = src[i];
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(cnt + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == (unsigned int)nsub - 1u) {                        // the peer's whole segment has left
+            __hip_atomic_store(cnt + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* flag = reinterpret_cast<unsigned long long*>(q.peers[p]) +
+                                       ((size_t)half * q.world + q.rank) * kP2PFlagStride;
+            __hip_atomic_store(flag, failed_before ? (kP2PAbort | q.seq) : q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        unsigned long long v = 0, why = failed_before ? 3 : 0;
+        if (!failed_before) {
+            const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(q.peers[q.rank]) +
+                                             ((size_t)half * q.world + p) * kP2PFlagStride;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (v & kP2PAbort) { why = 2; break; }
+                if (v >= q.seq) break;
+                if (wall_clock64() - t0 > q.timeout) { why = 1; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (why) {
+                const unsigned long long word = (why << 60) | ((unsigned long long)(q.stage & 0xff) << 52) |
+                                                ((unsigned long long)(p & 0xfff) << 40) | (q.seq & 0xffffffffffull);
+                if (atomicCAS(q.err_dev, 0ull, word) == 0ull)
+                    __hip_atomic_store(q.err_host, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        verdict = why;
+    }
+    __syncthreads();
+    if (verdict) return;
+    __threadfence_system();
+    {
+        const double* src = q.peers[q.rank] + p2p_data_offset(q.world) + ((size_t)half * q.world + p) * q.cap;
+        double* dst = q.local + (size_t)p * q.payload;
+        if (wide) {
+            for (int i = u0 + tid; i < u1; i += nt) *reinterpret_cast<d2*>(dst + 2 * i) = *reinterpret_cast<const d2*>(src + 2 * i);
+        } else {
+            for (int i = u0 + tid; i < u1; i += nt) dst[i] = src[i];
+        }
+    }
+}
+
 // self-test (bioen_hip_exchange_selftest): a rank's segment of exchange `rep` is a pattern of (rank, rep, index); after the
 // exchange every segment of the stage buffer must hold its owner's pattern.  Queued back to back, no host in between.
 __device__ __forceinline__ double p2p_pattern(int rank, int rep, int i) {
@@ -143,6 +216,16 @@ void launch_p2p_exchange(bioen_hip_ctx* c, int stage, size_t payload) {
     q.world = c->world;
     q.rank = c->rank;
     q.stage = stage;
+    static long big = -1;                  // doubles from which a segment is moved by several blocks per peer
+    if (big < 0) {
+        const char* e = std::getenv("BIOEN_HIP_P2P_BIG");
+        big = e ? std::max(1L, std::atol(e)) : 16384;
+    }
+    if ((long)payload >= big && c->p2p_cnt) {
+        const int nsub = (int)std::min<size_t>(16, std::max<size_t>(2, payload / 8192));
+        hipLaunchKernelGGL(k_p2p_exchange_big, dim3(c->world, nsub), dim3(1024), 0, c->stream, q, c->p2p_cnt);
+        return;
+    }
     // a block per peer; as many threads as the segment has 16-byte pieces, within [64, 1024]
     int threads = (int)std::min<size_t>(1024, std::max<size_t>(64, (payload / 2 + 63) / 64 * 64));
     hipLaunchKernelGGL(k_p2p_exchange, dim3(c->world), dim3(threads), 0, c->stream, q);

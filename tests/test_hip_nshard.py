@@ -38,7 +38,9 @@ def run_ranks(tmp_path, world, transport):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="nshard%d" % os.getpid(),
-                   BIOEN_TEST_TRANSPORT=transport, BIOEN_HIP_WAIT_TIMEOUT="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   BIOEN_TEST_TRANSPORT=transport.split("-")[0], BIOEN_HIP_WAIT_TIMEOUT="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if transport == "p2p-big":       # every segment of 256 doubles or more through the multi-block form of the exchange
+            env["BIOEN_HIP_P2P_BIG"] = "256"
         procs.append(subprocess.Popen([sys.executable, WORKER, str(out / "rank%d.npz")], env=env, cwd=ROOT))
     try:
         for p in procs:
@@ -76,6 +78,12 @@ def test_peer_to_peer_exchange_equals_host_staged_bitwise(tmp_path, world):
         assert int(zh[r]["counts"][1]) > 100 and int(zh[r]["counts"][2]) == 0
     print("exchange latency, %d ranks on one GPU: p2p %.1f us, host-staged %.1f us"
           % (world, float(zp[0]["probe_us"]), float(zh[0]["probe_us"])))
+    if world == 3:      # the multi-block form (large segments: the result gathers) delivers the same bytes
+        zb = run_ranks(tmp_path, world, "p2p-big")
+        for r in range(world):
+            for key in RESULT_KEYS:
+                assert np.array_equal(zh[r][key], zb[r][key]), (key, r)
+            assert int(zb[r]["counts"][2]) > 100
 
 
 @pytest.mark.parametrize("world", [2, 3])
