@@ -4,6 +4,8 @@
 namespace bioen {
 
 // (cache policy of the N-vector streams: device_utils.hpp, ld_hist / st_vec<POLICY>)
+// (k_logw_grad reads the adjoint output a and e for the last time in the round: nontemporal too under the policy, -0.4 ...
+// -0.7 % of the headline sweep; x, xp, g, gp of k_gram as well: no further gain)
 
 // ------------------------------------------------------------------------------
 // log-weights N-vector kernels (blockIdx.y = position a in the round's batch)
@@ -173,11 +175,11 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
         const d2 xv = ld_vec(x + j);
-        d2 wv = ld_vec(w + j);                                 // pad: e = 0  =>  g = 0
+        d2 wv = ld_hist<POLICY>(w + j);                        // pad: e = 0  =>  g = 0
         wv.x *= inv;
         wv.y *= inv;
         const d2 Gv = ld_vec(G + j);
-        const d2 aa = ld_vec(av + j);
+        const d2 aa = ld_hist<POLICY>(av + j);
         const d2 dv = ld_vec(d + j);
         d2 gv;
         gv.x = wv.x * (theta * ((xv.x - Gv.x) - P) + aa.x);
