@@ -280,11 +280,11 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         const int j = 2 * p;
         const d2 xv = *reinterpret_cast<const d2*>(x + j);
-        d2 wv = *reinterpret_cast<const d2*>(w + j);           // pad: e = 0  =>  g = 0
+        d2 wv = ld_hist<POLICY>(w + j);                        // pad: e = 0  =>  g = 0  (e and a: read for the last time)
         wv.x *= inv;
         wv.y *= inv;
         const d2 Gv = *reinterpret_cast<const d2*>(G + j);
-        const d2 aa = *reinterpret_cast<const d2*>(av + j);
+        const d2 aa = ld_hist<POLICY>(av + j);
         const d2 dv = *reinterpret_cast<const d2*>(d + j);
         d2 gv;
         gv.x = wv.x * (theta * ((xv.x - Gv.x) - Pp) + aa.x);
