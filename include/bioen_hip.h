@@ -7,7 +7,9 @@
  *
  * Ownership: every `const double*` / `double*` argument is a HOST buffer owned
  * by the caller and only read (inputs) or written (outputs) during the call;
- * nothing is retained after return.  Device memory belongs to the context and
+ * nothing is retained after return (the batch optimizers register large result arrays with the
+ * HIP runtime -- hipHostRegister -- while the call runs, so that finished problems leave by DMA,
+ * and unregister them before they return).  Device memory belongs to the context and
  * is released by bioen_hip_ctx_destroy().  A context is not re-entrant (one
  * HIP stream, one scratch set); distinct contexts are independent.
  *
