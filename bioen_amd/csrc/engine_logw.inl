@@ -23,6 +23,7 @@ struct LogwBatchEngine {
     bool speculate = true;
     int max_shadows = 2;                             // shadow evaluations per round at most (BIOEN_HIP_HOST_SHADOWS): both
                                                      // steps of the slowest problem (r02: every idle slot)
+    bool shadow_mixed_first = false;                 // third candidate of a search: the up-then-down step instead of stp / 4
     long long spec_launched = 0, spec_used = 0;      // shadow evaluations issued / adopted
 
     // Deliveries: the optimum and the weights of a finished problem (2 N doubles into the caller's pageable arrays,
@@ -43,6 +44,7 @@ struct LogwBatchEngine {
         const char* e = std::getenv("BIOEN_HIP_SPECULATE");
         speculate = !(e && e[0] == '0');
         if (const char* m = std::getenv("BIOEN_HIP_HOST_SHADOWS")) max_shadows = std::max(0, std::min((int)kMaxBatch, std::atoi(m)));
+        if (const char* m = std::getenv("BIOEN_HIP_SHADOW_MIXED")) shadow_mixed_first = m[0] == '1';
         const char* d = std::getenv("BIOEN_HIP_DELIVERY");
         async_delivery = !(d && d[0] == '0');
     }
@@ -489,15 +491,20 @@ struct LogwBatchEngine {
                     // The steps the search can ask for after this trial -- formed exactly as report_backtracking forms
                     // them (lbfgs.c:686-727): stp * 0.5 | stp * 2.1 -- and, should slots remain, the ones a rejected
                     // successor would ask for.  (Measured at the headline, r03: the two first-level steps for the slowest
-                    // theta catch every first rejection, 29 of its 45 extra evaluations; second-level shadows, or a
-                    // "the search keeps going the same way" guess for the second slot, save no further round.)
-                    double c1[2], cand[4];
+                    // theta catch every first rejection, 29 of its 45 extra evaluations.  The other 16 are second rejections
+                    // inside one search -- r04, BIOEN_HIP_SPEC_DEBUG: 4 x "up again" in the first search, 6 x "up, then down"
+                    // in one ping-pong search around evaluation 20, 6 x "down again" -- all but one within the first 36
+                    // evaluations, when the two reserved slots are the only free ones: a third candidate would need a third
+                    // theta to wait, for at most 5-6 of 406 rounds.)
+                    double c1[2], cand[5];
                     int nc = p.initial ? 0 : p.machine->speculative_steps(c1);
                     for (int i2 = 0; i2 < nc; ++i2) cand[i2] = c1[i2];
                     if (nc == 2) {
                         cand[2] = c1[0] * 0.5;
                         cand[3] = c1[1] * 2.1;
-                        nc = 4;
+                        cand[4] = c1[1] * 0.5;           // up, then down (= down, then up: the halving is exact)
+                        nc = 5;
+                        if (shadow_mixed_first) std::swap(cand[2], cand[4]);
                     } else if (nc == 1) {
                         cand[1] = c1[0] * 0.5;
                         nc = 2;
@@ -571,6 +578,13 @@ struct LogwBatchEngine {
                             if (shadow_owner[q] == a) { ++mine; hit += shadow_stp[q] == p.machine->trial_step(); }
                         ++dbg_rej[p.id];
                         if (!mine) ++dbg_noslot[p.id]; else if (!hit) ++dbg_miss[p.id];
+                        if (!hit) {
+                            std::fprintf(stderr, "spec debug: theta %g evaluation %d: trial %.17g rejected, asks %.17g (x %.3g); shadows:",
+                                         p.theta, p.machine->evaluations(), stp[a], p.machine->trial_step(), p.machine->trial_step() / stp[a]);
+                            for (int q = 0; q < nshadow; ++q)
+                                if (shadow_owner[q] == a) std::fprintf(stderr, " x %.3g", shadow_stp[q] / stp[a]);
+                            std::fprintf(stderr, "\n");
+                        }
                     }
                     // rejected: is the step it asks for next among this round's shadows?  An adopted evaluation may be
                     // rejected in its turn: its successor may be there too (second-level shadows)
@@ -581,7 +595,12 @@ struct LogwBatchEngine {
                         int q = 0;
                         for (; q < nshadow; ++q)
                             if (shadow_owner[q] == a && !used[q] && shadow_stp[q] == prev) break;
-                        if (q == nshadow) break;
+                        if (q == nshadow) {
+                            if (dbg && column != a)
+                                std::fprintf(stderr, "spec debug: theta %g evaluation %d: adopted x %.3g rejected in its turn, asks x %.4g\n",
+                                             p.theta, p.machine->evaluations(), c->host_scal[0] * 0 + shadow_stp[column - k] / stp[a], prev / stp[a]);
+                            break;
+                        }
                         used[q] = true;
                         ProblemSlot& sh = c->slot[shadow_slot[q]];
                         std::swap(sl.x, sh.x);           // the shadow's point, gradient, e and adjoint become the trial's
