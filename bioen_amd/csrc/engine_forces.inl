@@ -94,6 +94,17 @@ struct ForcesBatchEngine {
         }
     }
     bool live = false;
+    // BIOEN_HIP_FORCES_TIMING=1: where the host's share of a round goes (sums in microseconds, printed at the end of run)
+    bool timing = std::getenv("BIOEN_HIP_FORCES_TIMING") != nullptr;
+    double t_pack = 0, t_copy = 0, t_enq = 0, t_wait = 0, t_decide = 0;
+    long long t_rounds = 0;
+    std::chrono::steady_clock::time_point t_mark;
+    double lap() {
+        const auto now = std::chrono::steady_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(now - t_mark).count();
+        t_mark = now;
+        return us;
+    }
 
     // wait for round `round` of k_forces_publish; the stream is polled now and then so that a failed launch ends the
     // wait with its error instead of hanging the caller
@@ -119,11 +130,14 @@ struct ForcesBatchEngine {
     void evaluate(const int* slots, int k, const double* const* pts, const double* thetas, bool with_grad) {
         const int m = c->m;
         if (rc) return;
+        if (timing) { t_decide += lap(); ++t_rounds; }
         std::fill(um_h, um_h + (size_t)c->mp * k, 0.0);
         for (int a = 0; a < k; ++a)
             for (int i = 0; i < m; ++i) um_h[(size_t)i * k + a] = pts[a][i];
+        if (timing) t_pack += lap();
         note(hipMemcpyAsync(c->um, um_h, (size_t)c->mp * k * sizeof(double), hipMemcpyHostToDevice, c->stream),
              "forces H2D");
+        if (timing) t_copy += lap();
         const ForcesRound fr = make_forces_round(c, slots, k, thetas);
         const Round r = make_round(c, slots, k, nullptr, thetas);
         note(enqueue_forces_eval(c, fr, r, with_grad));
@@ -131,7 +145,9 @@ struct ForcesBatchEngine {
             const unsigned long long round = ++c->forces_round;
             launch_forces_publish(c, with_grad ? c->mp * k : 0, round);
             note(check_launch());
+            if (timing) t_enq += lap();
             if (!rc) note(await_page(round));
+            if (timing) t_wait += lap();
             gm_h = c->live_f;                       // compact [row * k + problem], as c->gm
             return;
         }
@@ -247,6 +263,7 @@ struct ForcesBatchEngine {
         const bool dbg = std::getenv("BIOEN_HIP_SPEC_DEBUG") != nullptr;
 
         for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
+        t_mark = std::chrono::steady_clock::now();
         while (active > 0 && !rc) {
             int list[kMaxBatch];
             double th[kMaxBatch];
@@ -411,6 +428,10 @@ struct ForcesBatchEngine {
         }
         c->spec_launched += issued;
         c->spec_used += adopted;
+        if (timing && t_rounds)
+            std::fprintf(stderr, "forces engine, host side per round (us, %lld rounds): decisions + points %.1f, packing %.1f, H2D call %.1f, "
+                         "launches %.1f, waiting for the device %.1f\n", t_rounds, t_decide / t_rounds, t_pack / t_rounds,
+                         t_copy / t_rounds, t_enq / t_rounds, t_wait / t_rounds);
         if (verbose && issued)
             std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n", issued, adopted);
         note(hipStreamSynchronize(c->stream), "sync");
