@@ -142,6 +142,112 @@ def test_forces_full_size_properties(M):
             assert rel(info.fmin, th * info.kl + info.chi2) < 1e-11
 
 
+def _generated_columns(bioen_amd, M, N, targets, seed, cols, world=64):
+    """Columns of the synthetic N-column matrix WITHOUT the big context: the generator is counter-based per (row, global
+    column), so the rank of a `world`-way decomposition that owns a column generates it at a small LOCAL index."""
+    out = np.empty((M, len(cols)))
+    per = -(-(-(-N // world)) // 128) * 128                     # api.hip: shard_columns
+    for k, j in enumerate(cols):
+        r = int(j) // per
+        with bioen_amd.Context.synthetic(M, N, *targets, seed=seed, rank=r, world=world) as part:
+            assert part.col0 <= j < part.col0 + part.n_local and part.n_local * M < 2 ** 31
+            out[:, k] = part.read_ytilde(col0=int(j) - part.col0, cols=1)[:, 0]
+    return out
+
+
+def test_logw_beyond_2_pow_32_matrix_elements():
+    """Maximum sizes: M x N = 1024 x 4.3e6 = 4.4e9 elements (35 GB a copy) -- every element offset beyond 2^31 and 2^32
+    has to come out of 64-bit index arithmetic, in the row-major matrix, in both strip copies, in the read-back and in
+    the passes.  The columns on either side of those boundaries are checked against the generator run at small local
+    indices (another decomposition's ranks), the passes against those columns."""
+    import bioen_amd
+    M, N = 1024, 4300032
+    assert M * N > 2 ** 32
+    targets = _targets(M)
+    YTilde = targets[3]
+    rng = np.random.default_rng(31)
+    # row-major: offset = row * ld + col crosses 2^31 at row 499 and 2^32 at row 998; strip-major: strip * 16384 crosses
+    # them at columns 2^21 and 2^22
+    cols = np.array([0, 2 ** 21 - 1, 2 ** 21, 2 ** 22 - 1, 2 ** 22, 2 ** 22 + 12345, N - 2, N - 1])
+    Y = _generated_columns(bioen_amd, M, N, targets, 12345, cols)
+    with bioen_amd.Context.synthetic(M, N, *targets, seed=12345) as ctx:
+        forms, nbytes = ctx.footprint()
+        assert "rowmajor" in forms and nbytes >= 8 * M * N
+        assert np.array_equal(_columns(ctx, cols), Y)                       # read-back of the row-major matrix
+        wts = rng.dirichlet(np.ones(cols.size))
+        w = np.zeros(N)
+        w[cols] = wts
+        chi2, yave = ctx.chi_squared(w)                                     # builds the row-sum order copy
+        expect = Y.dot(wts)
+        assert np.abs(yave - expect).max() <= 4e-16 * np.abs(expect).max() * cols.size
+        assert rel(chi2, 0.5 * np.sum((expect - YTilde) ** 2)) < 1e-13
+        theta = 10.0
+        G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+        g = G + 0.3 * rng.standard_normal(N)
+        f, grad = ctx.logw_fdf(g, G, theta)                                 # ... and the column-sum order copy
+        forms, _ = ctx.footprint()
+        assert "rowmajor" not in forms and {"strips", "strips_colsum"} <= forms    # the copies have replaced the matrix
+        assert np.array_equal(_columns(ctx, cols), Y)                       # read-back out of the strip copy
+        wg, logs = ctx.logw_weights(g)
+        chi2g, ybar = ctx.chi_squared(wg)
+        P = float(np.dot(wg, g - G))
+        logs0 = np.log(np.exp(G - G.max()).sum()) + G.max()
+        assert rel(f, theta * (P - logs + logs0) + chi2g) < 1e-12
+        a = (Y - ybar[:, None]).T.dot(ybar - YTilde)
+        expect_g = wg[cols] * (theta * ((g[cols] - G[cols]) - P) + a)
+        assert np.abs(grad[cols] - expect_g).max() <= 1e-11 * np.abs(expect_g).max()
+        assert abs(grad.sum()) < 1e-9 * np.abs(grad).sum()
+        # a short batched run on it: equal to the single runs bit for bit
+        G0 = np.zeros(N)
+        short = dict(LBFGS_DEFAULTS, max_iterations=3)
+        res, wopt, infos = ctx.opt_lbfgs_logw_batch([100.0, 3.0], G0, G0, short, max_batch=8)
+        gs, ws, info = ctx.opt_lbfgs_logw(G0, G0, 3.0, short)
+        assert infos[1].fmin == info.fmin and np.array_equal(res[1], gs) and np.array_equal(wopt[1], ws)
+        assert abs(ws.sum() - 1.0) < 1e-12
+
+
+def test_forces_beyond_2_pow_32_matrix_elements():
+    """The same for the forces method's strip passes: M x N = 512 x 8.6e6 (35 GB, one copy)."""
+    import bioen_amd
+    M, N = 512, 8600064
+    assert M * N > 2 ** 32
+    targets = _targets(M, seed=777)
+    rng = np.random.default_rng(6)
+    cols = np.array([0, 2 ** 22 - 1, 2 ** 22, 2 ** 23 - 1, 2 ** 23, N - 1])  # strip * 8192 crosses 2^31 / 2^32 at 2^22 / 2^23
+    Y = _generated_columns(bioen_amd, M, N, targets, 777, cols)
+    with bioen_amd.Context.synthetic(M, N, *targets, seed=777) as ctx:
+        w0 = rng.dirichlet(np.ones(N) * 2.0)
+        forces = 1e-3 * rng.standard_normal(M)
+        theta = 10.0
+        w = ctx.forces_weights(forces, w0)
+        assert abs(w.sum() - 1.0) < 1e-12
+        x = forces.dot(Y)
+        ratio = (w[cols] / w0[cols]) / (w[cols[0]] / w0[cols[0]])
+        assert np.abs(ratio - np.exp(x - x[0])).max() <= 1e-11 * ratio.max()
+        f, grad = ctx.forces_fdf(forces, w0, theta)                          # the strip passes
+        assert np.array_equal(_columns(ctx, cols), Y)
+        chi2, ybar = ctx.chi_squared(w)
+        kl = float(np.sum(w * np.log(w / w0)))
+        assert rel(f, theta * kl + chi2) < 1e-11
+        dirn = rng.standard_normal(M)
+        h = 1e-6
+        fp = ctx.forces_fdf(forces + h * dirn, w0, theta, need_grad=False)[0]
+        fm = ctx.forces_fdf(forces - h * dirn, w0, theta, need_grad=False)[0]
+        assert abs((fp - fm) / (2 * h) - grad.dot(dirn)) < 2e-5 * max(1.0, abs(grad.dot(dirn)))
+        # the gradient's rows against the sampled columns cannot be isolated (every column enters every row): a sparse
+        # prior does it -- w0 concentrated on the sampled columns makes them the whole ensemble
+        w0s = np.full(N, 1e-300)
+        w0s[cols] = 1.0 / cols.size
+        ws = ctx.forces_weights(forces, w0s)
+        es = np.exp(x - x.max()) / np.exp(x - x.max()).sum()
+        assert np.abs(ws[cols] - es).max() <= 1e-12
+        fs, grads = ctx.forces_fdf(forces, w0s, theta)
+        ybs = Y.dot(es)
+        t = (theta * (1.0 + np.log(es * cols.size)) + Y.T.dot(ybs - targets[3])) * es
+        expect = (Y - ybs[:, None]).dot(t)                                   # c_bioen_kernels_forces.c:280-340
+        assert np.abs(grads - expect).max() <= 1e-9 * np.abs(expect).max()
+
+
 def test_deer_nuisance_series_at_config4_scale():
     """BASELINE config 4: DEER refinement with a modulation-depth nuisance parameter, N = 5e5
     rotamers x M = 205 time points (SURVEY 8d).  The matrix F~ = (F - 1)/sigma is uploaded once;
