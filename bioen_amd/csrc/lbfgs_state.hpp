@@ -375,7 +375,12 @@ BIOEN_HD inline LbfgsAction on_initial(LbfgsState& m, const bioen_lbfgs_config& 
     double xnorm = dsqrt(xx);
     const double gnorm = dsqrt(gg);
     if (xnorm < 1.0) xnorm = 1.0;
-    if (gnorm / xnorm <= c.epsilon) return LbfgsAction{ACT_DONE, 0, 0, LBFGS_ALREADY_MINIMIZED, 0};
+    // lbfgs.c:447 writes `gnorm / xnorm <= epsilon`; the reference BUILDS its liblbfgs with -ffast-math (the library's own
+    // Makefile), where the test comes out as !(... > epsilon): a non-finite start (NaN / inf in g, G, yTilde,
+    // YTilde, theta, forces, w0) ends the run at once with LBFGS_ALREADY_MINIMIZED and the start point -- measured against
+    // oracle/_ref (tools/nan_probe.py, tests/test_hip_edgecases.py).  Under IEEE rules the `<=` form would iterate on NaN
+    // until max_iterations (5000 lock-step rounds of nothing).
+    if (!(gnorm / xnorm > c.epsilon)) return LbfgsAction{ACT_DONE, 0, 0, LBFGS_ALREADY_MINIMIZED, 0};
     m.k = 1;
     m.end = 0;
     begin_linesearch(m, c, 1.0 / gnorm);   // d = -g  =>  |d| = |g|   (lbfgs.c:456)
@@ -405,7 +410,7 @@ BIOEN_HD inline LbfgsAction on_trial(LbfgsState& m, const bioen_lbfgs_config& c,
     const double gnorm = dsqrt(t.gg);
     ++m.iterations;   // progress callback, c_bioen_kernels_logw.c:565-576
     if (xnorm < 1.0) xnorm = 1.0;
-    if (gnorm / xnorm <= c.epsilon) return LbfgsAction{ACT_DONE, 0, 0, LBFGS_CONVERGED, 1};
+    if (!(gnorm / xnorm > c.epsilon)) return LbfgsAction{ACT_DONE, 0, 0, LBFGS_CONVERGED, 1};   // NaN-aware, as on_initial
     if (m.npf > 0) {
         if (c.past <= m.k) {
             const double rate = (m.pf[m.k % c.past] - m.fx) / m.fx;

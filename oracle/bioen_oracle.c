@@ -518,7 +518,7 @@ static int lbfgs_minimize(problem_t* p, double* x, double* fx_out, oracle_lbfgs_
 
     double xnorm = sqrt(dot(x, x, n)), gnorm = sqrt(dot(g, g, n));
     if (xnorm < 1.0) xnorm = 1.0;
-    if (gnorm / xnorm <= c->epsilon) {
+    if (!(gnorm / xnorm > c->epsilon)) {      /* NaN ends the run: what the reference's -ffast-math build of lbfgs.c:447 does (tools/nan_probe.py) */
         status = ST_ALREADY_MINIMIZED;
         goto done;
     }
@@ -542,7 +542,7 @@ static int lbfgs_minimize(problem_t* p, double* x, double* fx_out, oracle_lbfgs_
         ++iterations; /* the progress callback, c_bioen_kernels_logw.c:565-576 */
 
         if (xnorm < 1.0) xnorm = 1.0;
-        if (gnorm / xnorm <= c->epsilon) { status = ST_CONVERGED; break; }
+        if (!(gnorm / xnorm > c->epsilon)) { status = ST_CONVERGED; break; }
 
         if (pf) {
             if (c->past <= k) {

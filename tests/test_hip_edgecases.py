@@ -242,3 +242,46 @@ def test_forces_theta_zero_at_configs1_size_against_the_reference_binary():
         assert rel(info.fmin, fmin_ref) < 1e-9 and info.fmin < 0.02 * f_ref
         assert np.abs(wo - w_ref).max() <= 1e-8 * w_ref.max()
         assert np.abs(fo - f_r).max() <= 1e-8 * np.abs(f_r).max()
+
+
+# ---- non-finite inputs ------------------------------------------------------------------------------------------------
+from test_oracle import NON_FINITE          # the same cases the CPU suite runs through the restatement
+
+
+@pytest.mark.parametrize("case", sorted(NON_FINITE))
+def test_non_finite_inputs_end_as_in_the_reference_binary(case):
+    """NaN / inf in any input: the reference's binary (liblbfgs built with -ffast-math: its start test lets NaN through as
+    "already minimal") returns status 2, the start point and a non-finite fmin after one evaluation.  The device does the
+    same -- it does not iterate on NaN until max_iterations, and nothing hangs."""
+    import bioen_amd as hip
+    R = require_reference()
+    method, kw = NON_FINITE[case]
+    params = dict(LBFGS_DEFAULTS, max_iterations=50)
+    with hip.Context(kw["yTilde"], kw["YTilde"]) as ctx:
+        if method == "logw":
+            x_r, f_r, code_r = R.opt_lbfgs_logw(kw["g0"], kw["G"], kw["yTilde"], kw["YTilde"], kw["theta"], params)
+            x_d, w_d, info = ctx.opt_lbfgs_logw(kw["g0"], kw["G"], kw["theta"], params)
+            start = kw["g0"]
+        else:
+            x_r, f_r, code_r = R.opt_lbfgs_forces(kw["f0"], kw["w0"], kw["yTilde"], kw["YTilde"], kw["theta"], params)
+            x_d, w_d, info = ctx.opt_lbfgs_forces(kw["f0"], kw["w0"], kw["theta"], params)
+            start = kw["f0"]
+    assert code_r == 2 and info.lbfgs_code == 2 and info.iterations == 0 and info.evaluations == 1
+    assert not np.isfinite(info.fmin) and np.isnan(info.fmin) == np.isnan(f_r)
+    assert np.array_equal(np.asarray(x_r).ravel(), start, equal_nan=True)
+    assert np.array_equal(np.asarray(x_d).ravel(), start, equal_nan=True)
+
+
+def test_a_non_finite_theta_in_a_batch_leaves_the_other_problems_alone():
+    """One member of a lock-step batch ends at once on NaN; the others run on and return the bits of their single runs."""
+    import bioen_amd as hip
+    method, kw = NON_FINITE["logw theta NaN"]
+    params = dict(LBFGS_DEFAULTS, max_iterations=40)
+    thetas = [10.0, float("nan"), 1.0]
+    with hip.Context(kw["yTilde"], kw["YTilde"]) as ctx:
+        res, w, infos = ctx.opt_lbfgs_logw_batch(thetas, kw["g0"], kw["G"], params, max_batch=8)
+        assert infos[1].lbfgs_code == 2 and infos[1].evaluations == 1 and not np.isfinite(infos[1].fmin)
+        for k in (0, 2):
+            gs, ws, info = ctx.opt_lbfgs_logw(kw["g0"], kw["G"], thetas[k], params)
+            assert infos[k].fmin == info.fmin and infos[k].iterations == info.iterations > 0
+            assert np.array_equal(res[k], gs) and np.array_equal(w[k], ws)

@@ -123,3 +123,63 @@ def test_oracle_vs_live_reference(name):
     fd = (O.logw_fdf(g + h * dirn, d["G"], d["yTilde"], d["YTilde"], d["theta"])[0] -
           O.logw_fdf(g - h * dirn, d["G"], d["yTilde"], d["YTilde"], d["theta"])[0]) / (2 * h)
     assert abs(fd - grad.dot(dirn)) < 1e-6 * max(1.0, abs(fd))
+
+
+def _non_finite_cases():
+    """-> name -> (method, kwargs): one non-finite entry in one input of a small clean problem"""
+    rng = np.random.default_rng(3)
+    M, N = 24, 300
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp, sig_sim = 0.1 * YTrue, 0.5 * YTrue
+    y = rng.normal(YTrue[:, None], sig_sim[:, None], (M, N)) / sig_exp[:, None]
+    YT = rng.normal(YTrue, sig_exp) / sig_exp
+    G, w0, f0 = np.zeros(N), np.full(N, 1.0 / N), np.zeros(M)
+    nan, inf = float("nan"), float("inf")
+
+    def poke(a, idx, v):
+        b = a.copy()
+        b[idx] = v
+        return b
+    base_l = dict(g0=G, G=G, yTilde=y, YTilde=YT, theta=10.0)
+    base_f = dict(f0=f0, w0=w0, yTilde=y, YTilde=YT, theta=10.0)
+    return {
+        "logw NaN in g0": ("logw", dict(base_l, g0=poke(G, 7, nan))),
+        "logw +inf in g0": ("logw", dict(base_l, g0=poke(G, 7, inf))),
+        "logw -inf in g0": ("logw", dict(base_l, g0=poke(G, 7, -inf))),
+        "logw NaN in G": ("logw", dict(base_l, G=poke(G, 7, nan))),
+        "logw NaN in yTilde": ("logw", dict(base_l, yTilde=poke(y, (3, 11), nan))),
+        "logw inf in yTilde": ("logw", dict(base_l, yTilde=poke(y, (3, 11), inf))),
+        "logw NaN in YTilde": ("logw", dict(base_l, YTilde=poke(YT, 5, nan))),
+        "logw theta NaN": ("logw", dict(base_l, theta=nan)),
+        "logw theta inf": ("logw", dict(base_l, theta=inf)),
+        "forces NaN in forces_init": ("forces", dict(base_f, f0=poke(f0, 2, nan))),
+        "forces NaN in w0": ("forces", dict(base_f, w0=poke(w0, 9, nan))),
+        "forces NaN in yTilde": ("forces", dict(base_f, yTilde=poke(y, (3, 11), nan))),
+        "forces NaN in YTilde": ("forces", dict(base_f, YTilde=poke(YT, 5, nan))),
+        "forces theta NaN": ("forces", dict(base_f, theta=nan)),
+    }
+
+
+NON_FINITE = _non_finite_cases()
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("case", sorted(NON_FINITE))
+def test_non_finite_inputs_end_as_in_the_reference_binary(case):
+    """The reference validates nothing (c_bioen.pyx:274-290) and builds liblbfgs with -ffast-math, where the start test
+    `gnorm / xnorm <= epsilon` (lbfgs.c:447) lets NaN through as "already minimal": status 2, the start point and a
+    non-finite fmin after ONE evaluation.  The restatement's test is written NaN-aware to the same effect."""
+    method, kw = NON_FINITE[case]
+    params = dict(LBFGS_DEFAULTS, max_iterations=50)
+    if method == "logw":
+        x_r, f_r, code_r = R.opt_lbfgs_logw(kw["g0"], kw["G"], kw["yTilde"], kw["YTilde"], kw["theta"], params)
+        x_o, f_o, code_o, it, ev = O.opt_lbfgs_logw(kw["g0"], kw["G"], kw["yTilde"], kw["YTilde"], kw["theta"], params)
+        start = kw["g0"]
+    else:
+        x_r, f_r, code_r = R.opt_lbfgs_forces(kw["f0"], kw["w0"], kw["yTilde"], kw["YTilde"], kw["theta"], params)
+        x_o, f_o, code_o, it, ev = O.opt_lbfgs_forces(kw["f0"], kw["w0"], kw["yTilde"], kw["YTilde"], kw["theta"], params)
+        start = kw["f0"]
+    assert code_r == 2 and code_o == 2 and it == 0 and ev == 1
+    assert not np.isfinite(f_r) and not np.isfinite(f_o) and np.isnan(f_r) == np.isnan(f_o)
+    assert np.array_equal(np.asarray(x_r).ravel(), start, equal_nan=True)
+    assert np.array_equal(np.asarray(x_o).ravel(), start, equal_nan=True)
