@@ -285,3 +285,60 @@ def test_a_non_finite_theta_in_a_batch_leaves_the_other_problems_alone():
             gs, ws, info = ctx.opt_lbfgs_logw(kw["g0"], kw["G"], thetas[k], params)
             assert infos[k].fmin == info.fmin and infos[k].iterations == info.iterations > 0
             assert np.array_equal(res[k], gs) and np.array_equal(w[k], ws)
+
+
+# ---- valid but degenerate inputs (tools/odd_probe.py) ---------------------------------------------------------------------
+def _odd_problem(M, N, seed=3):
+    rng = np.random.default_rng(seed)
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp, sig_sim = 0.1 * YTrue, 0.5 * YTrue
+    y = rng.normal(YTrue[:, None], sig_sim[:, None], (M, N)) / sig_exp[:, None]
+    return y, rng.normal(YTrue, sig_exp) / sig_exp
+
+
+def _odd_cases():
+    y, YT = _odd_problem(64, 4000)
+    y1, YT1 = _odd_problem(1, 500)
+    yn1, YTn1 = _odd_problem(16, 1)
+    same = y.copy()
+    same[:, :] = same[:, :1]
+    return {
+        # name -> (yTilde, YTilde, theta, statuses the two methods end with)
+        "theta = 0": (y, YT, 0.0, (0, 0)),
+        "theta = 1e-300": (y, YT, 1e-300, (0, 0)),
+        "theta = 1e-12": (y, YT, 1e-12, (0, 0)),
+        "one observable": (y1, YT1, 1.0, (0, 0)),
+        "one structure": (yn1, YTn1, 1.0, (2, 2)),                      # nothing to optimise: already minimal
+        "identical structures": (same, YT, 1.0, (2, 2)),               # the gradient is exactly zero
+        "zero matrix": (np.zeros_like(y), YT, 1.0, (2, 2)),
+        "chi^2 near overflow": (y * 1e150, YT, 1.0, (-995, 2)),        # log-weights: the first search finds no descent
+    }
+
+
+ODD = _odd_cases()
+
+
+@pytest.mark.parametrize("case", sorted(ODD))
+def test_degenerate_but_valid_inputs_against_the_reference_binary(case):
+    """Status, objective and weights of both methods on inputs at the edge of the domain -- prior switched off, a single
+    observable or structure, structures that cannot be told apart, an objective of 1e303 -- equal the reference binary's."""
+    import bioen_amd as hip
+    R = require_reference()
+    y, YT, theta, (code_l, code_f) = ODD[case]
+    M, N = y.shape
+    G, w0, f0 = np.zeros(N), np.full(N, 1.0 / N), np.zeros(M)
+    params = dict(LBFGS_DEFAULTS, max_iterations=300)
+    with hip.Context(y, YT) as ctx:
+        g_d, w_d, info_l = ctx.opt_lbfgs_logw(G, G, theta, params)
+        f_d, wf_d, info_f = ctx.opt_lbfgs_forces(f0, w0, theta, params)
+    g_r, fmin_l, cl = R.opt_lbfgs_logw(G, G, y, YT, theta, params)
+    f_r, fmin_f, cf = R.opt_lbfgs_forces(f0, w0, y, YT, theta, params)
+    assert (cl, cf) == (code_l, code_f) and (info_l.lbfgs_code, info_f.lbfgs_code) == (code_l, code_f)
+    # the objective to 1e-6 as everywhere -- in ABSOLUTE terms where it is the rounding residue of a perfect fit (theta -> 0)
+    assert abs(info_l.fmin - fmin_l) <= 1e-6 * max(abs(fmin_l), 1e-6)
+    assert abs(info_f.fmin - fmin_f) <= 1e-6 * max(abs(fmin_f), 1e-6)
+    w_r = np.exp(g_r - g_r.max())
+    w_r /= w_r.sum()
+    assert np.abs(np.asarray(w_d).ravel() - w_r).max() <= 1e-5 * w_r.max()
+    wf_r = np.asarray(R.forces_weights(f_r, w0, y)).ravel()
+    assert np.abs(np.asarray(wf_d).ravel() - wf_r).max() <= 1e-5 * wf_r.max()
