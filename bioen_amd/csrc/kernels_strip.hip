@@ -42,6 +42,8 @@
 //   of P1 without a single shuffle; all operand fetches of a phase are issued before its first instruction.
 //   Measured (r02, N = 1e6 x M = 512, 4.1 GB per pass): 0.60 / 0.62 ms per pass at K = 1 (6.7 TB/s), 0.68 /
 //   0.78 ms at K = 8, against 0.81 / 0.85 ms and 2.28 / 1.61 ms for the r01 kernels on the row-major matrix.
+#include <atomic>
+
 #include "device_utils.hpp"
 
 #ifndef STRIP_WAVES_PER_SIMD
@@ -1427,25 +1429,26 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     return 0;
 }
 
+// More than 64 KB of dynamic LDS needs an opt-in -- on the CURRENT device's copy of the kernel: once per (kernel, device),
+// contexts of one process may sit on different devices
+template <auto Kernel>
+static void allow_big_lds(const bioen_hip_ctx* c) {
+    static std::atomic<unsigned long long> done{0};
+    const unsigned long long bit = 1ull << (c->device & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.fetch_or(bit, std::memory_order_relaxed);
+}
+
 template <int K, bool NT, bool XY, int DEPTH>
 static void strip_launch_kd(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
-    static bool attr_done = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip<K, NT, XY, DEPTH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    allow_big_lds<&k_strip<K, NT, XY, DEPTH>>(c);
     BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY, DEPTH>), dim3(q.nblk), block, lds, q, fr);
 }
 // the same on the reduced-storage copies (experiment)
 template <int K, bool NT, bool XY, int DEPTH, int STORE>
 static void strip_launch_kds(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip<K, NT, XY, DEPTH, STORE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    allow_big_lds<&k_strip<K, NT, XY, DEPTH, STORE>>(c);
     BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, XY, DEPTH, STORE>), dim3(q.nblk), block, lds, q, fr);
 }
 
@@ -1476,19 +1479,13 @@ static void strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRou
 
 template <int K, bool NT, bool XY>
 static void strip2_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    allow_big_lds<&k_strip2<K, NT, XY>>(c);
     if (c->storage) {
-        static bool a1 = false, a2 = false;
         if (c->storage == 1) {
-            if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+            allow_big_lds<&k_strip2<K, NT, XY, 1>>(c);
             BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY, 1>), dim3(q.nblk), block, lds, q, fr);
         } else {
-            if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip2<K, NT, XY, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
+            allow_big_lds<&k_strip2<K, NT, XY, 2>>(c);
             BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY, 2>), dim3(q.nblk), block, lds, q, fr);
         }
         return;
@@ -1639,20 +1636,13 @@ static size_t adj_strip_lds_bytes(const bioen_hip_ctx* c, int wps) {
 
 template <int K, bool NT>
 static void adj_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const MVec8& out, const MVec8& scal, dim3 block, size_t lds) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_adj<K, NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    allow_big_lds<&k_strip_adj<K, NT>>(c);
     const dim3 grid((q.nblk + q.spb - 1) / q.spb);
     if (c->storage == 1) {
-        static bool a1 = false;
-        if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_adj<K, NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+        allow_big_lds<&k_strip_adj<K, NT, 1>>(c);
         BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT, 1>), grid, block, lds, q, out, scal);
     } else if (c->storage == 2) {
-        static bool a2 = false;
-        if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_adj<K, NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
+        allow_big_lds<&k_strip_adj<K, NT, 2>>(c);
         BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT, 2>), grid, block, lds, q, out, scal);
     } else {
         BIOEN_LAUNCH_TIMED(c, (k_strip_adj<K, NT>), grid, block, lds, q, out, scal);

@@ -504,3 +504,51 @@ def test_read_probe_streams_the_resident_matrix(optimize):
         gbs2, nbytes2 = ctx.read_probe(reps=3)
         assert nbytes2 == (N + 127) // 128 * 128 * 304 * 8 and gbs2 > 50.0   # one strip copy: rows padded to 16
         assert np.array_equal(ctx.read_ytilde(), Y)
+
+
+def test_two_threads_two_contexts_equal_the_serial_runs():
+    """SURVEY 8(b) threading: the reference is not re-entrant (globals in its C files); here all state is per context and
+    ctypes releases the GIL: two threads driving two contexts at once -- both methods, batched -- return the bits of the
+    runs done one after the other."""
+    import threading
+    import bioen_amd
+    from conftest import LBFGS_DEFAULTS
+    params = dict(LBFGS_DEFAULTS, max_iterations=60)
+
+    def problem(M, N, seed):
+        rng = np.random.default_rng(seed)
+        YTrue = rng.uniform(1, 10, M)
+        y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+        return y, rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+
+    jobs = [problem(96, 30000, 1), problem(600, 9000, 2)]
+    thetas = [100.0, 10.0, 1.0]
+
+    def solve(ctx, M, N):
+        G, w0 = np.zeros(N), np.full(N, 1.0 / N)
+        a = ctx.opt_lbfgs_logw_batch(thetas, G, G, params)
+        b = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, params)
+        return [a[0].tobytes(), a[1].tobytes(), [i.fmin for i in a[2]], b[0].tobytes(), b[1].tobytes(), [i.fmin for i in b[2]]]
+
+    ctxs = [bioen_amd.Context(y, YT) for y, YT in jobs]
+    try:
+        serial = [solve(c, *j[0].shape) for c, j in zip(ctxs, jobs)]
+        out, errs = [None, None], []
+
+        def work(k):
+            try:
+                for _ in range(3):
+                    out[k] = solve(ctxs[k], *jobs[k][0].shape)
+                    assert out[k] == serial[k]
+            except Exception as e:          # surfaces in the main thread below
+                errs.append(repr(e))
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        assert out == serial
+    finally:
+        for c in ctxs:
+            c.close()
