@@ -293,7 +293,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             bool have[kMaxBatch] = {};
             for (int s = 0; s < nslots; ++s) {               // keep what is still wanted, release the rest
                 if (shadow_owner[s] < 0) continue;
-                bool keep = !(s < kb && occupied[s]) && !slot_busy(s);
+                bool keep = !(s < kb && occupied[s]) && !slot_blocked(s);
                 int w = -1;
                 for (int i = 0; keep && i < nwant; ++i)
                     if (!have[i] && want_owner[i] == shadow_owner[s] && want_cand[i] == shadow_cand[s]) w = i;
@@ -307,7 +307,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             for (int i = 0; i < nwant; ++i) {
                 if (have[i]) continue;
                 for (int s = nslots - 1; s >= 0; --s) {
-                    if ((s < kb && occupied[s]) || shadow_owner[s] >= 0 || slot_busy(s)) continue;
+                    if ((s < kb && occupied[s]) || shadow_owner[s] >= 0 || slot_blocked(s)) continue;
                     if (round < release_round[s] + (unsigned long long)depth + 1) continue;
                     shadow_owner[s] = want_owner[i];
                     shadow_cand[s] = want_cand[i];

@@ -56,6 +56,13 @@ struct LogwBatchEngine {
     }
 
     bool slot_busy(int s) const { return pending[s] && !pending[s]->done.load(std::memory_order_acquire); }
+    // May slot s evaluate a speculative trial now?  Unsharded: not while its delivery still reads the slot's vectors.  On a
+    // sharded context a delivery reads the slot's own gather buffer (deliver_sharded: the vectors are free at once) -- and
+    // the answer MUST NOT depend on how far a helper thread has come: every rank has to compose the same round (the stage
+    // exchanges carry payloads that depend on the batch width).  Until r04 this asked slot_busy on every context: two
+    // ranks that disagreed on a delivery in flight enqueued rounds of different width and the next exchange failed
+    // (seen with a problem that ends in its first round while shadows want its slot; at scale any finishing theta).
+    bool slot_blocked(int s) const { return c->world == 1 && slot_busy(s); }
     void settle(int s) {
         if (!pending[s]) return;
         if (pending[s]->th.joinable()) pending[s]->th.join();
@@ -477,7 +484,7 @@ struct LogwBatchEngine {
             if (speculate && (nslots > kb || active < kb)) {
                 int free_slots[kMaxBatch], nfree = 0;
                 for (int s = 0; s < nslots; ++s)
-                    if ((s >= kb || !occupied[s]) && !slot_busy(s)) free_slots[nfree++] = s;
+                    if ((s >= kb || !occupied[s]) && !slot_blocked(s)) free_slots[nfree++] = s;
                 // Who gets the idle slots: the series ends when its SLOWEST member does, so a saved evaluation shortens it
                 // only on that member's path -- the smallest theta in every series measured (r03; r02 dealt stp / 2 to
                 // everybody first and reached the straggler last: 22 of its 45 rejected trials saved at the headline).

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         d2 v = *reinterpret_cast<const d2*>(w + 2 * p);
         v.x *= inv;
-        v.y *= inv;
+        v.y = (2 * p + 1 < n) ? v.y * inv : 0.0;      // the padding stays zero whatever the factor (see k_scale_w)
         *reinterpret_cast<d2*>(w + 2 * p) = v;
     }
 }

@@ -503,20 +503,25 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles, bool 
 }
 
 // w = e * scal[S_INV]: the weights themselves are only needed when a result is handed out
-__global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n2) {
+// The VALID entries only: the padding of e (columns n .. ld) is zero and must stay zero whatever the factor -- the matrix
+// passes multiply it with the zero columns of the strip copies, and k_logw_exp never rewrites it: scaled by a
+// non-finite 1 / sum e (a run on NaN input) it turned into NaN for good and 0 x NaN poisoned every later evaluation on
+// the context (r04, found by tools/nan_probe.py's successor in tests/test_hip_edgecases.py).
+__global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n) {
     const int a = blockIdx.y;
     const double inv = r.scal[a][S_INV];
     double* __restrict__ w = r.w[a];
+    const int n2 = (n + 1) >> 1;
     for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
         d2 v = *reinterpret_cast<d2*>(w + 2 * p);
         v.x *= inv;
-        v.y *= inv;
+        v.y = (2 * p + 1 < n) ? v.y * inv : 0.0;
         *reinterpret_cast<d2*>(w + 2 * p) = v;
     }
 }
 
 void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_scale_w, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, (int)(c->ld / 2));
+    hipLaunchKernelGGL(k_scale_w, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
 }
 
 int combine_grid(const bioen_hip_ctx*) { return 1; }

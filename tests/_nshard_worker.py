@@ -63,6 +63,17 @@ def main():
     same_without = same_without and same(full, full_plain)
     # the converged run the reference's golden pins (tests/golden: lbfgs_conv_*)
     gconv, wconv, iconv = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_CONV)
+    # a non-finite start in ONE rank's block (the last structure): every rank sees it after the exchange and ends the run
+    # the way the reference's binary does (status 2, one evaluation); a NaN theta ends alone inside a batch
+    g_nan = d["GInit"].ravel().copy()
+    g_nan[-1] = np.nan
+    _, _, inan = ctx.opt_lbfgs_logw(g_nan, d["G"], d["theta"], LBFGS_DEFAULTS)
+    nanb = ctx.opt_lbfgs_logw_batch([50.0, float("nan"), 5.0], d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    # ... and in the order in which the NaN problem takes the first slot and leaves it in the first round, while the
+    # shadows of the others want a slot: every rank must compose the same rounds whatever its delivery thread is doing
+    nanc = ctx.opt_lbfgs_logw_batch([float("nan"), 50.0, 5.0], d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+    assert [(i.fmin, i.iterations) for i in nanc[2][1:]] == [(i.fmin, i.iterations) for i in (nanb[2][0], nanb[2][2])]
+    assert np.array_equal(nanc[0][1:], nanb[0][[0, 2]])
     chi2, yave = ctx.chi_squared(w)
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
@@ -95,7 +106,10 @@ def main():
              spec=np.array(spec), same_without=same_without, counts=np.array(counts), probe_us=probe_us,
              wconv=wconv, fminconv=iconv.fmin, codeconv=iconv.lbfgs_code,
              fwconv=fwconv, ffminconv=ficonv.fmin, fcodeconv=ficonv.lbfgs_code,
-             f6res=f6res, f6w=f6w, f6fmin=np.array([i.fmin for i in f6infos]))
+             f6res=f6res, f6w=f6w, f6fmin=np.array([i.fmin for i in f6infos]),
+             nan_code=inan.lbfgs_code, nan_evals=inan.evaluations, nanb_codes=np.array([i.lbfgs_code for i in nanb[2]]),
+             nanb_evals=np.array([i.evaluations for i in nanb[2]]), nanb_fmin=np.array([i.fmin for i in nanb[2]]),
+             nanb_res=nanb[0][[0, 2]])
     comm.close()
 
 

@@ -342,3 +342,43 @@ def test_degenerate_but_valid_inputs_against_the_reference_binary(case):
     assert np.abs(np.asarray(w_d).ravel() - w_r).max() <= 1e-5 * w_r.max()
     wf_r = np.asarray(R.forces_weights(f_r, w0, y)).ravel()
     assert np.abs(np.asarray(wf_d).ravel() - wf_r).max() <= 1e-5 * wf_r.max()
+
+
+@pytest.mark.parametrize("engine", ["device", "host"])
+def test_a_context_is_clean_after_a_run_on_non_finite_input(engine, monkeypatch):
+    """A run that ended on NaN must leave nothing behind: the next runs and evaluations on the SAME context return the
+    bits a fresh context returns.  (Until r04 the weights' hand-out scaled the zero padding of e by a non-finite
+    1 / sum e: NaN for good, and 0 x NaN in the matrix passes poisoned every later evaluation in that batch slot.)"""
+    import bioen_amd as hip
+    monkeypatch.setenv("BIOEN_HIP_DEVICE_LS", "1" if engine == "device" else "0")
+    method, kw = NON_FINITE["logw NaN in g0"]
+    y, YT = kw["yTilde"], kw["YTilde"]
+    M, N = y.shape
+    G, w0, f0 = np.zeros(N), np.full(N, 1.0 / N), np.zeros(M)
+    params = dict(LBFGS_DEFAULTS, max_iterations=40)
+    thetas = [10.0, 1.0]
+
+    def clean(ctx):
+        a = ctx.opt_lbfgs_logw_batch(thetas, G, G, params)
+        b = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params)
+        f, grad = ctx.logw_fdf(G + 0.1, G, 3.0)
+        ff, fgrad = ctx.forces_fdf(f0 + 1e-3, w0, 3.0)
+        return (a[0].tobytes(), a[1].tobytes(), [i.fmin for i in a[2]], b[0].tobytes(), b[1].tobytes(), [i.fmin for i in b[2]],
+                f, grad.tobytes(), ff, fgrad.tobytes())
+
+    with hip.Context(y, YT) as ctx:
+        fresh = clean(ctx)
+    assert all(np.isfinite(v) for v in fresh[2] + fresh[5]) and np.isfinite(fresh[6]) and np.isfinite(fresh[8])
+    with hip.Context(y, YT) as ctx:
+        for name in sorted(NON_FINITE):
+            m, k = NON_FINITE[name]
+            if k["yTilde"] is not y or k["YTilde"] is not YT:
+                continue                                   # (those cases need a context of their own)
+            if m == "logw":
+                _, _, info = ctx.opt_lbfgs_logw(k["g0"], k["G"], k["theta"], params)
+                ctx.opt_lbfgs_logw_batch([10.0, k["theta"]], k["g0"], k["G"], params)
+            else:
+                _, _, info = ctx.opt_lbfgs_forces(k["f0"], k["w0"], k["theta"], params)
+                ctx.opt_lbfgs_forces_batch([10.0, k["theta"]], k["f0"], k["w0"], params)
+            assert info.lbfgs_code == 2, name
+            assert clean(ctx) == fresh, name

@@ -55,7 +55,7 @@ def run_ranks(tmp_path, world, transport):
 
 RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
                "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff",
-               "f6res", "f6w", "f6fmin")
+               "f6res", "f6w", "f6fmin", "nan_code", "nan_evals", "nanb_codes", "nanb_evals", "nanb_res")
 
 
 # BIOEN_TEST_WORLDS="2,3,4": more ranks on the one GPU (the 2000-column fixture shards over at most 4 ranks of 128-column blocks; 4 passes)
@@ -99,6 +99,15 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
                     "f6res", "f6w", "f6fmin"):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
         assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
+
+    # a NaN in the last rank's block of the start ends the run on EVERY rank as the reference's binary ends it; a NaN theta
+    # ends alone, its neighbours in the batch return the bits they return in the five-theta batch (thetas 50 and 5)
+    for r in range(world):
+        assert int(z[r]["nan_code"]) == 2 and int(z[r]["nan_evals"]) == 1
+        assert list(z[r]["nanb_codes"][[0, 2]]) == list(z[r]["codes"][[0, 1]]) and int(z[r]["nanb_codes"][1]) == 2
+        assert int(z[r]["nanb_evals"][1]) == 1 and not np.isfinite(z[r]["nanb_fmin"][1])
+        assert np.array_equal(z[r]["nanb_fmin"][[0, 2]], z[r]["fmin"][[0, 1]])
+        assert np.array_equal(z[r]["nanb_res"], z[r]["res"][[0, 1]])
 
     # the sharded engine's speculative trials (two slots' worth for the slowest thetas) ran, were adopted, and changed no bit
     for r in range(world):
