@@ -148,7 +148,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     std::deque<DevFlight> inflight;
     std::vector<int> start_order(ntheta);            // ascending theta: the slow problems first
     for (int i = 0; i < ntheta; ++i) start_order[i] = i;
-    std::stable_sort(start_order.begin(), start_order.end(), [&](int x, int y) { return thetas[x] < thetas[y]; });
+    std::stable_sort(start_order.begin(), start_order.end(), [&](int x, int y) { return theta_before(thetas[x], thetas[y]); });
 
     auto start_problem = [&](int s) {
         settle(s);                                   // the previous tenant's results have left
@@ -280,7 +280,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
                 if (seen_ev[s] < min_evals || rejected < shadow_rate * seen_ev[s]) continue;
                 order[no++] = s;
             }
-            std::sort(order, order + no, [&](int x, int y) { return thetas[prob[x]] < thetas[prob[y]]; });
+            std::sort(order, order + no, [&](int x, int y) { return theta_before(thetas[prob[x]], thetas[prob[y]]); });
             int want_owner[kMaxBatch], want_cand[kMaxBatch], nwant = 0;
             const int room = std::min(std::min(max_positions - r.nown, kMaxBatch - r.nown), max_shadows);
             for (int i = 0; i < no && nwant < room; ++i)

@@ -63,6 +63,13 @@ struct LogwBatchEngine {
     // ranks that disagreed on a delivery in flight enqueued rounds of different width and the next exchange failed
     // (seen with a problem that ends in its first round while shadows want its slot; at scale any finishing theta).
     bool slot_blocked(int s) const { return c->world == 1 && slot_busy(s); }
+    // the order of the thetas as a strict weak ordering whatever the caller passed: NaN sorts last (`<` alone is no
+    // ordering with NaN in the series, and a comparator that is none is undefined behaviour in std::sort)
+    static bool theta_before(double a, double b) {
+        if (a != a) return false;
+        if (b != b) return true;
+        return a < b;
+    }
     void settle(int s) {
         if (!pending[s]) return;
         if (pending[s]->th.joinable()) pending[s]->th.join();
@@ -344,7 +351,7 @@ struct LogwBatchEngine {
         // round on; the two fastest thetas wait for the first slots to come free (they need a fraction of the rounds).
         std::vector<int> start_order(ntheta);
         for (int i = 0; i < ntheta; ++i) start_order[i] = i;
-        std::stable_sort(start_order.begin(), start_order.end(), [&](int x, int y) { return thetas[x] < thetas[y]; });
+        std::stable_sort(start_order.begin(), start_order.end(), [&](int x, int y) { return theta_before(thetas[x], thetas[y]); });
         const bool backtracking = cfg.linesearch >= 1 && cfg.linesearch <= 3;
         if (speculate && backtracking && max_shadows >= 2 && kb == kMaxBatch && ntheta <= kMaxBatch) {
             const char* e = std::getenv("BIOEN_HIP_RESERVE");
@@ -491,7 +498,7 @@ struct LogwBatchEngine {
                 // Owners in ascending theta, both steps each, while slots last.
                 int order[kMaxBatch];
                 for (int a = 0; a < k; ++a) order[a] = a;
-                std::sort(order, order + k, [&](int x, int y) { return th[x] < th[y]; });
+                std::sort(order, order + k, [&](int x, int y) { return theta_before(th[x], th[y]); });
                 for (int i = 0; i < k && nfree > 0 && nshadow < max_shadows; ++i) {
                     const int a = order[i];
                     BatchProblem& p = slots[list[a]];
