@@ -416,6 +416,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
 
     while (active > 0 && !rc) {
+        jitter(2);
         while ((int)inflight.size() <= depth && !rc) enqueue_round();
         if (rc) break;
         const DevFlight f = inflight.front();

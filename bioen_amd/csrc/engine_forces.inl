@@ -94,6 +94,7 @@ struct ForcesBatchEngine {
         }
     }
     bool live = false;
+    int jitter_us = std::getenv("BIOEN_HIP_JITTER_US") ? std::max(0, std::atoi(std::getenv("BIOEN_HIP_JITTER_US"))) : 0;   // tests
     // BIOEN_HIP_FORCES_TIMING=1: where the host's share of a round goes (sums in microseconds, printed at the end of run)
     bool timing = std::getenv("BIOEN_HIP_FORCES_TIMING") != nullptr;
     double t_pack = 0, t_copy = 0, t_enq = 0, t_wait = 0, t_decide = 0;
@@ -265,6 +266,7 @@ struct ForcesBatchEngine {
         for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
         t_mark = std::chrono::steady_clock::now();
         while (active > 0 && !rc) {
+            if (jitter_us > 0) std::this_thread::sleep_for(std::chrono::microseconds((unsigned)std::rand() % (unsigned)jitter_us));
             int list[kMaxBatch];
             double th[kMaxBatch];
             const double* pts[kMaxBatch];

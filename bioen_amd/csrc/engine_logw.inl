@@ -38,6 +38,7 @@ struct LogwBatchEngine {
     };
     std::unique_ptr<Delivery> pending[kMaxBatch];
     bool async_delivery = true;
+    int jitter_us = 0;              // BIOEN_HIP_JITTER_US (tests): random pauses of this rank's host thread and delivery threads
 
     LogwBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
         : c(ctx), cfg(config), verbose(verb) {
@@ -47,6 +48,7 @@ struct LogwBatchEngine {
         if (const char* m = std::getenv("BIOEN_HIP_SHADOW_MIXED")) shadow_mixed_first = m[0] == '1';
         const char* d = std::getenv("BIOEN_HIP_DELIVERY");
         async_delivery = !(d && d[0] == '0');
+        if (const char* j = std::getenv("BIOEN_HIP_JITTER_US")) jitter_us = std::max(0, std::atoi(j));
     }
     ~LogwBatchEngine() {
         for (int s = 0; s < kMaxBatch; ++s) {
@@ -62,6 +64,17 @@ struct LogwBatchEngine {
     // exchanges carry payloads that depend on the batch width).  Until r04 this asked slot_busy on every context: two
     // ranks that disagreed on a delivery in flight enqueued rounds of different width and the next exchange failed
     // (seen with a problem that ends in its first round while shadows want its slot; at scale any finishing theta).
+    // tests (tests/test_hip_nshard.py): one rank of a sharded run dawdles at random -- its host thread up to jitter_us per
+    // round, its delivery threads up to ten times that before they report -- and the ranks must still compose the same
+    // rounds and land on the same bits
+    static void jitter_pause(int us, unsigned salt) {
+        if (us <= 0) return;
+        static std::atomic<unsigned> ctr{12345};
+        unsigned v = ctr.fetch_add(2654435761u) ^ (salt * 40503u);
+        v ^= v >> 13; v *= 0x5bd1e995u; v ^= v >> 15;
+        std::this_thread::sleep_for(std::chrono::microseconds(v % (unsigned)us));
+    }
+    void jitter(unsigned salt = 0) const { jitter_pause(jitter_us, salt); }
     bool slot_blocked(int s) const { return c->world == 1 && slot_busy(s); }
     // the order of the thetas as a strict weak ordering whatever the caller passed: NaN sorts last (`<` alone is no
     // ordering with NaN in the series, and a comparator that is none is undefined behaviour in std::sort)
@@ -89,7 +102,7 @@ struct LogwBatchEngine {
         }
         Delivery* d = new Delivery;
         pending[s].reset(d);
-        const int dev = c->device;
+        const int dev = c->device, jit = jitter_us;
         hipStream_t cs = c->copy_stream;
         const size_t bytes = (size_t)c->n * sizeof(double);
         auto work = [=]() {
@@ -100,6 +113,7 @@ struct LogwBatchEngine {
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             (void)hipEventDestroy(ev);
             d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
+            jitter_pause(10 * jit, 7);
             d->done.store(1, std::memory_order_release);
         };
         try {
@@ -142,7 +156,7 @@ struct LogwBatchEngine {
         }
         Delivery* d = new Delivery;
         pending[s].reset(d);
-        const int dev = c->device, world = c->world;
+        const int dev = c->device, world = c->world, jit = jitter_us;
         hipStream_t cs = c->copy_stream;
         const size_t ld = c->ld;
         const long long n_global = c->n_global;
@@ -164,6 +178,7 @@ struct LogwBatchEngine {
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             (void)hipEventDestroy(ev);
             d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
+            jitter_pause(10 * jit, 7);
             d->done.store(1, std::memory_order_release);
         };
         try {
@@ -469,6 +484,7 @@ struct LogwBatchEngine {
         static const int kEvalScal[][2] = {{S_F, 4}, {S_LOGS, 4}, {S_KL, 2}, {S_INV, 3}};
 
         while (active > 0 && !rc) {
+            jitter(1);
             // ---- one round: every active problem evaluates its next point -------------------------
             int list[kMaxBatch];
             double stp[kMaxBatch], th[kMaxBatch];

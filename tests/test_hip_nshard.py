@@ -41,6 +41,8 @@ def run_ranks(tmp_path, world, transport):
                    BIOEN_TEST_TRANSPORT=transport.split("-")[0], BIOEN_HIP_WAIT_TIMEOUT="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
         if transport == "p2p-big":       # every segment of 256 doubles or more through the multi-block form of the exchange
             env["BIOEN_HIP_P2P_BIG"] = "256"
+        if transport == "p2p-jitter" and rank == world - 1:   # the last rank's host and delivery threads pause at random
+            env["BIOEN_HIP_JITTER_US"] = "400"
         procs.append(subprocess.Popen([sys.executable, WORKER, str(out / "rank%d.npz")], env=env, cwd=ROOT))
     try:
         for p in procs:
@@ -84,6 +86,20 @@ def test_peer_to_peer_exchange_equals_host_staged_bitwise(tmp_path, world):
             for key in RESULT_KEYS:
                 assert np.array_equal(zh[r][key], zb[r][key]), (key, r)
             assert int(zb[r]["counts"][2]) > 100
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.timeout(600)
+def test_a_dawdling_rank_changes_no_bit(tmp_path, world):
+    """Every rank composes its rounds on its own host thread; what it composes must not depend on how fast that thread or
+    its delivery threads run -- the stage exchanges carry payloads that depend on the batch width.  One rank pausing up to
+    0.4 ms at random in every round and before every delivery completes: all results identical to the undisturbed run.
+    (r04: the choice of a shadow's slot used to ask whether a delivery had finished.)"""
+    calm = run_ranks(tmp_path, world, "p2p")
+    slow = run_ranks(tmp_path, world, "p2p-jitter")
+    for r in range(world):
+        for key in RESULT_KEYS:
+            assert np.array_equal(calm[r][key], slow[r][key]), (key, r)
 
 
 @pytest.mark.parametrize("world", [2, 3])
