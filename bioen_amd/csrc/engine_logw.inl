@@ -38,7 +38,8 @@ struct LogwBatchEngine {
     };
     std::unique_ptr<Delivery> pending[kMaxBatch];
     bool async_delivery = true;
-    int jitter_us = 0;              // BIOEN_HIP_JITTER_US (tests): random pauses of this rank's host thread and delivery threads
+    int jitter_us = 0, jitter_delivery_us = 0;   // BIOEN_HIP_JITTER_US / BIOEN_HIP_JITTER_DELIVERY_US (tests): random pauses of
+                                                 // this rank's host thread in every round / of its delivery threads before they report
 
     LogwBatchEngine(bioen_hip_ctx* ctx, const bioen_lbfgs_config& config, bool verb)
         : c(ctx), cfg(config), verbose(verb) {
@@ -49,6 +50,7 @@ struct LogwBatchEngine {
         const char* d = std::getenv("BIOEN_HIP_DELIVERY");
         async_delivery = !(d && d[0] == '0');
         if (const char* j = std::getenv("BIOEN_HIP_JITTER_US")) jitter_us = std::max(0, std::atoi(j));
+        if (const char* j = std::getenv("BIOEN_HIP_JITTER_DELIVERY_US")) jitter_delivery_us = std::max(0, std::atoi(j));
     }
     ~LogwBatchEngine() {
         for (int s = 0; s < kMaxBatch; ++s) {
@@ -64,9 +66,8 @@ struct LogwBatchEngine {
     // exchanges carry payloads that depend on the batch width).  Until r04 this asked slot_busy on every context: two
     // ranks that disagreed on a delivery in flight enqueued rounds of different width and the next exchange failed
     // (seen with a problem that ends in its first round while shadows want its slot; at scale any finishing theta).
-    // tests (tests/test_hip_nshard.py): one rank of a sharded run dawdles at random -- its host thread up to jitter_us per
-    // round, its delivery threads up to ten times that before they report -- and the ranks must still compose the same
-    // rounds and land on the same bits
+    // tests (tests/test_hip_nshard.py): the ranks of a sharded run dawdle at random -- their host threads in every round,
+    // ONE rank's delivery threads before they report -- and must still compose the same rounds and land on the same bits
     static void jitter_pause(int us, unsigned salt) {
         if (us <= 0) return;
         static std::atomic<unsigned> ctr{12345};
@@ -102,7 +103,7 @@ struct LogwBatchEngine {
         }
         Delivery* d = new Delivery;
         pending[s].reset(d);
-        const int dev = c->device, jit = jitter_us;
+        const int dev = c->device, jit = jitter_delivery_us;
         hipStream_t cs = c->copy_stream;
         const size_t bytes = (size_t)c->n * sizeof(double);
         auto work = [=]() {
@@ -113,7 +114,7 @@ struct LogwBatchEngine {
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             (void)hipEventDestroy(ev);
             d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
-            jitter_pause(10 * jit, 7);
+            jitter_pause(jit, 7);
             d->done.store(1, std::memory_order_release);
         };
         try {
@@ -156,7 +157,7 @@ struct LogwBatchEngine {
         }
         Delivery* d = new Delivery;
         pending[s].reset(d);
-        const int dev = c->device, world = c->world, jit = jitter_us;
+        const int dev = c->device, world = c->world, jit = jitter_delivery_us;
         hipStream_t cs = c->copy_stream;
         const size_t ld = c->ld;
         const long long n_global = c->n_global;
@@ -178,7 +179,7 @@ struct LogwBatchEngine {
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             (void)hipEventDestroy(ev);
             d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
-            jitter_pause(10 * jit, 7);
+            jitter_pause(jit, 7);
             d->done.store(1, std::memory_order_release);
         };
         try {

@@ -74,6 +74,13 @@ def main():
     nanc = ctx.opt_lbfgs_logw_batch([float("nan"), 50.0, 5.0], d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
     assert [(i.fmin, i.iterations) for i in nanc[2][1:]] == [(i.fmin, i.iterations) for i in (nanb[2][0], nanb[2][2])]
     assert np.array_equal(nanc[0][1:], nanb[0][[0, 2]])
+    # The smallest theta of a batch -- the one the shadows work for -- leaves in its first round (it starts at its own
+    # optimum) while the others run on: its shadows' slots rest for a few rounds, and the slot it has just freed is the
+    # only one a new shadow can take.  Whether that slot's result delivery has completed is a matter of thread timing on
+    # each rank; the rounds the ranks compose must not depend on it (test_a_dawdling_rank_changes_no_bit).
+    gopt = ctx.opt_lbfgs_logw(d["GInit"], d["G"], 0.5, LBFGS_CONV)[0]
+    starts = np.stack([gopt, d["GInit"].ravel(), d["GInit"].ravel()])
+    early = ctx.opt_lbfgs_logw_batch([0.5, 50.0, 5.0], starts, d["G"], LBFGS_DEFAULTS, max_batch=4)
     chi2, yave = ctx.chi_squared(w)
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
@@ -109,7 +116,8 @@ def main():
              f6res=f6res, f6w=f6w, f6fmin=np.array([i.fmin for i in f6infos]),
              nan_code=inan.lbfgs_code, nan_evals=inan.evaluations, nanb_codes=np.array([i.lbfgs_code for i in nanb[2]]),
              nanb_evals=np.array([i.evaluations for i in nanb[2]]), nanb_fmin=np.array([i.fmin for i in nanb[2]]),
-             nanb_res=nanb[0][[0, 2]])
+             nanb_res=nanb[0][[0, 2]], early_res=early[0], early_fmin=np.array([i.fmin for i in early[2]]),
+             early_codes=np.array([i.lbfgs_code for i in early[2]]), early_evals=np.array([i.evaluations for i in early[2]]))
     comm.close()
 
 

@@ -41,8 +41,10 @@ def run_ranks(tmp_path, world, transport):
                    BIOEN_TEST_TRANSPORT=transport.split("-")[0], BIOEN_HIP_WAIT_TIMEOUT="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
         if transport == "p2p-big":       # every segment of 256 doubles or more through the multi-block form of the exchange
             env["BIOEN_HIP_P2P_BIG"] = "256"
-        if transport == "p2p-jitter" and rank == world - 1:   # the last rank's host and delivery threads pause at random
-            env["BIOEN_HIP_JITTER_US"] = "400"
+        if transport == "p2p-jitter":    # every rank's host thread pauses at random in every round (rounds of ~0.5 ms instead
+            env["BIOEN_HIP_JITTER_US"] = "600"          # of 0.15), the LAST rank's delivery threads for up to 5 ms before they report
+            if rank == world - 1:
+                env["BIOEN_HIP_JITTER_DELIVERY_US"] = "5000"
         procs.append(subprocess.Popen([sys.executable, WORKER, str(out / "rank%d.npz")], env=env, cwd=ROOT))
     try:
         for p in procs:
@@ -57,7 +59,8 @@ def run_ranks(tmp_path, world, transport):
 
 RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
                "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff",
-               "f6res", "f6w", "f6fmin", "nan_code", "nan_evals", "nanb_codes", "nanb_evals", "nanb_res")
+               "f6res", "f6w", "f6fmin", "nan_code", "nan_evals", "nanb_codes", "nanb_evals", "nanb_res",
+               "early_res", "early_fmin", "early_codes", "early_evals")
 
 
 # BIOEN_TEST_WORLDS="2,3,4": more ranks on the one GPU (the 2000-column fixture shards over at most 4 ranks of 128-column blocks; 4 passes)
@@ -92,8 +95,9 @@ def test_peer_to_peer_exchange_equals_host_staged_bitwise(tmp_path, world):
 @pytest.mark.timeout(600)
 def test_a_dawdling_rank_changes_no_bit(tmp_path, world):
     """Every rank composes its rounds on its own host thread; what it composes must not depend on how fast that thread or
-    its delivery threads run -- the stage exchanges carry payloads that depend on the batch width.  One rank pausing up to
-    0.4 ms at random in every round and before every delivery completes: all results identical to the undisturbed run.
+    its delivery threads run -- the stage exchanges carry payloads that depend on the batch width.  Host threads pausing up
+    to 0.6 ms at random in every round, ONE rank's delivery threads up to 5 ms before they report: all results identical to
+    the undisturbed run.
     (r04: the choice of a shadow's slot used to ask whether a delivery had finished.)"""
     calm = run_ranks(tmp_path, world, "p2p")
     slow = run_ranks(tmp_path, world, "p2p-jitter")
