@@ -255,10 +255,11 @@ static int transport_error(bioen_hip_ctx* c) {
     if (c->p2p_err) {
         const unsigned long long w = __atomic_load_n(c->p2p_err, __ATOMIC_ACQUIRE);
         if (w) {
-            static const char* const why[] = {"?", "timed out waiting for", "received an ABORT flag from", "an earlier exchange failed; peer"};
+            static const char* const why[] = {"?", "timed out waiting for", "received an ABORT flag from", "an earlier exchange failed; peer",
+                                              "is OUT OF STEP (another stage or payload under this exchange number) with"};
             char buf[256];
             std::snprintf(buf, sizeof buf, "peer-to-peer exchange %llu (stage %d): %s rank %d (BIOEN_HIP_WAIT_TIMEOUT = %g s)",
-                          w & 0xffffffffffull, (int)((w >> 52) & 0xff), why[std::min<unsigned long long>(3, w >> 60)],
+                          w & 0xffffffffffull, (int)((w >> 52) & 0xff), why[std::min<unsigned long long>(4, w >> 60)],
                           (int)((w >> 40) & 0xfff), c->wait_timeout_s);
             if (!c->failed) c->failed_p2p = 1;
             c->failed = 1;

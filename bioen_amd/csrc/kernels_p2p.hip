@@ -15,6 +15,9 @@
 //     4. copies data[s&1][p] of its own mailbox into the stage buffer's segment p.
 // Why two halves are enough: r stores exchange s + 2 into the half p read for s only after r has seen p's flag s + 1, which p
 // released after its kernel of exchange s -- copy-out included -- had finished (stream order on p).
+// Beside its flag (second word of the flag's line) the sender leaves {stage, payload} of the exchange; a receiver that finds
+// another stage or size than its own there is OUT OF STEP with that peer (the ranks composed different rounds): an error
+// like the two below, instead of a stage buffer full of somebody else's numbers.
 // A wait that expires, or an ABORT flag from the peer, makes the kernel record {stage, peer, exchange} in the host-mapped
 // error word (the host's waits poll it) and in a device word; from then on every exchange of this rank delivers ABORT flags
 // and waits for nothing: the failure travels at flag speed and the stream drains.
@@ -38,6 +41,10 @@ struct P2PArgs {
     size_t cap;
     int payload, world, rank, stage;
 };
+
+__device__ __forceinline__ unsigned long long p2p_tag(const P2PArgs& q) {   // what an exchange is: its stage and its size
+    return ((unsigned long long)(q.stage & 0xff) << 32) | (unsigned int)q.payload;
+}
 
 __device__ __forceinline__ size_t p2p_data_offset(int world) {       // doubles in front of the data halves
     return (size_t)2 * world * kP2PFlagStride;
@@ -66,6 +73,7 @@ __global__ __launch_bounds__(1024) void k_p2p_exchange(P2PArgs q) {
     if (tid == 0) {
         unsigned long long* flag = reinterpret_cast<unsigned long long*>(q.peers[p]) +
                                    ((size_t)half * q.world + q.rank) * kP2PFlagStride;
+        __hip_atomic_store(flag + 1, p2p_tag(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // ordered by the release below
         __hip_atomic_store(flag, failed_before ? (kP2PAbort | q.seq) : q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         unsigned long long v = 0, why = failed_before ? 3 : 0;     // 3: an earlier exchange failed (nothing to wait for)
         if (!failed_before) {                                       // 3. peer p's segment
@@ -78,6 +86,10 @@ __global__ __launch_bounds__(1024) void k_p2p_exchange(P2PArgs q) {
                 if (v >= q.seq) break;
                 if (wall_clock64() - t0 > q.timeout) { why = 1; break; }
                 __builtin_amdgcn_s_sleep(4);
+            }
+            if (!why && v == q.seq) {             // 4: the peer's exchange of this number is another one than ours
+                __threadfence_system();           // (the tag was stored before the flag's release: read it behind an acquire)
+                if (__hip_atomic_load(mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != p2p_tag(q)) why = 4;
             }
             if (why) {      // first failure wins; {why:4 | stage:8 | peer:12 | exchange:40}
                 const unsigned long long word = (why << 60) | ((unsigned long long)(q.stage & 0xff) << 52) |
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(1024) void k_p2p_exchange_big(P2PArgs q, unsigned i
             __hip_atomic_store(cnt + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long* flag = reinterpret_cast<unsigned long long*>(q.peers[p]) +
                                        ((size_t)half * q.world + q.rank) * kP2PFlagStride;
+            __hip_atomic_store(flag + 1, p2p_tag(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(flag, failed_before ? (kP2PAbort | q.seq) : q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         unsigned long long v = 0, why = failed_before ? 3 : 0;
@@ -151,6 +164,10 @@ __global__ __launch_bounds__(1024) void k_p2p_exchange_big(P2PArgs q, unsigned i
                 if (v >= q.seq) break;
                 if (wall_clock64() - t0 > q.timeout) { why = 1; break; }
                 __builtin_amdgcn_s_sleep(4);
+            }
+            if (!why && v == q.seq) {             // 4: the peer's exchange of this number is another one than ours
+                __threadfence_system();           // (the tag was stored before the flag's release: read it behind an acquire)
+                if (__hip_atomic_load(mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != p2p_tag(q)) why = 4;
             }
             if (why) {
                 const unsigned long long word = (why << 60) | ((unsigned long long)(q.stage & 0xff) << 52) |
