@@ -4,7 +4,10 @@ mode "kill"  (host-staged transport): both ranks solve a theta series again and 
               middle of one; rank 0 must come back with BioenHipError instead of hanging.
 mode "stall" (peer-to-peer transport): rank 1 stops taking part after the first series (it sleeps); rank 0's exchange
               kernel must give up after BIOEN_HIP_WAIT_TIMEOUT, its host wait with it; rank 1, waking up later, must
-              fail as well (rank 0's ABORT flag, or its own bounded wait) instead of computing on a dead exchange."""
+              fail as well (rank 0's ABORT flag, or its own bounded wait) instead of computing on a dead exchange.
+mode "outofstep" (peer-to-peer transport): after a healthy series the ranks issue an exchange of DIFFERENT size under the
+              same number (what ranks that composed different rounds would do): both must get an error that says so,
+              at flag speed, instead of a stage buffer full of the other rank's numbers."""
 import json
 import os
 import sys
@@ -25,7 +28,7 @@ def main():
     d = load_golden("synth_logw_M64xN2000.npz")
     thetas = [50.0, 5.0, 500.0, 1.0, 20.0]
     ctx = bioen_amd.Context(d["yTilde"], d["YTilde"], device=0, rank=comm.rank, world=comm.world)
-    if mode == "stall":
+    if mode in ("stall", "outofstep"):
         assert sweep.init_p2p(ctx, comm)
     else:
         ctx.set_exchange(comm)
@@ -37,6 +40,19 @@ def main():
         time.sleep(float(os.environ.get("BIOEN_TEST_STALL", "12")))
     t0 = time.time()
     err, series = None, 0
+    if mode == "outofstep":
+        try:
+            ctx.exchange_probe(count=64 + comm.rank, reps=3)
+        except bioen_amd.BioenHipError as e:
+            err = str(e)
+        rec.update(error=err, series_completed=0, t_start=t0, t_end=time.time())
+        with open(os.path.join(out_dir, "result%d.json" % comm.rank), "w") as fp:
+            json.dump(rec, fp)
+        deadline = time.time() + 30          # stay mapped until the peer has its verdict too
+        while not os.path.exists(os.path.join(out_dir, "result%d.json" % (1 - comm.rank))) and time.time() < deadline:
+            time.sleep(0.05)
+        ctx.close()
+        return
     try:
         for _ in range(2000 if mode == "kill" else 1):
             ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)

@@ -83,3 +83,26 @@ def test_stalled_rank_times_out_peer_to_peer(tmp_path):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_out_of_step_get_an_error_not_each_others_numbers(tmp_path):
+    """Two ranks that issue DIFFERENT exchanges under the same number (another stage or payload: what ranks do that composed
+    different rounds) must both fail loudly and at once: the sender leaves {stage, payload} beside its flag, the receiver
+    compares.  (Before r04 the exchange kernel copied whatever the peer had left: garbage in the stage buffer, 1e33 in the
+    results of tests/test_hip_nshard.py's early-finisher scenario.)"""
+    procs = start(tmp_path, "outofstep", {"BIOEN_HIP_WAIT_TIMEOUT": "20"})
+    try:
+        for p in procs:
+            assert p.wait(timeout=200) == 0
+        for r in range(2):
+            with open(str(tmp_path / ("result%d.json" % r))) as fp:
+                rec = json.load(fp)
+            assert rec["transport"] == "p2p" and rec["first_codes"]
+            assert rec["error"] and "peer-to-peer exchange" in rec["error"], rec
+            assert "OUT OF STEP" in rec["error"] or "ABORT" in rec["error"], rec      # its own comparison, or the peer's verdict
+            assert rec["t_end"] - rec["t_start"] < 10.0, rec                          # at flag speed, not at the timeout
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()

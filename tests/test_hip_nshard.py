@@ -91,7 +91,7 @@ def test_peer_to_peer_exchange_equals_host_staged_bitwise(tmp_path, world):
             assert int(zb[r]["counts"][2]) > 100
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2])
 @pytest.mark.timeout(600)
 def test_a_dawdling_rank_changes_no_bit(tmp_path, world):
     """Every rank composes its rounds on its own host thread; what it composes must not depend on how fast that thread or
