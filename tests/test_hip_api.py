@@ -552,3 +552,35 @@ def test_two_threads_two_contexts_equal_the_serial_runs():
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("engine", ["device", "host"])
+def test_without_the_weights_the_optima_are_the_same(engine, monkeypatch):
+    """w_opt = NULL in the C ABI (want_weights=False): nothing but the hand-out of the weights is skipped -- optimum,
+    objective and counts of every problem keep their bits, both methods, batched and single, both engines."""
+    import bioen_amd
+    from conftest import LBFGS_DEFAULTS
+    monkeypatch.setenv("BIOEN_HIP_DEVICE_LS", "1" if engine == "device" else "0")
+    rng = np.random.default_rng(8)
+    M, N = 80, 6000
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G, w0, f0 = np.zeros(N), np.full(N, 1.0 / N), np.zeros(M)
+    params = dict(LBFGS_DEFAULTS, max_iterations=50)
+    thetas = [100.0, 10.0, 1.0]
+
+    def sig(infos):
+        return [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code, i.chi2, i.kl) for i in infos]
+
+    with bioen_amd.Context(y, YT) as ctx:
+        a = ctx.opt_lbfgs_logw_batch(thetas, G, G, params)
+        b = ctx.opt_lbfgs_logw_batch(thetas, G, G, params, want_weights=False)
+        assert b[1] is None and np.array_equal(a[0], b[0]) and sig(a[2]) == sig(b[2])
+        c1 = ctx.opt_lbfgs_logw(G, G, 10.0, params, want_weights=False)
+        assert c1[1] is None and np.array_equal(c1[0], a[0][1]) and sig([c1[2]]) == sig([a[2][1]])
+        fa = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params)
+        fb = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params, want_weights=False)
+        assert fb[1] is None and np.array_equal(fa[0], fb[0]) and sig(fa[2]) == sig(fb[2])
+        fc = ctx.opt_lbfgs_forces(f0, w0, 10.0, params, want_weights=False)
+        assert fc[1] is None and np.array_equal(fc[0], fa[0][1]) and sig([fc[2]]) == sig([fa[2][1]])
