@@ -584,3 +584,40 @@ def test_without_the_weights_the_optima_are_the_same(engine, monkeypatch):
         assert fb[1] is None and np.array_equal(fa[0], fb[0]) and sig(fa[2]) == sig(fb[2])
         fc = ctx.opt_lbfgs_forces(f0, w0, 10.0, params, want_weights=False)
         assert fc[1] is None and np.array_equal(fc[0], fa[0][1]) and sig([fc[2]]) == sig([fa[2][1]])
+
+
+def test_the_two_methods_leave_nothing_behind_for_each_other():
+    """Both methods share the batch slots' N-vectors (weights, adjoint / x_j, direction / t): a forces series after a
+    log-weights series on the same context -- and the other way round, and evaluations in between -- returns the bits it
+    returns on a fresh context."""
+    import bioen_amd
+    from conftest import LBFGS_DEFAULTS
+    rng = np.random.default_rng(9)
+    M, N = 72, 5001                      # odd N: the last pair of every N-vector is half padding
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    f0 = np.zeros(M)
+    params = dict(LBFGS_DEFAULTS, max_iterations=40)
+    thetas = [30.0, 3.0, 0.3]
+
+    def logw(ctx):
+        r = ctx.opt_lbfgs_logw_batch(thetas, G, G, params)
+        f, g = ctx.logw_fdf(G + 0.05, G, 2.0)
+        return (r[0].tobytes(), r[1].tobytes(), [i.fmin for i in r[2]], f, g.tobytes(), ctx.logw_weights(G + 0.05)[0].tobytes())
+
+    def forces(ctx):
+        r = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params)
+        f, g = ctx.forces_fdf(f0 + 1e-3, w0, 2.0)
+        return (r[0].tobytes(), r[1].tobytes(), [i.fmin for i in r[2]], f, g.tobytes(), ctx.forces_weights(f0 + 1e-3, w0).tobytes())
+
+    with bioen_amd.Context(y, YT) as ctx:
+        fresh_l = logw(ctx)
+    with bioen_amd.Context(y, YT) as ctx:
+        fresh_f = forces(ctx)
+    with bioen_amd.Context(y, YT) as ctx:
+        assert logw(ctx) == fresh_l and forces(ctx) == fresh_f and logw(ctx) == fresh_l and forces(ctx) == fresh_f
+    with bioen_amd.Context(y, YT) as ctx:
+        assert forces(ctx) == fresh_f and logw(ctx) == fresh_l
