@@ -85,6 +85,7 @@ struct LsState {
     int have_dginit;
     double finit, dginit, dgtest;
     int brackt, stage1, uinfo;
+    int not_descent;        // the search was refused before its first evaluation (0 < dginit): see on_trial
     double stx, fx, dgx, sty, fy, dgy;
     double stmin, stmax, width, prev_width;
 };
@@ -247,6 +248,7 @@ BIOEN_HD inline int ls_begin(LsState& s, const bioen_lbfgs_config& c, double fin
     BIOEN_NO_CONTRACT
     s.count = 0;
     s.have_dginit = 0;
+    s.not_descent = 0;
     s.finit = finit;
     if (stp0 <= 0.0) return LBFGSERR_INVALIDPARAMETERS;
     *stp = stp0;
@@ -335,7 +337,10 @@ BIOEN_HD inline int ls_report(LsState& s, const bioen_lbfgs_config& c, const Tri
         s.have_dginit = 1;
         s.dginit = t.dginit;
         // "make sure that s points to a descent direction" (lbfgs.c:671-674, :845-848)
-        if (0.0 < s.dginit) return LBFGSERR_INCREASEGRADIENT;
+        if (0.0 < s.dginit) {
+            s.not_descent = 1;
+            return LBFGSERR_INCREASEGRADIENT;
+        }
         s.dgtest = c.ftol * s.dginit;
         s.dgx = s.dgy = s.dginit;
     }
@@ -400,8 +405,13 @@ BIOEN_HD inline LbfgsAction on_trial(LbfgsState& m, const bioen_lbfgs_config& c,
     }
     if (st < 0) {
         // liblbfgs reverts to the previous point and returns the code; *ptr_fx keeps the last trial's value
-        // (lbfgs.c:476-481, 622-624)
-        m.fx = t.f;
+        // (lbfgs.c:476-481, 622-624) -- unless the search was refused BEFORE its first evaluation: "make sure that s points
+        // to a descent direction" (lbfgs.c:671-674, :845-848) returns with fx untouched, the accepted point's value.  Here
+        // the initial slope arrives with the first trial's results, i.e. one evaluation late: that evaluation is not the
+        // reference's (not counted) and its value is not the run's (r04, found by tools/fuzz_parity.py: fmin 139.1 where
+        // the reference and the restatement return 81.9, status -994 on all three).
+        if (m.ls.not_descent) --m.evaluations;
+        else m.fx = t.f;
         return LbfgsAction{ACT_DONE, 0, 0, st, 0};
     }
     // accepted

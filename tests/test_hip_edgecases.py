@@ -382,3 +382,29 @@ def test_a_context_is_clean_after_a_run_on_non_finite_input(engine, monkeypatch)
                 ctx.opt_lbfgs_forces_batch([10.0, k["theta"]], k["f0"], k["w0"], params)
             assert info.lbfgs_code == 2, name
             assert clean(ctx) == fresh, name
+
+
+def test_a_search_refused_for_a_non_descent_direction_returns_the_accepted_point():
+    """liblbfgs refuses a search whose direction does not descend BEFORE evaluating anything (lbfgs.c:671-674): status -994,
+    the accepted point and ITS objective.  The device learns the initial slope with the first trial's results -- that
+    evaluation is neither counted nor returned (r04: fmin was the trial's 139.1 instead of 81.9; tools/fuzz_parity.py, seed 69)."""
+    import bioen_amd as hip
+    R = require_reference()
+    rng = np.random.default_rng(1069)
+    M, N = 205, 12345
+    rng.choice(21); rng.choice(14)                           # (the draws of tools/fuzz_parity.py's seed 69 before the data)
+    YTrue = rng.uniform(1, 10, M)
+    sig = rng.uniform(0.05, 0.3, M) * YTrue
+    y = rng.normal(YTrue[:, None], rng.uniform(0.2, 0.8) * YTrue[:, None], (M, N)) / sig[:, None]
+    YT = rng.normal(YTrue, sig) / sig
+    theta = float(10.0 ** rng.uniform(-2, 3))
+    G = np.log(rng.dirichlet(np.ones(N) * rng.uniform(0.3, 3.0)) + 1e-300)
+    g = G + rng.uniform(0.0, 1.0) * rng.standard_normal(N)
+    params = dict(LBFGS_DEFAULTS, linesearch=1, max_iterations=9, past=0, delta=0.0, epsilon=1e-9)
+    with hip.Context(y, YT) as ctx:
+        x_d, w_d, info = ctx.opt_lbfgs_logw(g, G, theta, params)
+        f_at = ctx.logw_fdf(x_d, G, theta, need_grad=False)[0]
+    x_r, fmin_r, code_r = R.opt_lbfgs_logw(g, G, y, YT, theta, params)
+    assert code_r == -994 and info.lbfgs_code == -994 and info.iterations == 2 and info.evaluations == 7
+    assert rel(info.fmin, fmin_r) < 1e-9 and rel(f_at, info.fmin) < 1e-13       # the objective OF the returned point
+    assert np.abs(x_d - np.asarray(x_r).ravel()).max() <= 1e-7 * np.abs(x_r).max()

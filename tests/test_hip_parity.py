@@ -683,3 +683,19 @@ def test_forces_speculation_on_random_problems_changes_no_bit(hip, monkeypatch):
                                 [(i.fmin, i.chi2, i.kl, i.iterations, i.evaluations, i.lbfgs_code) for i in infos]))
         outs[tag] = res_all
     assert outs["1"] == outs["0"]
+
+
+def test_randomised_differential_run_against_the_restatement(hip):
+    """tools/fuzz_parity.py as a test: 80 random problems over every kernel geometry (15 ... 1100 rows, ragged column
+    counts), random priors, starts, thetas, all four line searches, random stop settings -- device against the CPU
+    restatement: f 1e-12, grad 1e-10 / 1e-9, weights 1e-13 / 1e-12, and runs capped at 3 ... 11 iterations with equal
+    status, iterations AND evaluations, fmin 1e-8.  (r04: 800 seeds of it found the run refused for a non-descent
+    direction -- status -994 -- returning the trial's value instead of the accepted point's.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    worst, bad = fuzz.run(0, 80, min_dim=15)
+    assert not bad, bad

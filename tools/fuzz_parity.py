@@ -1,0 +1,86 @@
+"""Development aid (GPU box): randomised differential run -- random shapes (all kernel geometries: 1 ... 1100 rows, ragged
+column counts), priors, starts, thetas and L-BFGS settings; device against the CPU restatement (oracle/): objective 1e-12,
+gradient 1e-10, weights 1e-13, and short L-BFGS runs (max_iterations capped: both sides walk the same steps) fmin 1e-8,
+status, iterations and evaluations equal.  SEEDS=n (default 60).  Prints the worst margins and every violation."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bioen_amd
+from oracle import oracle_binding as O
+from bench import LBFGS_DEFAULTS
+
+
+
+SHAPES_M = [1, 2, 3, 15, 16, 17, 63, 64, 65, 96, 129, 205, 511, 512, 513, 600, 808, 1023, 1024, 1025, 1100]
+SHAPES_N = [1, 2, 3, 15, 17, 127, 128, 129, 255, 1000, 2047, 2049, 5000, 12345]
+LIMITS = {"f": 1e-12, "grad": 1e-10, "w": 1e-13, "ff": 1e-12, "fgrad": 1e-9, "fw": 1e-12, "fmin": 1e-8, "ffmin": 1e-8}
+
+
+def run(first, nseeds, min_dim=1):
+    """-> (worst margins, violations).  min_dim: smallest M and N drawn (problems of one to three structures or observables
+    reach the rounding floor within the iteration cap, where the two codes' last line searches end differently)"""
+    worst = {k: 0.0 for k in LIMITS}
+    bad = []
+    for seed in range(first, first + nseeds):
+        rng = np.random.default_rng(1000 + seed)
+        M = int(rng.choice([v for v in SHAPES_M if v >= min_dim]))
+        N = int(rng.choice([v for v in SHAPES_N if v >= min_dim]))
+        if M * N > 6e6:
+            N = max(1, int(6e6 // M))
+        YTrue = rng.uniform(1, 10, M)
+        sig = rng.uniform(0.05, 0.3, M) * YTrue
+        y = rng.normal(YTrue[:, None], rng.uniform(0.2, 0.8) * YTrue[:, None], (M, N)) / sig[:, None]
+        YT = rng.normal(YTrue, sig) / sig
+        theta = float(10.0 ** rng.uniform(-2, 3))
+        G = np.log(rng.dirichlet(np.ones(N) * rng.uniform(0.3, 3.0)) + 1e-300)
+        g = G + rng.uniform(0.0, 1.0) * rng.standard_normal(N)
+        w0 = rng.dirichlet(np.ones(N) * rng.uniform(0.3, 3.0))
+        f0 = rng.uniform(0, 3e-3) * rng.standard_normal(M)
+        ls = int(rng.choice([0, 1, 2, 3]))
+        params = dict(LBFGS_DEFAULTS, linesearch=ls, max_iterations=int(rng.integers(3, 12)), past=int(rng.choice([0, 3, 10])),
+                      delta=float(rng.choice([0.0, 1e-6])), epsilon=float(rng.choice([1e-6, 1e-9])))
+        tag = "seed %d: M=%d N=%d theta=%.3g ls=%d it<=%d" % (seed, M, N, theta, ls, params["max_iterations"])
+        try:
+            with bioen_amd.Context(y, YT) as ctx:
+                f, grad = ctx.logw_fdf(g, G, theta)
+                w = ctx.logw_weights(g)[0]
+                ff, fgrad = ctx.forces_fdf(f0, w0, theta)
+                fw = ctx.forces_weights(f0, w0)
+                xo, wo, info = ctx.opt_lbfgs_logw(g, G, theta, params)
+                fxo, fwo, finfo = ctx.opt_lbfgs_forces(f0, w0, theta, params)
+            f_o, grad_o, w_o = O.logw_fdf(g, G, y, YT, theta)
+            ff_o, fgrad_o, fw_o = O.forces_fdf(f0, w0, y, YT, theta)
+            _, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_logw(g, G, y, YT, theta, params)
+            _, ffmin_o, fcode_o, fit_o, fev_o = O.opt_lbfgs_forces(f0, w0, y, YT, theta, params)
+        except Exception as e:
+            bad.append(tag + " EXCEPTION " + repr(e)[:200])
+            continue
+        # gradients relative to their largest entry -- or, where the true gradient vanishes (one structure: w = 1 whatever
+        # g), to the objective's scale
+        m = {"f": abs(f - f_o) / max(abs(f_o), 1e-300),
+             "grad": np.abs(grad - grad_o).max() / max(np.abs(grad_o).max(), 1e-2 * abs(f_o)),
+             "w": np.abs(w - w_o).max() / w_o.max(), "ff": abs(ff - ff_o) / max(abs(ff_o), 1e-300),
+             "fgrad": np.abs(fgrad - fgrad_o).max() / max(np.abs(fgrad_o).max(), 1e-2 * abs(ff_o)),
+             "fw": np.abs(fw - fw_o).max() / fw_o.max(),
+             "fmin": abs(info.fmin - fmin_o) / max(abs(fmin_o), 1e-300),
+             "ffmin": abs(finfo.fmin - ffmin_o) / max(abs(ffmin_o), 1e-300)}
+        for k in m:
+            worst[k] = max(worst[k], float(m[k]))
+            if not m[k] <= LIMITS[k]:
+                bad.append("%s: %s = %.3g > %.0e" % (tag, k, m[k], LIMITS[k]))
+        if (info.lbfgs_code, info.iterations, info.evaluations) != (code_o, it_o, ev_o):
+            bad.append("%s: logw run (code, iterations, evaluations) device %s oracle %s" % (
+                tag, (info.lbfgs_code, info.iterations, info.evaluations), (code_o, it_o, ev_o)))
+        if (finfo.lbfgs_code, finfo.iterations, finfo.evaluations) != (fcode_o, fit_o, fev_o):
+            bad.append("%s: forces run (code, iterations, evaluations) device %s oracle %s" % (
+                tag, (finfo.lbfgs_code, finfo.iterations, finfo.evaluations), (fcode_o, fit_o, fev_o)))
+    return worst, bad
+
+
+if __name__ == "__main__":
+    n = int(os.environ.get("SEEDS", "60"))
+    worst, bad = run(int(os.environ.get("FIRST", "0")), n, int(os.environ.get("MIN_DIM", "1")))
+    print("seeds", n, "worst margins", {k: "%.2e" % v for k, v in worst.items()})
+    print("violations:", len(bad))
+    for b in bad:
+        print("  ", b)
