@@ -337,7 +337,11 @@ BIOEN_HD inline int ls_report(LsState& s, const bioen_lbfgs_config& c, const Tri
         s.have_dginit = 1;
         s.dginit = t.dginit;
         // "make sure that s points to a descent direction" (lbfgs.c:671-674, :845-848)
-        if (0.0 < s.dginit) {
+        // NaN counts as "not a descent direction", as in the reference's build (-ffast-math: the test comes out as
+        // !(dginit <= 0)): beyond the rounding floor a pair with y.s = 0 turns the two-loop recursion's direction into NaN;
+        // the reference's binary ends such a run with -994 and the last accepted point (tools/fuzz_batch.py, seed 23: Armijo
+        // search, epsilon below the gradient's noise), IEEE rules would carry the NaN into x and call it converged
+        if (!(s.dginit <= 0.0)) {
             s.not_descent = 1;
             return LBFGSERR_INCREASEGRADIENT;
         }

@@ -275,7 +275,7 @@ static int search_backtracking(problem_t* p, double* x, double* f, double* g, co
     const int n = p->n;
     if (*stp <= 0.0) return ERR_INVALIDPARAMETERS;
     const double dginit = dot(g, d, n);
-    if (dginit > 0.0) return ERR_INCREASEGRADIENT;
+    if (!(dginit <= 0.0)) return ERR_INCREASEGRADIENT;   /* NaN too: what the reference's -ffast-math build of lbfgs.c:671 / :845 does (a direction out of a degenerate pair, y.s = 0, beyond the rounding floor) */
     const double finit = *f;
     const double dgtest = c->ftol * dginit;
     for (int count = 1;; ++count) {
@@ -419,7 +419,7 @@ static int search_morethuente(problem_t* p, double* x, double* f, double* g, con
     const int n = p->n;
     if (*stp <= 0.0) return ERR_INVALIDPARAMETERS;
     const double dginit = dot(g, d, n);
-    if (dginit > 0.0) return ERR_INCREASEGRADIENT;
+    if (!(dginit <= 0.0)) return ERR_INCREASEGRADIENT;   /* NaN too: what the reference's -ffast-math build of lbfgs.c:671 / :845 does (a direction out of a degenerate pair, y.s = 0, beyond the rounding floor) */
 
     int brackt = 0, stage1 = 1, uinfo = 0, count = 0;
     const double finit = *f, dgtest = c->ftol * dginit;

@@ -408,3 +408,36 @@ def test_a_search_refused_for_a_non_descent_direction_returns_the_accepted_point
     assert code_r == -994 and info.lbfgs_code == -994 and info.iterations == 2 and info.evaluations == 7
     assert rel(info.fmin, fmin_r) < 1e-9 and rel(f_at, info.fmin) < 1e-13       # the objective OF the returned point
     assert np.abs(x_d - np.asarray(x_r).ravel()).max() <= 1e-7 * np.abs(x_r).max()
+
+
+def test_beyond_the_rounding_floor_a_degenerate_pair_ends_the_run_as_in_the_reference_binary():
+    """An Armijo-only search with the gradient test set below the gradient's rounding noise walks on at the floor until a
+    pair with y.s = 0 turns the two-loop recursion's direction into NaN.  The reference's binary (its -ffast-math build
+    takes a NaN slope for "not a descent direction") ends with -994 and the last accepted point; so does the device --
+    until r04 it carried the NaN into the forces and reported status 0 (tools/fuzz_batch.py, seed 23)."""
+    import bioen_amd as hip
+    R = require_reference()
+    rng = np.random.default_rng(5023)
+    M, N = 28, 5000
+    rng.choice(8); rng.choice(4)                              # (the draws of tools/fuzz_batch.py's seed 23 before the data)
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    nt = int(rng.integers(1, 15))
+    thetas = 10.0 ** rng.uniform(-1.5, 3.0, nt)
+    if rng.random() < 0.3 and nt > 1:
+        thetas[rng.integers(0, nt)] = thetas[0]
+    rng.integers(1, 9)
+    rng.dirichlet(np.ones(N) * 2.0)
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    theta = float(thetas[1])
+    params = dict(LBFGS_DEFAULTS, linesearch=1, epsilon=1e-12, delta=0.0, past=0, max_iterations=60)
+    with hip.Context(y, YT) as ctx:
+        f_d, w_d, info = ctx.opt_lbfgs_forces(np.zeros(M), w0, theta, params)
+        f_at = ctx.forces_fdf(f_d, w0, theta, need_grad=False)[0]
+    f_r, fmin_r, code_r = R.opt_lbfgs_forces(np.zeros(M), w0, y, YT, theta, params)
+    assert code_r == -994 and info.lbfgs_code == -994
+    assert np.isfinite(f_d).all() and np.isfinite(w_d).all() and abs(w_d.sum() - 1.0) < 1e-12
+    assert rel(info.fmin, fmin_r) < 1e-12 and rel(f_at, info.fmin) < 1e-13
+    w_r = np.asarray(R.forces_weights(f_r, w0, y)).ravel()
+    assert np.abs(w_d - w_r).max() <= 1e-5 * w_r.max()

@@ -699,3 +699,17 @@ def test_randomised_differential_run_against_the_restatement(hip):
     spec.loader.exec_module(fuzz)
     worst, bad = fuzz.run(0, 80, min_dim=15)
     assert not bad, bad
+
+
+def test_randomised_batches_equal_their_single_runs(hip):
+    """tools/fuzz_batch.py as a test: 50 random series -- 1 ... 14 thetas over 1 ... 8 batch slots (slots reused, problems
+    finishing at different times, shadows coming and going), shared or own starts, all line searches, random caps, both
+    methods, both log-weights engines: every problem returns the bits of its single run, and finite numbers."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_batch", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_batch.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad = fuzz.run(0, 50)
+    assert not bad, bad
