@@ -199,3 +199,33 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         assert abs(z[0]["ffmin"][i] - info.fmin) <= 2e-5 * abs(info.fmin)
         assert abs(z[0]["fw"][i].sum() - 1.0) < 1e-12
         assert abs(z[0]["ffmin"][i] - (fthetas[i] * z[0]["fkl"][i] + z[0]["fchi2"][i])) <= 1e-10 * abs(info.fmin)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.timeout(600)
+def test_randomised_series_on_sharded_contexts(tmp_path, world):
+    """Random theta series (tools/fuzz_batch.py's recipe) on structure-sharded contexts over the peer-to-peer transport, the
+    ranks' host threads pausing at random and the last rank's delivery threads dawdling: every problem equals its single
+    run bit for bit, every rank holds the same bits, nothing is non-finite, no exchange fails."""
+    import ast
+    port = free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nshard_fuzz_worker.py")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="nfuzz%d" % os.getpid(), BIOEN_HIP_WAIT_TIMEOUT="30",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", BIOEN_HIP_JITTER_US="300")
+        if rank == world - 1:
+            env["BIOEN_HIP_JITTER_DELIVERY_US"] = "3000"
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path / "fuzz%d.txt"), "24"], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            assert p.wait(timeout=500) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs = [ast.literal_eval(open(str(tmp_path / ("fuzz%d.txt" % r))).read()) for r in range(world)]
+    for r, o in enumerate(outs):
+        assert not o["bad"], (r, o["bad"])
+        assert len(o["digests"]) == world and len(set(o["digests"])) == 1, (r, o["digests"])
