@@ -227,3 +227,16 @@ def test_lbfgs_after_gsl_run_on_the_same_context_is_unaffected():
         after = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_DEFAULTS)
     assert after[2].fmin == fresh[2].fmin and after[2].iterations == fresh[2].iterations
     assert np.array_equal(after[0], fresh[0]) and np.array_equal(after[1], fresh[1])
+
+
+def test_randomised_gsl_runs_against_the_restatement():
+    """tools/fuzz_gsl.py as a test: 40 random problems x one of the five GSL algorithms x random step / tolerance / iteration
+    cap, both methods -- status and iteration count equal the CPU restatement of GSL 2.5's multimin, fmin to 1e-8."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_gsl", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gsl.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    worst, bad = fuzz.run(0, 40)
+    assert not bad, bad

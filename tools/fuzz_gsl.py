@@ -1,0 +1,54 @@
+"""Development aid (GPU box): randomised differential run of the five GSL-style minimizers on the device objective against
+the CPU restatement of GSL 2.5's multimin (oracle/multimin_oracle.c; itself pinned bit for bit by 72 runs of the real GSL):
+status and iteration count equal, fmin 1e-8, both methods.  SEEDS=n (default 40)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bioen_amd
+from oracle import oracle_binding as O
+
+ALGS = ["conjugate_fr", "conjugate_pr", "bfgs2", "bfgs", "steepest_descent"]
+
+
+def run(first, nseeds):
+    bad, worst = [], 0.0
+    for seed in range(first, first + nseeds):
+        rng = np.random.default_rng(9000 + seed)
+        M = int(rng.choice([16, 28, 64, 205, 512, 600, 1030]))
+        N = int(rng.choice([17, 300, 1000, 2049, 5000]))
+        YTrue = rng.uniform(1, 10, M)
+        y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+        YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+        theta = float(10.0 ** rng.uniform(-1, 3))
+        G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+        g0 = G + 0.1 * rng.standard_normal(N)
+        w0 = rng.dirichlet(np.ones(N) * 2.0)
+        f0 = 1e-4 * rng.standard_normal(M)
+        alg = str(rng.choice(ALGS))
+        params = dict(step_size=float(rng.choice([0.01, 0.1])), tol=float(rng.choice([0.001, 0.1])),
+                      max_iterations=int(rng.integers(2, 25)))
+        tag = "seed %d: M=%d N=%d theta=%.3g %s %s" % (seed, M, N, theta, alg, params)
+        try:
+            with bioen_amd.Context(y, YT) as ctx:
+                x, w, info = ctx.opt_gsl_logw(g0, G, theta, alg, params)
+                fx, fw, finfo = ctx.opt_gsl_forces(f0, w0, theta, alg, params)
+            _, fmin_o, code_o, it_o, _ = O.opt_gsl_logw(g0, G, y, YT, theta, dict(params, algorithm=alg))
+            _, ffmin_o, fcode_o, fit_o, _ = O.opt_gsl_forces(f0, w0, y, YT, theta, dict(params, algorithm=alg))
+        except Exception as e:
+            bad.append(tag + " EXCEPTION " + repr(e)[:200])
+            continue
+        for name, a, b in (("logw", (info.lbfgs_code, info.iterations, info.fmin), (code_o, it_o, fmin_o)),
+                           ("forces", (finfo.lbfgs_code, finfo.iterations, finfo.fmin), (fcode_o, fit_o, ffmin_o))):
+            r = abs(a[2] - b[2]) / max(abs(b[2]), 1e-300)
+            worst = max(worst, r)
+            if a[:2] != b[:2] or not r <= 1e-8:
+                bad.append("%s: %s device (status %d, %d it, %.15g) restatement (status %d, %d it, %.15g)" % ((tag, name) + a + b))
+    return worst, bad
+
+
+if __name__ == "__main__":
+    n = int(os.environ.get("SEEDS", "40"))
+    worst, bad = run(int(os.environ.get("FIRST", "0")), n)
+    print("seeds", n, "worst fmin difference %.2e" % worst, "violations:", len(bad))
+    for b in bad:
+        print("  ", b)
