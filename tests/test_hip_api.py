@@ -621,3 +621,17 @@ def test_the_two_methods_leave_nothing_behind_for_each_other():
         assert logw(ctx) == fresh_l and forces(ctx) == fresh_f and logw(ctx) == fresh_l and forces(ctx) == fresh_f
     with bioen_amd.Context(y, YT) as ctx:
         assert forces(ctx) == fresh_f and logw(ctx) == fresh_l
+
+
+def test_randomised_context_data_paths():
+    """tools/fuzz_context.py as a test: 40 random shapes -- assembly from raw observables (row-major and structure-major),
+    read-back of random blocks before and after the strip copies replace the matrix (bit for bit), the affine model against a
+    rebuilt matrix, the plain model's bits back after it, a changed target against a fresh context."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_context", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_context.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad = fuzz.run(0, 40)
+    assert not bad, bad
