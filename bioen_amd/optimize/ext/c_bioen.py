@@ -54,18 +54,34 @@ def _cache_large():
     return os.environ.get("BIOEN_HIP_CACHE_LARGE", "0") == "1"
 
 
+try:                                   # byte-exact and 7 GB/s here; the fallback (zlib) is byte-exact too, at 1-3 GB/s
+    import xxhash as _xxhash
+except ImportError:                    # pragma: no cover - the image has it
+    _xxhash = None
+import zlib as _zlib
+
+
+def _digest(buf):
+    mv = memoryview(buf).cast("B")
+    if _xxhash is not None:
+        return _xxhash.xxh3_64_intdigest(mv)
+    return (_zlib.adler32(mv), _zlib.crc32(mv))
+
+
 def _fingerprint(a):
-    """Content check of the host matrix.  Up to BIOEN_HIP_CACHE_FULLCHECK_MB (default 256 MB) EVERY element
-    enters (sum and sum of squares over the whole buffer: two BLAS-speed passes, far cheaper than the
-    upload they save).  Beyond that size a complete check costs more than the upload it would save (8 GB:
-    ~1.6 s against 0.15-0.26 s), so such matrices are NOT cached at all (`_context_for`) -- unless the caller
-    opts in with BIOEN_HIP_CACHE_LARGE=1 and thereby promises not to edit the matrix in place: then a strided
-    sample of ~4 M elements spread over all rows and columns is all that is checked."""
+    """Content check of the host matrix: a hash of its BYTES.  Up to BIOEN_HIP_CACHE_FULLCHECK_MB (default 256 MB)
+    every byte enters (xxh3-64: 37 ms per 256 MB here, against the upload and the two strip copies it saves) -- any
+    in-place edit is seen, however small (a finite-difference perturbation below the rounding of a sum over the
+    buffer) and however symmetric (two structures swapped: sums over the buffer do not move; until r04 the check WAS
+    such sums).  Beyond that size a complete check costs more than the upload it would save (8 GB: ~1.2 s against
+    0.15-0.26 s), so such matrices are NOT cached at all (`_context_for`) -- unless the caller opts in with
+    BIOEN_HIP_CACHE_LARGE=1 and thereby promises not to edit the matrix in place: then a strided sample of ~4 M
+    elements spread over all rows and columns is all that is hashed."""
     flat = a.reshape(-1)
     if flat.nbytes > _FULL_CHECK_BYTES:
         stride = max(1, flat.size // (1 << 22)) | 1          # odd: walks through every column residue
-        flat = flat[::stride]
-    return (a.shape, float(flat.sum()), float(np.dot(flat, flat)), float(a[0, 0]), float(a[-1, -1]))
+        flat = np.ascontiguousarray(flat[::stride])
+    return (a.shape, _digest(flat))
 
 
 def _context_for(yTilde, YTilde):
@@ -73,8 +89,8 @@ def _context_for(yTilde, YTilde):
 
     A cached context is reused only for the VERY SAME live host object (identity through a weak
     reference -- a new array that happens to land on a freed address never matches) whose content check
-    still agrees (`_fingerprint`: every element, so in-place edits such as finite-difference perturbations
-    are seen).  Anything else is a miss and uploads afresh, which is what the reference does on every call
+    still agrees (`_fingerprint`: a hash of every byte, so in-place edits -- finite-difference perturbations,
+    reordered structures -- are seen).  Anything else is a miss and uploads afresh, which is what the reference does on every call
     (c_bioen.pyx:463-478).  Matrices above 256 MB (BIOEN_HIP_CACHE_FULLCHECK_MB) are never cached -- a
     complete check would cost more than the upload -- unless BIOEN_HIP_CACHE_LARGE=1 opts into a sampled
     check.  BIOEN_HIP_CACHE=0 switches the cache off."""

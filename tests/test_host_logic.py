@@ -219,6 +219,18 @@ def test_context_cache_fingerprint_is_content_sensitive():
         assert c_bioen._fingerprint(big) != fp, (i, j)
         big[i, j] = old
     assert c_bioen._fingerprint(big) == fp
+    # ... however small (below the rounding of any sum over the buffer) and however symmetric (r04: until then the check
+    # was {sum, sum of squares}: two structures swapped in place, or a 1e-13 nudge in 265 000 numbers, went unseen)
+    big[100, 500] = np.nextafter(big[100, 500], np.inf)
+    assert c_bioen._fingerprint(big) != fp
+    big[100, 500] = np.nextafter(big[100, 500], -np.inf)
+    assert c_bioen._fingerprint(big) == fp
+    big[:, [3, 900]] = big[:, [900, 3]]
+    assert c_bioen._fingerprint(big) != fp
+    big[:, [3, 900]] = big[:, [900, 3]]
+    assert c_bioen._fingerprint(big) == fp
+    big[[5, 200], :] = big[[200, 5], :]
+    assert c_bioen._fingerprint(big) != fp
 
 
 def test_context_cache_needs_the_same_live_object_and_the_same_content(monkeypatch):
