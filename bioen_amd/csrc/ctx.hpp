@@ -203,6 +203,7 @@ struct bioen_hip_ctx {
     int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)
     int strip_old = 0;               // BIOEN_HIP_STRIP_OLD=1: the r01 strip kernels on the row-major matrix (A/B)
     int strips_unavailable = 0;      // a strip copy could not be allocated: the streaming kernels serve this context
+    int strip_allocs = 0;            // strip-copy allocations attempted on this context (tests: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC=k fails the k-th)
     double* YT = nullptr;      // mp   experimental targets (YTilde)
     // affine observable model: yTilde_eff[i][j] = row_offset[i] + row_scale[i] * Y[i][j]
     // (default 0, 1).  DEER / SAXS nuisance parameters enter exactly like this, so a refit never

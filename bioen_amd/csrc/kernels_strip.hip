@@ -1200,6 +1200,15 @@ int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on t
     return std::min(std::min(256 * per_cu, kFusedBlocks), nstrips);
 }
 
+// Every allocation of a strip copy goes through here.  Tests: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC=k makes the k-th one of a
+// context fail as an exhausted device would (the fallback to the streaming kernels is otherwise never exercised).
+static hipError_t strip_malloc(bioen_hip_ctx* c, double** p, size_t bytes) {
+    ++c->strip_allocs;
+    if (const char* e = std::getenv("BIOEN_HIP_TEST_FAIL_STRIP_ALLOC"))
+        if (std::atoi(e) == c->strip_allocs) return hipErrorOutOfMemory;
+    return hipMalloc(reinterpret_cast<void**>(p), bytes);
+}
+
 // A failed allocation leaves the context WITHOUT strip copies (strips_unavailable): fwd_strip_blocks /
 // forces_fused_blocks then answer 0 and every caller takes the streaming kernels on the row-major matrix, which
 // need no extra memory.  The copy pointers are published only after the build kernel is enqueued.
@@ -1372,7 +1381,7 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
         double* made[bioen_hip_ctx::kMaxPanels] = {};
         for (int p = 0; p < panel_count(c); ++p) {
             const int mps = panel_mps(c, p);
-            hipError_t e = hipMalloc(reinterpret_cast<void**>(&made[p]), (size_t)nstrips * mps * kStripCols * sizeof(double));
+            hipError_t e = strip_malloc(c, &made[p], (size_t)nstrips * mps * kStripCols * sizeof(double));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream,
                                    c->Y + (size_t)p * kPanelRows * c->ld, c->ld, panel_mp(c, p), mps, c->n, made[p], nstrips,
@@ -1399,7 +1408,7 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     const int mps = strip_rows(c);
     const int nstrips = (int)(c->ld / kStripCols);
     double* ys = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
+    hipError_t e = strip_malloc(c, &ys, (size_t)nstrips * mps * kStripCols * sizeof(double));
     if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (strip-major copy of yTilde)");
     if (!c->strip_center) {
         double* cen = nullptr;
@@ -1600,7 +1609,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
         double* made[bioen_hip_ctx::kMaxPanels] = {};
         for (int p = 0; p < panel_count(c); ++p) {
             const int mps = panel_mps(c, p);
-            hipError_t e = hipMalloc(reinterpret_cast<void**>(&made[p]), (size_t)nstrips * mps * kStripCols * sizeof(double));
+            hipError_t e = strip_malloc(c, &made[p], (size_t)nstrips * mps * kStripCols * sizeof(double));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Yp[p], mps, made[p], nstrips);
                 e = hipGetLastError();
@@ -1620,7 +1629,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     const int mps = strip_rows(c);
     const int nstrips = (int)(c->ld / kStripCols);
     double* ys = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ys), (size_t)nstrips * mps * kStripCols * sizeof(double));
+    hipError_t e = strip_malloc(c, &ys, (size_t)nstrips * mps * kStripCols * sizeof(double));
     if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (column-sum strip copy of yTilde)");
     hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Ys, mps, ys, nstrips);
     e = hipGetLastError();

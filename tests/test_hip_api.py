@@ -658,3 +658,44 @@ def test_structures_reordered_in_place_are_not_served_from_the_cached_copy(optim
     lp(g, d["GInit"], d["G"], y, YT, 1.0)
     assert c_bioen._CACHE[id(y)] is not ctx_before
     c_bioen.clear_cache()
+
+
+@pytest.mark.parametrize("M,N", [(96, 4000), (600, 3000), (1100, 2500)])
+@pytest.mark.parametrize("fail_at", [1, 2])
+def test_a_strip_copy_that_cannot_be_allocated_falls_back_to_the_streaming_kernels(M, N, fail_at, monkeypatch):
+    """An exhausted device while the strip copies are built (the k-th allocation fails: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC) must
+    leave a context that still answers correctly -- on the streaming kernels over the row-major matrix, for good -- not one
+    that mixes kernel families inside an evaluation or holds half a copy: objective, gradient and short runs of both methods
+    against the restatement, the matrix still readable bit for bit, a second series the same as the first."""
+    import bioen_amd
+    from oracle import oracle_binding as O
+    from conftest import LBFGS_DEFAULTS
+    rng = np.random.default_rng(M + fail_at)
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    g = G + 0.2 * rng.standard_normal(N)
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    f0 = 1e-3 * rng.standard_normal(M)
+    params = dict(LBFGS_DEFAULTS, max_iterations=8)
+    monkeypatch.setenv("BIOEN_HIP_TEST_FAIL_STRIP_ALLOC", str(fail_at))
+    with bioen_amd.Context(y, YT) as ctx:
+        f, grad = ctx.logw_fdf(g, G, 5.0)
+        ff, fgrad = ctx.forces_fdf(f0, w0, 5.0)
+        a = ctx.opt_lbfgs_logw_batch([50.0, 5.0], g, G, params)
+        b = ctx.opt_lbfgs_forces_batch([50.0, 5.0], f0, w0, params)
+        a2 = ctx.opt_lbfgs_logw_batch([50.0, 5.0], g, G, params)
+        assert np.array_equal(a[0], a2[0]) and [i.fmin for i in a[2]] == [i.fmin for i in a2[2]]
+        assert np.array_equal(ctx.read_ytilde(), y)
+        forms, _ = ctx.footprint()
+    f_o, grad_o, _ = O.logw_fdf(g, G, y, YT, 5.0)
+    ff_o, fgrad_o, _ = O.forces_fdf(f0, w0, y, YT, 5.0)
+    assert abs(f - f_o) <= 1e-12 * abs(f_o) and np.abs(grad - grad_o).max() <= 1e-10 * np.abs(grad_o).max()
+    assert abs(ff - ff_o) <= 1e-12 * abs(ff_o) and np.abs(fgrad - fgrad_o).max() <= 1e-9 * np.abs(fgrad_o).max()
+    for k, th in enumerate([50.0, 5.0]):
+        _, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_logw(g, G, y, YT, th, params)
+        assert (a[2][k].lbfgs_code, a[2][k].iterations) == (code_o, it_o) and abs(a[2][k].fmin - fmin_o) <= 1e-8 * abs(fmin_o)
+        _, ffmin_o, fcode_o, fit_o, fev_o = O.opt_lbfgs_forces(f0, w0, y, YT, th, params)
+        assert (b[2][k].lbfgs_code, b[2][k].iterations) == (fcode_o, fit_o) and abs(b[2][k].fmin - ffmin_o) <= 1e-8 * abs(ffmin_o)
+    assert "rowmajor" in forms                      # what the streaming kernels read
