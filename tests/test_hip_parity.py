@@ -713,3 +713,49 @@ def test_randomised_batches_equal_their_single_runs(hip):
     spec.loader.exec_module(fuzz)
     bad = fuzz.run(0, 50)
     assert not bad, bad
+
+
+SWITCHES = [
+    {"BIOEN_HIP_LIVE": "0"},                      # no coherent host page: copies + stream synchronisation, host-driven engine
+    {"BIOEN_HIP_FORCES_LIVE": "0"},
+    {"BIOEN_HIP_DELIVERY": "0"},                  # results delivered synchronously
+    {"BIOEN_HIP_QUEUE": "0"}, {"BIOEN_HIP_QUEUE": "2"},
+    {"BIOEN_HIP_PIN_RESULTS": "0"},
+    {"BIOEN_HIP_NVEC_NT": "0"}, {"BIOEN_HIP_NVEC_NT": "1"},
+    {"BIOEN_HIP_STRIP_DEPTH5": "1"}, {"BIOEN_HIP_STRIP_DEPTH5": "2"},
+    {"BIOEN_HIP_HOST_SHADOWS": "0", "BIOEN_HIP_DEVICE_LS": "0"}, {"BIOEN_HIP_HOST_SHADOWS": "5", "BIOEN_HIP_DEVICE_LS": "0"},
+    {"BIOEN_HIP_RESERVE": "0", "BIOEN_HIP_DEVICE_LS": "0"}, {"BIOEN_HIP_RESERVE": "3", "BIOEN_HIP_DEVICE_LS": "0"},
+    {"BIOEN_HIP_KEEP_ROWMAJOR": "1"},
+    {"BIOEN_HIP_DEVICE_LS": "0"}, {"BIOEN_HIP_DEVICE_LS": "1"},
+    {"BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0", "BIOEN_HIP_DEVICE_LS": "1"},
+]
+
+
+@pytest.mark.parametrize("switch", SWITCHES, ids=lambda s: ",".join("%s=%s" % kv for kv in sorted(s.items())))
+def test_fallbacks_and_ab_switches_change_no_bit(hip, switch, monkeypatch):
+    """Every fallback a context takes when a resource is missing (no coherent host page: BIOEN_HIP_LIVE=0 /
+    BIOEN_HIP_FORCES_LIVE=0; synchronous deliveries) and every A/B switch that is documented as bit-preserving (queue depth,
+    cache policy, strip-kernel forms, shadow policies, either engine) returns the default configuration's bits: an eight-theta
+    log-weights series that fills the batch, a six-theta forces series (the K > 4 strip form), weights included."""
+    rng = np.random.default_rng(77)
+    M, N = 160, 9000
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G, w0, f0 = np.zeros(N), np.full(N, 1.0 / N), np.zeros(M)
+    params = dict(LBFGS_DEFAULTS, max_iterations=45)
+    th8 = list(np.logspace(2.5, -0.5, 8))
+    th6 = [300.0, 100.0, 30.0, 10.0, 3.0, 1.0]
+
+    def series():
+        with hip.Context(y, YT) as ctx:
+            a = ctx.opt_lbfgs_logw_batch(th8, G, G, params, max_batch=8)
+            b = ctx.opt_lbfgs_forces_batch(th6, f0, w0, params, max_batch=6)
+        return (a[0].tobytes(), a[1].tobytes(), [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code, i.chi2, i.kl) for i in a[2]],
+                b[0].tobytes(), b[1].tobytes(), [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code, i.chi2, i.kl) for i in b[2]])
+
+    if not hasattr(test_fallbacks_and_ab_switches_change_no_bit, "_default"):
+        test_fallbacks_and_ab_switches_change_no_bit._default = series()
+    for k, v in switch.items():
+        monkeypatch.setenv(k, v)
+    assert series() == test_fallbacks_and_ab_switches_change_no_bit._default
