@@ -190,7 +190,12 @@ int bioen_hip_logw_fdf(bioen_hip_ctx* ctx, const double* g, const double* G, dou
                        double* f, double* grad);
 /* _opt_lbfgs_logw, c_bioen_kernels_logw.c:581-669, with the liblbfgs loop
  * (lbfgs.c:245-641) device-resident.  result[n] = optimal log-weights;
- * w_opt[n] (optional, may be NULL) = softmax(result). */
+ * w_opt[n] (optional, may be NULL) = softmax(result).
+ * Inputs are not validated (the reference validates nothing, c_bioen.pyx:274-290).  Non-finite ones end the run the way the
+ * reference's binary -- liblbfgs built with -ffast-math -- ends it: NaN / inf in the start point, prior, matrix, targets
+ * or theta: lbfgs_code 2, the start point, a non-finite fmin, after one evaluation; a direction whose slope is not a
+ * number (a degenerate pair beyond the rounding floor) or positive: lbfgs_code -994 and the last accepted point with ITS
+ * objective.  The same holds for the forces method and for every member of a batch on its own. */
 int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* ctx, const double* g0, const double* G, double theta,
                              const bioen_lbfgs_config* config, const bioen_visual_params* visual,
                              double* result, double* w_opt, bioen_opt_result* info);
