@@ -699,3 +699,18 @@ def test_a_strip_copy_that_cannot_be_allocated_falls_back_to_the_streaming_kerne
         _, ffmin_o, fcode_o, fit_o, fev_o = O.opt_lbfgs_forces(f0, w0, y, YT, th, params)
         assert (b[2][k].lbfgs_code, b[2][k].iterations) == (fcode_o, fit_o) and abs(b[2][k].fmin - ffmin_o) <= 1e-8 * abs(ffmin_o)
     assert "rowmajor" in forms                      # what the streaming kernels read
+
+
+def test_randomised_last_average_is_that_of_the_returned_weights():
+    """tools/fuzz_last_average.py as a test: 50 random single-problem runs of both methods ending in every status (converged,
+    plateau, budget, failed and refused searches that revert to the previous point), either engine, with and without an
+    affine model -- the average left on the device for the nuisance refits equals yTilde . w of the returned weights."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_la", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_last_average.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, codes = fuzz.run(0, 50)
+    assert not bad, bad
+    assert len(codes) >= 4, codes
