@@ -86,6 +86,16 @@ def main():
     col0, n_local = ctx.col0, ctx.n_local
     counts = ctx.exchange_counts3()
     probe_us = ctx.exchange_probe(count=64 * 8, reps=200)
+    # transports come and go on a live context (bench.py measures them and detaches the slower one): the same series over
+    # the host-staged path after a detach, and over the mailboxes again after a second attach, returns the same bits
+    if transport == "p2p":
+        ctx.p2p_detach()
+        ctx.set_exchange(comm)
+        assert ctx.exchange_transport() == "host"
+        again_host = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+        assert sweep.init_p2p(ctx, comm) and ctx.exchange_transport() == "p2p"
+        again_p2p = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+        assert same((res, wopt, infos), again_host) and same((res, wopt, infos), again_p2p)
     ctx.close()
 
     # forces method on a sharded context (strip passes: 2 all-gathers per evaluation)
