@@ -648,9 +648,10 @@ def main():
     ap.add_argument("--shard", choices=("auto", "structures", "thetas"), default="auto",
                     help="multi-GPU decomposition: split the N structures (columns) of every pass, or deal "
                          "thetas; auto = structures when the measured all-gather latency makes it the faster one")
-    ap.add_argument("--transport", choices=("auto", "p2p", "rccl", "host"), default="auto",
+    ap.add_argument("--transport", choices=("auto", "p2p", "rccl", "host", "compare"), default="auto",
                     help="stage exchanges of a structure-sharded run: peer-to-peer mailboxes (hipIpc over xGMI, one kernel "
-                         "per all-gather), RCCL all-gathers, or host-staged; auto = the faster of p2p / rccl as measured")
+                         "per all-gather), RCCL all-gathers, or host-staged; auto = the mailboxes where they attach and pass "
+                         "their self-test, else RCCL, else host-staged; compare = p2p and RCCL both measured, the faster taken")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forces", action="store_true", help="skip the forces-method record (configs[4])")
     ap.add_argument("--no-matched", action="store_true", help="skip the matched CPU/GPU sweep at configs[1] size")
@@ -695,44 +696,60 @@ def main():
         gather, rccl = "none", False
         xinfo.clear()
         if world > 1:
-            try:
-                with stdout_to_stderr():
-                    rccl = sweep.init_rccl(ctx, comm)
-                gather = "rccl-allgather"
-            except bioen_amd.BioenHipError as e:   # report, keep the control-plane path
-                gather = "tcp-allgather (RCCL unavailable: %s)" % e
-                rccl = False
-            if not all(comm.allgather_object(rccl)):
-                rccl = False
-                gather = "tcp-allgather (RCCL init failed on some rank)"
-                ctx.comm_destroy()
-            if nshard:
-                count = M * min(8, len(thetas))
+            count = M * min(8, len(thetas))
 
-                def probe():          # slowest rank's view; inf where the transport does not work
-                    try:
-                        t = ctx.exchange_probe(count=count, reps=40)
-                    except bioen_amd.BioenHipError as e:
-                        xinfo.setdefault("probe_errors", []).append(str(e))
-                        t = float("inf")
-                    return max(comm.allgather_object(t))
-                if rccl and args.transport in ("auto", "rccl"):
-                    xinfo["rccl_us"] = probe()
+            def probe():          # slowest rank's view; inf where the transport does not work
+                try:
+                    t = ctx.exchange_probe(count=count, reps=40)
+                except bioen_amd.BioenHipError as e:
+                    xinfo.setdefault("probe_errors", []).append(str(e))
+                    t = float("inf")
+                return max(comm.allgather_object(t))
+
+            def start_rccl():     # -> (rccl, gather); the outcome agreed between the ranks
+                try:
+                    with stdout_to_stderr():
+                        ok = sweep.init_rccl(ctx, comm)
+                    how = "rccl-allgather"
+                except bioen_amd.BioenHipError as e:   # report, keep the control-plane path
+                    ok, how = False, "tcp-allgather (RCCL unavailable: %s)" % e
+                if not all(comm.allgather_object(bool(ok))):
+                    if ok:
+                        ctx.comm_destroy()
+                    ok, how = False, "tcp-allgather (RCCL init failed on some rank)"
+                return ok, how
+
+            if not nshard:
+                rccl, gather = start_rccl()            # theta-dealing: the results travel once, at the end
+            else:
+                # Stage exchanges of the sharded rounds.  auto: the peer-to-peer mailboxes where they attach (every rank
+                # maps every peer's mailbox and passes the self-test) -- no collective library on the path at all; RCCL
+                # where they do not; host-staged as the last resort.  compare: both measured, the faster one taken.
                 p2p = False
-                if args.transport in ("auto", "p2p"):
+                if args.transport == "compare":
+                    rccl, gather = start_rccl()
+                    if rccl:
+                        xinfo["rccl_us"] = probe()
+                if args.transport in ("auto", "p2p", "compare"):
                     p2p = sweep.init_p2p(ctx, comm)          # agreed between the ranks; self-tested
                     xinfo["p2p_attached"] = p2p
                     if p2p:
                         xinfo["p2p_us"] = probe()
-                        if args.transport == "auto" and xinfo.get("rccl_us", float("inf")) < xinfo["p2p_us"]:
+                        if args.transport == "compare" and xinfo.get("rccl_us", float("inf")) < xinfo["p2p_us"]:
                             ctx.p2p_detach()                 # RCCL is the faster one on this node
                             p2p = False
-                if not p2p and not (rccl and args.transport in ("auto", "rccl")):
+                if not p2p and args.transport in ("auto", "rccl") :
+                    rccl, gather = start_rccl()
                     if rccl:
-                        ctx.comm_destroy()
-                        rccl = False
+                        xinfo["rccl_us"] = probe()
+                if p2p and rccl and args.transport == "compare":
+                    ctx.comm_destroy()                       # measured, not chosen
+                    rccl = False
+                if not p2p and not rccl:
                     ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
                     xinfo["host_us"] = probe()
+                if gather == "none":
+                    gather = "stage exchanges only (every rank holds the results)"
                 xinfo["transport"] = ctx.exchange_transport()
                 xinfo["exchange_us"] = xinfo.get({"p2p": "p2p_us", "rccl": "rccl_us", "host": "host_us"}[xinfo["transport"]])
                 for k in list(xinfo):
