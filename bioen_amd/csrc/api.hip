@@ -1755,6 +1755,20 @@ int bioen_hip_p2p_attach(bioen_hip_ctx* c, const unsigned char* handles) {
         }
         c->p2p_mapped[r] = p;
         peers[r] = static_cast<double*>(p);
+        // a mailbox on ANOTHER device is only usable where this device reaches that one's memory: ask before the first kernel
+        // does (a store the fabric cannot route is a GPU fault, not an error code); where the runtime cannot tell, the
+        // self-test decides
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.device != c->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c->device, at.device) == hipSuccess && !can) {
+                char buf[160];
+                std::snprintf(buf, sizeof buf, "device %d has no peer access to device %d (rank %d's mailbox)", c->device, at.device, r);
+                rc = fail(BIOEN_HIP_ERCCL, buf);
+                break;
+            }
+        }
+        (void)hipGetLastError();
     }
     if (!rc && !c->p2p_err) {
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->p2p_err), 64, hipHostMallocCoherent | hipHostMallocMapped);
