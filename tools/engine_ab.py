@@ -30,6 +30,13 @@ VARIANTS = {
                      "BIOEN_HIP_DEV_RESERVE": "2"},
     "dev1-sharded-form": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "2", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0",
                           "BIOEN_HIP_DEV_RESERVE": "2", "BIOEN_HIP_SHADOW_GRAM": "1"},
+    # ... with more shadow slots (the two slowest thetas shadowed once slots come free / from the start)
+    "dev1-sharded-form-sh4": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "4", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0",
+                              "BIOEN_HIP_DEV_RESERVE": "2", "BIOEN_HIP_SHADOW_GRAM": "1"},
+    "dev1-sharded-form-sh4r4": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "4", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0",
+                                "BIOEN_HIP_DEV_RESERVE": "4", "BIOEN_HIP_SHADOW_GRAM": "1"},
+    "dev1-sharded-form-sh6": {"BIOEN_HIP_DEVICE_LS": "1", "BIOEN_HIP_SHADOWS": "6", "BIOEN_HIP_SHADOW_RATE": "0", "BIOEN_HIP_SHADOW_MINEV": "0",
+                              "BIOEN_HIP_DEV_RESERVE": "2", "BIOEN_HIP_SHADOW_GRAM": "1"},
     "host": {"BIOEN_HIP_DEVICE_LS": "0"},
     "host-nospec": {"BIOEN_HIP_DEVICE_LS": "0", "BIOEN_HIP_SPECULATE": "0"},
 }
