@@ -29,7 +29,7 @@ def main():
     for seed in range(nseeds):
         rng = np.random.default_rng(7000 + seed)
         M = int(rng.choice([int(v) for v in os.environ.get("NSHARD_FUZZ_M", "16,64,96,205,512,600").split(",")]))
-        N = int(rng.choice([1000, 2049, 5000]))
+        N = int(rng.choice([int(v) for v in os.environ.get("NSHARD_FUZZ_N", "1000,2049,5000").split(",")]))
         YTrue = rng.uniform(1, 10, M)
         y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
         YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
