@@ -26,7 +26,8 @@ def main():
     out_path, nseeds = sys.argv[1], int(sys.argv[2])
     comm = sweep.SocketComm()
     bad, digest = [], hashlib.sha256()
-    for seed in range(nseeds):
+    first = int(os.environ.get("NSHARD_FUZZ_FIRST", "0"))
+    for seed in range(first, first + nseeds):
         rng = np.random.default_rng(7000 + seed)
         M = int(rng.choice([int(v) for v in os.environ.get("NSHARD_FUZZ_M", "16,64,96,205,512,600").split(",")]))
         N = int(rng.choice([int(v) for v in os.environ.get("NSHARD_FUZZ_N", "1000,2049,5000").split(",")]))
