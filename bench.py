@@ -634,6 +634,76 @@ class stdout_to_stderr(object):
         os.close(self._saved)
 
 
+def choose_transport(ctx, comm, sweep, nshard, transport, count, xinfo, HipError, quiet=stdout_to_stderr):
+    """What the cross-rank traffic of a multi-rank run goes through -> (gather description, rccl in use).  Every decision is
+    taken on values all ranks have all-gathered, so every rank takes the same branch.
+
+    theta-dealing (nshard False): the results travel once, at the end: RCCL if every rank can initialise it, else TCP.
+    Structure sharding: the stage exchanges of the rounds.  auto = the peer-to-peer mailboxes where they attach (every
+    rank maps every peer's mailbox and passes the self-test) -- no collective library on the path at all; RCCL where they
+    do not; host-staged as the last resort.  compare = p2p and RCCL both measured, the faster one kept.  Fills xinfo with
+    what was measured ({p2p,rccl,host}_us: the slowest rank's microseconds per exchange, None where a probe failed)."""
+    def probe():          # slowest rank's view; inf where the transport does not work
+        try:
+            t = ctx.exchange_probe(count=count, reps=40)
+        except HipError as e:
+            xinfo.setdefault("probe_errors", []).append(str(e))
+            t = float("inf")
+        return max(comm.allgather_object(t))
+
+    def start_rccl():     # -> (rccl, gather); the outcome agreed between the ranks
+        try:
+            with quiet():
+                ok = sweep.init_rccl(ctx, comm)
+            how = "rccl-allgather"
+        except HipError as e:   # report, keep the control-plane path
+            ok, how = False, "tcp-allgather (RCCL unavailable: %s)" % e
+        if not all(comm.allgather_object(bool(ok))):
+            if ok:                                # this rank has a communicator the others cannot use
+                ctx.comm_destroy()
+                how = "tcp-allgather (RCCL init failed on some rank)"
+            elif not how.startswith("tcp"):
+                how = "tcp-allgather (RCCL init failed on this rank)"
+            ok = False
+        return ok, how
+
+    gather, rccl = "none", False
+    if not nshard:
+        rccl, gather = start_rccl()
+        return gather, rccl
+    p2p = False
+    if transport == "compare":
+        rccl, gather = start_rccl()
+        if rccl:
+            xinfo["rccl_us"] = probe()
+    if transport in ("auto", "p2p", "compare"):
+        p2p = sweep.init_p2p(ctx, comm)          # agreed between the ranks; self-tested
+        xinfo["p2p_attached"] = p2p
+        if p2p:
+            xinfo["p2p_us"] = probe()
+            if transport == "compare" and xinfo.get("rccl_us", float("inf")) < xinfo["p2p_us"]:
+                ctx.p2p_detach()                 # RCCL is the faster one on this node
+                p2p = False
+    if not p2p and transport in ("auto", "rccl"):
+        rccl, gather = start_rccl()
+        if rccl:
+            xinfo["rccl_us"] = probe()
+    if p2p and rccl:
+        ctx.comm_destroy()                       # measured, not chosen
+        rccl = False
+    if not p2p and not rccl:
+        ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
+        xinfo["host_us"] = probe()
+    if gather == "none":
+        gather = "stage exchanges only (every rank holds the results)"
+    xinfo["transport"] = ctx.exchange_transport()
+    xinfo["exchange_us"] = xinfo.get({"p2p": "p2p_us", "rccl": "rccl_us", "host": "host_us"}[xinfo["transport"]])
+    for k in list(xinfo):
+        if isinstance(xinfo[k], float) and not np.isfinite(xinfo[k]):
+            xinfo[k] = None
+    return gather, rccl
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -696,65 +766,8 @@ def main():
         gather, rccl = "none", False
         xinfo.clear()
         if world > 1:
-            count = M * min(8, len(thetas))
-
-            def probe():          # slowest rank's view; inf where the transport does not work
-                try:
-                    t = ctx.exchange_probe(count=count, reps=40)
-                except bioen_amd.BioenHipError as e:
-                    xinfo.setdefault("probe_errors", []).append(str(e))
-                    t = float("inf")
-                return max(comm.allgather_object(t))
-
-            def start_rccl():     # -> (rccl, gather); the outcome agreed between the ranks
-                try:
-                    with stdout_to_stderr():
-                        ok = sweep.init_rccl(ctx, comm)
-                    how = "rccl-allgather"
-                except bioen_amd.BioenHipError as e:   # report, keep the control-plane path
-                    ok, how = False, "tcp-allgather (RCCL unavailable: %s)" % e
-                if not all(comm.allgather_object(bool(ok))):
-                    if ok:
-                        ctx.comm_destroy()
-                    ok, how = False, "tcp-allgather (RCCL init failed on some rank)"
-                return ok, how
-
-            if not nshard:
-                rccl, gather = start_rccl()            # theta-dealing: the results travel once, at the end
-            else:
-                # Stage exchanges of the sharded rounds.  auto: the peer-to-peer mailboxes where they attach (every rank
-                # maps every peer's mailbox and passes the self-test) -- no collective library on the path at all; RCCL
-                # where they do not; host-staged as the last resort.  compare: both measured, the faster one taken.
-                p2p = False
-                if args.transport == "compare":
-                    rccl, gather = start_rccl()
-                    if rccl:
-                        xinfo["rccl_us"] = probe()
-                if args.transport in ("auto", "p2p", "compare"):
-                    p2p = sweep.init_p2p(ctx, comm)          # agreed between the ranks; self-tested
-                    xinfo["p2p_attached"] = p2p
-                    if p2p:
-                        xinfo["p2p_us"] = probe()
-                        if args.transport == "compare" and xinfo.get("rccl_us", float("inf")) < xinfo["p2p_us"]:
-                            ctx.p2p_detach()                 # RCCL is the faster one on this node
-                            p2p = False
-                if not p2p and args.transport in ("auto", "rccl") :
-                    rccl, gather = start_rccl()
-                    if rccl:
-                        xinfo["rccl_us"] = probe()
-                if p2p and rccl and args.transport == "compare":
-                    ctx.comm_destroy()                       # measured, not chosen
-                    rccl = False
-                if not p2p and not rccl:
-                    ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
-                    xinfo["host_us"] = probe()
-                if gather == "none":
-                    gather = "stage exchanges only (every rank holds the results)"
-                xinfo["transport"] = ctx.exchange_transport()
-                xinfo["exchange_us"] = xinfo.get({"p2p": "p2p_us", "rccl": "rccl_us", "host": "host_us"}[xinfo["transport"]])
-                for k in list(xinfo):
-                    if isinstance(xinfo[k], float) and not np.isfinite(xinfo[k]):
-                        xinfo[k] = None
+            gather, rccl = choose_transport(ctx, comm, sweep, nshard, args.transport, M * min(8, len(thetas)), xinfo,
+                                            bioen_amd.BioenHipError)
         return ctx, gather, rccl
 
     decision = None

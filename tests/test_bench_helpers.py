@@ -49,3 +49,115 @@ def test_profiler_detection_reads_the_environment(monkeypatch):
     assert not bench.under_profiler()
     monkeypatch.setenv("LD_PRELOAD", "/some/guard.so:/opt/rocm-7.2.0/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.under_profiler()
+
+
+# ---- which transport a multi-rank run ends up on (bench.choose_transport), with fakes of the context and the control plane ----
+class _Err(Exception):
+    pass
+
+
+class _Comm(object):
+    """one rank's view of a control plane whose other ranks answer `others(x)` to an all-gather of x"""
+    def __init__(self, others=lambda x: [x]):
+        self.others = others
+
+    def allgather_object(self, x):
+        return [x] + list(self.others(x))
+
+
+class _Ctx(object):
+    def __init__(self, us):
+        self.us, self.log, self.p2p, self.rccl, self.host = us, [], False, False, False
+
+    def exchange_transport(self):
+        return "p2p" if self.p2p else "rccl" if self.rccl else "host" if self.host else "none"
+
+    def exchange_probe(self, count, reps):
+        t = self.us[self.exchange_transport()]
+        if isinstance(t, Exception):
+            raise t
+        return t
+
+    def p2p_detach(self):
+        self.log.append("p2p_detach"); self.p2p = False
+
+    def comm_destroy(self):
+        self.log.append("comm_destroy"); self.rccl = False
+
+    def set_exchange(self, comm):
+        self.log.append("set_exchange"); self.host = True
+
+
+class _Sweep(object):
+    def __init__(self, p2p_ok=True, rccl_ok=True):
+        self.p2p_ok, self.rccl_ok, self.calls = p2p_ok, rccl_ok, []
+
+    def init_p2p(self, ctx, comm):
+        self.calls.append("init_p2p")
+        ctx.p2p = bool(self.p2p_ok)
+        return ctx.p2p
+
+    def init_rccl(self, ctx, comm):
+        self.calls.append("init_rccl")
+        if isinstance(self.rccl_ok, Exception):
+            raise self.rccl_ok
+        ctx.rccl = bool(self.rccl_ok)
+        return ctx.rccl
+
+
+class _Quiet(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _choose(transport, sweep, us, nshard=True, others=lambda x: [x]):
+    ctx, xinfo = _Ctx(us), {}
+    gather, rccl = bench.choose_transport(ctx, _Comm(others), sweep, nshard, transport, 8192, xinfo, _Err, quiet=_Quiet)
+    return ctx, sweep, xinfo, gather, rccl
+
+
+def test_auto_takes_the_mailboxes_and_never_touches_rccl():
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
+    assert sw.calls == ["init_p2p"] and ctx.log == [] and not rccl
+    assert x["transport"] == "p2p" and x["exchange_us"] == 5.0 and "rccl_us" not in x and "stage exchanges" in gather
+
+
+def test_auto_falls_back_to_rccl_then_to_the_host():
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(p2p_ok=False), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
+    assert sw.calls == ["init_p2p", "init_rccl"] and rccl and x["transport"] == "rccl" and x["exchange_us"] == 25.0
+    assert gather == "rccl-allgather" and x["p2p_attached"] is False
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(p2p_ok=False, rccl_ok=_Err("no librccl")), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
+    assert not rccl and x["transport"] == "host" and x["exchange_us"] == 90.0 and ctx.log == ["set_exchange"]
+    assert "RCCL unavailable" in gather
+
+
+def test_rccl_that_one_rank_could_not_initialise_is_given_up_by_all():
+    # this rank initialised its communicator, another one reports False: destroy it, host-staged for everybody
+    others = lambda v: [False] if isinstance(v, bool) else [v]
+    ctx, sw, x, gather, rccl = _choose("rccl", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0}, others=others)
+    assert not rccl and ctx.log == ["comm_destroy", "set_exchange"] and x["transport"] == "host"
+    assert "failed on some rank" in gather
+
+
+def test_compare_keeps_the_faster_of_the_two_and_drops_the_other():
+    ctx, sw, x, gather, rccl = _choose("compare", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
+    assert sw.calls == ["init_rccl", "init_p2p"] and x["transport"] == "p2p" and not rccl and ctx.log == ["comm_destroy"]
+    assert x["rccl_us"] == 25.0 and x["p2p_us"] == 5.0
+    ctx, sw, x, gather, rccl = _choose("compare", _Sweep(), {"p2p": 40.0, "rccl": 25.0, "host": 90.0})
+    assert x["transport"] == "rccl" and rccl and ctx.log == ["p2p_detach"] and x["exchange_us"] == 25.0
+
+
+def test_the_slowest_ranks_probe_counts_and_a_failed_probe_is_reported():
+    others = lambda v: [v * 3] if isinstance(v, float) else [v]
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0}, others=others)
+    assert x["p2p_us"] == 15.0
+    ctx, sw, x, gather, rccl = _choose("p2p", _Sweep(), {"p2p": _Err("exchange timed out"), "rccl": 25.0, "host": 90.0})
+    assert x["p2p_us"] is None and x["probe_errors"] == ["exchange timed out"] and x["transport"] == "p2p"
+
+
+def test_theta_dealing_only_wants_a_gather():
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0}, nshard=False)
+    assert sw.calls == ["init_rccl"] and rccl and gather == "rccl-allgather" and x == {}
