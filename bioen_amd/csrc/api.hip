@@ -1541,8 +1541,38 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     ncclUniqueId u;
     std::memcpy(u.internal, id, 128);
-    ncclComm_t comm = nullptr;
-    ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, u, rank);
+    // ncclCommInitRank is a collective of all ranks and has no time limit of its own: a rank that never calls it (it failed
+    // before, or died) would keep the others here for good.  It runs on a helper thread; this thread waits for it for three
+    // times the context's wait bound (topology detection on a full node takes seconds) and then gives the transport up --
+    // the helper stays behind, blocked, in a process that goes on without RCCL (the callers fall back).
+    struct InitJob {
+        ncclComm_t comm = nullptr;
+        ncclResult_t r = ncclSuccess;
+        std::atomic<int> done{0};
+    };
+    auto job = std::make_shared<InitJob>();
+    const int dev = c->device;
+    try {
+        std::thread([job, nranks, u, rank, dev]() {
+            if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
+            job->r = g_rccl.CommInitRank(&job->comm, nranks, u, rank);
+            job->done.store(1, std::memory_order_release);
+        }).detach();
+    } catch (...) {
+        return fail(BIOEN_HIP_ERCCL, "could not start the thread that initialises the RCCL communicator");
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(3.0 * std::max(c->wait_timeout_s, 1.0));
+    while (!job->done.load(std::memory_order_acquire)) {
+        if (std::chrono::steady_clock::now() > deadline) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "ncclCommInitRank (rank %d of %d) did not return within %g s: a rank is missing "
+                          "(3 x BIOEN_HIP_WAIT_TIMEOUT)", rank, nranks, 3.0 * std::max(c->wait_timeout_s, 1.0));
+            return fail(BIOEN_HIP_ERCCL, buf);
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    ncclComm_t comm = job->comm;
+    const ncclResult_t r = job->r;
     if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
     c->comm = comm;
     c->comm_rank = rank;

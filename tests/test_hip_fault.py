@@ -106,3 +106,38 @@ def test_ranks_out_of_step_get_an_error_not_each_others_numbers(tmp_path):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+
+
+@pytest.mark.timeout(300)
+def test_a_communicator_whose_peer_never_comes_is_given_up(tmp_path):
+    """ncclCommInitRank is a collective without a time limit: a rank whose peer never calls it must get an error within three
+    times the context's wait bound, not wait for good.  (Own process: the abandoned initialisation stays behind on a helper
+    thread.)"""
+    script = tmp_path / "lonely.py"
+    script.write_text('''
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import bioen_amd
+ctx = bioen_amd.Context(np.random.default_rng(0).normal(size=(8, 256)), np.zeros(8))
+ctx.set_wait_timeout(1.5)
+uid = ctx.comm_unique_id()
+t0 = time.time()
+try:
+    ctx.comm_init(uid, 0, 2)                      # rank 0 of 2; rank 1 does not exist
+    print("RESULT no error")
+except bioen_amd.BioenHipError as e:
+    print("RESULT %%.2f %%s" %% (time.time() - t0, e))
+f, g = ctx.logw_fdf(np.zeros(256), np.zeros(256), 1.0)          # the context itself is fine without the communicator
+print("AFTER", np.isfinite(f))
+sys.stdout.flush()
+import os
+os._exit(0)                                      # (the helper thread is still inside the library's bootstrap)
+''' % ROOT)
+    out = subprocess.run([sys.executable, str(script)], cwd=ROOT, capture_output=True, text=True, timeout=200)
+    lines = [l for l in out.stdout.splitlines() if l.startswith(("RESULT", "AFTER"))]
+    assert len(lines) == 2, (out.stdout[-2000:], out.stderr[-2000:])
+    res = lines[0].split(None, 2)
+    assert res[1] != "no" and "did not return within" in lines[0], lines
+    assert 4.0 <= float(res[1]) <= 12.0, lines                  # 3 x 1.5 s, with slack for the library's own start-up
+    assert lines[1] == "AFTER True"
