@@ -624,7 +624,7 @@ def test_the_two_methods_leave_nothing_behind_for_each_other():
 
 
 def test_randomised_context_data_paths():
-    """tools/fuzz_context.py as a test: 40 random shapes -- assembly from raw observables (row-major and structure-major),
+    """tools/fuzz_context.py as a test: 25 random shapes -- assembly from raw observables (row-major and structure-major),
     read-back of random blocks before and after the strip copies replace the matrix (bit for bit), the affine model against a
     rebuilt matrix, the plain model's bits back after it, a changed target against a fresh context."""
     import importlib.util
@@ -633,7 +633,7 @@ def test_randomised_context_data_paths():
         "fuzz_context", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_context.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
-    bad = fuzz.run(0, 40)
+    bad = fuzz.run(0, 25)
     assert not bad, bad
 
 
@@ -714,3 +714,18 @@ def test_randomised_last_average_is_that_of_the_returned_weights():
     bad, codes = fuzz.run(0, 50)
     assert not bad, bad
     assert len(codes) >= 4, codes
+
+
+def test_randomised_calls_of_the_bioen_optimize_layer():
+    """tools/fuzz_api.py as a test: 25 random find_optimum calls of both methods -- lbfgs, the five GSL algorithms, three scipy
+    algorithms on the device or the numpy objective, ndarray or np.matrix inputs: tuple shapes as the reference documents
+    them, weights normalised, fmin_final = f(returned point), yopt = y . wopt, fmin_final = theta S + chi^2 / 2, the lbfgs
+    runs bit for bit the context-level call, statuses outside {0, 1, 2} raised as the reference raises them."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_api", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_api.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad = fuzz.run(0, 25)
+    assert not bad, bad
