@@ -58,8 +58,9 @@ static int dalloc_zero(double** p, size_t count, hipStream_t s) {
     return 0;
 }
 
+// (per SEGMENT: the tiles are those of a GPU holding one segment; a context with vr of them has vr x as many)
 static void choose_fwd_tiling(bioen_hip_ctx* c) {
-    const int total_steps = (int)(c->ld / 128);
+    const int total_steps = c->segcols / 128;
     const int row_blocks = c->mp / kRowAlign;
     // Tiles of >= 42 steps (a block ends with a 63-shuffle reduction and K x 32 scattered stores),
     // between 512 and ~6144 blocks.  N = 1e6 x M = 1024: 5952 blocks (3072 and 2048 measured within
@@ -71,7 +72,7 @@ static void choose_fwd_tiling(bioen_hip_ctx* c) {
     int spt = (total_steps + want_tiles - 1) / want_tiles;
     if (spt & 1) ++spt;   // two 1-KiB steps in flight per row
     c->fwd_steps = spt;
-    c->fwd_ctiles = (total_steps + spt - 1) / spt;
+    c->fwd_ctiles = (total_steps + spt - 1) / spt * c->vr;
 }
 
 static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history, bool with_spare = false) {
@@ -87,7 +88,7 @@ static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history, bool with_spar
         sl.gp = sl.gb;
         sl.scal = c->scal + (size_t)s * kScalStride;
         sl.gram = c->gram + (size_t)s * kGramStride;
-        sl.part = c->part + (size_t)s * P_COUNT * kMaxPartials;
+        sl.part = c->part + (size_t)s * P_COUNT * kPartStride;
         sl.allocated = true;
     }
     if (with_history && !sl.history) {
@@ -104,16 +105,12 @@ static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history, bool with_spar
     return 0;
 }
 
-// columns [col0, col0 + n_local) of an n_global-column matrix go to `rank` of `world`
-static void shard_columns(long long n_global, int rank, int world, long long* col0, long long* n_local,
-                          long long* cols_per_rank) {
-    const long long per = (long long)round_up((size_t)((n_global + world - 1) / world), kColAlign);
-    *cols_per_rank = per;
-    *col0 = per * rank;
-    long long nl = n_global - *col0;
-    if (nl > per) nl = per;
-    if (nl < 0) nl = 0;
-    *n_local = nl;
+// Canonical segments (ctx.hpp): nseg = 8 whenever `world` divides 8, else world; segcols = ceil(n / nseg) rounded up
+// to 128; rank r holds the vr = nseg / world segments [r vr, (r + 1) vr), i.e. the columns [r vr segcols, ...).
+static void segment_geometry(long long n_global, int world, int* nseg, int* vr, long long* segcols) {
+    *nseg = (world <= kMaxSeg && kMaxSeg % world == 0) ? kMaxSeg : world;
+    *vr = *nseg / world;
+    *segcols = (long long)round_up((size_t)((n_global + *nseg - 1) / *nseg), kColAlign);
 }
 
 static int ctx_alloc(int m, long long n_global, int device, int rank, int world, bioen_hip_ctx** out) {
@@ -122,16 +119,19 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     if (m <= 0 || n_global <= 0) return fail(BIOEN_HIP_EINVAL, "m and n must be positive");
     if (world < 1 || world > kMaxPartials / 8 || rank < 0 || rank >= world)
         return fail(BIOEN_HIP_EINVAL, "bad rank / world");
-    long long col0 = 0, n_local = n_global, per = 0;
-    if (world > 1) {
-        shard_columns(n_global, rank, world, &col0, &n_local, &per);
-        // rank-independent test (every rank must fail together, else the others hang in the first collective):
-        // the LAST rank still has to own at least one column of its 128-aligned block
-        if ((long long)(world - 1) * per >= n_global)
-            return fail(BIOEN_HIP_EINVAL, "too few structures to shard: with 128-column blocks of ceil(n / world) the "
-                                          "last rank would be empty (need (world - 1) * round_up(ceil(n / world), 128) < n)");
-    }
-    if (n_local > 0x7fffffff) return fail(BIOEN_HIP_EINVAL, "n per GPU exceeds 2^31-1");
+    int nseg = 0, vr = 0;
+    long long segcols = 0;
+    segment_geometry(n_global, world, &nseg, &vr, &segcols);
+    const long long per = segcols * vr;
+    const long long col0 = per * rank;
+    long long n_local = std::max(0ll, std::min(per, n_global - col0));
+    // rank-independent test (every rank must fail together, else the others hang in the first collective):
+    // the LAST rank still has to own at least one column
+    if (world > 1 && (long long)(world - 1) * per >= n_global)
+        return fail(BIOEN_HIP_EINVAL, "too few structures to shard: the columns go to the ranks in runs of (8 / world) segments of "
+                                      "round_up(ceil(n / 8), 128) columns (world dividing 8; else one segment of round_up(ceil(n / "
+                                      "world), 128) per rank), and the last rank would be empty");
+    if (per > 0x7fffffff) return fail(BIOEN_HIP_EINVAL, "n per GPU exceeds 2^31-1");
     const int n = (int)n_local;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -149,7 +149,11 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     c->n_global = n_global;
     c->col0 = col0;
     c->mp = (int)round_up((size_t)m, kRowAlign);
-    c->ld = world > 1 ? (size_t)per : round_up((size_t)n, kColAlign);   // identical on every rank
+    c->nseg = nseg;
+    c->vr = vr;
+    c->seg0 = rank * vr;
+    c->segcols = (int)segcols;
+    c->ld = (size_t)per;                 // vr segments of segcols columns: identical on every rank
     choose_fwd_tiling(c);
     // stream yTilde with non-temporal loads once it no longer fits the 256 MiB Infinity Cache
     c->nontemporal = (size_t)c->mp * c->ld * sizeof(double) > (size_t)192 * 1024 * 1024;
@@ -161,9 +165,7 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
         if (v > 0.0) c->wait_timeout_s = v;
     }
     {
-        const char* e = std::getenv("BIOEN_HIP_STRIP_OLD");
-        c->strip_old = (e && e[0] == '1') ? 1 : 0;
-        e = std::getenv("BIOEN_HIP_KEEP_ROWMAJOR");    // A/B: keep the row-major matrix beside the strip copies
+        const char* e = std::getenv("BIOEN_HIP_KEEP_ROWMAJOR");    // A/B: keep the row-major matrix beside the strip copies
         c->keep_rowmajor = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_FWD_STREAM");       // A/B: the streaming forward kernel on the row-major matrix
         c->fwd_stream = (e && e[0] == '1') ? 1 : 0;
@@ -200,20 +202,27 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     TRY(dalloc_zero(&c->t, c->ld, c->stream));
     // per (row, problem) one partial per column tile of the forward pass, or per block of the fused
     // forces pass (forces_fused_blocks)
-    TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * std::max(c->fwd_ctiles, kFusedBlocks), c->stream));
-    TRY(dalloc_zero(&c->part, (size_t)kMaxBatch * P_COUNT * kMaxPartials, c->stream));
+    {
+        // (the sets the strip passes leave on this context: kernels.hpp: StripSets; an unfolded forward pass -- sharded
+        // contexts, BIOEN_HIP_STRIP_FOLD=0 -- leaves nch per group)
+        const StripSets fs = strip_sets(c), gs = forces_sets(c);
+        const long long sets = std::max<long long>((long long)fs.gs * fs.nch * c->vr, (long long)gs.sets * c->vr);
+        if (sets > kPartStride) { bioen_hip_ctx_destroy(c); return fail(BIOEN_HIP_EINVAL, "strip sets exceed kPartStride"); }
+        TRY(dalloc_zero(&c->fwd_partial, (size_t)kMaxBatch * c->mp * std::max<long long>(std::max(c->fwd_ctiles, kFusedBlocks), sets), c->stream));
+    }
+    TRY(dalloc_zero(&c->part, (size_t)kMaxBatch * P_COUNT * kPartStride, c->stream));
     TRY(dalloc_zero(&c->scal, (size_t)kMaxBatch * kScalStride, c->stream));
     TRY(dalloc_zero(&c->gram, (size_t)kMaxBatch * kGramStride, c->stream));
-    {   // exchange stages: [world][capacity]
+    {   // exchange stages: [nseg][capacity per segment] = [world][capacity per rank]
         const size_t npl = (size_t)vec_grid(c);
         const size_t arrays[X_COUNT] = {1, 3, 0, 3, 2, 1, 1, 1, 0, kGramDots, 0};
         for (int st = 0; st < X_COUNT; ++st) {
             size_t cap = arrays[st] * kMaxBatch * npl;
             if (st == X_YBAR) cap = (size_t)(c->mp + 3) * kMaxBatch;
-            if (st == X_GRAMR) cap = world > 1 ? (size_t)kDevRankSums * kMaxBatch : 0;
-            if (st == X_VEC) cap = world > 1 ? c->ld : 0;
-            c->xcap[st] = cap;
-            if (cap) TRY(dalloc_zero(&c->xbuf[st], cap * world, c->stream));
+            if (st == X_GRAMR) cap = (size_t)kDevRankSums * kMaxBatch;
+            if (st == X_VEC) cap = world > 1 ? (size_t)c->segcols : 0;
+            c->xcap[st] = cap * vr;
+            if (cap) TRY(dalloc_zero(&c->xbuf[st], cap * nseg, c->stream));
         }
     }
     TRY(alloc_slot(c, 0, false));
@@ -345,7 +354,12 @@ static bool exchanges_forced(const bioen_hip_ctx* c) {
     return c->world == 1 && c->force_exchange && (c->comm || c->exchange_cb || c->p2p_on);
 }
 
-static int exchange(bioen_hip_ctx* c, int stage, size_t payload) {
+// `seg_payload` = doubles per SEGMENT (what the kernels' stage views are built with); a rank ships its vr segments
+static int exchange_raw(bioen_hip_ctx* c, int stage, size_t payload);
+static int exchange(bioen_hip_ctx* c, int stage, size_t seg_payload) {
+    return exchange_raw(c, stage, seg_payload * (size_t)c->vr);
+}
+static int exchange_raw(bioen_hip_ctx* c, int stage, size_t payload) {      // payload = doubles per RANK
     if (c->world == 1 && !exchanges_forced(c)) return 0;
     if (c->failed) {
         const std::string m = "this context failed earlier and must be destroyed: " + c->fail_msg;
@@ -396,11 +410,11 @@ static int download_n(bioen_hip_ctx* c, double* dst_global, const double* src_lo
     double* base = c->xbuf[X_VEC];
     BIOEN_HIP_CHECK(hipMemcpyAsync(base + (size_t)c->rank * c->ld, src_local, c->ld * sizeof(double),
                                    hipMemcpyDeviceToDevice, c->stream));
-    int rc = exchange(c, X_VEC, c->ld);
+    int rc = exchange_raw(c, X_VEC, c->ld);
     if (rc) return rc;
     for (int r = 0; r < c->world; ++r) {
-        long long col0, nl, per;
-        shard_columns(c->n_global, r, c->world, &col0, &nl, &per);
+        long long col0, nl;
+        rank_columns(c, r, &col0, &nl);
         if (nl > 0)
             BIOEN_HIP_CHECK(hipMemcpyAsync(dst_global + col0, base + (size_t)r * c->ld, (size_t)nl * sizeof(double),
                                            hipMemcpyDeviceToHost, c->stream));
@@ -442,7 +456,7 @@ static int await_live(bioen_hip_ctx* c, unsigned long long round, const int* slo
 // without the 5-10 ms a host loop over 1e6 exponentials cost every run.
 static int enqueue_logs0(bioen_hip_ctx* c, const Round& r) {
     launch_logw_logs0_part(c);
-    const int rc = exchange(c, X_GRAD, 2 * (size_t)vec_grid(c));
+    const int rc = exchange(c, X_GRAD, 2 * (size_t)vec_grid(c));      // (per segment)
     if (rc) return rc;
     launch_logw_logs0_merge(c, r);
     return 0;
@@ -576,33 +590,13 @@ static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr, int p
 static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
     int nblk = forces_fused_blocks(c);
     int rc;
-    if (nblk > 0 && !c->strip_old && (rc = ensure_strip_copy(c))) {
+    if (nblk > 0 && (rc = ensure_strip_copy(c))) {
         if (!c->strips_unavailable) return rc;
         nblk = forces_fused_blocks(c);        // = 0 now: the kernels on the row-major matrix take over
     }
     c->last_width = r.n;
     c->last_pos = 0;
     c->last_centered = false;
-    if ((nblk > 0 && c->strip_old) || (nblk == 0 && forces_fused_blocks_old(c) > 0)) {        // r01 kernels on the row-major matrix, kept for A/B measurements
-        nblk = forces_fused_blocks_old(c);
-        if ((rc = ensure_rowmajor(c))) return rc;
-        launch_forces_xy_old(c, fr, nblk);
-        if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
-        launch_rows_combine(c, r, true);
-        if (with_grad) {
-            launch_forces_bt_old(c, fr, nblk);
-            if (c->world == 1) {
-                launch_fwd_rows_forces_grad(c, fr.n, nblk);
-            } else {
-                launch_fwd_rows_forces_grad_share(c, fr.n, nblk);
-                if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
-                launch_forces_grad_sum_ranks(c, fr.n);
-            }
-        } else {
-            launch_forces_w_from_x(c, fr);
-        }
-        return 0;
-    }
     if (nblk > 0) {
         // M <= 1024: two passes over LDS-resident column strips instead of four streaming ones.
         // Measured at N = 1e6 x M = 512 (r01): pass 2 alone 0.85 ms at K = 1 against 1.22 ms for the
@@ -619,13 +613,9 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         c->last_centered = true;               // ybar_c = ybar - strip_center (bioen_hip_last_average adds it back)
         if (with_grad) {
             launch_forces_bt(c, fr, nblk);    // F3: b, t, product with t            [matrix pass 2]
-            if (c->world == 1 && !exchanges_forced(c)) {
-                launch_fwd_rows_forces_grad(c, fr.n, nblk, &fr, true);
-            } else {
-                launch_fwd_rows_forces_grad_share(c, fr.n, nblk, &fr, true);
-                if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
-                launch_forces_grad_sum_ranks(c, fr.n);
-            }
+            launch_fwd_rows_forces_grad_share(c, fr.n, nblk, &fr, true);   // every segment's share (one GPU: all eight)
+            if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
+            launch_forces_grad_sum_ranks(c, fr.n);                         // ... added in segment order
         } else {
             launch_forces_w_from_x(c, fr);    // f-only evaluations hand out the weights
         }
@@ -1082,7 +1072,7 @@ int bioen_hip_logw_weights(bioen_hip_ctx* c, const double* g, double* w, double*
     const size_t gsz = (size_t)vec_grid(c);
     launch_max(c, r);
     launch_logw_exp(c, r);
-    if ((rc = exchange(c, X_EXP, 3 * gsz))) return rc;
+    if ((rc = exchange(c, X_EXP, 3 * gsz))) return rc;      // (per segment)
     launch_logw_norm(c, r);
     if ((rc = check_launch())) return rc;
     if (w && (rc = download_n(c, w, s0.w))) return rc;
@@ -1199,10 +1189,10 @@ static bool is_affine(const bioen_hip_ctx* c) { return c->affine; }
 
 static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
     // sharded contexts run the forces method through the strip passes only (M <= 1024)
-    if (c->world != 1 && !(strip_path_ok && (forces_fused_blocks(c) > 0 || forces_fused_blocks_old(c) > 0)))
+    if (c->world != 1 && !(strip_path_ok && forces_fused_blocks(c) > 0))
         return fail(BIOEN_HIP_ESTATE, "not available on this structure-sharded context");
     if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
-    if (c->storage && !(strip_path_ok && forces_fused_blocks(c) > 0 && !c->strip_old))
+    if (c->storage && !(strip_path_ok && forces_fused_blocks(c) > 0))
         return fail(BIOEN_HIP_ESTATE, "the reduced-storage experiment serves the strip passes (M <= 1024) only");
     return 0;
 }
@@ -1250,7 +1240,7 @@ int bioen_hip_speculation_stats(bioen_hip_ctx* c, long long* issued, long long* 
 // diagnostic builds (-DSTRIP_DIAG=4): phase-cycle sums of the last forces strip launch, [blocks][16][8]
 int bioen_hip_debug_strip_stamps(bioen_hip_ctx* c, int enable, long long* out, int nblocks) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    const size_t cnt = (size_t)kFusedBlocks * 16 * 8;
+    const size_t cnt = (size_t)kPartStride * 16 * 8;
     if (enable && !c->strip_stamps) {
         int rc = dalloc_zero(&c->strip_stamps, cnt, c->stream);
         if (rc) return rc;
@@ -1612,11 +1602,11 @@ int bioen_hip_exchange_probe(bioen_hip_ctx* c, size_t count, int reps, double* u
     if (count > c->xcap[X_YBAR]) count = c->xcap[X_YBAR];
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     int rc = 0;
-    for (int i = 0; i < 5 && !rc; ++i) rc = exchange(c, X_YBAR, count);   // warm-up (connection set-up)
+    for (int i = 0; i < 5 && !rc; ++i) rc = exchange_raw(c, X_YBAR, count);   // warm-up (connection set-up)
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < reps && !rc; ++i) rc = exchange(c, X_YBAR, count);
+    for (int i = 0; i < reps && !rc; ++i) rc = exchange_raw(c, X_YBAR, count);
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     if ((rc = transport_error(c))) return rc;
@@ -1637,12 +1627,12 @@ int bioen_hip_exchange_selftest(bioen_hip_ctx* c, int reps, long long* mismatche
     for (int rep = 0; rep < reps && !rc; ++rep) {
         const size_t payload = std::max<size_t>(1, std::min(cap, sizes[rep % (sizeof sizes / sizeof *sizes)]));
         launch_xch_fill(c, X_YBAR, (int)payload, rep);
-        rc = exchange(c, X_YBAR, payload);
+        rc = exchange_raw(c, X_YBAR, payload);
         if (!rc) launch_xch_check(c, X_YBAR, (int)payload, rep, bad);
         if (!rc && c->xcap[X_VEC] && rep % 8 == 7) {       // the result gathers' shape: a whole N-vector share per rank
             const size_t pv = rep % 16 == 7 ? c->xcap[X_VEC] : std::max<size_t>(1, c->xcap[X_VEC] - 1);
             launch_xch_fill(c, X_VEC, (int)pv, rep);
-            rc = exchange(c, X_VEC, pv);
+            rc = exchange_raw(c, X_VEC, pv);
             if (!rc) launch_xch_check(c, X_VEC, (int)pv, rep, bad);
         }
     }

@@ -34,7 +34,8 @@ constexpr int kColAlign = 128;     // doubles: one wave x 16 B
 constexpr int kRowAlign = 32;
 constexpr int kMaxPartials = 1024; // upper bound on any reduction grid
 constexpr int kMaxBatch = 8;       // thetas sharing one matrix pass
-constexpr int kScalStride = 32;    // doubles per slot in `scal`
+constexpr int kMaxSeg = 8;         // canonical column segments a context can hold (device_utils.hpp: segments)
+constexpr int kScalStride = 40;    // doubles per slot in `scal`
 constexpr int kLiveRing = 4;       // pages of the device engine's live ring (rounds in flight + being read)
 constexpr int kBasis = 2 * kHistory + 1;   // S[6], Y[6], g
 constexpr int kGramDots = 3 * kBasis;      // new s, new y, new g against the basis
@@ -62,8 +63,9 @@ enum ScalarSlot : int {
     S_SPARE1,
     S_YSH,                         // [kHistory] y.s per history slot
     S_ALPHA = S_YSH + kHistory,    // [kHistory]
-    S_INV = S_ALPHA + kHistory,    // w_j = e_j * S_INV on this rank (deferred softmax normalisation)
-    S_B0,                          // sum_i center_i r_i   (strip passes with centred operands: the adjoint's constant)
+    S_INV = S_ALPHA + kHistory,    // [kMaxSeg] w_j = e_j * S_INV[v] in local segment v (deferred softmax normalisation;
+                                   //           every segment shifts its exponentials by its own maximum)
+    S_B0 = S_INV + kMaxSeg,        // sum_i center_i r_i   (strip passes with centred operands: the adjoint's constant)
     S_UY,                          // sum_i ybar_raw_i r_i
     S_COUNT
 };
@@ -76,12 +78,17 @@ enum PartSlot : int {
 };
 
 // Exchange stages.  A reduction over the N structures is produced as per-block partials and
-// consumed by the NEXT kernel, which re-sums them in a fixed order in its prologue.  With the
-// structures sharded over `world` GPUs the partials of a stage live in one buffer laid out
-// [rank][problem a][array q][block], every rank writes its own segment, and ONE in-place
-// all-gather per stage (RCCL over xGMI) makes all segments visible everywhere -- so every rank
-// sums the same numbers in the same order and takes bit-identical decisions without any host
-// communication.  world == 1: same code, no collective.
+// consumed by the NEXT kernel, which re-sums them in a fixed order in its prologue.
+//
+// CANONICAL SEGMENTS (r05).  The N columns are cut into `nseg` segments of `segcols` columns (nseg = 8 whenever the
+// number of ranks divides 8 -- 1, 2, 4, 8 GPUs --, else nseg = world; segcols = ceil(N / nseg) rounded up to 128), and
+// EVERY reduction over structures has the shape  sum over segments (in index order) of [a fixed tree inside the
+// segment]:  the shape never depends on how many GPUs hold the segments.  A rank holds the vr = nseg / world
+// consecutive segments [seg0, seg0 + vr); a stage buffer is laid out [segment][problem a][array q][block]; a rank fills
+// its vr segments and ONE in-place all-gather per stage (vr x payload doubles per rank) makes all nseg visible
+// everywhere.  One GPU holds all eight segments and runs no collective -- and produces, bit for bit, what 2, 4 or 8
+// GPUs produce: the reference's fast_openmp = 0 guarantee (c_bioen_common.c:46-55, c_bioen_kernels_logw.c:58-93:
+// the same sums whatever the thread count), carried over to the rank count.
 enum XStage : int {
     X_MAX = 0,   // 1 array : block maxima of the trial point (consumed by the same rank: never exchanged)
     X_EXP,       // 3 arrays: sum e, sum e (x - G), [0] = this rank's shift m_r (rank-local; its per-rank
@@ -100,11 +107,13 @@ enum XStage : int {
 };
 
 struct Xch {              // one stage, as the kernels see it
-    double* base;         // [world][payload]
-    int payload;          // doubles per rank in this launch
-    int world;
-    int rank;
-    int npl;              // blocks per array (= grid of the producing N-vector kernel)
+    double* base;         // [nseg][payload]
+    int payload;          // doubles per SEGMENT in this launch
+    int world;            // nseg: segments in the stage (all ranks')
+    int rank;             // seg0: first segment this context fills
+    int npl;              // blocks per array and segment (= blocks per segment of the producing N-vector kernel)
+    int vr;               // segments this context fills (and holds the columns of)
+    int segcols;          // columns per segment
 };
 
 struct KernelTimer {
@@ -142,8 +151,10 @@ struct bioen_hip_ctx {
     // structure (column) sharding over GPUs: this context holds columns [col0, col0 + n) of n_global
     int rank = 0, world = 1;
     long long n_global = 0, col0 = 0;
+    // canonical segments (above): nseg in all, this context holds [seg0, seg0 + vr), each segcols columns; ld = vr * segcols
+    int nseg = 8, vr = 8, seg0 = 0, segcols = 0;
     double* xbuf[bioen::X_COUNT] = {};   // exchange stage buffers, each world * capacity doubles
-    size_t xcap[bioen::X_COUNT] = {};    // capacity (doubles) per rank
+    size_t xcap[bioen::X_COUNT] = {};    // capacity (doubles) per RANK (= vr segments)
     // host-staged exchange for processes that cannot share an RCCL communicator (tests)
     int (*exchange_cb)(void* user, double* host_buf, size_t count_per_rank) = nullptr;
     void* exchange_user = nullptr;
@@ -201,7 +212,6 @@ struct bioen_hip_ctx {
     int panel_off = 0;               // BIOEN_HIP_PANELS=0: the r01 streaming kernels for M > 1024 (A/B)
     double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
     int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)
-    int strip_old = 0;               // BIOEN_HIP_STRIP_OLD=1: the r01 strip kernels on the row-major matrix (A/B)
     int strips_unavailable = 0;      // a strip copy could not be allocated: the streaming kernels serve this context
     int strip_allocs = 0;            // strip-copy allocations attempted on this context (tests: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC=k fails the k-th)
     double* YT = nullptr;      // mp   experimental targets (YTilde)

@@ -100,8 +100,11 @@ __device__ __forceinline__ double max_partials(const double* __restrict__ p, int
 // idx0 + i -- lane j adds tiles j, j + 64, ... in turn -- and the 64 lane sums meet in wave_sum's pair order
 // (32, 16, ..., 1) through LDS: bit for bit the classic result, from 128-byte coalesced reads.
 // Returns the total of entry idx0 + (threadIdx.x & 15) in threads < 16.
+// fold > 1: "tile" b is a GROUP of `fold` consecutive sets -- the chunks of one group of the canonical strip sets
+// (kernels_strip.hip), written separately by the strip kernel -- and its value their sum in turn, from +0.0: what a
+// strip kernel that runs whole groups has formed in its registers.
 template <class Term>
-__device__ __forceinline__ double tiles_sum16(const double* __restrict__ P, size_t stride, int ctiles, size_t idx,
+__device__ __forceinline__ double tiles_sum16(const double* __restrict__ P, size_t stride, int ctiles, int fold, size_t idx,
                                               bool valid, double* lds /* [64 * 16] */, Term term) {
     const int i = threadIdx.x & 15, jg = threadIdx.x >> 4;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -112,7 +115,14 @@ __device__ __forceinline__ double tiles_sum16(const double* __restrict__ P, size
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const int b = base + 64 * m + 4 * jg + jj;
-                v[jj][m] = (valid && b < ctiles) ? P[(size_t)b * stride + idx] : 0.0;
+                if (fold <= 1) {
+                    v[jj][m] = (valid && b < ctiles) ? P[(size_t)b * stride + idx] : 0.0;
+                } else {
+                    double gsum = 0.0;
+                    if (valid && b < ctiles)
+                        for (int i = 0; i < fold; ++i) gsum += P[((size_t)b * fold + i) * stride + idx];
+                    v[jj][m] = gsum;
+                }
             }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -137,87 +147,105 @@ struct TermAdd {
     __device__ __forceinline__ double operator()(int, double v, double s) const { return s + v; }
 };
 
-// ---- exchange-stage accessors (ctx.hpp: XStage).  Layout [rank][problem a][array q][block].
-// put: this rank's block partial.  sum/max: over all ranks and blocks in a fixed order
-// (rank-major), identical on every rank.
+// ---- canonical segments (ctx.hpp: XStage) ---------------------------------------------------------------------
+// An N-vector kernel is launched with npl blocks per local segment (grid.x = npl * vr): block blockIdx.x works on
+// segment v = blockIdx.x / npl as its block b = blockIdx.x % npl -- exactly the columns, in exactly the order, that
+// block b of a GPU holding nothing but that segment would work on.  Local columns of the segment: [j0, jend).
+constexpr int kShRed = 128;            // LDS doubles of the stage-sum helpers below (>= nseg)
+
+struct SegPos {
+    int v, b;                          // local segment, block within it
+    int j0, jend;                      // first column of the segment, end of its VALID columns (jend <= j0: empty)
+};
+__device__ __forceinline__ SegPos seg_pos(int npl, int segcols, int n) {
+    SegPos s;
+    s.v = blockIdx.x / npl;
+    s.b = blockIdx.x - s.v * npl;
+    s.j0 = s.v * segcols;
+    const int e = s.j0 + segcols;
+    s.jend = n < e ? n : e;
+    return s;
+}
+// the block's walk over its segment, in 16-byte pairs: for (j = seg_first(...); j < sp.jend; j += seg_step(npl))
+__device__ __forceinline__ int seg_first(const SegPos& s) { return s.j0 + 2 * (s.b * kBlock + (int)threadIdx.x); }
+__device__ __forceinline__ int seg_step(int npl) { return 2 * npl * kBlock; }
+
+// ---- exchange-stage accessors.  Layout [segment][problem a][array q][block].
+// put: this block's partial (its segment, its block number there).
+template <int A>
+__device__ __forceinline__ const double* xseg_ptr(const Xch& x, int seg, int a, int q) {
+    return x.base + (size_t)seg * x.payload + (size_t)(a * A + q) * x.npl;
+}
 template <int A>
 __device__ __forceinline__ void xput(const Xch& x, int a, int q, double v) {
-    x.base[(size_t)x.rank * x.payload + (size_t)(a * A + q) * x.npl + blockIdx.x] = v;
+    const int vloc = blockIdx.x / x.npl;
+    x.base[(size_t)(x.rank + vloc) * x.payload + (size_t)(a * A + q) * x.npl + (blockIdx.x - vloc * x.npl)] = v;
 }
 
-template <int A>
-__device__ __forceinline__ double xsum(const Xch& x, int a, int q, double* sh) {
+// THE sum of one segment's block partials (every consumer forms it this way): by one wave, lane l adding the partials
+// l, l + 64, ... in turn, the 64 lane sums meeting in wave_sum's pair order.  Result in every lane.
+__device__ __forceinline__ double wave_seg_total(const double* __restrict__ p, int npl) {
     double s = 0.0;
-    for (int r = 0; r < x.world; ++r) {
-        const double* p = x.base + (size_t)r * x.payload + (size_t)(a * A + q) * x.npl;
-        for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
-    }
-    return block_sum(s, sh);
+    for (int k = threadIdx.x & 63; k < npl; k += 64) s += p[k];
+    return wave_sum(s);
+}
+__device__ __forceinline__ double wave_seg_max(const double* __restrict__ p, int npl) {
+    double s = -DBL_MAX;
+    for (int k = threadIdx.x & 63; k < npl; k += 64) s = fmax(s, p[k]);
+    return wave_max(s);
 }
 
-// sum over the blocks of ONE rank's segment
+// THE sum over structures: the segments' totals added in segment order, from +0.0 -- whichever GPU computed which.
+// (A block of four waves: wave w totals the segments w, w + 4, ...; every thread then adds them up.)
 template <int A>
-__device__ __forceinline__ double xsum_rank(const Xch& x, int rk, int a, int q, double* sh) {
+__device__ __forceinline__ double xsum(const Xch& x, int a, int q, double* sh /* [kShRed] */) {
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();   // protect sh against its previous use
+    for (int seg = wave; seg < x.world; seg += kWaves) {
+        const double t = wave_seg_total(xseg_ptr<A>(x, seg, a, q), x.npl);
+        if ((threadIdx.x & 63) == 0) sh[seg] = t;
+    }
+    __syncthreads();
     double s = 0.0;
-    const double* p = x.base + (size_t)rk * x.payload + (size_t)(a * A + q) * x.npl;
-    for (int k = threadIdx.x; k < x.npl; k += kBlock) s += p[k];
-    return block_sum(s, sh);
+    for (int seg = 0; seg < x.world; ++seg) s += sh[seg];
+    return s;
 }
-
-template <int A>
-__device__ __forceinline__ double xmax(const Xch& x, int a, int q, double* sh) {
-    double s = -DBL_MAX;
-    for (int r = 0; r < x.world; ++r) {
-        const double* p = x.base + (size_t)r * x.payload + (size_t)(a * A + q) * x.npl;
-        for (int k = threadIdx.x; k < x.npl; k += kBlock) s = fmax(s, p[k]);
+// NQ arrays of one problem at once (one barrier pair): out[q] = xsum<A>(x, a, q0 + q)
+template <int A, int NQ>
+__device__ __forceinline__ void xsum_multi(const Xch& x, int a, int q0, double* sh /* [NQ * kShRed] */, double (&out)[NQ]) {
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    for (int task = wave; task < NQ * x.world; task += kWaves) {
+        const int q = task / x.world, seg = task - q * x.world;
+        const double t = wave_seg_total(xseg_ptr<A>(x, seg, a, q0 + q), x.npl);
+        if ((threadIdx.x & 63) == 0) sh[q * kShRed + seg] = t;
     }
-    return block_max(s, sh);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double s = 0.0;
+        for (int seg = 0; seg < x.world; ++seg) s += sh[q * kShRed + seg];
+        out[q] = s;
+    }
 }
 
-// maximum over THIS rank's segment only (no exchange needed before it)
+// total of ONE segment (every wave of the block forms it for itself: no LDS, no barrier)
 template <int A>
-__device__ __forceinline__ double xmax_local(const Xch& x, int a, int q, double* sh) {
-    double s = -DBL_MAX;
-    const double* p = x.base + (size_t)x.rank * x.payload + (size_t)(a * A + q) * x.npl;
-    for (int k = threadIdx.x; k < x.npl; k += kBlock) s = fmax(s, p[k]);
-    return block_max(s, sh);
+__device__ __forceinline__ double xsum_seg(const Xch& x, int seg, int a, int q) {
+    return wave_seg_total(xseg_ptr<A>(x, seg, a, q), x.npl);
 }
 
-// The 39 Gram sums of one evaluation finished by ONE block of four waves (few partials per sum: npl * world <= 256):
-// wave w forms the sums w, w + 4, ..., lane l adding the partials l, l + 64, ... of each in turn, then the lanes' shares
-// meet in wave_sum's pair order.  r03: all loads of a wave in flight at once and ONE batched butterfly for its ten sums
-// (wave_multi_reduce: 15 shuffles instead of 60 dependent ones -- 8.7 k of the decision kernel's 33 k cycles were
-// spent here); every sum is formed from the same terms in the same order as before.
-__device__ __forceinline__ void fused_gram_dots(const Xch& xi, int a, double* dots /* LDS [kGramDots] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kPerWave = (kGramDots + kWaves - 1) / kWaves;
-    static_assert(kPerWave <= 16, "one 16-value butterfly per wave");
-    double acc[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
-    for (int r = 0; r < xi.world; ++r)
-        for (int k0 = 0; k0 < xi.npl; k0 += 256) {
-            double v[4][kPerWave];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 64 * j + lane;
-#pragma unroll
-                for (int u = 0; u < kPerWave; ++u) {
-                    const int c = wave + u * kWaves;
-                    v[j][u] = (k < xi.npl && c < kGramDots)
-                                  ? xi.base[(size_t)r * xi.payload + (size_t)(a * kGramDots + c) * xi.npl + k] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + 64 * j + lane < xi.npl) {
-#pragma unroll
-                    for (int u = 0; u < kPerWave; ++u) acc[u] += v[j][u];
-                }
-        }
-    wave_multi_reduce<16>(acc, lane);          // lane l now holds the total of value l >> 2
-    const int u = lane >> 2, c = wave + u * kWaves;
-    if ((lane & 3) == 0 && u < kPerWave && c < kGramDots) dots[c] = acc[0];
+// maximum over the segment THIS block works on (its own block maxima need no exchange before it)
+template <int A>
+__device__ __forceinline__ double xmax_local(const Xch& x, int a, int q) {
+    return wave_seg_max(xseg_ptr<A>(x, x.rank + (int)(blockIdx.x / x.npl), a, q), x.npl);
+}
+
+// finished per-segment totals (stages with npl = 1: X_GRAMR, the tail of X_YBAR): added in segment order from +0.0
+__device__ __forceinline__ double seg_order_sum(const double* __restrict__ first, size_t stride, int nseg) {
+    double s = 0.0;
+    for (int seg = 0; seg < nseg; ++seg) s += first[(size_t)seg * stride];
+    return s;
 }
 
 // The scalar part of the Gram-form direction (kernels_logw.hip: k_gram_solve; kernels_devls.hip: k_dev_decide), run by

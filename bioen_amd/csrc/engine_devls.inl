@@ -390,18 +390,12 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
             launch_adj(c, k, c->r_c, av, true);
         }
         launch_dev_grad_gram(c, r);
-        if (c->world > 1) {
-            launch_dev_rank_reduce(c, r);
-            note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
-        } else {                                    // one rank: nothing to do unless the exchanges are forced (tests)
-            note(exchange(c, X_GRAD, 3 * k * (size_t)vec_grid(c)));
-            note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));
-        }
+        launch_dev_rank_reduce(c, r);               // the local segments' totals of the 39 + 3 sums (sharded: what is shipped)
+        note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
         launch_dev_decide(c, r, cfg, round);
         if (r.n > r.nown && !sgram) {               // a round with shadows: one of them may have been adopted and accepted
             launch_dev_late_gram(c, r);
-            if (c->world > 1) note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
-            else note(exchange(c, X_GRAM, (size_t)kGramDots * k * vec_grid(c)));
+            note(exchange(c, X_GRAMR, (size_t)kDevRankSums * k));
             launch_dev_late_solve(c, r);
         }
         if (first_mask) {

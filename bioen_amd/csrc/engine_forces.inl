@@ -223,7 +223,7 @@ struct ForcesBatchEngine {
             std::memcpy(results + (size_t)p.id * m, res.data(), (size_t)m * sizeof(double));
             // weights, chi^2 and KL at the returned forces (forces.py:535-548 recomputes them too)
             int ws = s;
-            if (evalslot >= 0 && reuse_wanted && c->Ys && !c->strip_old && forces_fused_blocks(c) > 0) {   // the last round ran the strip passes
+            if (evalslot >= 0 && reuse_wanted && c->Ys && forces_fused_blocks(c) > 0) {   // the last round ran the strip passes
                 ws = evalslot;
                 c->last_pos = evalcol;                    // bioen_hip_last_average: the column of that round's ybar_c
                 if (w_opt) {

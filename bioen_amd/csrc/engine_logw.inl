@@ -145,7 +145,7 @@ struct LogwBatchEngine {
             note(hipMemcpyAsync(base + (size_t)c->rank * c->ld, srcs[v], c->ld * sizeof(double), hipMemcpyDeviceToDevice,
                                 c->stream), "gather: own segment");
             c->xbuf[X_VEC] = base;                     // the exchange works in place on the stage buffer it is handed
-            note(exchange(c, X_VEC, c->ld));
+            note(exchange_raw(c, X_VEC, c->ld));
             c->xbuf[X_VEC] = stage;
         }
         hipEvent_t ev = nullptr;
@@ -160,7 +160,7 @@ struct LogwBatchEngine {
         const int dev = c->device, world = c->world, jit = jitter_delivery_us;
         hipStream_t cs = c->copy_stream;
         const size_t ld = c->ld;
-        const long long n_global = c->n_global;
+        const bioen_hip_ctx* const cc = c;
         double* const gb = gather[s];
         auto work = [=]() {
             hipError_t e = hipSetDevice(dev);
@@ -169,8 +169,8 @@ struct LogwBatchEngine {
             for (int v = 0; v < 2 && e == hipSuccess; ++v) {
                 if (!dsts[v]) continue;
                 for (int r = 0; r < world && e == hipSuccess; ++r) {
-                    long long col0, nl, pr;
-                    shard_columns(n_global, r, world, &col0, &nl, &pr);
+                    long long col0, nl;
+                    rank_columns(cc, r, &col0, &nl);
                     if (nl > 0)
                         e = hipMemcpyAsync(dsts[v] + col0, gb + (size_t)v * ld * world + (size_t)r * ld,
                                            (size_t)nl * sizeof(double), hipMemcpyDeviceToHost, cs);
@@ -225,13 +225,9 @@ struct LogwBatchEngine {
             ga.bound[a] = p.bound;
         }
         launch_gram(c, ga);
-        if (c->world > 1) {                       // ship 39 totals per problem, not 39 x blocks partials
-            launch_gram_rank_reduce(c, ga.n);
-            note(exchange(c, X_GRAMR, (size_t)kGramDots * ga.n));
-        } else {                                  // one rank: nothing to do unless the exchanges are forced (tests)
-            note(exchange(c, X_GRAM, (size_t)kGramDots * ga.n * vec_grid(c)));
-        }
-        launch_gram_solve(c, ga);
+        launch_gram_rank_reduce(c, ga.n);         // the local segments' totals: 39 per problem and segment (sharded: what is shipped)
+        note(exchange(c, X_GRAMR, (size_t)kGramDots * ga.n));
+        launch_gram_solve(c, ga);                 // ... added in segment order, on one GPU as on eight
         launch_combine(c, ga);
         for (int s : list) {
             slots[s].need_direction = false;

@@ -45,7 +45,14 @@ void launch_p2p_exchange(bioen_hip_ctx* c, int stage, size_t payload);
 void launch_xch_fill(bioen_hip_ctx* c, int stage, int payload, int rep);    // self-test of a transport: pattern in, ...
 void launch_xch_check(bioen_hip_ctx* c, int stage, int payload, int rep, unsigned long long* bad);   // ... every segment checked
 
-int vec_grid(const bioen_hip_ctx* c);   // blocks used by every N-vector kernel of this context
+int vec_grid(const bioen_hip_ctx* c);   // blocks PER SEGMENT of every N-vector kernel of this context (a function of segcols and
+                                        // nseg alone: the same on 1, 2, 4 and 8 GPUs)
+int vec_blocks(const bioen_hip_ctx* c); // ... and their grid: vec_grid x the segments this context holds
+struct SegMap {                         // what an N-vector kernel without a stage view needs to walk its segment
+    int npl, segcols;
+};
+SegMap seg_map(const bioen_hip_ctx* c);
+void rank_columns(const bioen_hip_ctx* c, int rank, long long* col0, long long* n_local);   // columns of `rank` in this context's decomposition
 int rows_grid(const bioen_hip_ctx* c);
 
 // ---- matrix streaming kernels ------------------------------------------------
@@ -74,11 +81,29 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const stru
 //   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
 constexpr int kFusedBlocks = 1024;
+// Canonical partial sets of the row-sum strip passes (the log-weights forward pass, both forces passes).  Per SEGMENT
+// (ctx.hpp): its sps strips are dealt to gs groups (group g: strips g, g + gs, ...), a group's strips are cut into nch
+// chunks of tc consecutive ones, and a SET is the matrix-core accumulation chain over one chunk, from zero, in strip
+// order -- a function of (segcols, M) alone.  The log-weights sums are then formed as
+//     segment share = fixed tree over its groups of [ the group's chunks added in turn from +0.0 ],
+// the forces sums as the online-softmax merge over the segment's sets in set order.  How many sets one block runs is
+// a matter of the GPU count, not of the result: on 8 GPUs a block runs one chunk (gs x nch = a full grid per segment);
+// a context that holds all 8 segments lets the forward kernel run whole groups and add up their chunks in registers
+// (fold: one set per group reaches memory, and 256 blocks sweep the matrix exactly as before r05).
+struct StripSets {
+    int sps, gs, tc, nch;
+    int fold;           // 1: one physical slot per group, chunks folded in the kernel; 0: one per chunk
+    int slots;          // physical slots per segment = gs * (fold ? 1 : nch)
+    int sets;           // sets per segment that reach memory = slots
+};
+StripSets strip_sets(const bioen_hip_ctx* c);      // log-weights forward pass
+StripSets forces_sets(const bioen_hip_ctx* c);     // forces passes (never folded); gs = 0: the strip passes do not apply
+constexpr int kPartStride = 8192;                  // entries per local partial array (ctx.hpp: PartSlot): sets of a context
 void launch_read_probe(bioen_hip_ctx* c, const double* p, size_t doubles, double* out);   // bench: measured read ceiling
 // forces engine: the round's gradients and scalars straight into the host's page, then the round number into its flag
 void launch_forces_publish(bioen_hip_ctx* c, int ngrad, unsigned long long round);
 bool strip_panels(const bioen_hip_ctx* c);             // M > 1024: the strip kernels run over row panels
-int forces_fused_blocks(const bioen_hip_ctx* c);       // 0 when the context does not qualify
+int forces_fused_blocks(const bioen_hip_ctx* c);       // sets per segment of the forces strip passes; 0 when the context does not qualify
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
@@ -91,10 +116,7 @@ int ensure_rowmajor(bioen_hip_ctx* c);                 // the row-major matrix b
 int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, double* out);   // -> device out[rows][cols]
 int ensure_strip_copy_colsum(bioen_hip_ctx* c);        // builds ctx->Ys1 (column-sum operand order) on first use
 void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk, bool plain = false);
-void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk, bool tposed = false);
-int forces_fused_blocks_old(const bioen_hip_ctx* c);   // r01 strip kernels (A/B only)
-void launch_forces_xy_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
-void launch_forces_bt_old(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
+void launch_forces_blockmerge(bioen_hip_ctx* c, const struct ForcesRound& fr, int seg_sets, bool tposed = true);
 void launch_forces_grad_sum_ranks(bioen_hip_ctx* c, int K);                     //          shares -> gm
 // adjoint: out_a[j] = sum_i (Y[i][j] - [centred] ybar_c[i*K+a]) u_c[i*K+a]
 void launch_adj(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, bool centred = false);
@@ -220,7 +242,7 @@ struct DevSlot {                      // one per problem slot, device memory (ct
     int pad;
 };
 
-constexpr int kLiveRec = 48;          // doubles per published record
+constexpr int kLiveRec = 56;          // doubles per published record
 struct DevRecord {                    // what a decision publishes per position and round (host-mapped page)
     double scal[kScalStride];         // the problem's scalar slot (chi^2, KL pieces, ...) as it stands
     double* x; double* xp; double* g; double* gp;   // the roles after the decision

@@ -145,9 +145,8 @@ __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) 
         for (int c = 0; c < kBasis; ++c) cf[c] = coef[c];
     }
     double mx = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
-    const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);   // 16-byte pairs; vectors are zero-padded to an even length
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         d2 dv;
         if (combine) {
             const d2 gv = *reinterpret_cast<const d2*>(gn + j);
@@ -173,18 +172,18 @@ __global__ __launch_bounds__(kBlock) void k_dev_step(DevRound r, int n, Xch xo) 
         const d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
         st_vec<POLICY>(x + j, v);
         mx = fmax(mx, v.x);
-        if (j + 1 < n) mx = fmax(mx, v.y);
+        if (j + 1 < sp.jend) mx = fmax(mx, v.y);
         if (x1) {
             const d2 u = {fma(stp1, dv.x, pv.x), fma(stp1, dv.y, pv.y)};
             st_vec<POLICY>(x1 + j, u);
             mx1 = fmax(mx1, u.x);
-            if (j + 1 < n) mx1 = fmax(mx1, u.y);
+            if (j + 1 < sp.jend) mx1 = fmax(mx1, u.y);
         }
         if (x2) {
             const d2 u = {fma(stp2, dv.x, pv.x), fma(stp2, dv.y, pv.y)};
             st_vec<POLICY>(x2 + j, u);
             mx2 = fmax(mx2, u.x);
-            if (j + 1 < n) mx2 = fmax(mx2, u.y);
+            if (j + 1 < sp.jend) mx2 = fmax(mx2, u.y);
         }
     }
     mx = block_max(mx, sh);
@@ -208,16 +207,15 @@ __global__ __launch_bounds__(kBlock) void k_dev_exp(DevRound r, const double* __
     if (!dev_pos_live(r, a, &ost)) return;
     const double* __restrict__ x = r.tab[r.slot[a]].x;
     double* __restrict__ e = r.w[a];
-    const double gmax = xmax_local<1>(xmx, a, 0, sh);
+    const double gmax = xmax_local<1>(xmx, a, 0);
     double s = 0.0, pp = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 xv = *reinterpret_cast<const d2*>(x + j);
         const d2 Gv = *reinterpret_cast<const d2*>(G + j);
         d2 ev;
         ev.x = exp(xv.x - gmax);
-        ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
+        ev.y = (j + 1 < sp.jend) ? exp(xv.y - gmax) : 0.0;
         st_vec<POLICY>(e + j, ev);
         s += ev.x;
         pp = fma(ev.x, xv.x - Gv.x, pp);
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_exp(DevRound r, const double* __
     if (threadIdx.x == 0) {
         xput<3>(xo, a, 0, s);
         xput<3>(xo, a, 1, pp);
-        if (blockIdx.x == 0) xput<3>(xo, a, 2, gmax);
+        if (sp.b == 0) xput<3>(xo, a, 2, gmax);
     }
 }
 
@@ -255,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
     double* __restrict__ g = P.g;
     const double theta = r.theta[a];
     const double Pp = r.scal[a][S_P];
-    const double inv = r.scal[a][S_INV];      // w = e * inv
+    const SegPos sp = seg_pos(xg.npl, xg.segcols, n);
+    const double inv = r.scal[a][S_INV + sp.v];      // w = e * inv (the segment's own shift)
     // the evaluation of the start point has no pair to form; a shadow's is formed only if it is adopted AND accepted
     // (k_dev_late_gram): 14 vector passes per shadow and round for a pair that is used once in ten rounds -- unless the
     // round says otherwise (r.sgram: sharded contexts, where those passes are short and the late pass costs an all-gather)
@@ -276,9 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
     double acc[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xg.npl)) {
         const d2 xv = *reinterpret_cast<const d2*>(x + j);
         d2 wv = ld_hist<POLICY>(w + j);                        // pad: e = 0  =>  g = 0  (e and a: read for the last time)
         wv.x *= inv;
@@ -336,44 +333,32 @@ __global__ __launch_bounds__(kBlock) void k_dev_grad_gram(DevRound r, const doub
         __syncthreads();
         if (threadIdx.x < kGramDots) {
             const double v = (shg[0][threadIdx.x] + shg[1][threadIdx.x]) + (shg[2][threadIdx.x] + shg[3][threadIdx.x]);
-            xm.base[(size_t)xm.rank * xm.payload + (size_t)(a * kGramDots + threadIdx.x) * xm.npl + blockIdx.x] = v;
+            xput<kGramDots>(xm, a, (int)threadIdx.x, v);
         }
     }
 }
 
-// k_gram_reduce for the positions of a device round (many partials per sum: one block per (sum, position))
-__global__ __launch_bounds__(kBlock) void k_dev_gram_reduce(DevRound r, Xch xi) {
-    __shared__ double sh[kWaves];
-    const int c = blockIdx.x, a = blockIdx.y;
-    int ost;
-    if (!dev_pos_live(r, a, &ost) || ost != DS_RUNNING || (r.cand[a] != 0 && !r.sgram)) return;
-    const double v = xsum<kGramDots>(xi, a, c, sh);
-    if (threadIdx.x == 0) r.gram[a][kGramSums + c] = v;
-}
-
-// Sharded contexts: one block per (sum, position) totals THIS rank's block partials of the 39 Gram products and of
-// g.d, g.g, x.x into the compact X_GRAMR stage -- ONE all-gather of 42 doubles per position and rank then serves both
-// the line-search decision and the direction (the host-driven engine exchanges the gradient's sums and the Gram
-// products separately: three all-gathers per round instead of two).
-__global__ __launch_bounds__(kBlock) void k_dev_rank_reduce(DevRound r, Xch xg, Xch xm, Xch xo) {
-    __shared__ double sh[kWaves];
-    const int c = blockIdx.x, a = blockIdx.y;
+// One wave per (sum, position, local segment) totals the segment's block partials of the 39 Gram products and of
+// g.d, g.g, x.x into the compact X_GRAMR stage (wave_seg_total: THE sum of a segment's partials): 42 doubles per position
+// and segment serve both the line-search decision and the direction -- on sharded contexts after ONE all-gather (the
+// host-driven engine exchanges the gradient's sums and the Gram products separately: three all-gathers per round
+// instead of two), on one GPU straight away: the decision reads the same numbers in the same order either way.
+__global__ void k_dev_rank_reduce(DevRound r, Xch xg, Xch xm, Xch xo) {
+    const int c = blockIdx.x, a = blockIdx.y, v = threadIdx.x >> 6;
     int ost;
     if (!dev_pos_live(r, a, &ost)) return;
-    double v = 0.0;
+    double t = 0.0;
     if (c < kGramDots) {
-        if (ost == DS_RUNNING && (r.cand[a] == 0 || r.sgram)) v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
+        if (ost == DS_RUNNING && (r.cand[a] == 0 || r.sgram)) t = xsum_seg<kGramDots>(xm, xm.rank + v, a, c);
     } else {
-        v = xsum_rank<3>(xg, xg.rank, a, c - kGramDots, sh);
+        t = xsum_seg<3>(xg, xg.rank + v, a, c - kGramDots);
     }
-    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kDevRankSums + c] = v;
+    if ((threadIdx.x & 63) == 0) xo.base[(size_t)(xo.rank + v) * xo.payload + (size_t)a * kDevRankSums + c] = t;
 }
 
-// sum over the ranks' totals (rank order: identical on every rank); every thread computes it for itself
+// sum over the segments' totals (segment order: identical on every rank and GPU count); every thread computes it for itself
 __device__ __forceinline__ double dev_ranks_sum(const Xch& xr, int a, int c) {
-    double s = 0.0;
-    for (int rk = 0; rk < xr.world; ++rk) s += xr.base[(size_t)rk * xr.payload + (size_t)a * kDevRankSums + c];
-    return s;
+    return seg_order_sum(xr.base + (size_t)a * kDevRankSums + c, (size_t)xr.payload, xr.world);
 }
 
 // d = -gp and the partials of gp . d for the owners in `mask` whose start point was not already minimal
@@ -387,9 +372,8 @@ __global__ __launch_bounds__(kBlock) void k_dev_first_direction(DevRound r, int 
     double* __restrict__ d = r.d[a];
     const double* __restrict__ gp = T.gp;
     double acc = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xdgi.npl, xdgi.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xdgi.npl)) {
         const d2 gv = *reinterpret_cast<const d2*>(gp + j);
         d2 dv;
         dv.x = -gv.x;
@@ -403,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_first_direction(DevRound r, int 
 }
 
 __global__ __launch_bounds__(kBlock) void k_dev_store_dginit(DevRound r, int mask, Xch xd) {
-    __shared__ double sh[kWaves];
+    __shared__ double sh[kShRed];
     const int a = blockIdx.y;
     if (!((mask >> a) & 1)) return;
     if (r.tab[r.slot[a]].status != DS_RUNNING) return;
@@ -424,57 +408,24 @@ __global__ __launch_bounds__(kBlock) void k_dev_store_dginit(DevRound r, int mas
 //     k_dev_step forms d;
 //   * publish the problem's record into the round's page of the host-mapped ring, then the round number into its flag.
 // `spec` counts adopted shadows (device word, read by the host at the end of the run).
-// MODE 0: few block partials per sum, finished in-block; 1: k_dev_gram_reduce has left the Gram sums; 2: sharded
-// context, every sum = the ranks' totals out of the X_GRAMR stage (`xm`).
+// Every sum = the segments' totals out of the X_GRAMR stage (`xm`: k_dev_rank_reduce, and on sharded contexts the
+// all-gather behind it), added in segment order.
 //
 // Latency, not work, is what this kernel costs (one block per problem; its predecessor version took 15 us of a 160 us
 // round at N = 1e5 x M = 256): the problem's table entry, its scalar slot, the Gram matrix and ALL 42 sums of the
 // evaluation are fetched up front, side by side, into LDS -- one memory round trip -- and the single thread that then
 // walks the decision, the Gram update and the two-loop recursion touches LDS only; the entry is written back by the
 // whole block.  The sums are formed in the order of xsum / k_gram_solve: not a bit changes.
-__device__ __forceinline__ void dev_three_sums(const Xch& xg, int a, double (*sh3)[kWaves], double* out) {
-    // xsum<3> for q = 0, 1, 2 at once: per thread the partials k = t, t + 256, ... in turn, wave_sum, then the
-    // block's four wave totals as (w0 + w1) + (w2 + w3) -- block_sum's order
-    double s[3] = {0.0, 0.0, 0.0};
-    for (int rk = 0; rk < xg.world; ++rk)
-        for (int k = threadIdx.x; k < xg.npl; k += kBlock) {
-            double v[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) v[q] = xg.base[(size_t)rk * xg.payload + (size_t)(a * 3 + q) * xg.npl + k];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) s[q] += v[q];
-        }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) s[q] = wave_sum(s[q]);
-    __syncthreads();   // protect sh3 against its previous use
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) sh3[q][threadIdx.x >> 6] = s[q];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 3; ++q) out[q] = (sh3[q][0] + sh3[q][1]) + (sh3[q][2] + sh3[q][3]);
-}
-
-template <int MODE>
-__device__ __forceinline__ void dev_gram_dots(const DevRound& r, const Xch& xm, int pos, double* dots) {
-    if (MODE == 2) {
-        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = dev_ranks_sum(xm, pos, i);
-    } else if (MODE == 0) {
-        fused_gram_dots(xm, pos, dots);          // as k_gram_solve<true>
-    } else {
-        const double* Gq = r.gram[pos];
-        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = Gq[kGramSums + i];
-    }
+__device__ __forceinline__ void dev_gram_dots(const Xch& xm, int pos, double* dots) {
+    for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = dev_ranks_sum(xm, pos, i);
 }
 
 constexpr int kSlotWords = (int)(sizeof(DevSlot) / sizeof(unsigned long long));
 static_assert(sizeof(DevSlot) % sizeof(unsigned long long) == 0, "DevSlot is copied in 8-byte words");
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_config cfg, Xch xg, Xch xm,
+__global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_config cfg, Xch xm,
                                                        double* __restrict__ page, unsigned long long* __restrict__ flags,
                                                        unsigned long long round, unsigned long long* __restrict__ spec) {
-    __shared__ double sh3[3][kWaves];
     __shared__ double dots[kGramDots];
     __shared__ double Gs[kBasis * kBasis + kBasis];   // the Gram matrix | the direction's 13 coefficients
     __shared__ double alpha[kHistory];
@@ -500,17 +451,13 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
     if (threadIdx.x < kScalStride) scs[threadIdx.x] = scg[threadIdx.x];
     for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
     double sums[3];
-    if (MODE == 2) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sums[q] = dev_ranks_sum(xm, a, kGramDots + q);
-        __syncthreads();
-    } else {
-        dev_three_sums(xg, a, sh3, sums);     // (two barriers: Tw, scs, Gs are in place after it)
-    }
+    for (int q = 0; q < 3; ++q) sums[q] = dev_ranks_sum(xm, a, kGramDots + q);
+    __syncthreads();                          // Tw, scs, Gs are in place
     DSTAMP()                                                                     // 1: loads + three sums
     const int status = T.status;
     const bool alive = dev_alive(status);
-    if (alive && status == DS_RUNNING) dev_gram_dots<MODE>(r, xm, a, dots);      // block-uniform
+    if (alive && status == DS_RUNNING) dev_gram_dots(xm, a, dots);               // block-uniform
     DSTAMP()                                                                     // 2: gram dots
     int kind = ACT_DONE, evalpos = a;
     bool dirty = false;
@@ -551,13 +498,10 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
         __syncthreads();
         const int adopt = ctl[1];
         if (adopt >= 0) {                      // block-uniform, rare: the shadow's sums are fetched now
-            if (MODE == 2) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) sums[q] = dev_ranks_sum(xm, adopt, kGramDots + q);
-            } else {
-                dev_three_sums(xg, adopt, sh3, sums);
-            }
-            if (r.sgram) dev_gram_dots<MODE>(r, xm, adopt, dots);     // the shadow swept its own pair: its 39 products
+            for (int q = 0; q < 3; ++q) sums[q] = dev_ranks_sum(xm, adopt, kGramDots + q);
+            __syncthreads();                                       // (dots: every thread has read the owner's)
+            if (r.sgram) dev_gram_dots(xm, adopt, dots);           // the shadow swept its own pair: its 39 products
             if (threadIdx.x == 0) {
                 DevSlot* Q = r.tab + r.slot[adopt];           // the shadow's entry (nobody else touches it in this kernel)
                 double* t;
@@ -572,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_decide(DevRound r, bioen_lbfgs_c
                 for (int i = S_F; i < S_F + 4; ++i) scs[i] = qs[i];
                 for (int i = S_LOGS; i < S_LOGS + 4; ++i) scs[i] = qs[i];
                 for (int i = S_KL; i < S_KL + 2; ++i) scs[i] = qs[i];
-                for (int i = S_INV; i < S_INV + 3; ++i) scs[i] = qs[i];
+                for (int i = S_INV; i < S_INV + kMaxSeg + 2; ++i) scs[i] = qs[i];      // S_INV[kMaxSeg], S_B0, S_UY
                 scs[S_DG] = sums[0];
                 scs[S_GG] = sums[1];
                 scs[S_XX] = sums[2];
@@ -680,9 +624,8 @@ __global__ __launch_bounds__(kBlock) void k_dev_late_gram(DevRound r, int n, Xch
     double acc[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 a0 = *reinterpret_cast<const d2*>(xn + j), a1 = *reinterpret_cast<const d2*>(xo_ + j);
         const d2 gv = *reinterpret_cast<const d2*>(gn + j), g1 = *reinterpret_cast<const d2*>(go + j);
         const d2 sv = {a0.x - a1.x, a0.y - a1.y};
@@ -712,26 +655,22 @@ __global__ __launch_bounds__(kBlock) void k_dev_late_gram(DevRound r, int n, Xch
     __syncthreads();
     if (threadIdx.x < kGramDots) {
         const double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-        xo.base[(size_t)xo.rank * xo.payload + (size_t)(a * kGramDots + threadIdx.x) * xo.npl + blockIdx.x] = v;
+        xput<kGramDots>(xo, a, (int)threadIdx.x, v);
     }
 }
 
-// sharded: this rank's totals of the late sweep's 39 products -> X_GRAMR (the 3 gradient sums are not needed again)
-__global__ __launch_bounds__(kBlock) void k_dev_late_rank_reduce(DevRound r, Xch xm, Xch xo) {
-    __shared__ double sh[kWaves];
-    const int c = blockIdx.x, a = blockIdx.y;
+// the local segments' totals of the late sweep's 39 products -> X_GRAMR (the 3 gradient sums are not needed again)
+__global__ void k_dev_late_rank_reduce(DevRound r, Xch xm, Xch xo) {
+    const int c = blockIdx.x, a = blockIdx.y, v = threadIdx.x >> 6;
     const DevSlot& T = r.tab[r.slot[a]];
     if (T.status != DS_RUNNING || T.combine != 2) return;
-    const double v = xsum_rank<kGramDots>(xm, xm.rank, a, c, sh);
-    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kDevRankSums + c] = v;
+    const double t = xsum_seg<kGramDots>(xm, xm.rank + v, a, c);
+    if ((threadIdx.x & 63) == 0) xo.base[(size_t)(xo.rank + v) * xo.payload + (size_t)a * kDevRankSums + c] = t;
 }
 
-// ... and the recursion (k_gram_solve).  The 39 sums are formed in the order the decision kernel of this context forms
-// them (MODE as k_dev_decide; 1 = xsum's order, the one k_dev_gram_reduce / k_gram_reduce use), so a direction does not
-// depend on whether its step came out of a shadow.
-template <int MODE>
+// ... and the recursion (k_gram_solve).  The 39 sums are formed as the decision kernel forms them (the segments' totals
+// in segment order), so a direction does not depend on whether its step came out of a shadow.
 __global__ __launch_bounds__(kBlock) void k_dev_late_solve(DevRound r, Xch xm) {
-    __shared__ double sh[kWaves];
     __shared__ double dots[kGramDots];
     __shared__ double Gs[kBasis * kBasis];
     __shared__ double alpha[kHistory];
@@ -740,14 +679,7 @@ __global__ __launch_bounds__(kBlock) void k_dev_late_solve(DevRound r, Xch xm) {
     if (T.status != DS_RUNNING || T.combine != 2) return;
     double* G = r.gram[a];
     for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
-    if (MODE == 1) {
-        for (int c = 0; c < kGramDots; ++c) {
-            const double v = xsum<kGramDots>(xm, a, c, sh);
-            if (threadIdx.x == 0) dots[c] = v;
-        }
-    } else {
-        dev_gram_dots<MODE>(r, xm, a, dots);
-    }
+    dev_gram_dots(xm, a, dots);
     __syncthreads();
     if (threadIdx.x == 0) {
         gram_solve_thread0(G, Gs, dots, alpha, T.late_end, T.late_bound, r.scal[a]);
@@ -774,81 +706,67 @@ void launch_dev_table_init(bioen_hip_ctx* c, int nslots) {
 }
 
 void launch_dev_start(bioen_hip_ctx* c, const DevStart& s, const bioen_lbfgs_config& cfg) {
-    hipLaunchKernelGGL(k_dev_start, dim3(vec_grid(c), s.n), dim3(kBlock), 0, c->stream, s, cfg, (int)(c->ld / 2));
+    hipLaunchKernelGGL(k_dev_start, dim3(vec_blocks(c), s.n), dim3(kBlock), 0, c->stream, s, cfg, (int)(c->ld / 2));
 }
 
 void launch_dev_step(bioen_hip_ctx* c, const DevRound& r) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_step<true>, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_step<true>, dim3(vec_blocks(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
                                        make_xch(c, X_MAX, r.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_dev_step<false>, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
+    else hipLaunchKernelGGL(k_dev_step<false>, dim3(vec_blocks(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n,
                             make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_dev_exp(bioen_hip_ctx* c, const DevRound& r) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_exp<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_exp<true>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                                        make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_dev_exp<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    else hipLaunchKernelGGL(k_dev_exp<false>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                             make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
 void launch_dev_grad_gram(bioen_hip_ctx* c, const DevRound& r) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_grad_gram<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_dev_grad_gram<true>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                                        make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_dev_grad_gram<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    else hipLaunchKernelGGL(k_dev_grad_gram<false>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                             make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)));
 }
 
-int dev_all_fused(const bioen_hip_ctx* c) { return (long long)vec_grid(c) * c->world <= 256; }
+int dev_all_fused(const bioen_hip_ctx*) { return 0; }      // (r05: every context finishes its sums from the segments' totals)
 
-static Xch dev_rank_view(const bioen_hip_ctx* c, int n) {      // X_GRAMR: 42 values per (rank, position)
+static Xch dev_rank_view(const bioen_hip_ctx* c, int n) {      // X_GRAMR: 42 values per (segment, position)
     Xch x = make_xch(c, X_GRAMR, kDevRankSums * n);
     x.npl = 1;
     return x;
 }
 
 void launch_dev_rank_reduce(bioen_hip_ctx* c, const DevRound& r) {
-    hipLaunchKernelGGL(k_dev_rank_reduce, dim3(kDevRankSums, r.n), dim3(kBlock), 0, c->stream, r,
+    hipLaunchKernelGGL(k_dev_rank_reduce, dim3(kDevRankSums, r.n), dim3(64 * c->vr), 0, c->stream, r,
                        make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)), make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c)),
                        dev_rank_view(c, r.n));
 }
 
 void launch_dev_decide(bioen_hip_ctx* c, const DevRound& r, const bioen_lbfgs_config& cfg, unsigned long long round) {
-    const Xch xg = make_xch(c, X_GRAD, 3 * r.n * vec_grid(c));
-    const Xch xm = make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c));
     const int pg = (int)(round % kLiveRing);
     double* page = c->live2 + (size_t)pg * kMaxBatch * kLiveRec;
     unsigned long long* flags =
         reinterpret_cast<unsigned long long*>(c->live2 + (size_t)kLiveRing * kMaxBatch * kLiveRec) + (size_t)pg * kMaxBatch;
     unsigned long long* spec = reinterpret_cast<unsigned long long*>(static_cast<DevSlot*>(c->dev_tab) + kMaxBatch);
-    const dim3 grid(1, r.nown), block(kBlock);
-    if (c->world > 1) {                                  // the ranks' totals (after the X_GRAMR exchange)
-        hipLaunchKernelGGL(k_dev_decide<2>, grid, block, 0, c->stream, r, cfg, xg, dev_rank_view(c, r.n), page, flags, round, spec);
-    } else if (dev_all_fused(c)) {
-        hipLaunchKernelGGL(k_dev_decide<0>, grid, block, 0, c->stream, r, cfg, xg, xm, page, flags, round, spec);
-    } else {
-        hipLaunchKernelGGL(k_dev_gram_reduce, dim3(kGramDots, r.n), block, 0, c->stream, r, xm);
-        hipLaunchKernelGGL(k_dev_decide<1>, grid, block, 0, c->stream, r, cfg, xg, xm, page, flags, round, spec);
-    }
+    hipLaunchKernelGGL(k_dev_decide, dim3(1, r.nown), dim3(kBlock), 0, c->stream, r, cfg, dev_rank_view(c, r.n), page, flags,
+                       round, spec);
 }
 
 void launch_dev_late_gram(bioen_hip_ctx* c, const DevRound& r) {
     const Xch xm = make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c));
-    hipLaunchKernelGGL(k_dev_late_gram, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n, xm);
-    if (c->world > 1)
-        hipLaunchKernelGGL(k_dev_late_rank_reduce, dim3(kGramDots, r.nown), dim3(kBlock), 0, c->stream, r, xm,
-                           dev_rank_view(c, r.n));
+    hipLaunchKernelGGL(k_dev_late_gram, dim3(vec_blocks(c), r.nown), dim3(kBlock), 0, c->stream, r, c->n, xm);
+    hipLaunchKernelGGL(k_dev_late_rank_reduce, dim3(kGramDots, r.nown), dim3(64 * c->vr), 0, c->stream, r, xm,
+                       dev_rank_view(c, r.n));
 }
 
 void launch_dev_late_solve(bioen_hip_ctx* c, const DevRound& r) {
-    const Xch xm = make_xch(c, X_GRAM, kGramDots * r.n * vec_grid(c));
-    const dim3 grid(1, r.nown), block(kBlock);
-    if (c->world > 1) hipLaunchKernelGGL(k_dev_late_solve<2>, grid, block, 0, c->stream, r, dev_rank_view(c, r.n));
-    else if (dev_all_fused(c)) hipLaunchKernelGGL(k_dev_late_solve<0>, grid, block, 0, c->stream, r, xm);
-    else hipLaunchKernelGGL(k_dev_late_solve<1>, grid, block, 0, c->stream, r, xm);
+    hipLaunchKernelGGL(k_dev_late_solve, dim3(1, r.nown), dim3(kBlock), 0, c->stream, r, dev_rank_view(c, r.n));
 }
 
 void launch_dev_first_direction(bioen_hip_ctx* c, const DevRound& r, int mask) {
-    hipLaunchKernelGGL(k_dev_first_direction, dim3(vec_grid(c), r.nown), dim3(kBlock), 0, c->stream, r, mask, c->n,
+    hipLaunchKernelGGL(k_dev_first_direction, dim3(vec_blocks(c), r.nown), dim3(kBlock), 0, c->stream, r, mask, c->n,
                        make_xch(c, X_DGI, r.nown * vec_grid(c)));
 }
 

@@ -20,15 +20,14 @@ __global__ __launch_bounds__(kBlock) void k_trial(Round r, int n, Xch xo) {
     const double* __restrict__ d = r.d[a];
     const double stp = r.stp[a];
     double mx = -DBL_MAX;
-    const int n2 = (n + 1) >> 1;   // 16-byte pairs; vectors are zero-padded to an even length
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);   // 16-byte pairs; vectors are zero-padded to an even length
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 dv = ld_vec(d + j);
         const d2 pv = ld_vec(xp + j);
         d2 v = {fma(stp, dv.x, pv.x), fma(stp, dv.y, pv.y)};
         st_vec<POLICY>(x + j, v);
         mx = fmax(mx, v.x);
-        if (j + 1 < n) mx = fmax(mx, v.y);
+        if (j + 1 < sp.jend) mx = fmax(mx, v.y);
     }
     mx = block_max(mx, sh);
     if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
@@ -39,16 +38,16 @@ __global__ __launch_bounds__(kBlock) void k_max(Round r, int n, Xch xo) {
     const int a = blockIdx.y;
     const double* __restrict__ x = r.x[a];
     double mx = -DBL_MAX;
-    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) mx = fmax(mx, x[j]);
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = sp.j0 + sp.b * kBlock + threadIdx.x; j < sp.jend; j += xo.npl * kBlock) mx = fmax(mx, x[j]);
     mx = block_max(mx, sh);
     if (threadIdx.x == 0) xput<1>(xo, a, 0, mx);
 }
 
 // _get_weights (c_bioen_kernels_logw.c:55-94) with a max shift, first half:
 //   e_j = exp(x_j - m_r) ; partials of sum e and sum e (x - G)   (prior, :96-127)
-// m_r is the maximum over THIS rank's structures (its own block maxima need no exchange); it
-// travels with the sums (third array, entry 0) and k_logw_norm rescales by exp(m_r - max_r m_r),
-// which is exactly 1 on a single GPU.
+// m_v is the maximum over the structures of the block's SEGMENT (its own block maxima need no exchange); it
+// travels with the sums (third array, entry 0) and the consumers rescale by exp(m_v - max_v m_v).
 template <bool POLICY>
 __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __restrict__ G, int n, Xch xmx,
                                                      Xch xo) {
@@ -56,16 +55,15 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
     const int a = blockIdx.y;
     const double* __restrict__ x = r.x[a];
     double* __restrict__ e = r.w[a];
-    const double gmax = xmax_local<1>(xmx, a, 0, sh);
+    const double gmax = xmax_local<1>(xmx, a, 0);
     double s = 0.0, pp = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 xv = ld_vec(x + j);
         const d2 Gv = ld_vec(G + j);
         d2 ev;
         ev.x = exp(xv.x - gmax);
-        ev.y = (j + 1 < n) ? exp(xv.y - gmax) : 0.0;
+        ev.y = (j + 1 < sp.jend) ? exp(xv.y - gmax) : 0.0;
         st_vec<POLICY>(e + j, ev);
         s += ev.x;
         pp = fma(ev.x, xv.x - Gv.x, pp);
@@ -77,43 +75,35 @@ __global__ __launch_bounds__(kBlock) void k_logw_exp(Round r, const double* __re
     if (threadIdx.x == 0) {
         xput<3>(xo, a, 0, s);
         xput<3>(xo, a, 1, pp);
-        if (blockIdx.x == 0) xput<3>(xo, a, 2, gmax);
+        if (sp.b == 0) xput<3>(xo, a, 2, gmax);
     }
 }
 
 // second half: w = e / S ; scal[S_LOGS] = max + log S ; scal[S_P] = sum e (x-G) / S
 __global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
-    __shared__ double sh[kWaves];
     const int a = blockIdx.y;
     double* __restrict__ w = r.w[a];
-    // global shift M = max_r m_r ; S = sum_r e^{m_r - M} S_r   (rank order; e^0 = 1 on one GPU)
+    const SegPos sp = seg_pos(xe.npl, xe.segcols, n);
+    // global shift M = max_v m_v ; S = sum_v e^{m_v - M} S_v   (segment order)
     double gmax = -DBL_MAX;
-    for (int rk = 0; rk < xe.world; ++rk)
-        gmax = fmax(gmax, xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl]);
-    double S = 0.0;
-    for (int rk = 0; rk < xe.world; ++rk) {
-        const double mr = xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
-        S = fma(exp(mr - gmax), xsum_rank<3>(xe, rk, a, 0, sh), S);
+    for (int sg = 0; sg < xe.world; ++sg) gmax = fmax(gmax, xseg_ptr<3>(xe, sg, a, 2)[0]);
+    double S = 0.0, PP = 0.0;
+    for (int sg = 0; sg < xe.world; ++sg) {
+        const double fr = exp(xseg_ptr<3>(xe, sg, a, 2)[0] - gmax);
+        S = fma(fr, xsum_seg<3>(xe, sg, a, 0), S);
+        PP = fma(fr, xsum_seg<3>(xe, sg, a, 1), PP);
     }
-    const double mown = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+    const double mown = xseg_ptr<3>(xe, xe.rank + sp.v, a, 2)[0];
     const double inv = exp(mown - gmax) / S;
-    if (blockIdx.x == 0) {
-        double PP = 0.0;
-        for (int rk = 0; rk < xe.world; ++rk) {
-            const double mr = xe.base[(size_t)rk * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
-            PP = fma(exp(mr - gmax), xsum_rank<3>(xe, rk, a, 1, sh), PP);
-        }
-        if (threadIdx.x == 0) {
-            r.scal[a][S_LOGS] = gmax + log(S);
-            r.scal[a][S_P] = PP * (1.0 / S);
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        r.scal[a][S_LOGS] = gmax + log(S);
+        r.scal[a][S_P] = PP * (1.0 / S);
     }
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        d2 v = *reinterpret_cast<const d2*>(w + 2 * p);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xe.npl)) {
+        d2 v = *reinterpret_cast<const d2*>(w + j);
         v.x *= inv;
-        v.y = (2 * p + 1 < n) ? v.y * inv : 0.0;      // the padding stays zero whatever the factor (see k_scale_w)
-        *reinterpret_cast<d2*>(w + 2 * p) = v;
+        v.y = (j + 1 < sp.jend) ? v.y * inv : 0.0;      // the padding stays zero whatever the factor (see k_scale_w)
+        *reinterpret_cast<d2*>(w + j) = v;
     }
 }
 
@@ -122,10 +112,12 @@ __global__ __launch_bounds__(kBlock) void k_logw_norm(Round r, int n, Xch xe) {
 // at N = 1e6, 0.6 ms per run of a K = 1 series at N = 5e5): every block of the N-vector grid leaves {max, sum of
 // exp(G - max)} of its share, one block merges them in block order -- a fixed order, and for a uniform prior
 // (G = 0: every term is exactly 1, the sums are integers) the same bits as any other order.
-__global__ __launch_bounds__(kBlock) void k_logsumexp_part(const double* __restrict__ G, int n, double* __restrict__ part) {
+__global__ __launch_bounds__(kBlock) void k_logsumexp_part(const double* __restrict__ G, int n, SegMap sm, double* __restrict__ part) {
     __shared__ double sh[kWaves];
-    const int per = (n + gridDim.x - 1) / gridDim.x;
-    const int j0 = blockIdx.x * per, j1 = min(n, j0 + per);
+    // block b of a segment takes the b-th run of ceil(segcols / npl) of its columns: part[seg * npl + b] on every GPU count
+    const SegPos sp = seg_pos(sm.npl, sm.segcols, n);
+    const int per = (sm.segcols + sm.npl - 1) / sm.npl;
+    const int j0 = sp.j0 + sp.b * per, j1 = min(sp.jend, j0 + per);
     double mx = -DBL_MAX;
     for (int j = j0 + threadIdx.x; j < j1; j += kBlock) mx = fmax(mx, G[j]);
     mx = block_max(mx, sh);
@@ -169,11 +161,10 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
     double* __restrict__ g = r.g[a];
     const double theta = r.theta[a];
     const double P = r.scal[a][S_P];
-    const double inv = r.scal[a][S_INV];      // w = e * inv
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    const double inv = r.scal[a][S_INV + sp.v];      // w = e * inv (the segment's own shift)
     double dg = 0.0, gg = 0.0, xx = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 xv = ld_vec(x + j);
         d2 wv = ld_hist<POLICY>(w + j);                        // pad: e = 0  =>  g = 0
         wv.x *= inv;
@@ -206,11 +197,11 @@ __global__ __launch_bounds__(kBlock) void k_logw_grad(Round r, const double* __r
 // system-scope fence -- the round number into the problem's flag, which the host is spinning on.
 __global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg, double* __restrict__ live,
                                                         unsigned long long round) {
-    __shared__ double sh[kWaves];
+    __shared__ double sh[3 * kShRed];
     const int a = blockIdx.y;
-    const double dg = xsum<3>(xg, a, 0, sh);
-    const double gg = xsum<3>(xg, a, 1, sh);
-    const double xx = xsum<3>(xg, a, 2, sh);
+    double sums[3];
+    xsum_multi<3, 3>(xg, a, 0, sh, sums);
+    const double dg = sums[0], gg = sums[1], xx = sums[2];
     double* sc = r.scal[a];
     if (threadIdx.x == 0) {
         sc[S_DG] = dg;
@@ -235,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_eval(Round r, Xch xg, double*
 
 // gp . d of the freshly built direction -> scal[S_DGINIT] (the next line search's initial slope)
 __global__ __launch_bounds__(kBlock) void k_store_dginit(MVec8 scal, Xch xd) {
-    __shared__ double sh[kWaves];
+    __shared__ double sh[kShRed];
     const int a = blockIdx.y;
     const double di = xsum<1>(xd, a, 0, sh);
     if (threadIdx.x == 0) scal.p[a][S_DGINIT] = di;
@@ -256,9 +247,8 @@ __global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n, Xch xo)
     double* __restrict__ s = p.s[a];
     double* __restrict__ y = p.y[a];
     double ys = 0.0, yy = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int q = blockIdx.x * kBlock + threadIdx.x; q < n2; q += gridDim.x * kBlock) {
-        const int j = 2 * q;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 xa = *reinterpret_cast<const d2*>(x + j), xb = *reinterpret_cast<const d2*>(xp + j);
         const d2 ga = *reinterpret_cast<const d2*>(g + j), gb = *reinterpret_cast<const d2*>(gp + j);
         const d2 sv = {xa.x - xb.x, xa.y - xb.y};
@@ -288,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_update_sy(PairArgs p, int n, Xch xo)
 // and in the same sweep  out_partials = vdot . d  for the next step (or gp . d, the next
 // line search's initial slope).  mode -1: this problem has no step in this launch.
 __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int n, Xch xin, Xch xsy, Xch xrec, Xch xdgi) {
-    __shared__ double sh[kWaves];
+    __shared__ double sh[kShRed];
     const int a = blockIdx.y;
     const int mode = q.mode[a];
     if (mode < 0) return;
@@ -323,9 +313,8 @@ __global__ __launch_bounds__(kBlock) void k_recur(RecurArgs q, int n, Xch xin, X
         if (scale) sc = scal[S_YS] / scal[S_YY];
     }
     double acc = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xin.npl, xin.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xin.npl)) {
         d2 dv;
         if (mode == 0) {
             const d2 gv = *reinterpret_cast<const d2*>(gp + j);
@@ -372,9 +361,8 @@ __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
     double acc[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.0;
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        const int j = 2 * p;
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
         const d2 a0 = ld_vec(xn + j), a1 = ld_vec(xo_ + j);
         const d2 gv = ld_vec(gn + j), g1 = ld_vec(go + j);
         const d2 sv = {a0.x - a1.x, a0.y - a1.y};
@@ -404,35 +392,22 @@ __global__ __launch_bounds__(kBlock) void k_gram(GramArgs q, int n, Xch xo) {
     __syncthreads();
     if (threadIdx.x < kGramDots) {
         const double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-        xo.base[(size_t)xo.rank * xo.payload + (size_t)(a * kGramDots + threadIdx.x) * xo.npl + blockIdx.x] = v;
+        xput<kGramDots>(xo, a, (int)threadIdx.x, v);
     }
 }
 
-// Per problem (one block): finish the 39 sums, update the Gram matrix, run the two-loop recursion
-// (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
-// Sharded contexts: one block per (sum, problem) totals THIS rank's block partials into the compact
-// X_GRAMR stage, so that the all-gather ships 39 doubles per problem and rank instead of 39 x npl.
-__global__ __launch_bounds__(kBlock) void k_gram_rank_reduce(Xch xi, Xch xo) {
-    __shared__ double sh[kWaves];
-    const int c = blockIdx.x, a = blockIdx.y;
-    const double v = xsum_rank<kGramDots>(xi, xi.rank, a, c, sh);
-    if (threadIdx.x == 0) xo.base[(size_t)xo.rank * xo.payload + (size_t)a * kGramDots + c] = v;
+// One wave per (sum, problem, local segment) totals the segment's block partials into the compact X_GRAMR stage
+// (39 doubles per problem and segment): what sharded contexts exchange, and what every context -- one GPU or eight --
+// finishes the sums from.
+__global__ void k_gram_rank_reduce(Xch xi, Xch xo) {
+    const int c = blockIdx.x, a = blockIdx.y, v = threadIdx.x >> 6;
+    const double t = xsum_seg<kGramDots>(xi, xi.rank + v, a, c);
+    if ((threadIdx.x & 63) == 0) xo.base[(size_t)(xo.rank + v) * xo.payload + (size_t)a * kGramDots + c] = t;
 }
 
-// One block per (sum, problem) finishes the 39 sums (gram[kGramSums + c]); a single block doing
-// all of them walks 39 x npl partials as dependent L2 loads (66 us at N = 1e6, measured).
-__global__ __launch_bounds__(kBlock) void k_gram_reduce(GramArgs q, Xch xi) {
-    __shared__ double sh[kWaves];
-    const int c = blockIdx.x, a = blockIdx.y;
-    const double v = xsum<kGramDots>(xi, a, c, sh);
-    if (threadIdx.x == 0) q.gram[a][kGramSums + c] = v;
-}
-
-// The 13x13 matrix lives in LDS while one thread walks the two loops.  FUSED: few partials per sum
-// (small or sharded problems) -- the block also finishes the 39 sums, dealt to its 4 waves, which
-// saves the k_gram_reduce launch.  The order of the additions differs between the two paths, so
-// the choice depends on (npl, world) alone: every rank and every batch width takes the same one.
-template <bool FUSED>
+// Per problem (one block): finish the 39 sums from the segments' totals (segment order), update the Gram matrix, run
+// the two-loop recursion (lbfgs.c:571-598) on coefficients, leave them in gram[169..181] and gp.d in scal[S_DGINIT].
+// The 13x13 matrix lives in LDS while one thread walks the two loops.
 __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
     __shared__ double dots[kGramDots];
     __shared__ double Gs[kBasis * kBasis];
@@ -440,11 +415,8 @@ __global__ __launch_bounds__(kBlock) void k_gram_solve(GramArgs q, Xch xi) {
     const int a = blockIdx.y;
     double* G = q.gram[a];
     for (int i = threadIdx.x; i < kBasis * kBasis; i += kBlock) Gs[i] = G[i];
-    if (FUSED) {
-        fused_gram_dots(xi, a, dots);
-    } else {
-        for (int i = threadIdx.x; i < kGramDots; i += kBlock) dots[i] = G[kGramSums + i];
-    }
+    for (int i = threadIdx.x; i < kGramDots; i += kBlock)
+        dots[i] = seg_order_sum(xi.base + (size_t)a * kGramDots + i, (size_t)xi.payload, xi.world);
     __syncthreads();
     if (threadIdx.x != 0) return;
     gram_solve_thread0(G, Gs, dots, alpha, q.end[a], q.bound[a], q.scal[a]);
@@ -485,26 +457,26 @@ __global__ __launch_bounds__(kBlock) void k_combine(GramArgs q, int n) {
 
 // ---- log-weights vector kernels -----------------------------------------------------------
 void launch_trial(bioen_hip_ctx* c, const Round& r) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_trial<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_trial<true>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
                                        make_xch(c, X_MAX, r.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_trial<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+    else hipLaunchKernelGGL(k_trial<false>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
                             make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_max(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_max, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+    hipLaunchKernelGGL(k_max, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
                        make_xch(c, X_MAX, r.n * vec_grid(c)));
 }
 
 void launch_logw_exp(bioen_hip_ctx* c, const Round& r) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_logw_exp<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_logw_exp<true>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                                        make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_logw_exp<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    else hipLaunchKernelGGL(k_logw_exp<false>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                             make_xch(c, X_MAX, r.n * vec_grid(c)), make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
 void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logw_norm, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
+    hipLaunchKernelGGL(k_logw_norm, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->n,
                        make_xch(c, X_EXP, 3 * r.n * vec_grid(c)));
 }
 
@@ -512,17 +484,17 @@ void launch_logw_norm(bioen_hip_ctx* c, const Round& r) {
 // before a run's first evaluation; sharded contexts exchange the segments between the two launches (api.hip: enqueue_logs0)
 void launch_logw_logs0_part(bioen_hip_ctx* c) {
     const int g = vec_grid(c);
-    double* part = c->xbuf[X_GRAD] + (size_t)c->rank * 2 * g;
-    hipLaunchKernelGGL(k_logsumexp_part, dim3(g), dim3(kBlock), 0, c->stream, c->fixed, c->n, part);
+    double* part = c->xbuf[X_GRAD] + (size_t)c->seg0 * 2 * g;
+    hipLaunchKernelGGL(k_logsumexp_part, dim3(vec_blocks(c)), dim3(kBlock), 0, c->stream, c->fixed, c->n, seg_map(c), part);
 }
 void launch_logw_logs0_merge(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_logsumexp_merge, dim3(1), dim3(kBlock), 0, c->stream, c->xbuf[X_GRAD], vec_grid(c) * c->world, r);
+    hipLaunchKernelGGL(k_logsumexp_merge, dim3(1), dim3(kBlock), 0, c->stream, c->xbuf[X_GRAD], vec_grid(c) * c->nseg, r);
 }
 
 void launch_logw_grad(bioen_hip_ctx* c, const Round& r) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_logw_grad<true>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_logw_grad<true>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                                        make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_logw_grad<false>, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
+    else hipLaunchKernelGGL(k_logw_grad<false>, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->fixed, c->n,
                             make_xch(c, X_GRAD, 3 * r.n * vec_grid(c)));
 }
 
@@ -540,53 +512,43 @@ void launch_store_dginit(bioen_hip_ctx* c, int k, const MVec8& scal) {
 
 // ---- L-BFGS vector kernels ----------------------------------------------------------------------
 void launch_update_sy(bioen_hip_ctx* c, const PairArgs& a, int kdir) {
-    hipLaunchKernelGGL(k_update_sy, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+    hipLaunchKernelGGL(k_update_sy, dim3(vec_blocks(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
                        make_xch(c, X_SY, 2 * kdir * vec_grid(c)));
 }
 
 void launch_recur(bioen_hip_ctx* c, const RecurArgs& a, int step) {
     const int k = a.n, g = vec_grid(c);
     // step s reads the running dot its predecessor left in REC[(s-1)&1] and writes REC[s&1]
-    hipLaunchKernelGGL(k_recur, dim3(g, k), dim3(kBlock), 0, c->stream, a, c->n,
+    hipLaunchKernelGGL(k_recur, dim3(vec_blocks(c), k), dim3(kBlock), 0, c->stream, a, c->n,
                        make_xch(c, ((step - 1) & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_SY, 2 * k * g),
                        make_xch(c, (step & 1) ? X_REC1 : X_REC0, k * g), make_xch(c, X_DGI, k * g));
 }
 
 void launch_gram(bioen_hip_ctx* c, const GramArgs& a) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_gram<true>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+    if (c->nvec_nt) hipLaunchKernelGGL(k_gram<true>, dim3(vec_blocks(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
                                        make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
-    else hipLaunchKernelGGL(k_gram<false>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
+    else hipLaunchKernelGGL(k_gram<false>, dim3(vec_blocks(c), a.n), dim3(kBlock), 0, c->stream, a, c->n,
                             make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c)));
 }
 
-static Xch gram_rank_view(const bioen_hip_ctx* c, int k) {      // X_GRAMR: one value per (rank, problem, sum)
+static Xch gram_rank_view(const bioen_hip_ctx* c, int k) {      // X_GRAMR: one value per (segment, problem, sum)
     Xch x = make_xch(c, X_GRAMR, kGramDots * k);
     x.npl = 1;
     return x;
 }
 
 void launch_gram_rank_reduce(bioen_hip_ctx* c, int k) {
-    hipLaunchKernelGGL(k_gram_rank_reduce, dim3(kGramDots, k), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL(k_gram_rank_reduce, dim3(kGramDots, k), dim3(64 * c->vr), 0, c->stream,
                        make_xch(c, X_GRAM, kGramDots * k * vec_grid(c)), gram_rank_view(c, k));
 }
 
-void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {
-    if (c->world > 1) {                                  // the ranks' totals (after the X_GRAMR exchange)
-        hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, gram_rank_view(c, a.n));
-        return;
-    }
-    const Xch xi = make_xch(c, X_GRAM, kGramDots * a.n * vec_grid(c));
-    if ((long long)vec_grid(c) * c->world <= 256) {      // <= 4 dependent loads per lane and sum
-        hipLaunchKernelGGL(k_gram_solve<true>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);
-    } else {
-        hipLaunchKernelGGL(k_gram_reduce, dim3(kGramDots, a.n), dim3(kBlock), 0, c->stream, a, xi);
-        hipLaunchKernelGGL(k_gram_solve<false>, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, xi);
-    }
+void launch_gram_solve(bioen_hip_ctx* c, const GramArgs& a) {      // the segments' totals (after the X_GRAMR exchange)
+    hipLaunchKernelGGL(k_gram_solve, dim3(1, a.n), dim3(kBlock), 0, c->stream, a, gram_rank_view(c, a.n));
 }
 
 void launch_combine(bioen_hip_ctx* c, const GramArgs& a) {
-    if (c->nvec_nt) hipLaunchKernelGGL(k_combine<true>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
-    else hipLaunchKernelGGL(k_combine<false>, dim3(vec_grid(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+    if (c->nvec_nt) hipLaunchKernelGGL(k_combine<true>, dim3(vec_blocks(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
+    else hipLaunchKernelGGL(k_combine<false>, dim3(vec_blocks(c), a.n), dim3(kBlock), 0, c->stream, a, c->n);
 }
 
 

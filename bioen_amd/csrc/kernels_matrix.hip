@@ -33,16 +33,19 @@ template <int R, int K, int STEPS, bool NT, bool CENTER>
 __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict__ Y, size_t ld, Vec8 v,
                                                         const double* __restrict__ ybar_c,
                                                         double* __restrict__ partial, int ctiles,
-                                                        int steps_per_tile, int total_steps) {
+                                                        int steps_per_tile, int seg_tiles, int seg_steps) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // blockIdx.x = row block (fast index): consecutive blocks share the column tile, so the
     // tile's slice of v_a is fetched from HBM once per XCD and then served by L2
+    // tile t of segment v (seg_tiles tiles of steps_per_tile 128-column steps each, the last one shorter): the same
+    // columns on every GPU count
     const int tile = blockIdx.y;
     const int row0 = (blockIdx.x * kWaves + wave) * R;
-    int s = tile * steps_per_tile;
+    const int tseg = tile / seg_tiles, tl = tile - tseg * seg_tiles;
+    int s = tseg * seg_steps + tl * steps_per_tile;
     int s_end = s + steps_per_tile;
-    if (s_end > total_steps) s_end = total_steps;
+    if (s_end > (tseg + 1) * seg_steps) s_end = (tseg + 1) * seg_steps;
 
     const size_t col = (size_t)s * 128 + lane * 2;
     const double* yp = Y + (size_t)row0 * ld + col;
@@ -144,80 +147,89 @@ __global__ __launch_bounds__(kBlock) void k_fwd_partial(const double* __restrict
     }
 }
 
-// reduce the column tiles of one (row, problem) per wave (fixed order): this rank's share of
-// ybar, written into its segment of the X_YBAR stage (compact layout [row*K + a])
-// WITH_EXP (log-weights rounds): block 0 of each problem also totals this rank's softmax partials
-// and appends {sum e, sum e (x - G), m_r} to the rank's segment, so the normalisation needs no
+// reduce the column tiles of one (row, problem) per wave (fixed order): a SEGMENT's share of
+// ybar, written into that segment of the X_YBAR stage (compact layout [row*K + a]); blockIdx.z = local segment.
+// WITH_EXP (log-weights rounds): block 0 of each problem also totals the segment's softmax partials
+// and appends {sum e, sum e (x - G), m_v} to the segment, so the normalisation needs no
 // exchange of its own.
 template <bool WITH_EXP>
-__global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restrict__ partial, int ctiles,
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restrict__ partial, int ctiles, int seg_tiles,
                                                            int mp, int K, Xch xo, Xch xe) {
-    __shared__ double sh[kWaves];
-    const int a = blockIdx.y;
+    const int a = blockIdx.y, v = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    double* out = xo.base + (size_t)xo.rank * xo.payload;
+    double* out = xo.base + (size_t)(xo.rank + v) * xo.payload;
     if (WITH_EXP && blockIdx.x == 0) {
-        const double s = xsum_rank<3>(xe, xe.rank, a, 0, sh);
-        const double pp = xsum_rank<3>(xe, xe.rank, a, 1, sh);
+        const double s = xsum_seg<3>(xe, xe.rank + v, a, 0);
+        const double pp = xsum_seg<3>(xe, xe.rank + v, a, 1);
         if (threadIdx.x == 0) {
             double* tail = out + (size_t)mp * K + 3 * a;
             tail[0] = s;
             tail[1] = pp;
-            tail[2] = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+            tail[2] = xseg_ptr<3>(xe, xe.rank + v, a, 2)[0];
         }
     }
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
-        const double* p = partial + ((size_t)row * K + a) * ctiles;
+        const double* p = partial + ((size_t)row * K + a) * ctiles + (size_t)v * seg_tiles;
         double s = 0.0;
-        for (int k = lane; k < ctiles; k += 64) s += p[k];
+        for (int k = lane; k < seg_tiles; k += 64) s += p[k];
         s = wave_sum(s);
         if (lane == 0) out[(size_t)row * K + a] = s;
     }
 }
 
-// k_fwd_rows_local on transposed partials; the blocks beyond the entry tiles (one per problem) total the softmax partials
+// k_fwd_rows_local on transposed partials (the strip kernels: partial[set * stride + idx]); blockIdx.y = local segment,
+// whose sets are [v * seg_sets, (v + 1) * seg_sets) -- `fold` consecutive sets each (the chunks of one group, added
+// in turn from +0.0: kernels_strip.hip, canonical strip sets) when the strip kernel has not folded them itself.
+// The blocks beyond the entry tiles (one per problem) total the softmax partials.
 template <bool WITH_EXP>
-__global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __restrict__ partial, int ctiles, int mp,
-                                                             int K, int ntile, Xch xo, Xch xe) {
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __restrict__ partial, int seg_groups, int fold,
+                                                             int mp, int K, int ntile, Xch xo, Xch xe) {
     __shared__ double lds[64 * 16];
-    double* out = xo.base + (size_t)xo.rank * xo.payload;
+    const int v = blockIdx.y;
+    double* out = xo.base + (size_t)(xo.rank + v) * xo.payload;
     if (WITH_EXP && (int)blockIdx.x >= ntile) {
         const int a = blockIdx.x - ntile;
-        const double s = xsum_rank<3>(xe, xe.rank, a, 0, lds);
-        const double pp = xsum_rank<3>(xe, xe.rank, a, 1, lds);
+        const double s = xsum_seg<3>(xe, xe.rank + v, a, 0);
+        const double pp = xsum_seg<3>(xe, xe.rank + v, a, 1);
         if (threadIdx.x == 0) {
             double* tail = out + (size_t)mp * K + 3 * a;
             tail[0] = s;
             tail[1] = pp;
-            tail[2] = xe.base[(size_t)xe.rank * xe.payload + (size_t)(a * 3 + 2) * xe.npl];
+            tail[2] = xseg_ptr<3>(xe, xe.rank + v, a, 2)[0];
         }
         return;
     }
     const size_t n = (size_t)mp * K;
     const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s = tiles_sum16(partial, n, ctiles, idx, idx < n, lds, TermAdd());
+    const double s = tiles_sum16(partial + (size_t)v * seg_groups * fold * n, n, seg_groups, fold, idx, idx < n, lds, TermAdd());
     if (threadIdx.x < 16 && idx < n) out[idx] = s;
 }
 
-__global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double* __restrict__ partial, int ctiles,
-                                                                   int mp, int K, double* __restrict__ gm_c,
+// forces gradient from transposed partials (the strip kernels).  blockIdx.y = local segment v, whose sets are
+// [v * seg_sets, (v + 1) * seg_sets): the segment's share  sum_sets partial - ybar' T_v  (T_v = the sets' shares of
+// sum_j t_j, totalled in the same fixed order by every block) goes to out + v * out_stride -- the segment's part of the
+// X_YBAR stage (k_sum_ranks adds the segments up in order), or, with one "segment" holding every set, gm itself
+// (row panels of matrices taller than 1024 rows: unsharded contexts only).
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double* __restrict__ partial, int seg_sets,
+                                                                   int mp, int K, double* __restrict__ out, size_t out_stride,
                                                                    const double* __restrict__ ybar_c, MVec8 tpart) {
     __shared__ double lds[64 * 16];
     __shared__ double T[kMaxBatch];
+    const int v = blockIdx.y;
     if (ybar_c)
         for (int a = 0; a < K; ++a) {
-            const double t = sum_partials(tpart.p[a] + (size_t)P_KL * kMaxPartials, ctiles, lds);
+            const double t = sum_partials(tpart.p[a] + (size_t)P_KL * kPartStride + (size_t)v * seg_sets, seg_sets, lds);
             if (threadIdx.x == 0) T[a] = t;
         }
     __syncthreads();
     const size_t n = (size_t)mp * K;
     const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s = tiles_sum16(partial, n, ctiles, idx, idx < n, lds, TermAdd());
-    if (threadIdx.x < 16 && idx < n) gm_c[idx] = ybar_c ? fma(-ybar_c[idx], T[idx % K], s) : s;
+    const double s = tiles_sum16(partial + (size_t)v * seg_sets * n, n, seg_sets, 1, idx, idx < n, lds, TermAdd());
+    if (threadIdx.x < 16 && idx < n) (out + (size_t)v * out_stride)[idx] = ybar_c ? fma(-ybar_c[idx], T[idx % K], s) : s;
 }
 
-// add the ranks' shares (rank order) -> ybar, r = ybar - YT (compact) ; per-block partials of
+// add the segments' shares (segment order) -> ybar, r = ybar - YT (compact) ; per-block partials of
 // sum r^2 and sum ybar r.  Every rank computes the same numbers.
 // Affine observable model (ctx.hpp): ybar_eff_i = off_i + sc_i (Y w)_i  (sum w = 1), while ybar_c
 // keeps the RAW Y w, which is what the centred passes subtract: the offset cancels in
@@ -239,9 +251,8 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
         const int st = gate.tab[gate.slot[a]].status;
         if (!(st == DS_INITIAL || st == DS_RUNNING) || (gate.cand[a] != 0 && st != DS_RUNNING)) return;
     }
-    // LOGW: the shares are yTilde . e_r with e_r = exp(x - m_r) unnormalised; global shift
-    // M = max_r m_r, S = sum_r e^{m_r - M} S_r, and rank r's share enters with e^{m_r - M} / S
-    // (exactly 1 / S on one GPU).  _get_weights' normalisation (c_bioen_kernels_logw.c:84-90) is
+    // LOGW: the shares are yTilde . e_v with e_v = exp(x - m_v) unnormalised (segment v's own shift); global shift
+    // M = max_v m_v, S = sum_v e^{m_v - M} S_v, and segment v's share enters with e^{m_v - M} / S.  _get_weights' normalisation (c_bioen_kernels_logw.c:84-90) is
     // thereby applied to the M sums instead of the N weights.
     double gmax = 0.0, invS = 1.0;
     if (LOGW) {
@@ -258,10 +269,12 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
         invS = 1.0 / S;
         if (threadIdx.x == 0) {
             double* sc = rd.scal[a];
-            const double mown = xi.base[(size_t)xi.rank * xi.payload + (size_t)mp * K + 3 * a + 2];
             sc[S_LOGS] = gmax + log(S);
             sc[S_P] = PP * invS;
-            sc[S_INV] = exp(mown - gmax) * invS;
+            for (int v = 0; v < xi.vr; ++v) {      // w = e * S_INV[v] in local segment v (its own shift m_v)
+                const double mown = xi.base[(size_t)(xi.rank + v) * xi.payload + (size_t)mp * K + 3 * a + 2];
+                sc[S_INV + v] = exp(mown - gmax) * invS;
+            }
         }
     }
     double chi = 0.0, cc = 0.0, b0 = 0.0, uy = 0.0;
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             sc[S_F] = rd.theta[a] * sc[S_KL] + 0.5 * chi;
         } else {
             double* pa = part.p[a];
-            pa[(size_t)P_CHI * kMaxPartials] = chi;
-            pa[(size_t)P_C * kMaxPartials] = cc;
+            pa[(size_t)P_CHI * kPartStride] = chi;
+            pa[(size_t)P_C * kPartStride] = cc;
         }
     }
 }
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad(const double* _
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double T = 0.0;
-    if (ybar_c) T = sum_partials(tpart.p[a] + (size_t)P_KL * kMaxPartials, ctiles, sh);
+    if (ybar_c) T = sum_partials(tpart.p[a] + (size_t)P_KL * kPartStride, ctiles, sh);
     for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
         const double* p = partial + ((size_t)row * K + a) * ctiles;
         double s = 0.0;
@@ -417,21 +430,37 @@ __global__ __launch_bounds__(kBlock) void k_adj(const double* __restrict__ Y, si
 // ==============================================================================
 
 int vec_grid(const bioen_hip_ctx* c) {
-    // from ld (identical on every rank of a sharded context), 2 pairs (4 elements) per thread
-    long long b = ((long long)c->ld + 4 * kBlock - 1) / (4 * kBlock);
-    const long long cap = kMaxPartials / c->world;
+    // blocks per SEGMENT: from segcols and nseg alone (identical on every rank, and on every GPU count whose rank
+    // count divides 8), 2 pairs (4 elements) per thread
+    long long b = ((long long)c->segcols + 4 * kBlock - 1) / (4 * kBlock);
+    const long long cap = kMaxPartials / c->nseg;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
+}
+
+int vec_blocks(const bioen_hip_ctx* c) { return vec_grid(c) * c->vr; }
+
+SegMap seg_map(const bioen_hip_ctx* c) { return SegMap{vec_grid(c), c->segcols}; }
+
+void rank_columns(const bioen_hip_ctx* c, int rank, long long* col0, long long* n_local) {
+    const long long per = (long long)c->vr * c->segcols;
+    *col0 = per * rank;
+    long long nl = c->n_global - *col0;
+    if (nl > per) nl = per;
+    if (nl < 0) nl = 0;
+    *n_local = nl;
 }
 
 Xch make_xch(const bioen_hip_ctx* c, int stage, int payload) {
     Xch x;
     x.base = c->xbuf[stage];
     x.payload = payload;
-    x.world = c->world;
-    x.rank = c->rank;
+    x.world = c->nseg;
+    x.rank = c->seg0;
     x.npl = vec_grid(c);
+    x.vr = c->vr;
+    x.segcols = c->segcols;
     return x;
 }
 
@@ -446,10 +475,9 @@ int rows_grid(const bioen_hip_ctx* c) {
 // ---- forward ---------------------------------------------------------------------------
 template <int K, int STEPS, bool NT, bool CENTER>
 static void fwd_launch(bioen_hip_ctx* c, const Vec8& v) {
-    const int total_steps = (int)(c->ld / 128);
     dim3 grid(c->mp / kRowAlign, c->fwd_ctiles);
     BIOEN_LAUNCH_TIMED(c, (k_fwd_partial<8, K, STEPS, NT, CENTER>), grid, dim3(kBlock), 0, c->Y, c->ld, v,
-                       c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, total_steps);
+                       c->ybar_c, c->fwd_partial, c->fwd_ctiles, c->fwd_steps, c->fwd_ctiles / c->vr, c->segcols / 128);
 }
 
 // STEPS = 0: software-pipelined (next step's Y rows in flight during the FMAs).  Measured on the
@@ -483,23 +511,24 @@ int ybar_payload(const bioen_hip_ctx* c, int K, bool logw) { return c->mp * K + 
 void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, K, logw));
     const Xch xe = make_xch(c, X_EXP, 3 * K * vec_grid(c));
-    const int ct = ctiles > 0 ? ctiles : c->fwd_ctiles;
-    if (tposed) {
+    if (tposed) {          // the strip kernels' sets (kernels_strip.hip: strip_sets)
+        const StripSets ss = strip_sets(c);
         const int ntile = (c->mp * K + 15) / 16;
         if (logw)
-            hipLaunchKernelGGL(k_fwd_rows_local_t<true>, dim3(ntile + K), dim3(kBlock), 0, c->stream, c->fwd_partial, ct,
-                               c->mp, K, ntile, xo, xe);
+            hipLaunchKernelGGL(k_fwd_rows_local_t<true>, dim3(ntile + K, c->vr), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                               ss.gs, ss.fold ? 1 : ss.nch, c->mp, K, ntile, xo, xe);
         else
-            hipLaunchKernelGGL(k_fwd_rows_local_t<false>, dim3(ntile), dim3(kBlock), 0, c->stream, c->fwd_partial, ct,
-                               c->mp, K, ntile, xo, xe);
+            hipLaunchKernelGGL(k_fwd_rows_local_t<false>, dim3(ntile, c->vr), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                               ss.gs, ss.fold ? 1 : ss.nch, c->mp, K, ntile, xo, xe);
         return;
     }
+    const int ct = ctiles > 0 ? ctiles : c->fwd_ctiles;
     if (logw)
-        hipLaunchKernelGGL(k_fwd_rows_local<true>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                           ct, c->mp, K, xo, xe);
+        hipLaunchKernelGGL(k_fwd_rows_local<true>, dim3(rows_grid(c), K, c->vr), dim3(kBlock), 0, c->stream, c->fwd_partial,
+                           ct, ct / c->vr, c->mp, K, xo, xe);
     else
-        hipLaunchKernelGGL(k_fwd_rows_local<false>, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream,
-                           c->fwd_partial, ct, c->mp, K, xo, xe);
+        hipLaunchKernelGGL(k_fwd_rows_local<false>, dim3(rows_grid(c), K, c->vr), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, ct, ct / c->vr, c->mp, K, xo, xe);
 }
 
 // w = e * scal[S_INV]: the weights themselves are only needed when a result is handed out
@@ -507,21 +536,21 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles, bool 
 // passes multiply it with the zero columns of the strip copies, and k_logw_exp never rewrites it: scaled by a
 // non-finite 1 / sum e (a run on NaN input) it turned into NaN for good and 0 x NaN poisoned every later evaluation on
 // the context (r04, found by tools/nan_probe.py's successor in tests/test_hip_edgecases.py).
-__global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n) {
+__global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n, SegMap sm) {
     const int a = blockIdx.y;
-    const double inv = r.scal[a][S_INV];
+    const SegPos sp = seg_pos(sm.npl, sm.segcols, n);
+    const double inv = r.scal[a][S_INV + sp.v];      // the segment's own shift
     double* __restrict__ w = r.w[a];
-    const int n2 = (n + 1) >> 1;
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
-        d2 v = *reinterpret_cast<d2*>(w + 2 * p);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(sm.npl)) {
+        d2 v = *reinterpret_cast<d2*>(w + j);
         v.x *= inv;
-        v.y = (2 * p + 1 < n) ? v.y * inv : 0.0;
-        *reinterpret_cast<d2*>(w + 2 * p) = v;
+        v.y = (j + 1 < sp.jend) ? v.y * inv : 0.0;
+        *reinterpret_cast<d2*>(w + j) = v;
     }
 }
 
 void launch_scale_w(bioen_hip_ctx* c, const Round& r) {
-    hipLaunchKernelGGL(k_scale_w, dim3(vec_grid(c), r.n), dim3(kBlock), 0, c->stream, r, c->n);
+    hipLaunchKernelGGL(k_scale_w, dim3(vec_blocks(c), r.n), dim3(kBlock), 0, c->stream, r, c->n, seg_map(c));
 }
 
 int combine_grid(const bioen_hip_ctx*) { return 1; }
@@ -550,28 +579,23 @@ static MVec8 tsum_parts(const ForcesRound* fr) {
 }
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum, bool tposed) {
-    if (tposed) {
-        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16), dim3(kBlock), 0, c->stream,
-                           c->fwd_partial, ctiles, c->mp, K, c->gm, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
+    if (tposed) {          // every set of the context as one run (unsharded contexts: row panels, M > 1024)
+        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16, 1), dim3(kBlock), 0, c->stream,
+                           c->fwd_partial, ctiles, c->mp, K, c->gm, (size_t)0, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
         return;
     }
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
                        ctiles, c->mp, K, c->gm, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
 }
 
-// sharded: this rank's share of the forces gradient -> its X_YBAR segment; after the exchange
-// k_sum_ranks adds the shares in rank order (identical on every rank) -> gm
-void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum, bool tposed) {
+// strip passes (M <= 1024): every local segment's share of the forces gradient -> its X_YBAR segment; after the
+// exchange k_sum_ranks adds the shares in segment order (identical on every rank, and on every GPU count) -> gm
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int seg_sets, const ForcesRound* tsum, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, c->mp * K);
-    if (tposed) {
-        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16), dim3(kBlock), 0, c->stream,
-                           c->fwd_partial, ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload,
-                           tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
-        return;
-    }
-    hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       ctiles, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, tsum ? c->ybar_c : nullptr,
-                       tsum_parts(tsum));
+    (void)tposed;
+    hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16, c->vr), dim3(kBlock), 0, c->stream,
+                       c->fwd_partial, seg_sets, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, (size_t)xo.payload,
+                       tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_ranks(Xch xi, int count, double* __restrict__ out) {

@@ -192,16 +192,16 @@ void launch_read_probe(bioen_hip_ctx* c, const double* p, size_t doubles, double
 
 // ---- level-1 algebra (multimin) -------------------------------------------------------------
 void launch_vaxpy(bioen_hip_ctx* c, double a, const double* x, double* y) {
-    hipLaunchKernelGGL(k_vaxpy, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, y, (int)(c->ld / 2));
+    hipLaunchKernelGGL(k_vaxpy, dim3(vec_blocks(c)), dim3(kBlock), 0, c->stream, a, x, y, (int)(c->ld / 2));
 }
 void launch_vscal(bioen_hip_ctx* c, double a, double* x) {
-    hipLaunchKernelGGL(k_vscal, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, a, x, (int)(c->ld / 2));
+    hipLaunchKernelGGL(k_vscal, dim3(vec_blocks(c)), dim3(kBlock), 0, c->stream, a, x, (int)(c->ld / 2));
 }
 void launch_vstep(bioen_hip_ctx* c, const double* x, const double* p, double coef, double* x1, double* dx) {
-    hipLaunchKernelGGL(k_vstep, dim3(vec_grid(c)), dim3(kBlock), 0, c->stream, x, p, coef, x1, dx, (int)(c->ld / 2));
+    hipLaunchKernelGGL(k_vstep, dim3(vec_blocks(c)), dim3(kBlock), 0, c->stream, x, p, coef, x1, dx, (int)(c->ld / 2));
 }
 void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out) {
-    const int g = vec_grid(c);
+    const int g = vec_blocks(c);
     hipLaunchKernelGGL(k_vdots, dim3(g), dim3(kBlock), 0, c->stream, q, (int)(c->ld / 2), part);
     hipLaunchKernelGGL(k_vdots_finish, dim3(1), dim3(kBlock), 0, c->stream, part, g, q.k, q.mode, out);
 }

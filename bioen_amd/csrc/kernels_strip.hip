@@ -236,8 +236,11 @@ struct StripArgs {
     int nstrips;
     int n;                  // valid columns
     int K;
-    int nblk;               // partial sets (k_strip: = blocks)
+    int nblk;               // k_strip_adj: strip slots of the launch
     int wps, spb;           // k_strip_fwd / k_strip_adj: waves per strip slot, strips per block and iteration
+    // canonical partial sets (kernels.hpp: StripSets) of the row-sum passes: k_strip_fwd, k_strip, k_strip2
+    int sps, gs, tc, nch, fold, slots;
+    int nslots;             // physical slots of the launch = slots x local segments
     const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
     const double* w0;
     double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
@@ -245,6 +248,31 @@ struct StripArgs {
     int accumulate;         // k_strip_adj: 0 = start at `shift`, 1 = add to the outputs of the panels before this one, 2 = start at 0
     long long* stamps;      // diagnostic builds (STRIP_DIAG & 4): per wave 8 phase-cycle sums
 };
+
+// What physical slot `ps` of a row-sum pass works on (kernels.hpp: StripSets): the strips first, first + gs, ... (count
+// of them) of local segment v = ps / slots -- a whole group (fold), or chunk cg of group g (slot r = cg gs + g of the
+// segment: consecutive blocks read consecutive strips) -- and the set its sums go to.  count = 0: an empty chunk (a
+// short group's last one) or a slot beyond the launch; its set is all zeros.
+struct SlotWork {
+    int first, count, set;
+    bool live;
+};
+__device__ __forceinline__ SlotWork strip_slot(const StripArgs& q, int ps) {
+    SlotWork w;
+    w.live = ps < q.nslots;
+    const int pss = w.live ? ps : 0;
+    const int v = pss / q.slots, r = pss - v * q.slots;
+    const int cg = r / q.gs, g = r - cg * q.gs;                 // fold: cg = 0
+    const int tg = (q.sps - g + q.gs - 1) / q.gs;               // strips of group g (g < gs <= sps: at least one)
+    const int t0 = q.fold ? 0 : cg * q.tc;
+    const int t1 = q.fold ? tg : min(tg, t0 + q.tc);
+    w.first = v * q.sps + g + q.gs * t0;
+    w.count = (w.live && t1 > t0) ? t1 - t0 : 0;
+    w.set = q.fold ? v * q.gs + g : (v * q.gs + g) * q.nch + cg;
+    return w;
+}
+// forces passes: flat sets, slot r of segment v -> set v slots + r (never folded)
+__device__ __forceinline__ int forces_set(const StripArgs& q, int ps) { return ps; }
 
 // dynamic LDS: tile[mps * 16] | ul[mps * 8] | red[waves][8][16] | v[8][16] | scale[8]
 //
@@ -256,6 +284,22 @@ struct StripArgs {
 // strip s deferred behind the first barrier of strip s + 1, where it runs beside P2 of that strip on the waves P2 leaves
 // idle: ONE barrier per strip, P3 off the serial chain (the partial-sum, e | t and rescale buffers are doubled by strip
 // parity).  Same operands, same order of every sum: the bits of a problem do not depend on which form served it.
+// the set of an empty chunk: zero sums; pass 1: no exponentials (maximum -DBL_MAX, weight exp(-DBL_MAX - m) = 0)
+template <bool XY>
+__device__ __forceinline__ void strip_empty_set(const StripArgs& q, const ForcesRound& fr, int set, int K) {
+    for (int i = threadIdx.x; i < q.mp * K; i += blockDim.x) q.partial[(size_t)set * q.mp * K + i] = 0.0;
+    if ((int)threadIdx.x < K) {
+        double* pa = fr.part[threadIdx.x];
+        if (XY) {
+            pa[(size_t)P_MAX * kPartStride + set] = -DBL_MAX;
+            pa[(size_t)P_SUM * kPartStride + set] = 0.0;
+            pa[(size_t)P_PP * kPartStride + set] = 0.0;
+        } else {
+            pa[(size_t)P_KL * kPartStride + set] = 0.0;
+        }
+    }
+}
+
 template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH, int STORE = 0>
 __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
     constexpr int NK = (K + 3) / 4;                 // problem quads
@@ -281,6 +325,12 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     const int rbase = wave * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
+    const SlotWork wk = strip_slot(q, blockIdx.x);
+    const int myset = forces_set(q, blockIdx.x);
+    if (wk.count == 0) {                            // an empty chunk (block-uniform): its set is all zeros
+        strip_empty_set<XY>(q, fr, myset, K);
+        return;
+    }
 
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
@@ -351,7 +401,8 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         }
 #endif
     };
-    const int G = gridDim.x;
+    const int G = q.gs;                             // strips between the slot's consecutive strips
+    const int s_end = wk.first + G * wk.count;      // (one past the slot's last strip, in steps of G)
 #if STRIP_DIAG & 4
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_amdgcn_s_memtime();
@@ -432,7 +483,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        fetch(s + SETS * G < q.nstrips ? s + SETS * G : s, pre);      // unconditional, see k_strip_adj
+        fetch(s + SETS * G < s_end ? s + SETS * G : s, pre);          // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
         {
@@ -534,27 +585,27 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
         // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
     };
-    int s = blockIdx.x;
-    fetch(s, preA);                                                // grid <= strips: every block has a first strip
+    int s = wk.first;
+    fetch(s, preA);                                                // count >= 1: the slot has a first strip
     if constexpr (DEPTH == 2) {
-        fetch(s + G < q.nstrips ? s + G : s, preB);
+        fetch(s + G < s_end ? s + G : s, preB);
         __syncthreads();                                          // ul / tv / scale initialised
         // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
-        for (; s + G < q.nstrips; s += 2 * G) {
+        for (; s + G < s_end; s += 2 * G) {
             one_strip(s, preA, 0);
             one_strip(s + G, preB, 1);
         }
-        if (s < q.nstrips) one_strip(s, preA, 0);
+        if (s < s_end) one_strip(s, preA, 0);
     } else if constexpr (DEFER) {
         __syncthreads();
         int par = 0;
-        one_strip(s, preA, 0, true);                              // (grid <= strips: every block has a first strip)
-        for (s += G, par = 1; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
+        one_strip(s, preA, 0, true);
+        for (s += G, par = 1; s < s_end; s += G, par ^= 1) one_strip(s, preA, par);
         __syncthreads();                                          // the last strip's e | t are in place
         p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
     } else {
         __syncthreads();
-        for (int par = 0; s < q.nstrips; s += G, par ^= 1) one_strip(s, preA, par);
+        for (int par = 0; s < s_end; s += G, par ^= 1) one_strip(s, preA, par);
     }
 #if STRIP_DIAG & 4
     if (q.stamps && lane == 0)
@@ -571,7 +622,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
                 // transposed: a block's sums are one run; rows between the strip's last row block and mp exist only in
                 // the M-vectors: their sums are zero (the wave computed a redirected row block's there)
                 if (row < q.mp && k < K)
-                    q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
+                    q.partial[(size_t)myset * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
             }
     }
     // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
@@ -585,11 +636,11 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         if (p2 && pc == 0) {
             double* pa = pak;
             if (XY) {
-                pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;
-                pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
-                pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = px;
+                pa[(size_t)P_MAX * kPartStride + myset] = m_run;
+                pa[(size_t)P_SUM * kPartStride + myset] = z;
+                pa[(size_t)P_PP * kPartStride + myset] = px;
             } else {
-                pa[(size_t)P_KL * kMaxPartials + blockIdx.x] = z;        // this block's share of sum_j t_j
+                pa[(size_t)P_KL * kPartStride + myset] = z;        // this set's share of sum_j t_j
             }
         }
     }
@@ -627,6 +678,12 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     const int rbase = wave * WR;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
+    const SlotWork wk = strip_slot(q, blockIdx.x);
+    const int myset = forces_set(q, blockIdx.x);
+    if (wk.count == 0) {                            // an empty chunk (block-uniform): its set is all zeros
+        strip_empty_set<XY>(q, fr, myset, K);
+        return;
+    }
 
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
@@ -703,7 +760,8 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     // K > 4: the operand batches of the column-sum product do not fit beside a3 AND the whole prefetch (7-12 registers
     // spilled per strip); the second half of the prefetch is issued behind that product instead
     constexpr int SPLIT = NK > 1 ? WR / 16 : WR / 8;
-    const int G = gridDim.x;
+    const int G = q.gs;                             // strips between the slot's consecutive strips
+    const int s_end = wk.first + G * wk.count;
     auto one_strip = [&](int s) {
         // the strip's centred values: the row-sum operands of P3, and the source of the LDS image below
         double a3[4][WR / 16];
@@ -729,7 +787,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        const int nxt = s + G < q.nstrips ? s + G : s;
+        const int nxt = s + G < s_end ? s + G : s;
         fetch_part(nxt, 0, SPLIT);                 // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k], half by half through the LDS image ----
         {
@@ -855,10 +913,10 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
         // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
     };
-    int s = blockIdx.x;
-    fetch(s);                                                      // grid <= strips: every block has a first strip
+    int s = wk.first;
+    fetch(s);                                                      // count >= 1: the slot has a first strip
     __syncthreads();                                              // ul / tv / scale / cl initialised
-    for (; s < q.nstrips; s += G) one_strip(s);
+    for (; s < s_end; s += G) one_strip(s);
     {
         // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
         const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
@@ -870,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
                 // transposed: a block's sums are one run; rows between the strip's last row block and mp exist only in
                 // the M-vectors: their sums are zero (the wave computed a redirected row block's there)
                 if (row < q.mp && k < K)
-                    q.partial[(size_t)blockIdx.x * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
+                    q.partial[(size_t)myset * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
             }
     }
     // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
@@ -884,11 +942,11 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         if (p2 && pc == 0) {
             double* pa = pak;
             if (XY) {
-                pa[(size_t)P_MAX * kMaxPartials + blockIdx.x] = m_run;
-                pa[(size_t)P_SUM * kMaxPartials + blockIdx.x] = z;
-                pa[(size_t)P_PP * kMaxPartials + blockIdx.x] = px;
+                pa[(size_t)P_MAX * kPartStride + myset] = m_run;
+                pa[(size_t)P_SUM * kPartStride + myset] = z;
+                pa[(size_t)P_PP * kPartStride + myset] = px;
             } else {
-                pa[(size_t)P_KL * kMaxPartials + blockIdx.x] = z;        // this block's share of sum_j t_j
+                pa[(size_t)P_KL * kPartStride + myset] = z;        // this set's share of sum_j t_j
             }
         }
     }
@@ -921,7 +979,6 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     const int rbase = rw * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;
     const int lq = lane >> 4, lj = lane & 3;
-    const int stride = gridDim.x * q.spb;                          // strips between a slot's consecutive strips
 
     double acc[kWaveRows / 16][NK];
 #pragma unroll
@@ -966,15 +1023,26 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
             }
         }
     };
-    int base = blockIdx.x * q.spb;                                 // strip of slot 0: < nstrips for every block
-    int sw = base + sub;                                           // this wave's strip (a slot beyond the last strip works on
-    int sp = base + psub;                                          //   a valid one against e = 0 and contributes nothing)
-    double ecur = (p2 && sp < q.nstrips) ? vk[(size_t)sp * kStripCols + pc] : 0.0;
-    fetch(sw < q.nstrips ? sw : base);
+    // canonical sets (kernels.hpp: StripSets): the wave's slot and the slot this thread stages e for
+    const SlotWork mw = strip_slot(q, blockIdx.x * q.spb + sub);
+    const SlotWork pw = strip_slot(q, blockIdx.x * q.spb + psub);
+    int trips = 0;                                                 // the block's iterations: its longest slot's (block-uniform)
+    for (int i = 0; i < q.spb; ++i) trips = max(trips, strip_slot(q, blockIdx.x * q.spb + i).count);
+    const int safe = mw.count > 0 ? mw.first : 0;                  // a strip the wave may touch when it has none of its own left
+    double ecur = (p2 && pw.count > 0) ? vk[(size_t)pw.first * kStripCols + pc] : 0.0;
+    fetch(safe);
     __syncthreads();
-    for (int par = 0; base < q.nstrips; base += stride, sw += stride, sp += stride, par ^= 1) {
+    // fold: the slot runs a whole group and adds up its chunks (tc strips each) in turn, from +0.0 -- what the consumer
+    // does with the sets of a launch that runs one chunk per slot (k_fwd_rows_local_t): the same bits either way
+    double tot[kWaveRows / 16][NK];
+#pragma unroll
+    for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) tot[h][kq] = 0.0;
+    int tcnt = 0;
+    for (int it = 0, par = 0; it < trips; ++it, par ^= 1) {
         if (p2) tv[par][psub][pk * 16 + pc] = ecur;               // loaded during the previous strip
-        ecur = (p2 && sp + stride < q.nstrips) ? vk[(size_t)(sp + stride) * kStripCols + pc] : 0.0;   // (without these loads: -2 %; nontemporal: +1 %)
+        ecur = (p2 && it + 1 < pw.count) ? vk[(size_t)(pw.first + q.gs * (it + 1)) * kStripCols + pc] : 0.0;   // (without these loads: -2 %; nontemporal: +1 %)
         __syncthreads();                                           // this strip's e is in place; the buffer of parity
                                                                    // `par` is rewritten two strips on, behind another barrier
         double bv[4][NK];
@@ -1003,21 +1071,35 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
                     acc[h][kq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bv[qq][kq], acc[h][kq], 0, 0, 0);
             }
         // unconditional (see k_strip_adj); the operands are consumed at issue.  Past its last strip a wave re-reads a
-        // strip it may touch (its own, or slot 0's)
-        const int nxt = sw + stride;
-        fetch(nxt < q.nstrips ? nxt : (sw < q.nstrips ? sw : base));
+        // strip it may touch (its last one, or strip 0) against e = 0
+        fetch(it + 1 < mw.count ? mw.first + q.gs * (it + 1) : (mw.count > 0 ? mw.first + q.gs * (mw.count - 1) : 0));
+        if (q.fold && ++tcnt == q.tc) {                            // a chunk ends (block-uniform; registers only)
+            tcnt = 0;
+#pragma unroll
+            for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+                for (int kq = 0; kq < NK; ++kq) {
+                    tot[h][kq] += acc[h][kq];
+                    acc[h][kq] = 0.0;
+                }
+        }
+    }
+    if (q.fold) {                                                  // the group's last, shorter chunk (or + 0.0)
+#pragma unroll
+        for (int h = 0; h < kWaveRows / 16; ++h)
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) acc[h][kq] = tot[h][kq] + acc[h][kq];
     }
     {
         // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
-        const int set = blockIdx.x * q.spb + sub;
         const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
 #pragma unroll
         for (int h = 0; h < kWaveRows / 16; ++h)
 #pragma unroll
             for (int kq = 0; kq < NK; ++kq) {
                 const int row = rr + 16 * h, k = 4 * kq + lj;
-                if (set < q.nblk && row < q.mp && k < K)     // transposed: a set's sums are one run; rows beyond the strip: zero
-                    q.partial[(size_t)set * q.pstride * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
+                if (mw.live && row < q.mp && k < K)     // transposed: a set's sums are one run; rows beyond the strip: zero
+                    q.partial[(size_t)mw.set * q.pstride * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
             }
     }
 }
@@ -1185,19 +1267,43 @@ static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
     return (waves * kWaveRows * (kStripCols + 8 + 1) + waves * 128 + 128 + 16) * sizeof(double);   // 64 rows per wave
 }
 
-int forces_fused_blocks(const bioen_hip_ctx* c) {      // 0: not applicable on this context
-    static int tall_off = -1;                          // BIOEN_HIP_STRIP_TALL=0: the r01 kernels for 512 < M <= 1024 (A/B)
-    if (tall_off < 0) {
-        const char* e = std::getenv("BIOEN_HIP_STRIP_TALL");
-        tall_off = (e && std::atoi(e) == 0) ? 1 : 0;
-    }
-    if (c->mp > 1024 || (c->mp > 512 && tall_off) || c->strips_unavailable) return 0;
-    const int nstrips = (int)(c->ld / kStripCols);
+static int env_flag(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
+// canonical sets of a row-sum pass whose full grid is `gs_nominal` slots per segment (kernels.hpp: StripSets)
+static StripSets make_sets(const bioen_hip_ctx* c, int gs_nominal, bool may_fold) {
+    StripSets ss{};
+    ss.sps = c->segcols / kStripCols;
+    ss.gs = std::max(1, std::min(ss.sps, gs_nominal));
+    const int tmax = (ss.sps + ss.gs - 1) / ss.gs;
+    ss.tc = (tmax + 7) / 8;
+    ss.nch = (tmax + ss.tc - 1) / ss.tc;
+    // a context that holds all eight segments runs whole groups per slot (8 x gs slots: the full grid) and adds up the
+    // chunks in registers; BIOEN_HIP_STRIP_FOLD=0: one chunk per slot there too (tests: the same bits)
+    ss.fold = (may_fold && c->vr >= 8 && env_flag("BIOEN_HIP_STRIP_FOLD", 1) != 0) ? 1 : 0;
+    ss.slots = ss.gs * (ss.fold ? 1 : ss.nch);
+    ss.sets = ss.slots;
+    return ss;
+}
+
+static int forces_per_cu(const bioen_hip_ctx* c) {
     // blocks per CU: LDS (160 KiB) and the waves per SIMD the kernel's register budget admits
     const int by_lds = (int)((size_t)160 * 1024 / strip_lds_bytes(c));
     const int by_waves = 4 * STRIP_WAVES_PER_SIMD / (strip_threads(c) / 64);
-    const int per_cu = std::max(1, std::min(by_lds, by_waves));
-    return std::min(std::min(256 * per_cu, kFusedBlocks), nstrips);
+    return std::max(1, std::min(std::min(by_lds, by_waves), 4));
+}
+
+StripSets forces_sets(const bioen_hip_ctx* c) {        // gs = 0: the strip passes do not apply to this context
+    static int tall_off = -1;                          // BIOEN_HIP_STRIP_TALL=0: the streaming kernels for 512 < M <= 1024 (A/B)
+    if (tall_off < 0) tall_off = env_flag("BIOEN_HIP_STRIP_TALL", 1) == 0 ? 1 : 0;
+    if (c->mp > 1024 || (c->mp > 512 && tall_off) || c->strips_unavailable) return StripSets{};
+    return make_sets(c, 32 * forces_per_cu(c), false);
+}
+
+int forces_fused_blocks(const bioen_hip_ctx* c) {      // sets per SEGMENT of the forces strip passes; 0: not applicable
+    return forces_sets(c).sets;
 }
 
 // Every allocation of a strip copy goes through here.  Tests: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC=k makes the k-th one of a
@@ -1535,16 +1641,21 @@ static int fa_spb_rows(int mps) { return std::max(1, std::min(16 / fa_wps_rows(m
 static int fa_spb(const bioen_hip_ctx* c) { return fa_spb_rows(paneled(c) ? kPanelRows : strip_rows(c)); }
 
 // forward pass of the log-weights method on the strip copy (all K <= 8): the number of partial sets
+StripSets strip_sets(const bioen_hip_ctx* c) {        // paneled: every panel uses the sets of a full 1024-row panel
+    return make_sets(c, 32 * fa_spb(c), true);
+}
+
+// > 0: the log-weights matrix passes run on the strip copies; the value = sets of the forward pass that reach memory
+// on this context (all local segments: what a consumer that totals them as one run is given)
 int fwd_strip_blocks(const bioen_hip_ctx* c) {
     if (c->fwd_stream || c->strips_unavailable) return 0;
     if (paneled(c) && (c->panel_off || panel_count(c) > bioen_hip_ctx::kMaxPanels)) return 0;
-    const int nstrips = (int)(c->ld / kStripCols);
-    return std::min(256 * fa_spb(c), nstrips);         // paneled: every panel uses the sets of a full 1024-row panel
+    return strip_sets(c).sets * c->vr;
 }
 
 template <int K, bool NT>
 static void fwd_strip_launch_k(bioen_hip_ctx* c, const StripArgs& q, const Vec8& v, dim3 block) {
-    const dim3 grid((q.nblk + q.spb - 1) / q.spb);
+    const dim3 grid((q.nslots + q.spb - 1) / q.spb);
     if (c->storage == 1) { BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT, 1>), grid, block, 0, q, v); }
     else if (c->storage == 2) { BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT, 2>), grid, block, 0, q, v); }
     else { BIOEN_LAUNCH_TIMED(c, (k_strip_fwd<K, NT>), grid, block, 0, q, v); }
@@ -1583,7 +1694,10 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
         q.nstrips = (int)(c->ld / kStripCols);
         q.n = c->n;
         q.K = K;
-        q.nblk = nblk;
+        (void)nblk;
+        const StripSets ss = strip_sets(c);
+        q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = ss.nch; q.fold = ss.fold; q.slots = ss.slots;
+        q.nslots = ss.slots * c->vr;
         q.partial = c->fwd_partial + (size_t)row0 * K;
         q.pstride = c->mp;
         q.wps = fa_wps_rows(q.mps);
@@ -1690,7 +1804,8 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
         q.nstrips = (int)(c->ld / kStripCols);
         q.n = c->n;
         q.K = K;
-        q.nblk = nblk;
+        (void)nblk;                                      // no sum over columns here: any assignment of strips to slots gives the same bits
+        q.nblk = std::min(256 * fa_spb(c), q.nstrips);
         q.u_c = u_c + (size_t)row0 * K;
         q.accumulate = p > 0 ? 1 : (plain ? 2 : 0);
         q.wps = fa_wps_rows(q.mps);
@@ -1716,7 +1831,11 @@ static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, cons
     q.nstrips = (int)(c->ld / kStripCols);
     q.n = c->n;
     q.K = fr.n;
-    q.nblk = nblk;
+    (void)nblk;
+    const StripSets ss = forces_sets(c);
+    q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = ss.nch; q.fold = 0; q.slots = ss.slots;
+    q.nslots = ss.slots * c->vr;
+    q.nblk = q.nslots;
     q.u_c = u_c;
     q.w0 = c->fixed;
     q.partial = c->fwd_partial;
@@ -1727,31 +1846,33 @@ static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, cons
     else strip_launch_nt<false, XY>(c, q, fr, block, lds);
 }
 
-// Merge the blocks of the xy pass on THIS rank (one block per problem): m_r = max_b m_b,
-// Z_r = sum_b e^{m_b - m_r} Z_b, likewise sum e x; P_MAX[b] <- e^{m_b - m_r}, the weight of block
-// b's raw sums.  The rank totals {Z_r, sum e x, m_r} go to the tail of the rank's X_YBAR segment --
+// Merge the sets of the xy pass per SEGMENT (one block per problem and local segment; set order): m_v = max_b m_b,
+// Z_v = sum_b e^{m_b - m_v} Z_b, likewise sum e x; P_MAX[b] <- e^{m_b - m_v}, the weight of set
+// b's raw sums.  The segment totals {Z_v, sum e x, m_v} go to the tail of the segment's part of X_YBAR --
 // the layout of the log-weights rounds -- so k_rows_combine<true> finishes both methods alike:
 //   scal[S_LOGS] = M + log Z  (w_j = w0_j exp(x_j - S_LOGS)),  scal[S_P] = sum_j w_j x_j,
 //   KL = sum_j w_j log(w_j / w0_j) = S_P - S_LOGS   (c_bioen_kernels_forces.c:246-258, with
 //   log w_j - log w0_j = x_j - S_LOGS; the prior constant S_LOGS0 is zero for this method).
-__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int nblk, int mp, int K, Xch xo) {
+__global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, int seg_sets, int mp, int K, Xch xo) {
     __shared__ double sh[kWaves];
-    const int a = blockIdx.y;
+    const int a = blockIdx.y, v = blockIdx.z;
     double* pa = fr.part[a];
-    double* pm = pa + (size_t)P_MAX * kMaxPartials;
-    const double mr = max_partials(pm, nblk, sh);
+    double* pm = pa + (size_t)P_MAX * kPartStride + (size_t)v * seg_sets;
+    const double* ps = pa + (size_t)P_SUM * kPartStride + (size_t)v * seg_sets;
+    const double* pp = pa + (size_t)P_PP * kPartStride + (size_t)v * seg_sets;
+    const double mr = max_partials(pm, seg_sets, sh);
     double z = 0.0, px = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += kBlock) {
+    for (int b = threadIdx.x; b < seg_sets; b += kBlock) {
         const double fb = exp(pm[b] - mr);
-        z = fma(fb, pa[(size_t)P_SUM * kMaxPartials + b], z);
-        px = fma(fb, pa[(size_t)P_PP * kMaxPartials + b], px);
+        z = fma(fb, ps[b], z);
+        px = fma(fb, pp[b], px);
     }
     z = block_sum(z, sh);
     px = block_sum(px, sh);
     __syncthreads();
-    for (int b = threadIdx.x; b < nblk; b += kBlock) pm[b] = exp(pm[b] - mr);
+    for (int b = threadIdx.x; b < seg_sets; b += kBlock) pm[b] = exp(pm[b] - mr);
     if (threadIdx.x == 0) {
-        double* tail = xo.base + (size_t)xo.rank * xo.payload + (size_t)mp * K + 3 * a;
+        double* tail = xo.base + (size_t)(xo.rank + v) * xo.payload + (size_t)mp * K + 3 * a;
         tail[0] = z;
         tail[1] = px;
         tail[2] = mr;
@@ -1759,32 +1880,17 @@ __global__ __launch_bounds__(kBlock) void k_forces_blockstats(ForcesRound fr, in
     }
 }
 
-// this rank's share of ybar' : sum_b weight_b raw_i,b   (a wave per (row, problem), fixed order)
-__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted(const double* __restrict__ partial, int nblk, int mp,
-                                                                 int K, ForcesRound fr, Xch xo) {
-    const int a = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const double* __restrict__ wb = fr.part[a] + (size_t)P_MAX * kMaxPartials;
-    double* out = xo.base + (size_t)xo.rank * xo.payload;
-    for (int row = blockIdx.x * kWaves + wave; row < mp; row += gridDim.x * kWaves) {
-        const double* p = partial + ((size_t)row * K + a) * nblk;
-        double s = 0.0;
-        for (int b = lane; b < nblk; b += 64) s = fma(wb[b], p[b], s);
-        s = wave_sum(s);
-        if (lane == 0) out[(size_t)row * K + a] = s;
-    }
-}
-
-// the same on transposed partials (the strip kernels of this file)
+// a segment's share of ybar' : sum_b weight_b raw_i,b over the segment's sets, on transposed partials (the strip kernels
+// of this file); blockIdx.y = local segment
 struct TermWeighted {
     const double* wb;
     __device__ __forceinline__ double operator()(int b, double v, double s) const { return fma(wb[b], v, s); }
 };
 
-__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted_t(const double* __restrict__ partial, int nblk, int mp,
+__global__ __launch_bounds__(kBlock) void k_forces_rows_weighted_t(const double* __restrict__ partial, int seg_sets, int mp,
                                                                    int K, ForcesRound fr, Xch xo) {
     __shared__ double lds[64 * 16];
+    const int v = blockIdx.y;
     const size_t n = (size_t)mp * K;
     const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
     const int a = (int)(idx % K);
@@ -1792,8 +1898,9 @@ __global__ __launch_bounds__(kBlock) void k_forces_rows_weighted_t(const double*
 #pragma unroll
     for (int k = 1; k < kMaxBatch; ++k)
         if (k == a) wb = fr.part[k];
-    const double s = tiles_sum16(partial, n, nblk, idx, idx < n, lds, TermWeighted{wb + (size_t)P_MAX * kMaxPartials});
-    if (threadIdx.x < 16 && idx < n) (xo.base + (size_t)xo.rank * xo.payload)[idx] = s;
+    const double s = tiles_sum16(partial + (size_t)v * seg_sets * n, n, seg_sets, 1, idx, idx < n, lds,
+                                 TermWeighted{wb + (size_t)P_MAX * kPartStride + (size_t)v * seg_sets});
+    if (threadIdx.x < 16 && idx < n) (xo.base + (size_t)(xo.rank + v) * xo.payload)[idx] = s;
 }
 
 // w_j = w0_j exp(x_j - S_LOGS): the weights themselves, when a result is handed out
@@ -1805,16 +1912,12 @@ __global__ __launch_bounds__(kBlock) void k_forces_w_from_x(ForcesRound fr, cons
     for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) w[j] = w0[j] * exp(x[j] - logz);
 }
 
-void launch_forces_blockmerge(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, bool tposed) {
+void launch_forces_blockmerge(bioen_hip_ctx* c, const ForcesRound& fr, int seg_sets, bool tposed) {
+    (void)tposed;
     const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, fr.n, true));
-    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n), dim3(kBlock), 0, c->stream, fr, nblk, c->mp, fr.n, xo);
-    if (tposed) {
-        hipLaunchKernelGGL(k_forces_rows_weighted_t, dim3((c->mp * fr.n + 15) / 16), dim3(kBlock), 0, c->stream,
-                           c->fwd_partial, nblk, c->mp, fr.n, fr, xo);
-        return;
-    }
-    hipLaunchKernelGGL(k_forces_rows_weighted, dim3(rows_grid(c), fr.n), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       nblk, c->mp, fr.n, fr, xo);
+    hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n, c->vr), dim3(kBlock), 0, c->stream, fr, seg_sets, c->mp, fr.n, xo);
+    hipLaunchKernelGGL(k_forces_rows_weighted_t, dim3((c->mp * fr.n + 15) / 16, c->vr), dim3(kBlock), 0, c->stream,
+                       c->fwd_partial, seg_sets, c->mp, fr.n, fr, xo);
 }
 
 // pass 1: x' = Y'^T f, online softmax, raw ybar' per block; then the block merge and ybar' -> X_YBAR
@@ -1833,7 +1936,7 @@ void launch_forces_bt(bioen_hip_ctx* c, const ForcesRound& fr, int nblk) {
 }
 
 void launch_forces_w_from_x(bioen_hip_ctx* c, const ForcesRound& fr) {
-    hipLaunchKernelGGL(k_forces_w_from_x, dim3(vec_grid(c), fr.n), dim3(kBlock), 0, c->stream, fr, c->fixed, c->n);
+    hipLaunchKernelGGL(k_forces_w_from_x, dim3(vec_blocks(c), fr.n), dim3(kBlock), 0, c->stream, fr, c->fixed, c->n);
 }
 
 }  // namespace bioen

@@ -63,8 +63,9 @@ RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "c
                "early_res", "early_fmin", "early_codes", "early_evals")
 
 
-# BIOEN_TEST_WORLDS="2,3,4": more ranks on the one GPU (the 2000-column fixture shards over at most 4 ranks of 128-column blocks; 4 passes)
-WORLDS = [int(w) for w in os.environ.get("BIOEN_TEST_WORLDS", "2,3").split(",")]
+# BIOEN_TEST_WORLDS="2,3,4,5": the ranks on the one GPU (2 and 4 divide the 8 canonical segments: their runs must equal the
+# single-GPU run bit for bit; 3: one segment per rank, its own reduction shape)
+WORLDS = [int(w) for w in os.environ.get("BIOEN_TEST_WORLDS", "2,3,4").split(",")]
 
 
 @pytest.mark.parametrize("world", WORLDS)
@@ -106,11 +107,13 @@ def test_a_dawdling_rank_changes_no_bit(tmp_path, world):
             assert np.array_equal(calm[r][key], slow[r][key]), (key, r)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.timeout(300)
 def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     import bioen_amd
     z = run_ranks(tmp_path, world, "p2p")
+    canonical = 8 % world == 0       # the rank count divides the 8 canonical column segments: every sum over structures has
+                                     # the single-GPU shape -- results equal the single-GPU run BIT FOR BIT
 
     # (a) every rank holds identical (gathered) results
     for r in range(1, world):
@@ -153,11 +156,26 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     assert abs(float(z[0]["fminconv"]) - float(d["lbfgs_conv_fmin"])) <= 1e-6 * abs(float(d["lbfgs_conv_fmin"]))
     assert np.abs(z[0]["wconv"] - wref).max() <= 1e-5 * wref.max()
 
-    # (c) against the single-GPU run: same mathematics, different reduction tree
+    # (c) against the single-GPU run: the same sums in the same order when the rank count divides 8 (the reference's
+    # fast_openmp = 0 promise -- test/optimize/test_logw_reproducibility.py:14-46: the same bits whatever the thread count --
+    # carried over to the GPU count); else the same mathematics in another reduction tree
+    from conftest import LBFGS_CONV
     with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx:
         w1, logs1 = ctx.logw_weights(g)
         f1, grad1 = ctx.logw_fdf(g, d["G"], d["theta"])
         res1, wopt1, infos1 = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+        gconv1, wconv1, iconv1 = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_CONV)
+        chi2w1, yave1g = ctx.chi_squared(w1)
+    if canonical:
+        assert np.array_equal(z[0]["w"], w1) and float(z[0]["logs"]) == logs1
+        assert float(z[0]["f"]) == f1 and np.array_equal(z[0]["grad"], grad1)
+        assert np.array_equal(z[0]["res"], res1) and np.array_equal(z[0]["wopt"], wopt1)          # the yaml-default series
+        assert [(float(a), int(b), int(c_), int(e)) for a, b, c_, e in zip(z[0]["fmin"], z[0]["iters"], z[0]["evals"], z[0]["codes"])] == \
+               [(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in infos1]
+        assert np.array_equal(z[0]["chi2"], [i.chi2 for i in infos1]) and np.array_equal(z[0]["kl"], [i.kl for i in infos1])
+        assert np.array_equal(z[0]["wconv"], wconv1) and float(z[0]["fminconv"]) == iconv1.fmin      # the converged run
+        assert int(z[0]["codeconv"]) == iconv1.lbfgs_code
+        assert float(z[0]["chi2w"]) == chi2w1 and np.array_equal(z[0]["yave"], yave1g)
     assert np.abs(z[0]["w"] - w1).max() <= 1e-13 * w1.max() and abs(z[0]["logs"] - logs1) < 1e-12
     yave1 = d["yTilde"].dot(z[0]["w"])
     for r in range(world):
@@ -187,11 +205,20 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     with bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as ctx:
         ff1, fgrad1 = ctx.forces_fdf(f0, fd["w0"], 10.0)
         fres1, fw1, finfos1 = ctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
-        _, _, f6infos1 = ctx.opt_lbfgs_forces_batch([300.0, 100.0, 30.0, 10.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
-                                                    LBFGS_DEFAULTS, max_batch=6)
+        f6res1, f6w1, f6infos1 = ctx.opt_lbfgs_forces_batch([300.0, 100.0, 30.0, 10.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
+                                                            LBFGS_DEFAULTS, max_batch=6)
+        fconv1, fwconv1, ficonv1 = ctx.opt_lbfgs_forces(fd["forces_init"], fd["w0"], fd["theta"], LBFGS_CONV)
     for i, info in enumerate(f6infos1):          # the six-wide batch (K > 4 strip form) against the single-GPU run
         assert abs(z[0]["f6fmin"][i] - info.fmin) <= 2e-5 * abs(info.fmin)
         assert abs(z[0]["f6w"][i].sum() - 1.0) < 1e-12
+    if canonical:                                # the forces method: both strip passes, bit for bit the single-GPU run
+        assert float(z[0]["ff"]) == ff1 and np.array_equal(z[0]["fgrad"], fgrad1)
+        assert np.array_equal(z[0]["fres"], fres1) and np.array_equal(z[0]["fw"], fw1)
+        assert [(float(a), int(b), int(c_)) for a, b, c_ in zip(z[0]["ffmin"], z[0]["fiters"], z[0]["fcodes"])] == \
+               [(i.fmin, i.iterations, i.lbfgs_code) for i in finfos1]
+        assert np.array_equal(z[0]["fwconv"], fwconv1) and float(z[0]["ffminconv"]) == ficonv1.fmin
+        assert np.array_equal(z[0]["f6res"], f6res1) and np.array_equal(z[0]["f6w"], f6w1)
+        assert np.array_equal(z[0]["f6fmin"], [i.fmin for i in f6infos1])
     assert abs(z[0]["ff"] - ff1) <= 1e-13 * abs(ff1)
     assert np.abs(z[0]["fgrad"] - fgrad1).max() <= 1e-10 * np.abs(fgrad1).max()
     for i, info in enumerate(finfos1):
