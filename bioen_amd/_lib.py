@@ -67,6 +67,7 @@ _SIGNATURES = {
     "bioen_hip_ctx_shard": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "bioen_hip_ctx_set_force_exchange": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_ctx_set_mirror_exchange": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_exchange_counts": (C.c_int, [ctx_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_ctx_destroy": (C.c_int, [ctx_p]),
     "bioen_hip_ctx_shape": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -154,6 +155,16 @@ def check(rc):
         L = lib()
         raise BioenHipError("libbioen_hip: %s (%d): %s" % (L.bioen_hip_strerror(rc).decode(), rc,
                                                           L.bioen_hip_last_error().decode()))
+
+
+def column_segments(n, world=1):
+    """The canonical column segments of an n-structure problem on `world` ranks (csrc/ctx.hpp: XStage; api.hip:
+    segment_geometry): -> (nseg, segcols, columns per rank).  nseg = 8 whenever world divides 8 -- every sum over
+    structures then has ONE shape on 1, 2, 4 and 8 GPUs, and their results are bit-identical --, else world;
+    segcols = ceil(n / nseg) rounded up to 128; a rank holds nseg / world consecutive segments."""
+    nseg = 8 if (world <= 8 and 8 % world == 0) else world
+    segcols = (-(-n // nseg) + 127) // 128 * 128
+    return nseg, segcols, segcols * (nseg // world)
 
 
 def device_count():
@@ -616,6 +627,11 @@ class Context(object):
         """world = 1 only: execute the stage all-gathers of the sharded code path anyway (needs comm_init(id, 0, 1)
         or set_exchange); results do not change by a bit.  Puts the RCCL stage path under single-GPU tests."""
         check(lib().bioen_hip_ctx_set_force_exchange(self._h, 1 if on else 0))
+
+    def set_mirror_exchange(self, on=True):
+        """Measurement aid: the stage all-gathers of this rank-r-of-world context copy ITS part over every other rank's --
+        the work one rank of a `world`-GPU run does per round, alone on one GPU (include/bioen_hip.h)."""
+        check(lib().bioen_hip_ctx_set_mirror_exchange(self._h, 1 if on else 0))
 
     def exchange_counts(self):
         """(through RCCL, through the host callback): stage all-gathers executed on this context so far"""

@@ -366,6 +366,10 @@ static int exchange_raw(bioen_hip_ctx* c, int stage, size_t payload) {      // p
         return fail(BIOEN_HIP_ESTATE, m.c_str());
     }
     double* base = c->xbuf[stage];
+    if (c->mirror_exchange) {      // measurement aid: this rank's part over every other rank's (one kernel)
+        launch_xch_mirror(c, stage, payload);
+        return 0;
+    }
     if (c->p2p_on) {          // stores into the peers' mailboxes + flags, one kernel (kernels_p2p.hip)
         if (payload > c->p2p_cap) return fail(BIOEN_HIP_EINVAL, "exchange payload exceeds the mailbox slot");
         ++c->n_p2p_exchanges;
@@ -864,6 +868,12 @@ int bioen_hip_ctx_set_exchange_callback(bioen_hip_ctx* c, bioen_hip_exchange_fn 
 int bioen_hip_ctx_set_force_exchange(bioen_hip_ctx* c, int on) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
     c->force_exchange = on ? 1 : 0;
+    return 0;
+}
+
+int bioen_hip_ctx_set_mirror_exchange(bioen_hip_ctx* c, int on) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    c->mirror_exchange = on ? 1 : 0;
     return 0;
 }
 

@@ -163,6 +163,7 @@ struct bioen_hip_ctx {
     int exchange_error = 0;
     int force_exchange = 0;              // world == 1: run the stage exchanges all the same (through the communicator or the
                                          // callback, if there is one) -- puts the RCCL stage path under single-GPU tests
+    int mirror_exchange = 0;             // measurement aid (bioen_hip_ctx_set_mirror_exchange): an exchange copies this rank's part over the others'
     long long n_rccl_exchanges = 0, n_host_exchanges = 0;   // stage all-gathers executed so far, by transport
     long long n_p2p_exchanges = 0;
     // Peer-to-peer stage exchange (r04; kernels_p2p.hip): every rank owns a MAILBOX in its HBM -- two halves (by the

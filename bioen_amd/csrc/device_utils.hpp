@@ -93,59 +93,45 @@ __device__ __forceinline__ double max_partials(const double* __restrict__ p, int
     return block_max(s, sh);
 }
 
-// ---- consumers of TRANSPOSED partials (the strip kernels): P[tile * stride + idx], idx = row K + a ---------------
-// A strip block writes its mp K sums as one contiguous run (a scattered 8-byte store per (row, problem, block) cost
-// the K = 8 launch 20 us of 70 at N = 1e5 x M = 256).  Here a block of 256 threads totals 16 consecutive entries
-// over all tiles: thread (jg, i) plays the lanes 4 jg .. 4 jg + 3 of the classic wave-per-entry consumer for entry
-// idx0 + i -- lane j adds tiles j, j + 64, ... in turn -- and the 64 lane sums meet in wave_sum's pair order
-// (32, 16, ..., 1) through LDS: bit for bit the classic result, from 128-byte coalesced reads.
-// Returns the total of entry idx0 + (threadIdx.x & 15) in threads < 16.
-// fold > 1: "tile" b is a GROUP of `fold` consecutive sets -- the chunks of one group of the canonical strip sets
-// (kernels_strip.hip), written separately by the strip kernel -- and its value their sum in turn, from +0.0: what a
-// strip kernel that runs whole groups has formed in its registers.
-template <class Term>
-__device__ __forceinline__ double tiles_sum16(const double* __restrict__ P, size_t stride, int ctiles, int fold, size_t idx,
-                                              bool valid, double* lds /* [64 * 16] */, Term term) {
-    const int i = threadIdx.x & 15, jg = threadIdx.x >> 4;
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int base = 0; base < ctiles; base += 1024) {     // 1024 tiles per trip: all 64 loads of a thread in flight at once
-        double v[4][16];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int b = base + 64 * m + 4 * jg + jj;
-                if (fold <= 1) {
-                    v[jj][m] = (valid && b < ctiles) ? P[(size_t)b * stride + idx] : 0.0;
-                } else {
-                    double gsum = 0.0;
-                    if (valid && b < ctiles)
-                        for (int i = 0; i < fold; ++i) gsum += P[((size_t)b * fold + i) * stride + idx];
-                    v[jj][m] = gsum;
-                }
-            }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int b = base + 64 * m + 4 * jg + jj;
-                if (valid && b < ctiles) s[jj] = term(b, v[jj][m], s[jj]);
-            }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) lds[(4 * jg + jj) * 16 + i] = s[jj];
-    __syncthreads();
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        for (int e = threadIdx.x; e < o * 16; e += kBlock) lds[e] += lds[e + o * 16];
-        __syncthreads();
-    }
-    return lds[i];
-}
-
+// ---- consumers of TRANSPOSED partials (the strip kernels): P[set * n + idx], idx = row K + a ------------------------
 struct TermAdd {
     __device__ __forceinline__ double operator()(int, double v, double s) const { return s + v; }
 };
+
+// ---- r05: consumers of the strip kernels' sets, per SEGMENT.  P -> entry `idx` of the segment's first set; set b at
+// P[b n].  THE share of an entry in a segment: its sets' terms are dealt to EIGHT running sums (part p: sets p, p + 8, ...
+// in turn, from +0.0; fold > 1: "set" b is a GROUP of `fold` consecutive sets -- the chunks the forward kernel has not
+// folded itself -- whose value is their sum in turn from +0.0), which meet as ((s0 + s4) + (s2 + s6)) + ((s1 + s5) +
+// (s3 + s7)).  A block = 8 parts x 32 entries: every load of a wave is 32 consecutive entries of one set (256 B).  The
+// classic wave-per-entry tree (tiles_sum16, r02-r04) had half its lanes idle on a segment's 32 groups and cost 8 x its
+// time over the eight segments.  Returns the share in threads < 32 (entry blockIdx.x * 32 + threadIdx.x).
+template <class Term>
+__device__ __forceinline__ double sets_sum8(const double* __restrict__ P, size_t n, int nsets, int fold,
+                                            double (*lds)[32] /* [8][32] */, Term term) {
+    const int p = threadIdx.x >> 5, el = threadIdx.x & 31;
+    double s = 0.0;
+    if (fold <= 1) {
+        int b = p;
+        for (; b + 24 < nsets; b += 32) {                      // four of the part's sets at a time: their loads in flight together
+            const double v0 = P[(size_t)b * n], v1 = P[(size_t)(b + 8) * n], v2 = P[(size_t)(b + 16) * n], v3 = P[(size_t)(b + 24) * n];
+            s = term(b, v0, s);
+            s = term(b + 8, v1, s);
+            s = term(b + 16, v2, s);
+            s = term(b + 24, v3, s);
+        }
+        for (; b < nsets; b += 8) s = term(b, P[(size_t)b * n], s);
+    } else {
+        for (int b = p; b < nsets; b += 8) {
+            double gv = 0.0;
+            for (int i = 0; i < fold; ++i) gv += P[((size_t)b * fold + i) * n];
+            s = term(b, gv, s);
+        }
+    }
+    __syncthreads();      // protect lds against its previous use
+    lds[p][el] = s;
+    __syncthreads();
+    return ((lds[0][el] + lds[4][el]) + (lds[2][el] + lds[6][el])) + ((lds[1][el] + lds[5][el]) + (lds[3][el] + lds[7][el]));
+}
 
 // ---- canonical segments (ctx.hpp: XStage) ---------------------------------------------------------------------
 // An N-vector kernel is launched with npl blocks per local segment (grid.x = npl * vr): block blockIdx.x works on

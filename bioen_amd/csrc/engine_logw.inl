@@ -478,7 +478,7 @@ struct LogwBatchEngine {
         for (int s = 0; s < kb && next < ntheta; ++s) start_problem(s);
 
         // The evaluation-owned entries of a slot's scalars (the rest -- y.s, alpha, gp.d -- belongs to the problem)
-        static const int kEvalScal[][2] = {{S_F, 4}, {S_LOGS, 4}, {S_KL, 2}, {S_INV, 3}};
+        static const int kEvalScal[][2] = {{S_F, 4}, {S_LOGS, 4}, {S_KL, 2}, {S_INV, kMaxSeg + 2}};      // (S_INV[kMaxSeg], S_B0, S_UY)
 
         while (active > 0 && !rc) {
             jitter(1);

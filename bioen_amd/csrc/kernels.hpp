@@ -42,6 +42,7 @@ Xch make_xch(const bioen_hip_ctx* c, int stage, int payload);   // stage view fo
 // peer-to-peer stage exchange (kernels_p2p.hip): one kernel per all-gather, stores into the peers' mailboxes + flags
 size_t p2p_mailbox_doubles(int world, size_t cap);
 void launch_p2p_exchange(bioen_hip_ctx* c, int stage, size_t payload);
+void launch_xch_mirror(bioen_hip_ctx* c, int stage, size_t payload);        // measurement aid: this rank's part over every other rank's
 void launch_xch_fill(bioen_hip_ctx* c, int stage, int payload, int rep);    // self-test of a transport: pattern in, ...
 void launch_xch_check(bioen_hip_ctx* c, int stage, int payload, int rep, unsigned long long* bad);   // ... every segment checked
 

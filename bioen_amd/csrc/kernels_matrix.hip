@@ -178,14 +178,18 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local(const double* __restr
     }
 }
 
-// k_fwd_rows_local on transposed partials (the strip kernels: partial[set * stride + idx]); blockIdx.y = local segment,
-// whose sets are [v * seg_sets, (v + 1) * seg_sets) -- `fold` consecutive sets each (the chunks of one group, added
-// in turn from +0.0: kernels_strip.hip, canonical strip sets) when the strip kernel has not folded them itself.
-// The blocks beyond the entry tiles (one per problem) total the softmax partials.
+// k_fwd_rows_local on transposed partials (the strip kernels: partial[set * n + entry], entry = row K + a, n = mp K).
+// blockIdx.y = local segment v, whose sets are [v gs fold, (v + 1) gs fold).  THE share of an entry in a segment
+// (kernels.hpp: StripSets): the values of its gs groups -- each the sum of its `fold` chunk sets in turn from +0.0 where
+// the strip kernel has not folded them itself -- are dealt to EIGHT running sums (part p: groups p, p + 8, ... in turn,
+// from +0.0), which meet as ((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7)).  A block = 8 parts x 32 entries: every
+// load of a wave is 32 consecutive entries of one set (256 B), 2048 blocks at the headline; the classic
+// wave-per-entry tree of r02-r04 (tiles_sum16) had 32 of its 64 lanes idle on the 32 groups of a segment and cost 8 x its
+// time over the eight segments.  The blocks beyond the entry tiles (one per problem) total the softmax partials.
 template <bool WITH_EXP>
-__global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __restrict__ partial, int seg_groups, int fold,
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __restrict__ partial, int gs, int fold,
                                                              int mp, int K, int ntile, Xch xo, Xch xe) {
-    __shared__ double lds[64 * 16];
+    __shared__ double lds[8][32];
     const int v = blockIdx.y;
     double* out = xo.base + (size_t)(xo.rank + v) * xo.payload;
     if (WITH_EXP && (int)blockIdx.x >= ntile) {
@@ -201,9 +205,10 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __res
         return;
     }
     const size_t n = (size_t)mp * K;
-    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s = tiles_sum16(partial + (size_t)v * seg_groups * fold * n, n, seg_groups, fold, idx, idx < n, lds, TermAdd());
-    if (threadIdx.x < 16 && idx < n) out[idx] = s;
+    const size_t idx = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool valid = idx < n;
+    const double s = sets_sum8(partial + (size_t)v * gs * fold * n + (valid ? idx : 0), n, gs, fold, lds, TermAdd());
+    if (threadIdx.x < 32 && valid) out[idx] = s;
 }
 
 // forces gradient from transposed partials (the strip kernels).  blockIdx.y = local segment v, whose sets are
@@ -214,19 +219,20 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __res
 __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double* __restrict__ partial, int seg_sets,
                                                                    int mp, int K, double* __restrict__ out, size_t out_stride,
                                                                    const double* __restrict__ ybar_c, MVec8 tpart) {
-    __shared__ double lds[64 * 16];
+    __shared__ double lds[8][32];
     __shared__ double T[kMaxBatch];
     const int v = blockIdx.y;
     if (ybar_c)
         for (int a = 0; a < K; ++a) {
-            const double t = sum_partials(tpart.p[a] + (size_t)P_KL * kPartStride + (size_t)v * seg_sets, seg_sets, lds);
+            const double t = sum_partials(tpart.p[a] + (size_t)P_KL * kPartStride + (size_t)v * seg_sets, seg_sets, &lds[0][0]);
             if (threadIdx.x == 0) T[a] = t;
         }
     __syncthreads();
     const size_t n = (size_t)mp * K;
-    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s = tiles_sum16(partial + (size_t)v * seg_sets * n, n, seg_sets, 1, idx, idx < n, lds, TermAdd());
-    if (threadIdx.x < 16 && idx < n) (out + (size_t)v * out_stride)[idx] = ybar_c ? fma(-ybar_c[idx], T[idx % K], s) : s;
+    const size_t idx = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool valid = idx < n;
+    const double s = sets_sum8(partial + (size_t)v * seg_sets * n + (valid ? idx : 0), n, seg_sets, 1, lds, TermAdd());
+    if (threadIdx.x < 32 && valid) (out + (size_t)v * out_stride)[idx] = ybar_c ? fma(-ybar_c[idx], T[idx % K], s) : s;
 }
 
 // add the segments' shares (segment order) -> ybar, r = ybar - YT (compact) ; per-block partials of
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
     // LOGW: the shares are yTilde . e_v with e_v = exp(x - m_v) unnormalised (segment v's own shift); global shift
     // M = max_v m_v, S = sum_v e^{m_v - M} S_v, and segment v's share enters with e^{m_v - M} / S.  _get_weights' normalisation (c_bioen_kernels_logw.c:84-90) is
     // thereby applied to the M sums instead of the N weights.
+    __shared__ double fac[kShRed];     // LOGW: e^{m_v - M} / S per segment
     double gmax = 0.0, invS = 1.0;
     if (LOGW) {
         gmax = -DBL_MAX;
@@ -267,6 +274,9 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             PP = fma(fr, tail[1], PP);
         }
         invS = 1.0 / S;
+        for (int r = threadIdx.x; r < xi.world; r += kBlock)
+            fac[r] = exp(xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2] - gmax) * invS;
+        __syncthreads();
         if (threadIdx.x == 0) {
             double* sc = rd.scal[a];
             sc[S_LOGS] = gmax + log(S);
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
         double s = 0.0;
         for (int r = 0; r < xi.world; ++r) {
             const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
-            if (LOGW) s = fma(exp(xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2] - gmax) * invS, v, s);
+            if (LOGW) s = fma(fac[r], v, s);
             else s += v;
         }
         const double sc = row_scale[row];
@@ -513,7 +523,7 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles, bool 
     const Xch xe = make_xch(c, X_EXP, 3 * K * vec_grid(c));
     if (tposed) {          // the strip kernels' sets (kernels_strip.hip: strip_sets)
         const StripSets ss = strip_sets(c);
-        const int ntile = (c->mp * K + 15) / 16;
+        const int ntile = (c->mp * K + 31) / 32;
         if (logw)
             hipLaunchKernelGGL(k_fwd_rows_local_t<true>, dim3(ntile + K, c->vr), dim3(kBlock), 0, c->stream, c->fwd_partial,
                                ss.gs, ss.fold ? 1 : ss.nch, c->mp, K, ntile, xo, xe);
@@ -580,7 +590,7 @@ static MVec8 tsum_parts(const ForcesRound* fr) {
 
 void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum, bool tposed) {
     if (tposed) {          // every set of the context as one run (unsharded contexts: row panels, M > 1024)
-        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16, 1), dim3(kBlock), 0, c->stream,
+        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 31) / 32, 1), dim3(kBlock), 0, c->stream,
                            c->fwd_partial, ctiles, c->mp, K, c->gm, (size_t)0, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
         return;
     }
@@ -593,7 +603,7 @@ void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const Forc
 void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int seg_sets, const ForcesRound* tsum, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, c->mp * K);
     (void)tposed;
-    hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 15) / 16, c->vr), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 31) / 32, c->vr), dim3(kBlock), 0, c->stream,
                        c->fwd_partial, seg_sets, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, (size_t)xo.payload,
                        tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
 }

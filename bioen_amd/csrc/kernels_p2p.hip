@@ -209,6 +209,19 @@ __global__ void k_xch_check(const double* base, int payload, int world, int rep,
     }
     if (mine) atomicAdd(bad, mine);
 }
+// mirror exchange (bioen_hip_ctx_set_mirror_exchange): block p copies this rank's part of the stage onto rank p's
+__global__ void k_xch_mirror(double* base, int payload, int rank) {
+    const int p = blockIdx.x;
+    if (p == rank) return;
+    const double* src = base + (size_t)rank * payload;
+    double* dst = base + (size_t)p * payload;
+    for (int i = threadIdx.x; i < payload; i += blockDim.x) dst[i] = src[i];
+}
+void launch_xch_mirror(bioen_hip_ctx* c, int stage, size_t payload) {
+    const int threads = (int)std::min<size_t>(1024, std::max<size_t>(64, (payload + 63) / 64 * 64));
+    hipLaunchKernelGGL(k_xch_mirror, dim3(c->world), dim3(threads), 0, c->stream, c->xbuf[stage], (int)payload, c->rank);
+}
+
 void launch_xch_fill(bioen_hip_ctx* c, int stage, int payload, int rep) {
     hipLaunchKernelGGL(k_xch_fill, dim3(8), dim3(256), 0, c->stream, c->xbuf[stage] + (size_t)c->rank * payload, payload, c->rank, rep);
 }

@@ -240,7 +240,8 @@ struct StripArgs {
     int wps, spb;           // k_strip_fwd / k_strip_adj: waves per strip slot, strips per block and iteration
     // canonical partial sets (kernels.hpp: StripSets) of the row-sum passes: k_strip_fwd, k_strip, k_strip2
     int sps, gs, tc, nch, fold, slots;
-    int nslots;             // physical slots of the launch = slots x local segments
+    int nslots;             // physical slots of the launch = slots x local segments (forces passes: = gs)
+    int nlocal;             // local segments (forces passes: a block runs its group through all of them)
     const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
     const double* w0;
     double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
@@ -255,6 +256,7 @@ struct StripArgs {
 // short group's last one) or a slot beyond the launch; its set is all zeros.
 struct SlotWork {
     int first, count, set;
+    int nsets, set_stride;      // forces passes: the sets the slot writes (set, set + set_stride, ...: one per chunk)
     bool live;
 };
 __device__ __forceinline__ SlotWork strip_slot(const StripArgs& q, int ps) {
@@ -269,10 +271,31 @@ __device__ __forceinline__ SlotWork strip_slot(const StripArgs& q, int ps) {
     w.first = v * q.sps + g + q.gs * t0;
     w.count = (w.live && t1 > t0) ? t1 - t0 : 0;
     w.set = q.fold ? v * q.gs + g : (v * q.gs + g) * q.nch + cg;
+    w.nsets = 1;
+    w.set_stride = 0;
     return w;
 }
-// forces passes: flat sets, slot r of segment v -> set v slots + r (never folded)
-__device__ __forceinline__ int forces_set(const StripArgs& q, int ps) { return ps; }
+// Forces passes: set (v, g) = the matrix-core chain over the strips g, g + gs, ... of segment v (gs = min(sps, full
+// grid) groups per segment; no chunks).  Block g runs its group through the context's local segments one after the other
+// -- all eight on one GPU, the 256 blocks sweeping one segment's strips side by side as they swept the whole matrix
+// before r05; one on each of eight GPUs -- and writes a set at every segment's end.  Its strips as ONE sequence:
+// number i is strip (i / tg) sps + g + gs (i % tg), tg = the group's strips per segment.
+struct ForcesSlot {
+    int g, tg, total, sps, gs;
+    __device__ __forceinline__ int strip(int i) const {
+        const int v = i / tg;
+        return v * sps + g + gs * (i - v * tg);
+    }
+};
+__device__ __forceinline__ ForcesSlot forces_slot(const StripArgs& q, int ps) {
+    ForcesSlot w;
+    w.g = ps;
+    w.sps = q.sps;
+    w.gs = q.gs;
+    w.tg = (q.sps - ps + q.gs - 1) / q.gs;      // (ps < gs <= sps: at least one)
+    w.total = w.tg * q.nlocal;
+    return w;
+}
 
 // dynamic LDS: tile[mps * 16] | ul[mps * 8] | red[waves][8][16] | v[8][16] | scale[8]
 //
@@ -284,22 +307,6 @@ __device__ __forceinline__ int forces_set(const StripArgs& q, int ps) { return p
 // strip s deferred behind the first barrier of strip s + 1, where it runs beside P2 of that strip on the waves P2 leaves
 // idle: ONE barrier per strip, P3 off the serial chain (the partial-sum, e | t and rescale buffers are doubled by strip
 // parity).  Same operands, same order of every sum: the bits of a problem do not depend on which form served it.
-// the set of an empty chunk: zero sums; pass 1: no exponentials (maximum -DBL_MAX, weight exp(-DBL_MAX - m) = 0)
-template <bool XY>
-__device__ __forceinline__ void strip_empty_set(const StripArgs& q, const ForcesRound& fr, int set, int K) {
-    for (int i = threadIdx.x; i < q.mp * K; i += blockDim.x) q.partial[(size_t)set * q.mp * K + i] = 0.0;
-    if ((int)threadIdx.x < K) {
-        double* pa = fr.part[threadIdx.x];
-        if (XY) {
-            pa[(size_t)P_MAX * kPartStride + set] = -DBL_MAX;
-            pa[(size_t)P_SUM * kPartStride + set] = 0.0;
-            pa[(size_t)P_PP * kPartStride + set] = 0.0;
-        } else {
-            pa[(size_t)P_KL * kPartStride + set] = 0.0;
-        }
-    }
-}
-
 template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH, int STORE = 0>
 __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
     constexpr int NK = (K + 3) / 4;                 // problem quads
@@ -325,12 +332,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     const int rbase = wave * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
-    const SlotWork wk = strip_slot(q, blockIdx.x);
-    const int myset = forces_set(q, blockIdx.x);
-    if (wk.count == 0) {                            // an empty chunk (block-uniform): its set is all zeros
-        strip_empty_set<XY>(q, fr, myset, K);
-        return;
-    }
+    const ForcesSlot wk = forces_slot(q, blockIdx.x);
 
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
@@ -401,8 +403,6 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         }
 #endif
     };
-    const int G = q.gs;                             // strips between the slot's consecutive strips
-    const int s_end = wk.first + G * wk.count;      // (one past the slot's last strip, in steps of G)
 #if STRIP_DIAG & 4
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_amdgcn_s_memtime();
@@ -438,7 +438,66 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         acc[0][0] += a3x[0][0] * tvp[lj * 16];
 #endif
     };
-    auto one_strip = [&](int s, Regs& pre, int par, bool first = false) {
+    // A segment's sums leave as one set: the row sums and the set statistics; then everything starts from zero again
+    // (pass 1: running maximum -DBL_MAX, so the next strip rescales by exp(-DBL_MAX - m) = 0 exactly as a block's first).
+    // WHERE it is issued matters (r05, measured): the wave has two strips of loads in flight and waits for them with
+    // vmcnt(N), N = the loads the compiler counts behind the one it needs.  Stores it does not count (they sit under a
+    // block-uniform branch) issued BEHIND those loads make every such wait longer by as many of the YOUNGER loads -- the
+    // strip after next -- as there are stores: 3-4 us per flush and block, 5-10 % of a pass with eight segments per block.
+    // So the set of a finished segment leaves at the start of the NEXT segment's first strip, behind the wait for that
+    // strip's own data and in front of its prefetch: then only the (fast) stores themselves stand in the way of a wait.
+    auto flush = [&](int set) {
+        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j.  Row block by row block (16 rows x K
+        // sums = one run of <= 128 doubles of the set) through the wave's own slice of `red` -- free here: the column sums of
+        // the strip before have been consumed -- so that the sums leave as contiguous stores: as 8-byte stores 8 K bytes apart
+        // (r02-r04, once per launch) eight flushes per block cost 7 % of a pass at K = 4 (partial-line writes: 0.75 TB/s)
+        int lz = lane;
+        asm volatile("" : "+v"(lz));      // opaque: keeps the address arithmetic of these stores out of the strip loop's registers
+        double* const stg = red + wave * 128;
+        const int rl = 4 * ((lz >> 2) & 3) + (lz >> 4);
+#pragma unroll
+        for (int h = 0; h < kWaveRows / 16; ++h) {
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const int k = 4 * kq + (lz & 3);
+                // rows between the strip's last row block and mp exist only in the M-vectors: their sums are zero (the
+                // wave computed a redirected row block's there)
+                if (k < K) stg[rl * K + k] = rbase + 16 * h + rl < q.mps ? acc[h][kq] : 0.0;
+                acc[h][kq] = 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nrun = min(16, q.mp - (rbase + 16 * h)) * K;          // (<= 0: rows beyond the operands; the idle second wave of a 64-row strip)
+            double* const dst = q.partial + ((size_t)set * q.mp + rbase + 16 * h) * K;
+            for (int i = lz; i < nrun; i += 64) __builtin_nontemporal_store(stg[i], dst + i);   // streamed: see k_strip_adj's outputs
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // set statistics per problem: sums over the problem's 16 columns (its 16-lane group)
+        double z = zacc, px = pxacc;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            z += __shfl_xor(z, o, 64);
+            px += __shfl_xor(px, o, 64);
+        }
+        if (p2 && pc == 0) {
+            double* pa = pak;
+            if (XY) {
+                pa[(size_t)P_MAX * kPartStride + set] = m_run;
+                pa[(size_t)P_SUM * kPartStride + set] = z;
+                pa[(size_t)P_PP * kPartStride + set] = px;
+            } else {
+                pa[(size_t)P_KL * kPartStride + set] = z;        // this set's share of sum_j t_j
+            }
+        }
+        m_run = -DBL_MAX;
+        zacc = 0.0;
+        pxacc = 0.0;
+    };
+    auto one_strip = [&](int si, Regs& pre, int par, bool first, int flush_set) {      // si: number of the strip in the slot's sequence
+        const int s = wk.strip(si);
         double* const redp = red + (DEFER ? par * nwaves * 128 : 0);
         double* const tvp = tv + (DEFER ? par * 128 : 0);
         double* const scp = scale + (DEFER ? par * 16 : 0);
@@ -475,6 +534,13 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(0)    // waited for the strip, copied it to LDS
+        if (flush_set >= 0) {                       // (block-uniform) the first strip of a segment: the set of the one before it
+            if constexpr (DEFER) {                  // ... whose last strip's deferred row sums run now
+                __syncthreads();                    // its e | t are in place
+                p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
+            }
+            flush(flush_set);
+        }
         // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
         // prefetch would wait for the whole strip after next
         const size_t col = (size_t)s * kStripCols + pc;
@@ -483,7 +549,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        fetch(s + SETS * G < s_end ? s + SETS * G : s, pre);          // unconditional, see k_strip_adj
+        fetch(si + SETS < wk.total ? wk.strip(si + SETS) : s, pre);   // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + lq][c = 4 blk + i = lr]; B: lane (kk = lq, blk, j) = u[r0 + lq][4 kq + j]
         {
@@ -585,65 +651,53 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
         // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
     };
-    int s = wk.first;
-    fetch(s, preA);                                                // count >= 1: the slot has a first strip
-    if constexpr (DEPTH == 2) {
-        fetch(s + G < s_end ? s + G : s, preB);
-        __syncthreads();                                          // ul / tv / scale initialised
-        // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
-        for (; s + G < s_end; s += 2 * G) {
-            one_strip(s, preA, 0);
-            one_strip(s + G, preB, 1);
+    // The slot's strips, number 0 .. total - 1, straight through the local segments.  The two register sets of DEPTH 2
+    // alternate strip by strip whatever the segments' lengths; the first strip of a segment carries the flush of the
+    // segment before it (above), the last segment's set leaves behind the loop.
+    int cnt = 0, vloc = 0;
+    auto pending = [&](int i) { return (i > 0 && cnt == 0) ? (vloc - 1) * q.gs + wk.g : -1; };   // the set to flush at strip i
+    auto count = [&]() {
+        if (++cnt == wk.tg) {
+            cnt = 0;
+            ++vloc;
         }
-        if (s < s_end) one_strip(s, preA, 0);
+    };
+    fetch(wk.strip(0), preA);                                      // total >= 1: the slot has a first strip
+    if constexpr (DEPTH == 2) fetch(wk.total > 1 ? wk.strip(1) : wk.strip(0), preB);
+    __syncthreads();                                              // ul / tv / scale initialised
+    if constexpr (DEPTH == 2) {
+        // both halves and both prefetches unconditional inside the loop (see k_strip_adj); an odd last strip is peeled
+        int i = 0;
+        for (; i + 1 < wk.total; i += 2) {
+            one_strip(i, preA, 0, false, pending(i));
+            count();
+            one_strip(i + 1, preB, 1, false, pending(i + 1));
+            count();
+        }
+        if (i < wk.total) {
+            one_strip(i, preA, 0, false, pending(i));
+            count();
+        }
     } else if constexpr (DEFER) {
-        __syncthreads();
         int par = 0;
-        one_strip(s, preA, 0, true);
-        for (s += G, par = 1; s < s_end; s += G, par ^= 1) one_strip(s, preA, par);
+        for (int i = 0; i < wk.total; ++i, par ^= 1) {
+            const int fs = pending(i);
+            one_strip(i, preA, par, i == 0 || fs >= 0, fs);       // (a segment's first strip: the deferred row sums of the strip
+            count();                                              //  before it have run with the flush)
+        }
         __syncthreads();                                          // the last strip's e | t are in place
         p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
     } else {
-        __syncthreads();
-        for (int par = 0; s < s_end; s += G, par ^= 1) one_strip(s, preA, par);
+        for (int i = 0, par = 0; i < wk.total; ++i, par ^= 1) {
+            one_strip(i, preA, par, false, pending(i));
+            count();
+        }
     }
+    flush((vloc - 1) * q.gs + wk.g);                              // the last segment's set
 #if STRIP_DIAG & 4
     if (q.stamps && lane == 0)
         for (int i = 0; i < 8; ++i) q.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + i] = tacc[i];
 #endif
-    {
-        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
-        const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
-#pragma unroll
-        for (int h = 0; h < kWaveRows / 16; ++h)
-#pragma unroll
-            for (int kq = 0; kq < NK; ++kq) {
-                const int row = rr + 16 * h, k = 4 * kq + lj;
-                // transposed: a block's sums are one run; rows between the strip's last row block and mp exist only in
-                // the M-vectors: their sums are zero (the wave computed a redirected row block's there)
-                if (row < q.mp && k < K)
-                    q.partial[(size_t)myset * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
-            }
-    }
-    // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
-    {
-        double z = zacc, px = pxacc;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            z += __shfl_xor(z, o, 64);
-            px += __shfl_xor(px, o, 64);
-        }
-        if (p2 && pc == 0) {
-            double* pa = pak;
-            if (XY) {
-                pa[(size_t)P_MAX * kPartStride + myset] = m_run;
-                pa[(size_t)P_SUM * kPartStride + myset] = z;
-                pa[(size_t)P_PP * kPartStride + myset] = px;
-            } else {
-                pa[(size_t)P_KL * kPartStride + myset] = z;        // this set's share of sum_j t_j
-            }
-        }
-    }
 }
 
 // ---- the same two passes for 512 < M <= 1024 (r03; until then the r01 kernels on the row-major matrix: 4.8 TB/s at K = 1,
@@ -678,12 +732,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     const int rbase = wave * WR;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
-    const SlotWork wk = strip_slot(q, blockIdx.x);
-    const int myset = forces_set(q, blockIdx.x);
-    if (wk.count == 0) {                            // an empty chunk (block-uniform): its set is all zeros
-        strip_empty_set<XY>(q, fr, myset, K);
-        return;
-    }
+    const ForcesSlot wk = forces_slot(q, blockIdx.x);
 
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
@@ -760,9 +809,57 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     // K > 4: the operand batches of the column-sum product do not fit beside a3 AND the whole prefetch (7-12 registers
     // spilled per strip); the second half of the prefetch is issued behind that product instead
     constexpr int SPLIT = NK > 1 ? WR / 16 : WR / 8;
-    const int G = q.gs;                             // strips between the slot's consecutive strips
-    const int s_end = wk.first + G * wk.count;
-    auto one_strip = [&](int s) {
+    auto flush = [&](int set) {                                    // a segment's sums leave as one set; then everything starts from zero (k_strip)
+        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j.  Row block by row block (16 rows x K
+        // sums = one run of <= 128 doubles of the set) through the wave's own slice of `red` -- free here: the column sums of
+        // the strip before have been consumed -- so that the sums leave as contiguous stores: as 8-byte stores 8 K bytes apart
+        // (r02-r04, once per launch) eight flushes per block cost 7 % of a pass at K = 4 (partial-line writes: 0.75 TB/s)
+        int lz = lane;
+        asm volatile("" : "+v"(lz));      // opaque: keeps the address arithmetic of these stores out of the strip loop's registers
+        double* const stg = red + wave * 128;
+        const int rl = 4 * ((lz >> 2) & 3) + (lz >> 4);
+#pragma unroll
+        for (int h = 0; h < WR / 16; ++h) {
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const int k = 4 * kq + (lz & 3);
+                // rows between the strip's last row block and mp exist only in the M-vectors: their sums are zero (the
+                // wave computed a redirected row block's there)
+                if (k < K) stg[rl * K + k] = rbase + 16 * h + rl < q.mps ? acc[h][kq] : 0.0;
+                acc[h][kq] = 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nrun = min(16, q.mp - (rbase + 16 * h)) * K;          // (<= 0: rows beyond the operands; the idle second wave of a 64-row strip)
+            double* const dst = q.partial + ((size_t)set * q.mp + rbase + 16 * h) * K;
+            for (int i = lz; i < nrun; i += 64) __builtin_nontemporal_store(stg[i], dst + i);   // streamed: see k_strip_adj's outputs
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        double z = zacc, px = pxacc;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            z += __shfl_xor(z, o, 64);
+            px += __shfl_xor(px, o, 64);
+        }
+        if (p2 && pc == 0) {
+            double* pa = pak;
+            if (XY) {
+                pa[(size_t)P_MAX * kPartStride + set] = m_run;
+                pa[(size_t)P_SUM * kPartStride + set] = z;
+                pa[(size_t)P_PP * kPartStride + set] = px;
+            } else {
+                pa[(size_t)P_KL * kPartStride + set] = z;        // this set's share of sum_j t_j
+            }
+        }
+        m_run = -DBL_MAX;
+        zacc = 0.0;
+        pxacc = 0.0;
+    };
+    auto one_strip = [&](int si, int flush_set) {   // si: number of the strip in the slot's sequence (k_strip)
+        const int s = wk.strip(si);
         // the strip's centred values: the row-sum operands of P3, and the source of the LDS image below
         double a3[4][WR / 16];
         {
@@ -779,6 +876,8 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
                 }
             }
         }
+        if (flush_set >= 0) flush(flush_set);      // (block-uniform) a segment's first strip: the set of the segment before it,
+                                                   // behind the wait for this strip's data and in front of its prefetch (k_strip)
         // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
         // prefetch would wait for the whole strip after next
         const size_t col = (size_t)s * kStripCols + pc;
@@ -787,7 +886,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
             w0v = q.w0[col];
             if (!XY) xv = ak[col];
         }
-        const int nxt = s + G < s_end ? s + G : s;
+        const int nxt = si + 1 < wk.total ? wk.strip(si + 1) : s;
         fetch_part(nxt, 0, SPLIT);                 // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k], half by half through the LDS image ----
         {
@@ -913,43 +1012,18 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
         // every wave has finished P2 of this strip (second barrier above), v only after the next first barrier.
     };
-    int s = wk.first;
-    fetch(s);                                                      // count >= 1: the slot has a first strip
+    fetch(wk.strip(0));                                            // total >= 1: the slot has a first strip
     __syncthreads();                                              // ul / tv / scale / cl initialised
-    for (; s < s_end; s += G) one_strip(s);
-    {
-        // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j
-        const int rr = rbase + 4 * ((lane >> 2) & 3) + lq;
-#pragma unroll
-        for (int h = 0; h < WR / 16; ++h)
-#pragma unroll
-            for (int kq = 0; kq < NK; ++kq) {
-                const int row = rr + 16 * h, k = 4 * kq + lj;
-                // transposed: a block's sums are one run; rows between the strip's last row block and mp exist only in
-                // the M-vectors: their sums are zero (the wave computed a redirected row block's there)
-                if (row < q.mp && k < K)
-                    q.partial[(size_t)myset * q.mp * K + (size_t)row * K + k] = row < q.mps ? acc[h][kq] : 0.0;
-            }
-    }
-    // block statistics per problem: sums over the problem's 16 columns (its 16-lane group)
-    {
-        double z = zacc, px = pxacc;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            z += __shfl_xor(z, o, 64);
-            px += __shfl_xor(px, o, 64);
-        }
-        if (p2 && pc == 0) {
-            double* pa = pak;
-            if (XY) {
-                pa[(size_t)P_MAX * kPartStride + myset] = m_run;
-                pa[(size_t)P_SUM * kPartStride + myset] = z;
-                pa[(size_t)P_PP * kPartStride + myset] = px;
-            } else {
-                pa[(size_t)P_KL * kPartStride + myset] = z;        // this set's share of sum_j t_j
-            }
+    // straight through the local segments; a segment's first strip carries the flush of the segment before it (k_strip)
+    int cnt = 0, vloc = 0;
+    for (int i = 0; i < wk.total; ++i) {
+        one_strip(i, (i > 0 && cnt == 0) ? (vloc - 1) * q.gs + wk.g : -1);
+        if (++cnt == wk.tg) {
+            cnt = 0;
+            ++vloc;
         }
     }
+    flush((vloc - 1) * q.gs + wk.g);                              // the last segment's set
 }
 
 // ---- log-weights forward pass on the strip copy: partial[set mp K + row K + k] = sum_{j in the set's strips} Y'[row][j] e_k[j]
@@ -1299,7 +1373,17 @@ StripSets forces_sets(const bioen_hip_ctx* c) {        // gs = 0: the strip pass
     static int tall_off = -1;                          // BIOEN_HIP_STRIP_TALL=0: the streaming kernels for 512 < M <= 1024 (A/B)
     if (tall_off < 0) tall_off = env_flag("BIOEN_HIP_STRIP_TALL", 1) == 0 ? 1 : 0;
     if (c->mp > 1024 || (c->mp > 512 && tall_off) || c->strips_unavailable) return StripSets{};
-    return make_sets(c, 32 * forces_per_cu(c), false);
+    // one set per (segment, group): gs = the full grid of a GPU holding ONE segment (or every strip of the segment); a
+    // block runs its group through the local segments (kernels_strip.hip: ForcesSlot)
+    StripSets ss{};
+    ss.sps = c->segcols / kStripCols;
+    ss.gs = std::max(1, std::min(ss.sps, 256 * forces_per_cu(c)));
+    ss.tc = (ss.sps + ss.gs - 1) / ss.gs;
+    ss.nch = 1;
+    ss.fold = 0;
+    ss.slots = ss.gs;
+    ss.sets = ss.gs;
+    return ss;
 }
 
 int forces_fused_blocks(const bioen_hip_ctx* c) {      // sets per SEGMENT of the forces strip passes; 0: not applicable
@@ -1833,8 +1917,9 @@ static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, cons
     q.K = fr.n;
     (void)nblk;
     const StripSets ss = forces_sets(c);
-    q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = ss.nch; q.fold = 0; q.slots = ss.slots;
-    q.nslots = ss.slots * c->vr;
+    q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = 1; q.fold = 0; q.slots = ss.gs;
+    q.nslots = ss.gs;                                  // one block per group; it runs the local segments in turn
+    q.nlocal = c->vr;
     q.nblk = q.nslots;
     q.u_c = u_c;
     q.w0 = c->fixed;
@@ -1889,18 +1974,19 @@ struct TermWeighted {
 
 __global__ __launch_bounds__(kBlock) void k_forces_rows_weighted_t(const double* __restrict__ partial, int seg_sets, int mp,
                                                                    int K, ForcesRound fr, Xch xo) {
-    __shared__ double lds[64 * 16];
+    __shared__ double lds[8][32];
     const int v = blockIdx.y;
     const size_t n = (size_t)mp * K;
-    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const size_t idx = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool valid = idx < n;
     const int a = (int)(idx % K);
     const double* wb = fr.part[0];
 #pragma unroll
     for (int k = 1; k < kMaxBatch; ++k)
         if (k == a) wb = fr.part[k];
-    const double s = tiles_sum16(partial + (size_t)v * seg_sets * n, n, seg_sets, 1, idx, idx < n, lds,
-                                 TermWeighted{wb + (size_t)P_MAX * kPartStride + (size_t)v * seg_sets});
-    if (threadIdx.x < 16 && idx < n) (xo.base + (size_t)(xo.rank + v) * xo.payload)[idx] = s;
+    const double s = sets_sum8(partial + (size_t)v * seg_sets * n + (valid ? idx : 0), n, seg_sets, 1, lds,
+                               TermWeighted{wb + (size_t)P_MAX * kPartStride + (size_t)v * seg_sets});
+    if (threadIdx.x < 32 && valid) (xo.base + (size_t)(xo.rank + v) * xo.payload)[idx] = s;
 }
 
 // w_j = w0_j exp(x_j - S_LOGS): the weights themselves, when a result is handed out
@@ -1916,7 +2002,7 @@ void launch_forces_blockmerge(bioen_hip_ctx* c, const ForcesRound& fr, int seg_s
     (void)tposed;
     const Xch xo = make_xch(c, X_YBAR, ybar_payload(c, fr.n, true));
     hipLaunchKernelGGL(k_forces_blockstats, dim3(1, fr.n, c->vr), dim3(kBlock), 0, c->stream, fr, seg_sets, c->mp, fr.n, xo);
-    hipLaunchKernelGGL(k_forces_rows_weighted_t, dim3((c->mp * fr.n + 15) / 16, c->vr), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL(k_forces_rows_weighted_t, dim3((c->mp * fr.n + 31) / 32, c->vr), dim3(kBlock), 0, c->stream,
                        c->fwd_partial, seg_sets, c->mp, fr.n, fr, xo);
 }
 

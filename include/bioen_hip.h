@@ -135,6 +135,13 @@ int bioen_hip_ctx_shard(const bioen_hip_ctx* ctx, int* rank, int* world, long lo
  * BIOEN_HIP_FORCE_EXCHANGE=1 in the environment at context creation.  bioen_hip_exchange_counts tells how
  * many stage all-gathers went through RCCL / through the host callback so far. */
 int bioen_hip_ctx_set_force_exchange(bioen_hip_ctx* ctx, int on);
+/* Measurement aid: a MIRROR exchange.  A context created as rank r of `world` whose stage all-gathers copy ITS OWN part
+ * into every other rank's part of the stage buffer -- one small kernel per exchange, no peer, no host.  The run is that of
+ * a problem whose `world` column blocks are all equal to this rank's: numerically a valid problem, and kernel for kernel
+ * the work ONE rank of a `world`-GPU run does per round, measured on a single GPU (bench.py, tools/engine_ab.py: the
+ * per-rank share behind the multi-GPU projection).  Results are returned as for any sharded context (every block of
+ * the gathered vectors equals this rank's). */
+int bioen_hip_ctx_set_mirror_exchange(bioen_hip_ctx* ctx, int on);
 int bioen_hip_exchange_counts(const bioen_hip_ctx* ctx, long long* rccl, long long* host_staged);
 int bioen_hip_ctx_destroy(bioen_hip_ctx* ctx);
 int bioen_hip_ctx_shape(const bioen_hip_ctx* ctx, int* m, int* n);

@@ -343,7 +343,8 @@ def test_strip_copies_replace_the_rowmajor_matrix(optimize, M, N):
     w_any = rng.uniform(0.0, 2.0, N)                       # not normalised
     params = dict(linesearch=2, max_iterations=30, delta=1e-6, epsilon=1e-6, ftol=1e-5, gtol=0.9, wolfe=0.9, past=10,
                   max_linesearch=100)
-    unit = M * ((N + 127) // 128 * 128) * 8               # lower bound of one copy
+    from bioen_amd._lib import column_segments
+    unit = M * column_segments(N)[2] * 8                  # lower bound of one copy: 8 column segments, each padded to 128
     with bioen_amd.Context(Y, YT) as ctx:
         assert ctx.footprint()[0] == {"rowmajor"}
         assert np.array_equal(ctx.read_ytilde(), Y)
@@ -502,7 +503,8 @@ def test_read_probe_streams_the_resident_matrix(optimize):
         assert nbytes == ctx.footprint()[1] and gbs > 50.0                  # row-major form
         ctx.logw_fdf(np.zeros(N), np.zeros(N), 1.0)                          # builds the strip copies, frees the row-major one
         gbs2, nbytes2 = ctx.read_probe(reps=3)
-        assert nbytes2 == (N + 127) // 128 * 128 * 304 * 8 and gbs2 > 50.0   # one strip copy: rows padded to 16
+        from bioen_amd._lib import column_segments
+        assert nbytes2 == column_segments(N)[2] * 304 * 8 and gbs2 > 50.0     # one strip copy: rows padded to 16, 8 column segments
         assert np.array_equal(ctx.read_ytilde(), Y)
 
 

@@ -48,7 +48,10 @@ names = [n for n in VARIANTS if not only or n in only.split(",")]
 thetas = np.logspace(3, -0.5, 8)
 for (M, N) in sizes:
     YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
-    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED) as ctx:
+    world = int(os.environ.get("WORLD", "1"))          # WORLD=8: rank 0 of an 8-rank decomposition alone on this GPU, its
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED, rank=0, world=world) as ctx:
+        if world > 1:                                  # exchanges mirrored (Context.set_mirror_exchange): a rank's share per round
+            ctx.set_mirror_exchange(True)
         G = np.zeros(N)
         times = {n: [] for n in names}
         rounds = {}
@@ -78,6 +81,6 @@ for (M, N) in sizes:
                     times[n].append(dt)
         for n in names:
             t = sorted(times[n])
-            print("M=%d N=%d %-16s best %.4f s  median %.4f s  rounds %d -> %.1f us/round" % (
+            print(("WORLD=%d rank share  " % world if world > 1 else "") + "M=%d N=%d %-16s best %.4f s  median %.4f s  rounds %d -> %.1f us/round" % (
                 M, N, n, t[0], t[len(t) // 2], rounds[n], 1e6 * t[0] / max(rounds[n], 1)))
         sys.stdout.flush()

@@ -14,7 +14,10 @@ if os.environ.get("THETAS"):                       # e.g. THETAS=10 for a K = 1 
     thetas = np.array([float(v) for v in os.environ["THETAS"].split(",")])
 for (M, N) in sizes:
     YTrue, sig_sim, sig_exp, YTilde = synthetic_targets(M)
-    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED) as ctx:
+    world = int(os.environ.get("WORLD", "1"))          # WORLD=8: rank 0 of an 8-rank decomposition, exchanges mirrored
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED, rank=0, world=world) as ctx:
+        if world > 1:
+            ctx.set_mirror_exchange(True)
         G = np.zeros(N)
         sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS)
         ctx.synchronize()
