@@ -672,8 +672,10 @@ def choose_transport(ctx, comm, sweep, nshard, transport, count, xinfo, HipError
         rccl, gather = start_rccl()
         return gather, rccl
     p2p = False
+    rccl_tried = False
     if transport == "compare":
         rccl, gather = start_rccl()
+        rccl_tried = True
         if rccl:
             xinfo["rccl_us"] = probe()
     if transport in ("auto", "p2p", "compare"):
@@ -684,18 +686,28 @@ def choose_transport(ctx, comm, sweep, nshard, transport, count, xinfo, HipError
             if transport == "compare" and xinfo.get("rccl_us", float("inf")) < xinfo["p2p_us"]:
                 ctx.p2p_detach()                 # RCCL is the faster one on this node
                 p2p = False
-    if not p2p and transport in ("auto", "rccl"):
+    if not p2p and transport in ("auto", "rccl") and not rccl_tried:
         rccl, gather = start_rccl()
+        rccl_tried = True
         if rccl:
             xinfo["rccl_us"] = probe()
-    if p2p and rccl:
-        ctx.comm_destroy()                       # measured, not chosen
-        rccl = False
+    stage_rccl = rccl and not p2p                # what the rounds' stage exchanges go through
     if not p2p and not rccl:
         ctx.set_exchange(comm)   # host-staged all-gathers: correct but slow (ranks sharing one GPU)
         xinfo["host_us"] = probe()
-    if gather == "none":
-        gather = "stage exchanges only (every rank holds the results)"
+    # r05: whatever carries the stage exchanges, EVERY multi-rank run owns an RCCL communicator over all its ranks for the
+    # final all-gather of (fmin, chi^2, S, iterations, status, weights) per theta (north_star: "an RCCL gather over xGMI of
+    # the final (S, chi^2, weights) per theta") -- initialised here, outside the timed region; the mailboxes keep the
+    # in-loop exchanges (the library prefers them: api.hip: exchange).  If RCCL cannot be had the run goes on, and says so.
+    if not rccl_tried and transport != "host":     # (host forced: a communicator would take the stage exchanges over)
+        rccl, gather = start_rccl()
+    elif not rccl_tried:
+        gather = "tcp-allgather (--transport host: RCCL not initialised)"
+    xinfo["rccl_gather"] = bool(rccl)
+    if not rccl:
+        xinfo["rccl_error"] = gather
+    if not stage_rccl:
+        gather = "stage exchanges (every rank holds the results) + %s" % ("one rccl-allgather of the results" if rccl else gather)
     xinfo["transport"] = ctx.exchange_transport()
     xinfo["exchange_us"] = xinfo.get({"p2p": "p2p_us", "rccl": "rccl_us", "host": "host_us"}[xinfo["transport"]])
     for k in list(xinfo):
@@ -857,6 +869,19 @@ def main():
     stats = ctx.kernel_stats()
     ctx.kernel_stats_enable(False)
 
+    # r05: the final (S, chi^2, weights) per theta once more through ONE RCCL all-gather over all ranks -- in a
+    # structure-sharded run the cross-rank consistency check (every rank must hold the same bytes), after the timed region;
+    # theta-dealing runs have gathered through RCCL inside it (sweep.theta_sweep) and are checked the same way.  A failure
+    # is reported in the line, never fatal.
+    final_gather = None
+    if world > 1:
+        try:
+            final_gather = sweep.gather_results(ctx, results, comm, rccl=bool(rccl))
+            final_gather["seconds"] = comm.max(final_gather["seconds"])
+            final_gather["consistent"] = bool(all(comm.allgather_object(final_gather["consistent"])))
+        except bioen_amd.BioenHipError as e:
+            final_gather = {"error": str(e), "via": "rccl" if rccl else "tcp"}
+
     iters_per_sweep = sum(r["iterations"] for r in results)
     evals_per_sweep = sum(r["evaluations"] for r in results)
     total_iters = iters_per_sweep * args.steps
@@ -1017,6 +1042,10 @@ def main():
                        if nshard else ("theta round-robin over %d rank(s)" % world), "gather": gather,
                        "max_batch": args.max_batch, "shard_decision": decision,
                        "rccl_ranks": world if rccl else (0 if world > 1 else None),
+                       "rccl_error": xinfo.get("rccl_error") if (world > 1 and not rccl) else None,
+                       "rccl_gather_us": (1e6 * final_gather["seconds"] if final_gather and final_gather.get("via") == "rccl"
+                                          and "seconds" in final_gather else None),
+                       "final_gather": final_gather,
                        "exchange_transport": xinfo.get("transport") if nshard else None,
                        "exchange_us": xinfo.get("exchange_us") if xinfo else (decision or {}).get("exchange_us"),
                        "exchange_us_by_transport": {k[:-3]: xinfo[k] for k in ("p2p_us", "rccl_us", "host_us") if k in xinfo},

@@ -448,6 +448,9 @@ static int await_live(bioen_hip_ctx* c, unsigned long long round, const int* slo
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // the flags are there -- but a round whose exchange kernel gave up (ABORT from a peer, OUT OF STEP, a deadline) still
+    // publishes them, from stale stage buffers: scalars behind a failed exchange are not results (one host-mapped word)
+    if (const int te = transport_error(c)) return te;
     for (int a = 0; a < n; ++a)
         std::memcpy(c->host_scal + (size_t)slots[a] * kScalStride, c->live + (size_t)a * kScalStride,
                     kScalStride * sizeof(double));

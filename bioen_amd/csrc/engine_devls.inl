@@ -77,7 +77,7 @@ int LogwBatchEngine::await_flight(const DevFlight& f) {
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return 0;
+    return transport_error(c);      // decisions taken behind a failed exchange are not results (api.hip: await_live)
 }
 
 int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* g0_host, size_t g0_stride,
@@ -433,6 +433,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
     }
     note(hipStreamSynchronize(c->stream), "sync");      // rounds still in flight are dead ones: every problem has finished
     note(check_launch());
+    note(transport_error(c));                           // ... and none of their exchanges may have failed: deliveries are settled below
     for (int s = 0; s < kMaxBatch; ++s) settle(s);
     if (!rc) {
         unsigned long long used = 0;

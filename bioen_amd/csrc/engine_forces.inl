@@ -120,6 +120,7 @@ struct ForcesBatchEngine {
             if (t > 0) break;
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (const int te = transport_error(c)) return te;      // results behind a failed exchange are not results (api.hip: await_live)
         std::memcpy(c->host_scal, c->live_f + scal_at, (size_t)kMaxBatch * kScalStride * sizeof(double));
         return 0;
     }
@@ -437,6 +438,7 @@ struct ForcesBatchEngine {
         if (verbose && issued)
             std::printf("\tspeculative line-search evaluations: %lld issued in idle batch slots, %lld adopted\n", issued, adopted);
         note(hipStreamSynchronize(c->stream), "sync");
+        note(transport_error(c));              // no exchange of the run may have failed (api.hip: await_live)
         return rc;
     }
 };

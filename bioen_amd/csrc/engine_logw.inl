@@ -667,6 +667,7 @@ struct LogwBatchEngine {
         }
         note(hipStreamSynchronize(c->stream), "sync");
         note(check_launch());
+        note(transport_error(c));              // no exchange of the run may have failed (api.hip: await_live)
         for (int s = 0; s < kMaxBatch; ++s) settle(s);
         c->spec_launched += spec_launched;
         c->spec_used += spec_used;

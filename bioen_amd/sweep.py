@@ -404,6 +404,31 @@ def theta_sweep(ctx, thetas, solve, comm=None, rccl=False, n=None, presolved=Non
     return out
 
 
+def gather_results(ctx, results, comm, rccl=True):
+    """ONE all-gather of the final (theta, fmin, chi^2, S, iterations, evaluations, status, seconds, weights[n]) of every theta
+    of `results` (a sweep's return value) over all ranks -- through RCCL (``ctx.comm_allgather``: ncclAllGather over xGMI)
+    when `rccl`, else through the control plane.  On a structure-sharded run every rank already holds every result (the
+    library gathers the vectors): the gather is then the cross-rank CONSISTENCY check -- every rank's record of every theta
+    must be the same bytes.  -> {"seconds", "bytes_per_rank", "consistent", "ranks", "via"}"""
+    import time
+    n = results[0]["w"].size
+    buf = np.empty((len(results), HEADER + n))
+    for k, r in enumerate(results):
+        buf[k, :HEADER] = (r["theta"], r["fmin"], r["chi2"], -r["S"], r["iterations"], r["evaluations"], r["code"], 0.0)
+        buf[k, HEADER:] = r["w"]
+    flat = buf.reshape(-1)
+    t0 = time.perf_counter()
+    if rccl:
+        got = ctx.comm_allgather(flat, comm.world)
+    else:
+        got = comm.allgather_array(flat)
+    dt = time.perf_counter() - t0
+    got = np.asarray(got).reshape(comm.world, -1)
+    same = all(np.array_equal(got[r].view(np.uint64), flat.view(np.uint64)) for r in range(comm.world))
+    return {"seconds": dt, "bytes_per_rank": int(flat.nbytes), "consistent": bool(same), "ranks": int(comm.world),
+            "via": "rccl" if rccl else "tcp"}
+
+
 def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=False, verbose=False, max_batch=8):
     """Cold-started log-weights series (every theta starts from g_init, as
     procedure.py:46,66 does for generic data).  The thetas of a rank run as ONE lock-step

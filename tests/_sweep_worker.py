@@ -37,11 +37,20 @@ def main():
 
     res = sweep.theta_sweep(None, thetas, solve, comm=comm, rccl=False, n=d["G"].size)
     tmax = comm.max(float(comm.rank + 1))
+    # the final all-gather of the results as the cross-rank consistency check (sweep.gather_results; the GPU ranks send it
+    # through RCCL): identical records on both ranks -> consistent; one rank's weights nudged by an ulp -> not
+    g_ok = sweep.gather_results(None, res, comm, rccl=False)
+    bent = [dict(r) for r in res]
+    if comm.rank == 1:
+        bent[2] = dict(bent[2], w=np.nextafter(bent[2]["w"], 1.0))
+    g_bad = sweep.gather_results(None, bent, comm, rccl=False)
     comm.barrier()
     np.savez(out_path % comm.rank, thetas=np.array([r["theta"] for r in res]),
              fmin=np.array([r["fmin"] for r in res]), ranks=np.array([r["rank"] for r in res]),
              iters=np.array([r["iterations"] for r in res]), w=np.stack([r["w"] for r in res]), tmax=tmax,
-             objs=np.array([x for x in comm.allgather_object(comm.rank * 10)]))
+             objs=np.array([x for x in comm.allgather_object(comm.rank * 10)]),
+             gather_ok=g_ok["consistent"], gather_bad=g_bad["consistent"], gather_ranks=g_ok["ranks"],
+             gather_bytes=g_ok["bytes_per_rank"])
     comm.close()
     if mode == "gloo":
         import torch.distributed as dist

@@ -119,19 +119,38 @@ def _choose(transport, sweep, us, nshard=True, others=lambda x: [x]):
     return ctx, sweep, xinfo, gather, rccl
 
 
-def test_auto_takes_the_mailboxes_and_never_touches_rccl():
+def test_auto_takes_the_mailboxes_for_the_rounds_and_rccl_for_the_final_gather():
+    """r05: every multi-rank run owns an RCCL communicator over all ranks for the final all-gather of the results; the
+    mailboxes keep the in-loop stage exchanges (the library prefers them)"""
     ctx, sw, x, gather, rccl = _choose("auto", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
-    assert sw.calls == ["init_p2p"] and ctx.log == [] and not rccl
+    assert sw.calls == ["init_p2p", "init_rccl"] and ctx.log == [] and rccl and x["rccl_gather"] is True
     assert x["transport"] == "p2p" and x["exchange_us"] == 5.0 and "rccl_us" not in x and "stage exchanges" in gather
+    assert "rccl-allgather of the results" in gather and "rccl_error" not in x
+
+
+def test_rccl_down_beside_working_mailboxes_is_reported_not_fatal():
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(rccl_ok=_Err("ncclCommInitRank: invalid usage")), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
+    assert sw.calls == ["init_p2p", "init_rccl"] and not rccl and x["rccl_gather"] is False and x["transport"] == "p2p"
+    assert "invalid usage" in x["rccl_error"] and ctx.log == []
+    # ... and when another rank could not: this rank gives its communicator up again, the mailboxes stay
+    others = lambda v: [False] if isinstance(v, bool) else [v]
+    ctx, sw, x, gather, rccl = _choose("auto", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0}, others=others)
+    assert not rccl and ctx.log == ["comm_destroy", "set_exchange"] or (not rccl and "comm_destroy" in ctx.log)
+    assert x["rccl_gather"] is False and "failed on some rank" in x["rccl_error"]
 
 
 def test_auto_falls_back_to_rccl_then_to_the_host():
     ctx, sw, x, gather, rccl = _choose("auto", _Sweep(p2p_ok=False), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
     assert sw.calls == ["init_p2p", "init_rccl"] and rccl and x["transport"] == "rccl" and x["exchange_us"] == 25.0
-    assert gather == "rccl-allgather" and x["p2p_attached"] is False
+    assert gather == "rccl-allgather" and x["p2p_attached"] is False and x["rccl_gather"] is True
     ctx, sw, x, gather, rccl = _choose("auto", _Sweep(p2p_ok=False, rccl_ok=_Err("no librccl")), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
     assert not rccl and x["transport"] == "host" and x["exchange_us"] == 90.0 and ctx.log == ["set_exchange"]
-    assert "RCCL unavailable" in gather
+    assert "RCCL unavailable" in gather and "RCCL unavailable" in x["rccl_error"] and sw.calls == ["init_p2p", "init_rccl"]
+
+
+def test_forced_host_transport_leaves_rccl_alone():
+    ctx, sw, x, gather, rccl = _choose("host", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
+    assert sw.calls == [] and not rccl and x["transport"] == "host" and x["rccl_gather"] is False and "host" in x["rccl_error"]
 
 
 def test_rccl_that_one_rank_could_not_initialise_is_given_up_by_all():
@@ -144,7 +163,7 @@ def test_rccl_that_one_rank_could_not_initialise_is_given_up_by_all():
 
 def test_compare_keeps_the_faster_of_the_two_and_drops_the_other():
     ctx, sw, x, gather, rccl = _choose("compare", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0})
-    assert sw.calls == ["init_rccl", "init_p2p"] and x["transport"] == "p2p" and not rccl and ctx.log == ["comm_destroy"]
+    assert sw.calls == ["init_rccl", "init_p2p"] and x["transport"] == "p2p" and rccl and ctx.log == []   # kept: the final gather's
     assert x["rccl_us"] == 25.0 and x["p2p_us"] == 5.0
     ctx, sw, x, gather, rccl = _choose("compare", _Sweep(), {"p2p": 40.0, "rccl": 25.0, "host": 90.0})
     assert x["transport"] == "rccl" and rccl and ctx.log == ["p2p_detach"] and x["exchange_us"] == 25.0

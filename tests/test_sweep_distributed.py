@@ -41,6 +41,9 @@ def check(tmp_path, tag):
         z = np.load(str(tmp_path / ("%s_rank%d.npz" % (tag, rank))))
         assert np.array_equal(z["thetas"], np.array(THETAS))
         assert z["tmax"] == 2.0 and list(z["objs"]) == [0, 10]
+        # sweep.gather_results: one all-gather of every theta's (scalars, weights); consistent only if all ranks hold the same bytes
+        assert bool(z["gather_ok"]) and not bool(z["gather_bad"]) and int(z["gather_ranks"]) == 2
+        assert int(z["gather_bytes"]) == len(THETAS) * (sweep.HEADER + 500) * 8
         for i, (fmin, it, w) in enumerate(ref):
             assert z["fmin"][i] == fmin and z["iters"][i] == it
             assert np.array_equal(z["w"][i], w)
