@@ -185,7 +185,7 @@ def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
     }
 
 
-def cpu_fullsize(ctx, M, N, YTilde, thetas):
+def cpu_fullsize(ctx, M, N, YTilde, thetas, mid_thetas=(), mid_budget_s=170.0):
     """A direct CPU number ON the headline config: the reference's own _opt_lbfgs_logw on the FULL matrix (read back
     from HBM, transposed cache built blockwise) for the cheapest thetas of the series, next to the device solving the
     same single problem.  Skipped when the host lacks the memory for matrix + transposed cache."""
@@ -229,6 +229,57 @@ def cpu_fullsize(ctx, M, N, YTilde, thetas):
     out["cpu_s"] = sum(r["cpu_s"] for r in out["per_theta"])
     out["gpu_s"] = sum(r["gpu_s"] for r in out["per_theta"])
     out["speedup"] = out["cpu_s"] / out["gpu_s"]
+    if mid_thetas:
+        # r05: parity ON the headline config for a theta that matters (the six slow thetas carry 95 % of the sweep's
+        # iterations).  Reference: its yaml-default run, then CONTINUED from that point under the converged settings
+        # (epsilon 1e-9, delta 0, past 0: no plateau stop) -- one pass gives both its default minimum and the optimum.
+        # Device: the same two settings from the cold start.  North-star gate: 1e-6 on fmin, 1e-5 max(w) on the weights,
+        # at the optimum; and how far either side's yaml-default stop sits from that optimum.
+        # The candidates are tried in turn: the reference's _get_weights exponentiates WITHOUT a maximum shift
+        # (c_bioen_kernels_logw.c:55-94), so a long trial step of its line search can overflow exp() -- at theta = 31.6 on
+        # this matrix a trial point reaches max g = 712 in the fourth iteration, the objective is NaN from there on, and its
+        # -ffast-math liblbfgs returns that as status 0.  (The device shifts by the maximum and walks on: same trajectory
+        # to 1e-12 up to that point.)  Such a theta is recorded as what it is and the next one is taken.
+        ms_it = 1e3 * out["cpu_s"] / max(sum(r["gpu_iterations"] for r in out["per_theta"]), 1)
+        conv = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iterations=600)
+        out["mid_theta"] = {"reference_failures": []}
+        spent = 0.0
+        for mid_theta in mid_thetas:
+            if spent + 1e-3 * ms_it * 500.0 > mid_budget_s:
+                out["mid_theta"]["skipped"] = "budget: %.0f s spent, ~%.0f s more needed at %.0f ms per reference iteration (budget %.0f s)" \
+                                              % (spent, 1e-3 * ms_it * 500.0, ms_it, mid_budget_s)
+                break
+            g_def, f_def_ref, c_def_ref, s_def = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, mid_theta, LBFGS_DEFAULTS)
+            spent += s_def
+            if not np.isfinite(f_def_ref):
+                out["mid_theta"]["reference_failures"].append(
+                    {"theta": float(mid_theta), "fmin": "nan", "code": c_def_ref, "seconds": s_def, "max_abs_g": float(np.nanmax(np.abs(g_def))),
+                     "why": "exp() overflow at a trial point of the reference's line search (no maximum shift in _get_weights); "
+                            "liblbfgs (-ffast-math) reports status %d" % c_def_ref})
+                continue
+            g_ref, f_ref, c_ref, s_conv = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, mid_theta, conv, g_start=g_def)
+            spent += s_conv
+            t0 = time.perf_counter()
+            _, _, i_def = ctx.opt_lbfgs_logw(G, G, mid_theta, LBFGS_DEFAULTS, want_weights=False)
+            g_dev, w_dev, i_conv = ctx.opt_lbfgs_logw(G, G, mid_theta, conv)
+            gpu_s = time.perf_counter() - t0
+            w_ref = np.exp(g_ref - g_ref.max())
+            w_ref /= w_ref.sum()
+            f_star = min(f_ref, i_conv.fmin)
+            out["mid_theta"].update({
+                "theta": float(mid_theta), "settings": "converged: epsilon 1e-9, delta 0, past 0, <= 600 iterations (reference continued from its yaml-default stop)",
+                "reference": {"code_default": c_def_ref, "fmin_default": f_def_ref, "code_converged": c_ref, "fmin_converged": f_ref,
+                              "seconds": s_def + s_conv},
+                "device": {"code_default": i_def.lbfgs_code, "fmin_default": i_def.fmin, "iterations_default": i_def.iterations,
+                           "code_converged": i_conv.lbfgs_code, "fmin_converged": i_conv.fmin, "iterations_converged": i_conv.iterations,
+                           "seconds": gpu_s},
+                "fmin_rel_diff_converged": abs(i_conv.fmin - f_ref) / abs(f_ref),
+                "w_diff_over_max_w": float(np.abs(w_dev - w_ref).max() / w_ref.max()),
+                "within_north_star": bool(abs(i_conv.fmin - f_ref) <= 1e-6 * abs(f_ref) and
+                                          np.abs(w_dev - w_ref).max() <= 1e-5 * w_ref.max()),
+                "default_stop_above_optimum_rel": {"reference": (f_def_ref - f_star) / abs(f_star), "device": (i_def.fmin - f_star) / abs(f_star)},
+            })
+            break
     return out
 
 
@@ -265,11 +316,11 @@ def cpu_baseline_forces(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
             "ms_per_iteration": 1e3 * dt / max(iters, 1)}
 
 
-def _ref_lbfgs_logw(R, yT, yTT, YT, G, theta, params):
+def _ref_lbfgs_logw(R, yT, yTT, YT, G, theta, params, g_start=None):
     """the reference's own _opt_lbfgs_logw on host arrays (transposed cache given) -> (gopt, fmin, code, seconds)"""
     import ctypes as C
     M, cols = yT.shape
-    g0 = G.copy()
+    g0 = (G if g_start is None else g_start).copy()
     w = np.empty(cols); tmp_n = np.empty(cols); tmp_m = np.empty(M); result = np.empty(cols)
     p = R.params_t()
     p.g, p.G, p.yTilde, p.YTilde, p.w, p.result = R._p(g0), R._p(G), R._p(yT), R._p(YT), R._p(w), R._p(result)
@@ -446,12 +497,19 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=
         except Exception as e:
             split = {"error": repr(e)}
         cpu = None
+        failed_ref = None
         if with_cpu:     # the reference's _opt_lbfgs_forces (c_bioen_kernels_forces.c:574-662) on a column block of THIS matrix
             try:
                 cpu = cpu_baseline_forces(ctx, M, N, YTilde, 10.0, 262144, 40)
             except Exception as e:
                 cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
-    its = int(sum(i.iterations for i in infos))
+            try:         # thetas that end outside liblbfgs' success codes here: what does the REFERENCE do with them?
+                failed_ref = forces_failed_thetas(bioen_amd, ctx, M, N, YTilde,
+                                                  [float(t) for t, i in zip(thetas, infos) if i.lbfgs_code not in (0, 1, 2)])
+            except Exception as e:
+                failed_ref = {"error": repr(e)}
+    ok = [i for i in infos if i.lbfgs_code in (0, 1, 2)]          # through the kept API a failed theta is a RuntimeError, as in the
+    its = int(sum(i.iterations for i in ok))                      # reference (c_bioen.pyx:516-520): its iterations are not counted
     kern = {}
     for name, which in (("xy", "adjoint"), ("bt", "forward")):       # timer slots of launch_forces_xy / _bt
         s_ = st[which]
@@ -468,6 +526,8 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=
             "value": its * float(N) * M / dt, "unit": "iter*N*M/s", "ms_per_step": 1e3 * dt, "iterations": its,
             "evaluations": int(sum(i.evaluations for i in infos)),
             "cpu_baseline": cpu,
+            "thetas_counted": len(ok), "thetas_failed": [float(t) for t, i in zip(thetas, infos) if i.lbfgs_code not in (0, 1, 2)],
+            "failed_thetas_vs_reference": failed_ref,
             "storage_experiment_split": split,
             "speedup_vs_cpu": (its * float(N) * M / dt) / cpu["value"] if cpu and cpu.get("value") else None,
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
@@ -475,6 +535,29 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=
                          "traffic": None, "kernels": kern},
             "per_theta": [{"theta": float(t), "iterations": i.iterations, "evaluations": i.evaluations, "code": i.lbfgs_code,
                            "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "seconds": i.seconds} for t, i in zip(thetas, infos)]}
+
+
+def forces_failed_thetas(bioen_amd, ctx, M, N, YTilde, thetas, cols=131072):
+    """The thetas of configs[4]'s series whose runs end outside liblbfgs' success codes (-998: the line search has used
+    its max_linesearch trials; at large theta the start is the optimum to rounding) -- like for like against the
+    reference's own _opt_lbfgs_forces (c_bioen_kernels_forces.c:574-662, lbfgs.c:645-734) on a column block of the same
+    matrix, the device solving the SAME block: status and fmin of both."""
+    from oracle import ref_binding as R
+    if not thetas or not R.available():
+        return None
+    sample = ctx.read_ytilde(0, M, 0, cols)
+    w0 = np.full(cols, 1.0 / cols)
+    out = {"sample": "columns [0,%d) of the same matrix, forces_init = 0, yaml-default liblbfgs" % cols, "per_theta": []}
+    with bioen_amd.Context(sample, YTilde) as blk:
+        for th in thetas:
+            _, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, sample, YTilde, th, LBFGS_DEFAULTS)
+            _, _, info = blk.opt_lbfgs_forces(np.zeros(M), w0, th, LBFGS_DEFAULTS, want_weights=False)
+            out["per_theta"].append({"theta": th, "reference_code": int(code_ref), "device_code": int(info.lbfgs_code),
+                                     "reference_fmin": float(fmin_ref), "device_fmin": float(info.fmin),
+                                     "fmin_rel_diff": abs(info.fmin - fmin_ref) / abs(fmin_ref),
+                                     "device_iterations": info.iterations, "device_evaluations": info.evaluations})
+    out["same_status_everywhere"] = all(r["reference_code"] == r["device_code"] for r in out["per_theta"])
+    return out
 
 
 def deer_trace(d_nm, t_ns):
@@ -619,6 +702,63 @@ def ala5_record(bioen_amd, seed, with_cpu=True):
     return out
 
 
+def api_record(bioen_amd, yTilde, YTilde, thetas, label, with_unheld):
+    """"theta-sweep wall-clock (upload/generation excluded AND included, both stated)".  The headline `value` has
+    the matrix generated in HBM; this is what a caller of the kept Python API pays who holds a HOST numpy matrix
+    (bioen/analyze/procedure.py:62-77's shape): wall time INCLUDING the upload and the two strip-copy builds, and the
+    number of uploads, for
+      series        one `log_weights.find_optimum_series` call (all thetas one lock-step batch),
+      analyze_loop  `find_optimum` per theta inside ``with optimize.resident(yTilde):`` -- one upload for the loop,
+      unheld_loop   the same loop without the hold: one upload per call (r04: three per call)  [smaller size only],
+    each result the 5-tuple of the reference's API (weights, averages, optimum, fmin_initial, fmin_final)."""
+    from bioen_amd import optimize
+    from bioen_amd.optimize.ext import c_bioen
+    c_bioen.clear_cache()
+    M, N = yTilde.shape
+    G = np.zeros((N, 1))
+    YT = np.asarray(YTilde, dtype=np.float64).reshape(1, -1)
+    cfg = optimize.minimize.Parameters("lbfgs")
+    cfg["verbose"] = False
+    rec = {"workload": "%s: host numpy yTilde %d x %d (%.2f GB), %d thetas, bioen_amd.optimize.log_weights API, yaml-default lbfgs"
+                       % (label, M, N, yTilde.nbytes / 1e9, len(thetas)), "N": N, "M": M, "host_matrix_bytes": int(yTilde.nbytes)}
+
+    def timed(fn):
+        u0, t0 = c_bioen.uploads, time.perf_counter()
+        out = fn()
+        return out, time.perf_counter() - t0, c_bioen.uploads - u0
+
+    out, dt, up = timed(lambda: optimize.log_weights.find_optimum_series(G, G, yTilde, yTilde, YT, thetas, cfg))
+    its = sum(i.iterations for i in c_bioen.last_opt_info)
+    rec["series"] = {"wall_s": dt, "uploads": up, "iterations": int(its), "value_incl_upload": its * float(N) * M / dt,
+                     "fmin": [float(o[4]) for o in out]}
+    c_bioen.clear_cache()
+
+    def loop(held):
+        per, its_ = [], 0
+        def body():
+            nonlocal its_
+            for th in thetas:
+                t0 = time.perf_counter()
+                optimize.log_weights.find_optimum(G, G, yTilde, yTilde, YT, float(th), cfg)
+                per.append(time.perf_counter() - t0)
+                its_ += c_bioen.last_opt_info.iterations
+        if held:
+            with optimize.resident(yTilde):
+                body()
+        else:
+            body()
+        return per, its_
+    (per, its), dt, up = timed(lambda: loop(True))
+    rec["analyze_loop"] = {"wall_s": dt, "uploads": up, "iterations": int(its), "per_theta_s": per,
+                           "value_incl_upload": its * float(N) * M / dt}
+    c_bioen.clear_cache()
+    if with_unheld:
+        (per, its), dt, up = timed(lambda: loop(False))
+        rec["unheld_loop"] = {"wall_s": dt, "uploads": up, "iterations": int(its)}
+        c_bioen.clear_cache()
+    return rec
+
+
 class stdout_to_stderr(object):
     """librccl prints a version banner on stdout when a communicator is created; keep this
     process' stdout for the ONE JSON line."""
@@ -745,6 +885,10 @@ def main():
                     help="skip the live rocprofv3 --pmc passes for roofline.traffic (falls back to profiles/traffic.json)")
     ap.add_argument("--no-storage-experiment", action="store_true",
                     help="skip the reduced-byte storage side record (fp32 + bf16 split / fp32 copies of the matrix)")
+    ap.add_argument("--no-cpu-mid", action="store_true",
+                    help="skip the full-size converged parity run of the reference at theta = 31.6 (~1.5-2 minutes of CPU)")
+    ap.add_argument("--no-api", action="store_true",
+                    help="skip the api_end_to_end record (the kept Python API on a host numpy matrix, upload included)")
     ap.add_argument("--no-cpu-fullsize", action="store_true",
                     help="skip the reference run on the FULL headline matrix (two cheapest thetas, ~1 minute)")
     args = ap.parse_args()
@@ -951,10 +1095,20 @@ def main():
             if cpu is not None and not forces_mode and not args.no_cpu_fullsize and N * float(M) >= 5e8:
                 try:     # the same CONFIG on the CPU, not a sample: the two cheapest thetas of the series
                     cheap = sorted(results, key=lambda r: r["evaluations"])[:2]
-                    cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap])
+                    # the mid-series thetas nearest 31.6 first (the cheap ones above excluded)
+                    mids = [] if args.no_cpu_mid else sorted((r["theta"] for r in results if r not in cheap and 2.0 < r["theta"] < 60.0),
+                                                           key=lambda t: abs(np.log(t / 31.6)))
+                    cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap], mid_thetas=mids)
                 except Exception as e:
                     cpu["full_size"] = {"error": repr(e)}
 
+        api = None
+        host_matrix = None
+        if world == 1 and not forces_mode and not args.no_api:
+            try:      # the headline matrix on the host, as a caller of the Python API holds it (read back: the same numbers)
+                host_matrix = ctx.read_ytilde()
+            except Exception as e:
+                api = {"error": repr(e)}
         storage = None
         if world == 1 and not forces_mode and M <= 1024 and not args.no_storage_experiment:
             try:
@@ -980,6 +1134,17 @@ def main():
                     forces["roofline"]["traffic"] = tj_f.get("k_strip_N1000000_M512")
             except Exception as e:
                 forces = {"error": repr(e)}
+        if host_matrix is not None:
+            ctx.close()
+            try:
+                api = {"headline": api_record(bioen_amd, host_matrix, YTilde, thetas, "BASELINE configs[2]", False)}
+                del host_matrix
+                y1, Y1 = survey_inputs(256, 100000)
+                api["configs1"] = api_record(bioen_amd, y1, Y1, thetas, "BASELINE configs[1] (SURVEY 8(d)'s numpy stream)", True)
+                del y1
+                api["kernel_only_sweep_s"] = dt / max(args.steps, 1)
+            except Exception as e:
+                api = dict(api or {}, error=repr(e))
         deer = None
         if world == 1 and not args.no_deer and not args.no_forces and not forces_mode:
             try:
@@ -1056,6 +1221,7 @@ def main():
             "cpu_baseline": cpu,
             "forces": forces,
             "storage_experiment": storage,
+            "api_end_to_end": api,
             "deer": deer,
             "ala5": ala5,
             "sweep_wall_s": dt / max(args.steps, 1),

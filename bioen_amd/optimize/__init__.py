@@ -5,5 +5,6 @@ from . import util
 from . import minimize
 from . import forces
 from . import log_weights
+from .ext.c_bioen import hold as resident      # ``with optimize.resident(yTilde): <theta loop>``: one upload for the block
 
-__all__ = ["common", "util", "minimize", "forces", "log_weights"]
+__all__ = ["common", "util", "minimize", "forces", "log_weights", "resident"]

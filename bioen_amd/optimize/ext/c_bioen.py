@@ -9,8 +9,11 @@ Differences from the reference, on purpose:
   matrix again (scipy's separate f / f' callbacks, a theta series) reuse the
   device copy instead of re-uploading -- see ``_context_for`` -- as long as the WHOLE host
   buffer can be re-checked for in-place edits (up to 256 MB); larger matrices are uploaded
-  afresh on every call, exactly the reference's behaviour (fresh pointers per call,
-  c_bioen.pyx:463-478), unless ``BIOEN_HIP_CACHE_LARGE=1`` opts into a sampled check.
+  afresh by every call of THIS module that is not inside a hold (the reference hands a pointer over and
+  pays no upload: c_bioen.pyx:463-478), unless ``BIOEN_HIP_CACHE_LARGE=1`` opts into a sampled check.
+  ``hold`` (= ``bioen_amd.optimize.resident``) pins one device copy for a block of calls: the library's
+  ``find_optimum*`` hold the matrix for the duration of a call (ONE upload per call at any size), a caller
+  looping over theta wraps its loop.
 * ``caching`` / ``cache_ytilde_transposed`` are accepted and ignored: both matrix passes stream
   strip-major copies of the matrix built on the device (``csrc/kernels_strip.hip``); no host-side
   transposed copy exists.
@@ -84,6 +87,55 @@ def _fingerprint(a):
     return (a.shape, _digest(flat))
 
 
+# Holds (r05).  One `find_optimum` makes three or four calls of this module on the same matrix (the initial objective, the
+# optimisation, the averages of the optimum), and a caller like bioen/analyze/procedure.py:62-77 repeats that for every
+# theta.  A HELD matrix is served from one device context for as long as the hold lasts -- no upload, and no hashing of
+# the host buffer either (the holder vouches for it: the library's own `find_optimum*` hold the matrix for the duration
+# of the call, in which nobody else can edit it; a caller's `with optimize.resident(yTilde):` around its theta loop
+# promises not to edit the matrix in place inside the block).  Matrices of any size, including those above the 256 MB
+# the cache refuses.
+_HELD = {}                             # id(host object) -> [object, context, cached, depth]
+uploads = 0                            # device contexts created by this module so far (= uploads of a matrix): tests, bench.py
+
+
+def _new_context(yT, YT):
+    global uploads
+    uploads += 1
+    return _lib.Context(yT, YT)
+
+
+class hold(object):
+    """``with hold(yTilde, YTilde):`` -- every call of this module on THIS matrix object inside the block is served by one
+    resident device copy: at most one upload, no per-call hashing.  Nestable; the targets YTilde may change from call to
+    call (they are re-sent, M doubles).  Exported as ``bioen_amd.optimize.resident``."""
+
+    def __init__(self, yTilde, YTilde=None):
+        self.obj, self.YT = yTilde, YTilde
+
+    def __enter__(self):
+        e = _HELD.get(id(self.obj))
+        if e is not None and e[0] is self.obj:
+            e[3] += 1
+            return self
+        YT = self.YT if self.YT is not None else np.zeros(np.shape(self.obj)[0])
+        ctx, cached = _context_for(self.obj, YT)
+        if not hasattr(ctx, "_YT_host"):
+            ctx._YT_host = _lib.as_f64(YT).ravel().copy()
+        _HELD[id(self.obj)] = [self.obj, ctx, cached, 1]
+        return self
+
+    def __exit__(self, *exc):
+        e = _HELD.get(id(self.obj))
+        if e is None or e[0] is not self.obj:
+            return False
+        e[3] -= 1
+        if e[3] == 0:
+            del _HELD[id(self.obj)]
+            if not e[2]:
+                e[1].close()
+        return False
+
+
 def _context_for(yTilde, YTilde):
     """Return a device context holding yTilde, creating/uploading it if needed.
 
@@ -94,13 +146,21 @@ def _context_for(yTilde, YTilde):
     (c_bioen.pyx:463-478).  Matrices above 256 MB (BIOEN_HIP_CACHE_FULLCHECK_MB) are never cached -- a
     complete check would cost more than the upload -- unless BIOEN_HIP_CACHE_LARGE=1 opts into a sampled
     check.  BIOEN_HIP_CACHE=0 switches the cache off."""
+    held = _HELD.get(id(yTilde))
+    if held is not None and held[0] is yTilde:             # held (above): the resident copy, unchecked
+        ctx = held[1]
+        YT = _lib.as_f64(YTilde).ravel()
+        if not np.array_equal(ctx._YT_host, YT):
+            ctx.set_target(YT)
+            ctx._YT_host = YT.copy()
+        return ctx, True
     yT = _lib.as_f64(yTilde)
     if yT.ndim != 2:
         raise ValueError("yTilde must be a 2-D (M x N) array")
     YT = _lib.as_f64(YTilde).ravel()
     weakable = isinstance(yTilde, np.ndarray)              # np.matrix included; lists etc. are never cached
     if _CACHE_MAX <= 0 or not weakable or (yT.nbytes > _FULL_CHECK_BYTES and not _cache_large()):
-        return _lib.Context(yT, YT), False
+        return _new_context(yT, YT), False
     key = id(yTilde)
     fp = _fingerprint(yT)
     ctx = _CACHE.get(key)
@@ -112,7 +172,7 @@ def _context_for(yTilde, YTilde):
                 ctx._YT_host = YT.copy()
             return ctx, True
         _CACHE.pop(key).close()                            # same id, other object or other content: stale
-    ctx = _lib.Context(yT, YT)
+    ctx = _new_context(yT, YT)
     ctx._YT_host = YT.copy()
     ctx._fingerprint = fp
     ctx._host_ref = weakref.ref(yTilde)

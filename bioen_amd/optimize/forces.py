@@ -144,11 +144,24 @@ class _DeviceFdf(object):
 
 
 def find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg):
+    """Minimise over the m generalised forces (forces.py:336-548): see `_find_optimum`.  The matrix is HELD for the
+    duration of the call (ext/c_bioen.py: hold): the initial objective, the optimisation, chi^2 / S and the averages of the
+    optimum are served by one device copy -- at most ONE upload per call whatever the size of the matrix."""
+    check_params_forces(forcesInit, w0, y, yTilde, YTilde)
+    if str(cfg["minimizer"]).upper() not in ('LIBLBFGS', 'LBFGS', 'GSL', 'SCIPY'):      # rejected before anything touches the device
+        raise RuntimeError("Library " + cfg["minimizer"] +
+                           " not recognized (valid values =  'LIBLBFGS', 'GSL', 'scipy', 'scipy' ) ")
+    if not (str(cfg["minimizer"]).upper() == 'SCIPY' and not bool(cfg["use_c_functions"])):
+        with c_bioen.hold(yTilde, YTilde):
+            return _find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg)
+    return _find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg)
+
+
+def _find_optimum(forcesInit, w0, y, yTilde, YTilde, theta, cfg):
     """Minimise over the m generalised forces (forces.py:336-548).
 
     Returns (wopt (n,1), yopt (m,), forces_opt (m,), fmin_initial, fmin_final,
     chiSqr (= 0.5 chi^2), S (= sum w log(w/w0)))."""
-    check_params_forces(forcesInit, w0, y, yTilde, YTilde)
 
     caching = cfg["cache_ytilde_transposed"]
     if caching == "auto":

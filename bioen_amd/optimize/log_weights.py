@@ -206,7 +206,27 @@ def _run_scipy(cfg, f, fprime, x0, args, flavour, show_caching):
     return driver(f, x0, **kw)
 
 
+def _uses_device(cfg):
+    return not (str(cfg["minimizer"]).upper() == 'SCIPY' and not bool(cfg["use_c_functions"]))
+
+
 def find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
+    """Minimise the BioEn negative log-posterior over the n log-weights (log_weights.py:409-621): see `_find_optimum`.
+    The matrix is HELD for the duration of the call (ext/c_bioen.py: hold): the initial objective, the optimisation and
+    the averages of the optimum are served by one device copy -- at most ONE upload per call whatever the size of the
+    matrix (none inside a caller's ``with optimize.resident(yTilde):``), as the reference's one ``yTilde.T.copy()`` per
+    call (c_bioen.pyx:463-473)."""
+    check_params_logweights(GInit, G, y, yTilde, YTilde)
+    if str(cfg["minimizer"]).upper() not in ('LIBLBFGS', 'LBFGS', 'GSL', 'SCIPY'):      # rejected before anything touches the device
+        raise RuntimeError("Library " + cfg["minimizer"] +
+                           " not recognized (valid values =  'LIBLBFGS', 'GSL', 'scipy', 'scipy' ) ")
+    if _uses_device(cfg):
+        with c_bioen.hold(yTilde, YTilde):
+            return _find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg)
+    return _find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg)
+
+
+def _find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
     """Minimise the BioEn negative log-posterior over the n log-weights
     (log_weights.py:409-621).
 
@@ -214,7 +234,6 @@ def find_optimum(GInit, G, y, yTilde, YTilde, theta, cfg):
     cfg comes from ``minimize.Parameters``; minimizer "lbfgs"/"liblbfgs" runs the
     device-resident L-BFGS, "scipy" drives the device (or, with
     use_c_functions False, the numpy) objective from the host; "gsl": the library's GSL-style minimizers with all vectors in HBM."""
-    check_params_logweights(GInit, G, y, yTilde, YTilde)
 
     caching = cfg["cache_ytilde_transposed"]
     if caching == "auto":
@@ -286,11 +305,12 @@ def find_optimum_series(GInit, G, y, yTilde, YTilde, thetas, cfg):
         raise RuntimeError("find_optimum_series needs the lbfgs minimizer, got " + str(cfg["minimizer"]))
     g = GInit.copy()
     gPrime = np.asarray(g[:].T)[0]
-    fmin_initial = [c_bioen.bioen_log_posterior_logw(gPrime, g, G, yTilde, YTilde, float(t)) for t in thetas]
-    gopts, fmins = c_bioen.bioen_opt_lbfgs_logw_series(gPrime, G, yTilde, YTilde, [float(t) for t in thetas], cfg)
-    out = []
-    for k in range(len(fmins)):
-        wopt = getWOpt(G, gopts[k])
-        yopt = c_bioen.get_ave(wopt, yTilde, YTilde) if y is yTilde else common.getAve(wopt, y)
-        out.append((wopt, yopt, gopts[k], fmin_initial[k], fmins[k]))
+    with c_bioen.hold(yTilde, YTilde):                 # one device copy for the whole series: at most one upload
+        fmin_initial = [c_bioen.bioen_log_posterior_logw(gPrime, g, G, yTilde, YTilde, float(t)) for t in thetas]
+        gopts, fmins = c_bioen.bioen_opt_lbfgs_logw_series(gPrime, G, yTilde, YTilde, [float(t) for t in thetas], cfg)
+        out = []
+        for k in range(len(fmins)):
+            wopt = getWOpt(G, gopts[k])
+            yopt = c_bioen.get_ave(wopt, yTilde, YTilde) if y is yTilde else common.getAve(wopt, y)
+            out.append((wopt, yopt, gopts[k], fmin_initial[k], fmins[k]))
     return out

@@ -164,8 +164,18 @@ def install_oracle_fakes(monkeypatch):
     def get_ave(w, yTilde, YTilde):
         return O.chi_squared(flat(w), np.asarray(yTilde), flat(YTilde))[1]
 
+    class hold(object):                        # find_optimum holds the matrix for the call (one device copy): nothing to hold here
+        def __init__(self, yTilde, YTilde=None):
+            calls.append("hold")
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
     for fn in (bioen_log_posterior_logw, bioen_opt_lbfgs_logw, bioen_log_posterior_forces, bioen_opt_lbfgs_forces,
-               chi2_and_kl_forces, get_ave):
+               chi2_and_kl_forces, get_ave, hold):
         monkeypatch.setattr(c_bioen, fn.__name__, fn)
     return calls
 
