@@ -505,7 +505,8 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=
                 cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
             try:         # thetas that end outside liblbfgs' success codes here: what does the REFERENCE do with them?
                 failed_ref = forces_failed_thetas(bioen_amd, ctx, M, N, YTilde,
-                                                  [float(t) for t, i in zip(thetas, infos) if i.lbfgs_code not in (0, 1, 2)])
+                                                  [float(t) for t, i in zip(thetas, infos) if i.lbfgs_code not in (0, 1, 2)],
+                                                  {float(t): i for t, i in zip(thetas, infos)})
             except Exception as e:
                 failed_ref = {"error": repr(e)}
     ok = [i for i in infos if i.lbfgs_code in (0, 1, 2)]          # through the kept API a failed theta is a RuntimeError, as in the
@@ -537,25 +538,38 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=
                            "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "seconds": i.seconds} for t, i in zip(thetas, infos)]}
 
 
-def forces_failed_thetas(bioen_amd, ctx, M, N, YTilde, thetas, cols=131072):
+def forces_failed_thetas(bioen_amd, ctx, M, N, YTilde, thetas, results):
     """The thetas of configs[4]'s series whose runs end outside liblbfgs' success codes (-998: the line search has used
     its max_linesearch trials; at large theta the start is the optimum to rounding) -- like for like against the
-    reference's own _opt_lbfgs_forces (c_bioen_kernels_forces.c:574-662, lbfgs.c:645-734) on a column block of the same
-    matrix, the device solving the SAME block: status and fmin of both."""
+    reference's own _opt_lbfgs_forces (c_bioen_kernels_forces.c:574-662, lbfgs.c:645-734) on the SAME full matrix
+    (read back from HBM; the reference builds its transposed cache per call): status and fmin of both.  Is the ending
+    the reference's behaviour on this problem, or the device's own?"""
     from oracle import ref_binding as R
+    from oracle import cpus
     if not thetas or not R.available():
         return None
-    sample = ctx.read_ytilde(0, M, 0, cols)
-    w0 = np.full(cols, 1.0 / cols)
-    out = {"sample": "columns [0,%d) of the same matrix, forces_init = 0, yaml-default liblbfgs" % cols, "per_theta": []}
-    with bioen_amd.Context(sample, YTilde) as blk:
-        for th in thetas:
-            _, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, sample, YTilde, th, LBFGS_DEFAULTS)
-            _, _, info = blk.opt_lbfgs_forces(np.zeros(M), w0, th, LBFGS_DEFAULTS, want_weights=False)
-            out["per_theta"].append({"theta": th, "reference_code": int(code_ref), "device_code": int(info.lbfgs_code),
-                                     "reference_fmin": float(fmin_ref), "device_fmin": float(info.fmin),
-                                     "fmin_rel_diff": abs(info.fmin - fmin_ref) / abs(fmin_ref),
-                                     "device_iterations": info.iterations, "device_evaluations": info.evaluations})
+    need = 2.2 * M * N * 8
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    if avail < 1.3 * need:
+        return {"skipped": "host memory: %.1f GB free, %.1f GB needed" % (avail / 1e9, 1.3 * need / 1e9)}
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cpus.usable_cpus())
+    yT = ctx.read_ytilde()
+    w0 = np.full(N, 1.0 / N)
+    out = {"sample": "the full %d x %d matrix, forces_init = 0, yaml-default liblbfgs, %d OpenMP threads" % (M, N, cpus.usable_cpus()),
+           "per_theta": []}
+    for th in thetas:
+        t0 = time.perf_counter()
+        _, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, yT, YTilde, th, LBFGS_DEFAULTS)
+        dev = results[th]
+        out["per_theta"].append({"theta": th, "reference_code": int(code_ref), "device_code": int(dev.lbfgs_code),
+                                 "reference_fmin": float(fmin_ref), "device_fmin": float(dev.fmin),
+                                 "fmin_rel_diff": abs(dev.fmin - fmin_ref) / abs(fmin_ref),
+                                 "device_iterations": dev.iterations, "device_evaluations": dev.evaluations,
+                                 "reference_seconds": time.perf_counter() - t0})
     out["same_status_everywhere"] = all(r["reference_code"] == r["device_code"] for r in out["per_theta"])
     return out
 

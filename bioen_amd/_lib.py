@@ -426,7 +426,9 @@ class Context(object):
     def set_storage(self, fmt):
         """EXPERIMENT (opt-in, never the default): the log-weights matrix passes stream the centred matrix as
         'split' (fp32 + bf16 residual, 6 bytes per element, 2^-33 relative) or 'fp32' (4 bytes) instead of 'f64';
-        reassembled to FP64 in registers, all sums FP64.  M <= 1024, log-weights method only."""
+        reassembled to FP64 in registers, all sums FP64.  M <= 1024; served: the log-weights passes and the forces method's
+        fused strip passes (forces_fdf(_batch), the forces optimizers); everything else of the forces method (forces_weights)
+        raises BioenHipError (invalid state) while a reduced format is selected (the contract as implemented)."""
         check(lib().bioen_hip_ctx_set_storage(self._h, self.STORAGE_FORMATS[fmt]))
 
     def synchronize(self):

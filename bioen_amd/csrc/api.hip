@@ -1212,7 +1212,26 @@ static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
 
 int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const double* w0, double* w) {
     if (!c || !forces || !w0 || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
-    int rc = forces_guard(c, false);          // streaming kernels: unsharded contexts only
+    int rc;
+    if (forces_fused_blocks(c) > 0 && !c->storage) {
+        // M <= 1024 (r05): pass 1 of the strip evaluation IS _get_weights_from_forces -- x = yTilde^T f, the softmax over all
+        // structures merged segment by segment -- so sharded contexts serve the call too (one stage exchange), and every rank
+        // count returns the single-GPU bits
+        if ((rc = forces_guard(c))) return rc;
+        BIOEN_HIP_CHECK(hipSetDevice(c->device));
+        if ((rc = upload_n(c, c->fixed, w0))) return rc;
+        bioen_lbfgs_config dummy{};
+        ForcesBatchEngine eng(c, dummy, false);
+        const int one[1] = {0};
+        const double* pt[1] = {forces};
+        const double theta0 = 0.0;
+        eng.evaluate(one, 1, pt, &theta0, false);          // an f-only evaluation hands out the weights (slot 0)
+        if (eng.rc) return eng.rc;
+        if ((rc = download_n(c, w, c->slot[0].w))) return rc;
+        BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return transport_error(c);
+    }
+    rc = forces_guard(c, false);              // streaming kernels (M > 1024): unsharded contexts only
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     if ((rc = upload_n(c, c->fixed, w0))) return rc;

@@ -22,7 +22,7 @@ public:
         const int one[1] = {0};
         base = make_round(c, one, 1, nullptr, &theta);
     }
-    int size() const { return c->n; }
+    int size() const { return (int)std::min<long long>(c->n_global, 0x7fffffff); }      // the problem's dimension (all ranks')
     double* data(int h) { return v[h]; }
     bool failed() const { return rc != 0; }
     int error() const { return rc; }
@@ -155,7 +155,9 @@ private:
             a.y[q] = v[ys[q]];
         }
         ProblemSlot& s = c->slot[0];
-        launch_vdots(c, a, s.part, s.scal + S_SPARE0 + 0);
+        launch_vdots_part(c, a);
+        keep(exchange(c, X_GRAD, 4 * (size_t)vec_grid(c)));      // sharded contexts: every rank sums the same segments' partials
+        launch_vdots_finish(c, a, s.scal + S_SPARE0 + 0);
         // S_SPARE0, S_SPARE1, S_YSH.. are contiguous: 4 doubles are free while no L-BFGS history is live
         double* host = c->host_scal + kScalStride;   // second slot's mirror: untouched by read_scalars(c, 1)
         note(hipMemcpyAsync(host, s.scal + S_SPARE0, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -195,7 +197,6 @@ int bioen_hip_opt_gsl_logw(bioen_hip_ctx* c, const double* g0, const double* G, 
                            double* w_opt, bioen_opt_result* info) {
     if (!c || !g0 || !G || !config || !result || !info) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     if (config->algorithm < 0 || config->algorithm > 4) return fail(BIOEN_HIP_EINVAL, "unknown GSL algorithm id");
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "the GSL-style minimizers run on an unsharded context");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     const bool verbose = visual && visual->verbose;
     print_gsl_config(*config, verbose);

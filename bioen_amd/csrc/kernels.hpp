@@ -163,7 +163,8 @@ struct VDotArgs {
 void launch_vaxpy(bioen_hip_ctx* c, double a, const double* x, double* y);                  // y += a x
 void launch_vscal(bioen_hip_ctx* c, double a, double* x);
 void launch_vstep(bioen_hip_ctx* c, const double* x, const double* p, double coef, double* x1, double* dx);
-void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out);          // out: device, k doubles
+void launch_vdots_part(bioen_hip_ctx* c, const VDotArgs& q);                                // block partials -> X_GRAD stage   [exchange]
+void launch_vdots_finish(bioen_hip_ctx* c, const VDotArgs& q, double* out);                 // out: device, k doubles
 
 // ---- L-BFGS vector kernels (device-resident scalars) -------------------------------
 struct PairArgs {      // s = x - xp ; y = g - gp for the accepting problems

@@ -40,23 +40,28 @@ __global__ __launch_bounds__(kBlock) void k_vstep(const double* x, const double*
     }
 }
 
-// up to 4 inner products in one pass; mode 1: [0] = #(x != y), [1] = max |x|
-__global__ __launch_bounds__(kBlock) void k_vdots(VDotArgs q, int n2, double* part) {
+// up to 4 inner products in one pass; mode 1: [0] = #(x != y), [1] = max |x|.  r05: the block partials go to the X_GRAD
+// stage, per canonical segment (ctx.hpp) -- a sum over structures like every other one: the segments' totals in segment
+// order, the same bits on 1, 2, 4 and 8 GPUs, and (after ONE stage exchange) the same value on every rank of a sharded
+// context, so the GSL-style minimizers take identical decisions everywhere.
+__global__ __launch_bounds__(kBlock) void k_vdots(VDotArgs q, int n, Xch xo) {
     __shared__ double sh[kWaves];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n2; p += gridDim.x * kBlock) {
+    const SegPos sp = seg_pos(xo.npl, xo.segcols, n);
+    for (int j = seg_first(sp); j < sp.jend; j += seg_step(xo.npl)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < q.k) {
-                const d2 xv = *reinterpret_cast<const d2*>(q.x[k] + 2 * p);
-                const d2 yv = *reinterpret_cast<const d2*>(q.y[k] + 2 * p);
+                const d2 xv = *reinterpret_cast<const d2*>(q.x[k] + j);
+                d2 yv = *reinterpret_cast<const d2*>(q.y[k] + j);
+                if (j + 1 >= sp.jend) yv.y = (q.mode == 0) ? 0.0 : xv.y;      // (padding: zero anyway; kept out explicitly)
                 if (q.mode == 0) {
                     acc[k] = fma(xv.x, yv.x, acc[k]);
                     acc[k] = fma(xv.y, yv.y, acc[k]);
                 } else if (k == 0) {
                     acc[0] += (xv.x != yv.x ? 1.0 : 0.0) + (xv.y != yv.y ? 1.0 : 0.0);
                 } else {
-                    acc[1] = fmax(acc[1], fmax(fabs(xv.x), fabs(xv.y)));
+                    acc[1] = fmax(acc[1], fmax(fabs(xv.x), j + 1 < sp.jend ? fabs(xv.y) : 0.0));
                 }
             }
         }
@@ -65,22 +70,21 @@ __global__ __launch_bounds__(kBlock) void k_vdots(VDotArgs q, int n2, double* pa
     for (int k = 0; k < 4; ++k) {
         if (k < q.k) {
             const double v = (q.mode == 1 && k == 1) ? block_max(acc[k], sh) : block_sum(acc[k], sh);
-            if (threadIdx.x == 0) part[(size_t)k * kMaxPartials + blockIdx.x] = v;
+            if (threadIdx.x == 0) xput<4>(xo, 0, k, v);
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_vdots_finish(const double* part, int np, int k, int mode, double* out) {
-    __shared__ double sh[kWaves];
+__global__ __launch_bounds__(kBlock) void k_vdots_finish(Xch xi, int k, int mode, double* out) {
+    __shared__ double sh[kShRed];
     for (int q = 0; q < k; ++q) {
-        const double* p = part + (size_t)q * kMaxPartials;
         double v;
         if (mode == 1 && q == 1) {
             double s = 0.0;
-            for (int i = threadIdx.x; i < np; i += kBlock) s = fmax(s, p[i]);
-            v = block_max(s, sh);
+            for (int seg = 0; seg < xi.world; ++seg) s = fmax(s, wave_seg_max(xseg_ptr<4>(xi, seg, 0, q), xi.npl));
+            v = s;
         } else {
-            v = sum_partials(p, np, sh);
+            v = xsum<4>(xi, 0, q, sh);
         }
         if (threadIdx.x == 0) out[q] = v;
     }
@@ -200,10 +204,11 @@ void launch_vscal(bioen_hip_ctx* c, double a, double* x) {
 void launch_vstep(bioen_hip_ctx* c, const double* x, const double* p, double coef, double* x1, double* dx) {
     hipLaunchKernelGGL(k_vstep, dim3(vec_blocks(c)), dim3(kBlock), 0, c->stream, x, p, coef, x1, dx, (int)(c->ld / 2));
 }
-void launch_vdots(bioen_hip_ctx* c, const VDotArgs& q, double* part, double* out) {
-    const int g = vec_blocks(c);
-    hipLaunchKernelGGL(k_vdots, dim3(g), dim3(kBlock), 0, c->stream, q, (int)(c->ld / 2), part);
-    hipLaunchKernelGGL(k_vdots_finish, dim3(1), dim3(kBlock), 0, c->stream, part, g, q.k, q.mode, out);
+void launch_vdots_part(bioen_hip_ctx* c, const VDotArgs& q) {          // [exchange X_GRAD, 4 * vec_grid per segment]
+    hipLaunchKernelGGL(k_vdots, dim3(vec_blocks(c)), dim3(kBlock), 0, c->stream, q, c->n, make_xch(c, X_GRAD, 4 * vec_grid(c)));
+}
+void launch_vdots_finish(bioen_hip_ctx* c, const VDotArgs& q, double* out) {
+    hipLaunchKernelGGL(k_vdots_finish, dim3(1), dim3(kBlock), 0, c->stream, make_xch(c, X_GRAD, 4 * vec_grid(c)), q.k, q.mode, out);
 }
 
 void launch_rows_div(bioen_hip_ctx* c, const double* sigma) {

@@ -88,8 +88,11 @@ const char* bioen_hip_strerror(int code);
 const char* bioen_hip_last_error(void);
 /* replaces lbfgs_strerror(), bioen/optimize/ext/c_bioen_error.c:23-115 */
 const char* bioen_hip_lbfgs_strerror(int lbfgs_code);
-/* replace _set_fast_openmp_flag/_get_fast_openmp_flag (c_bioen_common.c:46-55):
- * accepted and stored; device reductions are fixed-order either way. */
+/* replace _set_fast_openmp_flag/_get_fast_openmp_flag (c_bioen_common.c:46-55): accepted and stored.  What the
+ * reference's flag = 0 buys -- the same bits whatever the thread count (serial sums, c_bioen_kernels_logw.c:58-93;
+ * test/optimize/test_logw_reproducibility.py:14-46) -- holds here for BOTH values, and across GPU counts: every sum over
+ * structures is formed per canonical column segment and the segments' totals are added in segment order (see the
+ * sharded contexts below), so 1, 2, 4 and 8 GPUs return identical bits. */
 void bioen_hip_set_fast_openmp_flag(int flag);
 int bioen_hip_get_fast_openmp_flag(void);
 
@@ -106,15 +109,19 @@ int bioen_hip_ctx_create(int m, int n, const double* yTilde, const double* YTild
 int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const double* sig_sim,
                                    const double* sig_exp, const double* YTilde,
                                    unsigned long long seed, int device, bioen_hip_ctx** ctx);
-/* Structure-sharded contexts (multi-GPU, one process per GPU): rank r of `world` keeps the
- * column block [r*P, min(n, (r+1)*P)), P = ceil(n/world) rounded up to 128, of the n-column
- * matrix -- `yTilde` is the caller's FULL row-major matrix, only the block is uploaded
- * (resp. generated).  All N-vector arguments of the calls below stay GLOBAL (n long) on every
- * rank; the library slices inputs and gathers outputs.  Reductions over structures are
- * completed by one in-place all-gather per stage over RCCL (bioen_hip_comm_init) or, for
- * processes that cannot share an RCCL communicator, through a host callback.  Every rank must
- * issue the same calls in the same order.  Supported on sharded contexts: logw_weights,
- * logw_fdf, opt_lbfgs_logw, opt_lbfgs_logw_batch. */
+/* Structure-sharded contexts (multi-GPU, one process per GPU).  The n columns are cut into CANONICAL SEGMENTS: 8 of
+ * them whenever `world` divides 8 (1, 2, 4, 8 GPUs), else `world`; S = ceil(n / segments) rounded up to 128 columns each.
+ * Rank r keeps the (segments / world) consecutive segments from r * (segments / world) on, i.e. the column block
+ * [r*P, min(n, (r+1)*P)), P = S * segments / world -- `yTilde` is the caller's FULL row-major matrix, only the block is
+ * uploaded (resp. generated).  All N-vector arguments of the calls below stay GLOBAL (n long) on every
+ * rank; the library slices inputs and gathers outputs.  Every reduction over structures is formed per segment and the
+ * segments' totals are added in segment order -- the SAME shape on every GPU count, a single GPU included: contexts of
+ * 1, 2, 4 and 8 ranks return bit-identical results.  Across ranks a reduction is completed by one in-place all-gather
+ * per stage through the peer-to-peer mailboxes (bioen_hip_p2p_attach), RCCL (bioen_hip_comm_init) or, for
+ * processes that can share neither, a host callback.  Every rank must
+ * issue the same calls in the same order.  Supported on sharded contexts: logw_weights, logw_fdf, chi_squared,
+ * opt_lbfgs_logw(_batch), opt_gsl_logw, and for M <= 1024 the forces method (forces_weights, forces_fdf(_batch),
+ * opt_lbfgs_forces(_batch), opt_gsl_forces). */
 int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const double* YTilde,
                                  int device, int rank, int world, bioen_hip_ctx** ctx);
 int bioen_hip_ctx_create_synthetic_sharded(int m, long long n, const double* YTrue,
@@ -171,8 +178,9 @@ int bioen_hip_ctx_set_affine(bioen_hip_ctx* ctx, const double* row_offset, const
  * FP64 matrix-core products (all sums stay FP64):
  *   format 1: fp32 high part + bf16 residual, 6 bytes per element, |error| <= 2^-33 of the centred element;
  *   format 2: fp32, 4 bytes, 2^-25;       format 0: back to FP64 (8 bytes, exact).
- * The FP64 row-major matrix stays resident beside them (read-back, chi_squared).  M <= 1024; the forces method returns
- * BIOEN_HIP_ESTATE while a reduced format is selected.  No reference counterpart: the reference computes in double
+ * The FP64 row-major matrix stays resident beside them (read-back, chi_squared).  M <= 1024.  The forces method's fused
+ * strip passes (M <= 1024: forces_fdf(_batch), the forces optimizers) stream the same reduced copy; everything else of
+ * the forces method (forces_weights, M > 1024) returns BIOEN_HIP_ESTATE while a reduced format is selected.  No reference counterpart: the reference computes in double
  * throughout (bioen/optimize/ext/c_bioen_common.c:70-108). */
 int bioen_hip_ctx_set_storage(bioen_hip_ctx* ctx, int format);
 /* How the L-BFGS direction d = -H g is formed on the device.
@@ -294,9 +302,9 @@ int bioen_hip_debug_strip_stamps(bioen_hip_ctx* ctx, int enable, long long* out,
 int bioen_hip_selftest_lbfgs(int kind, int n, const double* x0, const bioen_lbfgs_config* config,
                              double* x_out, bioen_opt_result* info);
 
-/* Forces method on structure-sharded contexts: bioen_hip_forces_fdf and the forces optimizers work
- * for M <= 1024 (two all-gathers per evaluation); bioen_hip_forces_weights and
- * larger M return BIOEN_HIP_ESTATE there. */
+/* Forces method on structure-sharded contexts: bioen_hip_forces_weights (one all-gather), bioen_hip_forces_fdf and the
+ * forces optimizers (two all-gathers per evaluation) work for M <= 1024 -- the strip passes; larger M
+ * (row panels: four passes whose partial sums are not canonical segments) returns BIOEN_HIP_ESTATE there. */
 
 /* ---- yTilde assembled on the device from raw observables ---------------------------------
  * Replaces the host loops of bioen/analyze/observables/observables.py:110-143 (sim / sigma built
@@ -319,7 +327,8 @@ int bioen_hip_ctx_create_raw(int m, long long n, int structure_major, const doub
  * info->lbfgs_code carries the GSL status: 0 success, -2 GSL_CONTINUE (iteration budget used),
  * 27 GSL_ENOPROG, 13 GSL_EBADTOL -- the reference treats {0, -2, 27} as success
  * (c_bioen.pyx:109-116).  info->iterations = driver iterations, info->evaluations = f + gradient
- * evaluations.  Unsharded contexts only. */
+ * evaluations.  Sharded contexts (r05): served -- the minimizers' inner products and norms are sums over structures
+ * like every other one (per canonical segment, one stage all-gather each), so every rank takes the same steps. */
 const char* bioen_hip_gsl_strerror(int gsl_code);   /* replaces bioen_gsl_error(), c_bioen_error.c:14-20 */
 int bioen_hip_opt_gsl_logw(bioen_hip_ctx* ctx, const double* g0, const double* G, double theta,
                            const bioen_gsl_config* config, const bioen_visual_params* visual,

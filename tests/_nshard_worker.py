@@ -82,6 +82,11 @@ def main():
     starts = np.stack([gopt, d["GInit"].ravel(), d["GInit"].ravel()])
     early = ctx.opt_lbfgs_logw_batch([0.5, 50.0, 5.0], starts, d["G"], LBFGS_DEFAULTS, max_batch=4)
     chi2, yave = ctx.chi_squared(w)
+    # r05: the GSL-style minimizers on a sharded context -- their inner products and norms are sums over
+    # structures like every other one (canonical segments, one stage all-gather each)
+    ggsl, wgsl, igsl = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "bfgs2", dict(step_size=0.01, tol=1e-3, max_iterations=200))
+    gcg, _, icg = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "conjugate_pr", dict(step_size=0.01, tol=1e-3, max_iterations=60),
+                                   want_weights=False)
     block = ctx.read_ytilde()
     col0, n_local = ctx.col0, ctx.n_local
     counts = ctx.exchange_counts3()
@@ -103,6 +108,7 @@ def main():
     fctx = bioen_amd.Context(fd["yTilde"], fd["YTilde"], device=0, rank=comm.rank, world=comm.world)
     attach(fctx)
     f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
+    fwts = fctx.forces_weights(f0, fd["w0"])           # r05: served on sharded contexts (pass 1 of the strip evaluation)
     ff, fgrad = fctx.forces_fdf(f0, fd["w0"], 10.0)
     fthetas = [100.0, 10.0, 1000.0]
     fres, fw, finfos = fctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
@@ -127,7 +133,9 @@ def main():
              nan_code=inan.lbfgs_code, nan_evals=inan.evaluations, nanb_codes=np.array([i.lbfgs_code for i in nanb[2]]),
              nanb_evals=np.array([i.evaluations for i in nanb[2]]), nanb_fmin=np.array([i.fmin for i in nanb[2]]),
              nanb_res=nanb[0][[0, 2]], early_res=early[0], early_fmin=np.array([i.fmin for i in early[2]]),
-             early_codes=np.array([i.lbfgs_code for i in early[2]]), early_evals=np.array([i.evaluations for i in early[2]]))
+             early_codes=np.array([i.lbfgs_code for i in early[2]]), early_evals=np.array([i.evaluations for i in early[2]]),
+             ggsl=ggsl, wgsl=wgsl, gsl_stat=np.array([igsl.fmin, igsl.lbfgs_code, igsl.iterations, igsl.evaluations]),
+             gcg=gcg, cg_stat=np.array([icg.fmin, icg.lbfgs_code, icg.iterations, icg.evaluations]), fwts=fwts)
     comm.close()
 
 

@@ -60,7 +60,8 @@ def run_ranks(tmp_path, world, transport):
 RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
                "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff",
                "f6res", "f6w", "f6fmin", "nan_code", "nan_evals", "nanb_codes", "nanb_evals", "nanb_res",
-               "early_res", "early_fmin", "early_codes", "early_evals")
+               "early_res", "early_fmin", "early_codes", "early_evals",
+               "ggsl", "wgsl", "gsl_stat", "gcg", "cg_stat", "fwts")
 
 
 # BIOEN_TEST_WORLDS="2,3,4,5": the ranks on the one GPU (2 and 4 divide the 8 canonical segments: their runs must equal the
@@ -119,7 +120,7 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     for r in range(1, world):
         for key in ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
                     "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv",
-                    "f6res", "f6w", "f6fmin"):
+                    "f6res", "f6w", "f6fmin", "ggsl", "wgsl", "gsl_stat", "gcg", "cg_stat", "fwts"):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
         assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
 
@@ -166,6 +167,16 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         res1, wopt1, infos1 = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
         gconv1, wconv1, iconv1 = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_CONV)
         chi2w1, yave1g = ctx.chi_squared(w1)
+        ggsl1, wgsl1, igsl1 = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "bfgs2", dict(step_size=0.01, tol=1e-3, max_iterations=200))
+        gcg1, _, icg1 = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "conjugate_pr", dict(step_size=0.01, tol=1e-3, max_iterations=60),
+                                         want_weights=False)
+    # the GSL-style minimizers on the sharded context: the single-GPU run's optimum (to the stopping rule's width; bit for bit
+    # when the rank count divides 8), the oracle's gradient test at the result
+    assert int(z[0]["gsl_stat"][1]) in (0, -2, 27) and abs(z[0]["wgsl"].sum() - 1.0) < 1e-12
+    assert abs(float(z[0]["gsl_stat"][0]) - igsl1.fmin) <= 1e-6 * abs(igsl1.fmin)
+    assert np.abs(z[0]["wgsl"] - wgsl1).max() <= 1e-3 * wgsl1.max()
+    f_at, grad_at, _ = O.logw_fdf(z[0]["ggsl"], d["G"], d["yTilde"], d["YTilde"], d["theta"])
+    assert abs(f_at - float(z[0]["gsl_stat"][0])) <= 1e-12 * abs(f_at)
     if canonical:
         assert np.array_equal(z[0]["w"], w1) and float(z[0]["logs"]) == logs1
         assert float(z[0]["f"]) == f1 and np.array_equal(z[0]["grad"], grad1)
@@ -176,6 +187,9 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         assert np.array_equal(z[0]["wconv"], wconv1) and float(z[0]["fminconv"]) == iconv1.fmin      # the converged run
         assert int(z[0]["codeconv"]) == iconv1.lbfgs_code
         assert float(z[0]["chi2w"]) == chi2w1 and np.array_equal(z[0]["yave"], yave1g)
+        assert np.array_equal(z[0]["ggsl"], ggsl1) and np.array_equal(z[0]["wgsl"], wgsl1) and np.array_equal(z[0]["gcg"], gcg1)
+        assert list(z[0]["gsl_stat"]) == [igsl1.fmin, igsl1.lbfgs_code, igsl1.iterations, igsl1.evaluations]
+        assert list(z[0]["cg_stat"]) == [icg1.fmin, icg1.lbfgs_code, icg1.iterations, icg1.evaluations]
     assert np.abs(z[0]["w"] - w1).max() <= 1e-13 * w1.max() and abs(z[0]["logs"] - logs1) < 1e-12
     yave1 = d["yTilde"].dot(z[0]["w"])
     for r in range(world):
@@ -203,6 +217,7 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     assert np.abs(z[0]["fwconv"] - fwref).max() <= 1e-5 * fwref.max()
     fthetas = [100.0, 10.0, 1000.0]
     with bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as ctx:
+        fwts1 = ctx.forces_weights(f0, fd["w0"])
         ff1, fgrad1 = ctx.forces_fdf(f0, fd["w0"], 10.0)
         fres1, fw1, finfos1 = ctx.opt_lbfgs_forces_batch(fthetas, fd["forces_init"], fd["w0"], LBFGS_DEFAULTS)
         f6res1, f6w1, f6infos1 = ctx.opt_lbfgs_forces_batch([300.0, 100.0, 30.0, 10.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
@@ -211,7 +226,10 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     for i, info in enumerate(f6infos1):          # the six-wide batch (K > 4 strip form) against the single-GPU run
         assert abs(z[0]["f6fmin"][i] - info.fmin) <= 2e-5 * abs(info.fmin)
         assert abs(z[0]["f6w"][i].sum() - 1.0) < 1e-12
+    fw_o = O.forces_weights(f0, fd["w0"], fd["yTilde"])
+    assert np.abs(z[0]["fwts"] - fw_o).max() <= 1e-12 * fw_o.max() and abs(z[0]["fwts"].sum() - 1.0) < 1e-12
     if canonical:                                # the forces method: both strip passes, bit for bit the single-GPU run
+        assert np.array_equal(z[0]["fwts"], fwts1)
         assert float(z[0]["ff"]) == ff1 and np.array_equal(z[0]["fgrad"], fgrad1)
         assert np.array_equal(z[0]["fres"], fres1) and np.array_equal(z[0]["fw"], fw1)
         assert [(float(a), int(b), int(c_)) for a, b, c_ in zip(z[0]["ffmin"], z[0]["fiters"], z[0]["fcodes"])] == \
