@@ -1256,7 +1256,9 @@ def main():
     if failed:
         print("bench.py: --shard structures requested, but the run fell back (transport: %s, decomposition: %s)"
               % (xinfo.get("transport"), "structures" if nshard else "thetas"), file=sys.stderr)
-        sys.exit(3)
+    # (a rank whose RCCL initialisation was abandoned at its time bound leaves through os._exit: _lib.leave_process)
+    from bioen_amd import _lib as _l
+    _l.leave_process(3 if failed else 0)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "bioen_hip_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "bioen_hip_comm_init": (C.c_int, [ctx_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
     "bioen_hip_comm_allgather": (C.c_int, [ctx_p, dp, C.c_size_t, dp]),
+    "bioen_hip_comm_init_abandoned": (C.c_int, []),
     "bioen_hip_exchange_probe": (C.c_int, [ctx_p, C.c_size_t, C.c_int, dp]),
     "bioen_hip_read_probe": (C.c_int, [ctx_p, C.c_int, C.c_int, dp, C.POINTER(C.c_longlong)]),
     "bioen_hip_comm_destroy": (C.c_int, [ctx_p]),
@@ -155,6 +156,26 @@ def check(rc):
         L = lib()
         raise BioenHipError("libbioen_hip: %s (%d): %s" % (L.bioen_hip_strerror(rc).decode(), rc,
                                                           L.bioen_hip_last_error().decode()))
+
+
+def leave_process(status=0):
+    """End the process the safe way for a rank whose RCCL initialisation was abandoned at its time bound: a helper thread
+    is then still blocked inside ncclCommInitRank, and normal interpreter teardown would run librccl's / HIP's static
+    destructors under it (hang or crash at exit).  Flushes stdio and leaves through os._exit in that case; a plain
+    sys.exit otherwise.  Never re-executes anything."""
+    import sys
+    abandoned = False
+    try:
+        abandoned = bool(_lib is not None and _lib.bioen_hip_comm_init_abandoned())
+    except Exception:
+        abandoned = False
+    if abandoned:
+        try:
+            sys.stdout.flush()
+            sys.stderr.flush()
+        finally:
+            os._exit(int(status))
+    sys.exit(int(status))
 
 
 def column_segments(n, world=1):

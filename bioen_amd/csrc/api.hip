@@ -1532,6 +1532,8 @@ static int rccl_async_error(bioen_hip_ctx* c) {
     return 0;
 }
 
+static std::atomic<int> g_comm_init_abandoned{0};      // a bounded ncclCommInitRank was given up and its helper thread is still inside RCCL
+
 static void rccl_abort(bioen_hip_ctx* c) {
     if (!c->comm) return;
     if (g_rccl.CommAbort) g_rccl.CommAbort(static_cast<ncclComm_t>(c->comm));    // frees the communicator as well
@@ -1571,6 +1573,7 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
         ncclComm_t comm = nullptr;
         ncclResult_t r = ncclSuccess;
         std::atomic<int> done{0};
+        std::atomic<int> abandoned{0};      // the caller has given up: a late success is nobody's communicator
     };
     auto job = std::make_shared<InitJob>();
     const int dev = c->device;
@@ -1579,6 +1582,13 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
             if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
             job->r = g_rccl.CommInitRank(&job->comm, nranks, u, rank);
             job->done.store(1, std::memory_order_release);
+            // a peer that arrived late completes the init after this rank has walked away: the orphan is aborted here, so
+            // that the peers' collectives on it fail fast instead of waiting for a rank that will never join them
+            if (job->abandoned.load(std::memory_order_acquire) && job->r == ncclSuccess && job->comm) {
+                if (g_rccl.CommAbort) g_rccl.CommAbort(job->comm);
+                else if (g_rccl.CommDestroy) g_rccl.CommDestroy(job->comm);
+                g_comm_init_abandoned.store(0, std::memory_order_release);      // nothing is blocked inside RCCL any more
+            }
         }).detach();
     } catch (...) {
         return fail(BIOEN_HIP_ERCCL, "could not start the thread that initialises the RCCL communicator");
@@ -1589,6 +1599,11 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
             char buf[200];
             std::snprintf(buf, sizeof buf, "ncclCommInitRank (rank %d of %d) did not return within %g s: a rank is missing "
                           "(3 x BIOEN_HIP_WAIT_TIMEOUT)", rank, nranks, 3.0 * std::max(c->wait_timeout_s, 1.0));
+            // A helper thread stays behind, blocked inside RCCL: static destructors of librccl / HIP running under it at
+            // interpreter teardown can hang or crash.  The process-wide flag (bioen_hip_comm_init_abandoned) tells the
+            // host layer to leave through os._exit after flushing its output (bioen_amd/_lib.py: leave_process).
+            job->abandoned.store(1, std::memory_order_release);
+            if (!job->done.load(std::memory_order_acquire)) g_comm_init_abandoned.store(1, std::memory_order_release);
             return fail(BIOEN_HIP_ERCCL, buf);
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
@@ -1601,6 +1616,8 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
     c->comm_nranks = nranks;
     return 0;
 }
+
+int bioen_hip_comm_init_abandoned(void) { return g_comm_init_abandoned.load(std::memory_order_acquire); }
 
 int bioen_hip_comm_allgather(bioen_hip_ctx* c, const double* send, size_t count, double* recv) {
     if (!c || !send || !recv || count == 0) return fail(BIOEN_HIP_EINVAL, "bad argument");

@@ -262,7 +262,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         // Speculation: idle slots evaluate the steps a backtracking search may ask for next (stp / 2, 2.1 stp) in the
         // round's matrix passes.  A shadow costs ten N-vector passes, widens the batch and adds the two (gated) late-Gram
         // launches to the round; it pays only where a saved evaluation shortens the SERIES -- for the stragglers -- and
-        // where trials are rejected often enough.  Measured (tools/spec_probe.py, r03): shadows in every idle slot made
+        // where trials are rejected often enough.  Measured (tools/attic/spec_probe.py, r03): shadows in every idle slot made
         // the N = 1e5 x M = 256 series (4-5 % of the stragglers' trials rejected) 8 % slower than none, while the
         // headline series (10-12 %) gains 3 %.  So: a problem is shadowed once it has shown a rejection rate of
         // `shadow_rate` (8 %) over >= 24 evaluations, and at most `max_shadows` (2) slots shadow at a time: both steps of

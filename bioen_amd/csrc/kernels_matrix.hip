@@ -545,7 +545,7 @@ void launch_fwd_rows_local(bioen_hip_ctx* c, int K, bool logw, int ctiles, bool 
 // The VALID entries only: the padding of e (columns n .. ld) is zero and must stay zero whatever the factor -- the matrix
 // passes multiply it with the zero columns of the strip copies, and k_logw_exp never rewrites it: scaled by a
 // non-finite 1 / sum e (a run on NaN input) it turned into NaN for good and 0 x NaN poisoned every later evaluation on
-// the context (r04, found by tools/nan_probe.py's successor in tests/test_hip_edgecases.py).
+// the context (r04, found by tools/attic/nan_probe.py's successor in tests/test_hip_edgecases.py).
 __global__ __launch_bounds__(kBlock) void k_scale_w(Round r, int n, SegMap sm) {
     const int a = blockIdx.y;
     const SegPos sp = seg_pos(sm.npl, sm.segcols, n);

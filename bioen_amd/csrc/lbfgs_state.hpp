@@ -387,7 +387,7 @@ BIOEN_HD inline LbfgsAction on_initial(LbfgsState& m, const bioen_lbfgs_config& 
     // lbfgs.c:447 writes `gnorm / xnorm <= epsilon`; the reference BUILDS its liblbfgs with -ffast-math (the library's own
     // Makefile), where the test comes out as !(... > epsilon): a non-finite start (NaN / inf in g, G, yTilde,
     // YTilde, theta, forces, w0) ends the run at once with LBFGS_ALREADY_MINIMIZED and the start point -- measured against
-    // oracle/_ref (tools/nan_probe.py, tests/test_hip_edgecases.py).  Under IEEE rules the `<=` form would iterate on NaN
+    // oracle/_ref (tools/attic/nan_probe.py, tests/test_hip_edgecases.py).  Under IEEE rules the `<=` form would iterate on NaN
     // until max_iterations (5000 lock-step rounds of nothing).
     if (!(gnorm / xnorm > c.epsilon)) return LbfgsAction{ACT_DONE, 0, 0, LBFGS_ALREADY_MINIMIZED, 0};
     m.k = 1;

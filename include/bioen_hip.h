@@ -357,6 +357,11 @@ int bioen_hip_comm_unique_id(unsigned char id[128]);
 int bioen_hip_comm_init(bioen_hip_ctx* ctx, const unsigned char id[128], int rank, int nranks);
 /* all-gather of `count` doubles per rank, host in / host out (staged through HBM, RCCL over xGMI) */
 int bioen_hip_comm_allgather(bioen_hip_ctx* ctx, const double* send, size_t count, double* recv);
+/* != 0: a bioen_hip_comm_init was given up at its time bound (a rank never called it) and its helper thread is still
+ * blocked inside ncclCommInitRank.  The process goes on without RCCL; it should leave through _exit (after flushing its
+ * output) rather than through normal teardown, where the collective library's static destructors would run under that
+ * thread.  Reset if the late peer shows up (the orphaned communicator is then aborted). */
+int bioen_hip_comm_init_abandoned(void);
 /* average wall time (microseconds) of one stage exchange of `count` doubles per rank on a sharded
  * context, back to back on the context's stream: lets the host decide whether splitting the
  * structures beats dealing thetas for a given problem size */

@@ -191,7 +191,7 @@ def test_logw_analyze_style_log_weights_evaluation_against_the_reference_binary(
 @pytest.mark.parametrize("last_tiny,thetas", [(True, (100.0, 10.0)), (False, (10.0,))])
 def test_logw_analyze_style_converged_against_the_reference_binary(last_tiny, thetas):
     """M = 64 x N = 4000, epsilon = 1e-12 (|x| ~ 2e4: at 1e-9 the gradient test stops both codes on a slope), where the
-    reference's two line searches pin the optimum to 3e-8 / 2e-6 among themselves (tools/edge_probe2.py)"""
+    reference's two line searches pin the optimum to 3e-8 / 2e-6 among themselves (tools/attic/edge_probe2.py)"""
     import bioen_amd
     from oracle import cpus
     R = require_reference()
@@ -287,7 +287,7 @@ def test_a_non_finite_theta_in_a_batch_leaves_the_other_problems_alone():
             assert np.array_equal(res[k], gs) and np.array_equal(w[k], ws)
 
 
-# ---- valid but degenerate inputs (tools/odd_probe.py) ---------------------------------------------------------------------
+# ---- valid but degenerate inputs (tools/attic/odd_probe.py) ---------------------------------------------------------------------
 def _odd_problem(M, N, seed=3):
     rng = np.random.default_rng(seed)
     YTrue = rng.uniform(1, 10, M)
