@@ -98,6 +98,48 @@ class TorchComm(object):
         pass
 
 
+class ThreadComm(object):
+    """`world` ranks as THREADS of one process (``ThreadComm.create(world)`` -> one object per rank): the control plane and
+    the host-staged stage exchange of structure-sharded contexts that all live on one GPU of one process.  What it is for:
+    a GPU box admits a handful of processes per card, threads it does not count -- eight ranks, the decomposition of a
+    full node, run here under test (tests/test_hip_nshard.py).  Same interface as SocketComm."""
+
+    class _Shared(object):
+        def __init__(self, world, timeout):
+            import threading
+            self.world, self.timeout = world, timeout
+            self.slots = [None] * world
+            self.barrier = threading.Barrier(world)
+
+    def __init__(self, shared, rank):
+        self._s, self.rank, self.world = shared, rank, shared.world
+
+    @classmethod
+    def create(cls, world, timeout=120.0):
+        shared = cls._Shared(world, timeout)
+        return [cls(shared, r) for r in range(world)]
+
+    def allgather_object(self, obj):
+        s = self._s
+        s.slots[self.rank] = obj
+        s.barrier.wait(s.timeout)              # everybody has written
+        out = list(s.slots)
+        s.barrier.wait(s.timeout)              # everybody has read: the slots may be rewritten
+        return out
+
+    def allgather_array(self, a):
+        return np.stack(self.allgather_object(np.array(a, dtype=np.float64, copy=True)))
+
+    def barrier(self):
+        self._s.barrier.wait(self._s.timeout)
+
+    def max(self, x):
+        return max(self.allgather_object(float(x)))
+
+    def close(self):
+        pass
+
+
 def _enc(obj):
     """Small control objects only (None, bool, numbers, str, bytes, lists / tuples of those): JSON, no pickle."""
     def conv(o):

@@ -274,3 +274,78 @@ def test_randomised_series_on_sharded_contexts(tmp_path, world):
     for r, o in enumerate(outs):
         assert not o["bad"], (r, o["bad"])
         assert len(o["digests"]) == world and len(set(o["digests"])) == 1, (r, o["digests"])
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_equal_the_single_gpu_run_bit_for_bit():
+    """The decomposition of a full node -- EIGHT ranks, one canonical column segment each -- under test on one GPU: the
+    ranks are threads of this process (sweep.ThreadComm: a box admits six processes per card, threads it does not count),
+    their stage all-gathers go through the host-staged transport.  Every rank must return, bit for bit, what the single
+    GPU returns: evaluations, the yaml-default series, converged runs, both methods, a GSL-style minimizer.  (What the
+    driver's 8-GPU run differs in is the transport -- mailboxes over xGMI, or RCCL -- not the arithmetic.)"""
+    import threading
+    import bioen_amd
+    from bioen_amd import sweep
+    from conftest import LBFGS_CONV
+    world = 8
+    d = load_golden("synth_logw_M64xN2000.npz")
+    fd = load_golden("synth_forces_M96xN3000.npz")
+    thetas = [50.0, 5.0, 500.0, 1.0, 20.0]
+    g = d["GInit"].ravel() + 0.2 * np.random.default_rng(99).standard_normal(d["GInit"].size)
+    f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
+    gsl_params = dict(step_size=0.01, tol=1e-3, max_iterations=120)
+
+    def workload(ctx, fctx):
+        out = {}
+        out["w"], out["logs"] = ctx.logw_weights(g)
+        out["f"], out["grad"] = ctx.logw_fdf(g, d["G"], d["theta"])
+        res, wopt, infos = ctx.opt_lbfgs_logw_batch(thetas, d["GInit"], d["G"], LBFGS_DEFAULTS, max_batch=4)
+        out["res"], out["wopt"] = res, wopt
+        out["stat"] = np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code, i.chi2, i.kl) for i in infos])
+        gc, wc, ic = ctx.opt_lbfgs_logw(d["GInit"], d["G"], d["theta"], LBFGS_CONV)
+        out["wconv"], out["conv"] = wc, np.array([ic.fmin, ic.iterations, ic.lbfgs_code])
+        gg, wg, ig = ctx.opt_gsl_logw(d["GInit"], d["G"], d["theta"], "bfgs2", gsl_params)
+        out["ggsl"], out["gsl"] = gg, np.array([ig.fmin, ig.iterations, ig.evaluations, ig.lbfgs_code])
+        out["chi2w"], out["yave"] = ctx.chi_squared(out["w"])
+        out["fwts"] = fctx.forces_weights(f0, fd["w0"])
+        out["ff"], out["fgrad"] = fctx.forces_fdf(f0, fd["w0"], 10.0)
+        fres, fw, finfos = fctx.opt_lbfgs_forces_batch([100.0, 10.0, 1000.0, 30.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
+                                                       LBFGS_DEFAULTS, max_batch=6)
+        out["fres"], out["fw"] = fres, fw
+        out["fstat"] = np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in finfos])
+        return out
+
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx, bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as fctx:
+        single = workload(ctx, fctx)
+
+    comms = sweep.ThreadComm.create(world)
+    results, errors = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            ctx = bioen_amd.Context(d["yTilde"], d["YTilde"], device=0, rank=r, world=world)
+            fctx = bioen_amd.Context(fd["yTilde"], fd["YTilde"], device=0, rank=r, world=world)
+            try:
+                ctx.set_exchange(comms[r])
+                fctx.set_exchange(comms[r])
+                results[r] = workload(ctx, fctx)
+            finally:
+                ctx.close()
+                fctx.close()
+        except BaseException as e:          # noqa: B902 -- reported below; the other ranks leave through the barrier's bound
+            errors[r] = e
+            try:
+                comms[r]._s.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=500)
+    assert not any(t.is_alive() for t in threads), "a rank did not finish"
+    assert all(e is None for e in errors), errors
+    for r in range(world):
+        for key, val in single.items():
+            assert np.array_equal(np.asarray(results[r][key]), np.asarray(val)), (r, key)

@@ -199,3 +199,24 @@ comm.close()
             assert kinds[-1] == "detach"                                              # every rank lets go
             assert ("attach" in kinds) == (fault != "export")
             assert ("selftest" in kinds) == (fault == "selftest")
+
+
+def test_thread_comm_is_an_allgather_between_threads():
+    """sweep.ThreadComm: ranks as threads of one process (the 8-rank GPU test's control plane and host-staged transport)"""
+    import threading
+    comms = sweep.ThreadComm.create(3)
+    out = [None] * 3
+
+    def rank_main(r):
+        a = comms[r].allgather_array(np.arange(4.0) + 10 * r)
+        b = comms[r].allgather_array(np.full(2, float(r)))          # back to back: the slots are reused safely
+        out[r] = (a, b, comms[r].max(r + 0.5), comms[r].allgather_object({"rank": r}))
+        comms[r].barrier()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(3)]
+    [t.start() for t in ts]
+    [t.join(timeout=30) for t in ts]
+    for r in range(3):
+        a, b, mx, objs = out[r]
+        assert a.shape == (3, 4) and np.array_equal(a[:, 0], [0.0, 10.0, 20.0]) and np.array_equal(b[:, 1], [0.0, 1.0, 2.0])
+        assert mx == 2.5 and [o["rank"] for o in objs] == [0, 1, 2] and comms[r].rank == r and comms[r].world == 3
