@@ -4,7 +4,7 @@
 # record is left out of them so that only the two headline sizes launch the strip kernels), then the default
 # bench unprofiled with those traffic figures in place.  usage: tools/profile_round.sh <tag>
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -28,6 +28,15 @@ timeout -k 10 600 python bench.py > $OUT/bench_N1.json 2> $OUT/bench_N1.err
 echo "bench done"
 # the launch-bound regime: wall time per lock-step round (both engines, one process, interleaved) and the per-kernel split
 REPS=4 SIZES=256:100000,1024:125000,205:500000,64:20000,28:50001 VARIANTS=device,host,host-nospec timeout -k 10 300 python tools/engine_ab.py > $OUT/engine_ab.txt 2>&1
+# r05: the headline, both engines; and ONE RANK'S SHARE of the headline at 8 / 4 / 2 GPUs (rank 0 of the decomposition alone on
+# this GPU, exchanges mirrored): wall per round, then the 8-GPU share's per-kernel timeline
+REPS=2 SIZES=1024:1000000 VARIANTS=host,dev1 timeout -k 10 300 python tools/engine_ab.py > $OUT/engine_ab_headline.txt 2>&1
+for W in 8 4 2; do WORLD=$W REPS=2 SIZES=1024:1000000 VARIANTS=device timeout -k 10 300 python tools/engine_ab.py >> $OUT/engine_ab_rank_share.txt 2>&1; done
+WORLD=8 SIZES=1024:1000000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/w8 -o w8 -- $PY tools/small_timeline.py > $OUT/w8.log 2>&1
+python tools/trace_gaps.py $OUT/w8/w8_kernel_trace.csv > $OUT/round_rank_share_8gpu_1024x1000000.txt
+SIZES=1024:1000000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/big -o big -- $PY tools/small_timeline.py > $OUT/big.log 2>&1
+python tools/trace_gaps.py $OUT/big/big_kernel_trace.csv k_trial > $OUT/round_1024x1000000.txt
+timeout -k 10 200 python tools/canon_probe.py quick > $OUT/canon_probe.txt 2>&1
 SIZES=256:100000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/small -o small -- $PY tools/small_timeline.py > $OUT/small.log 2>&1
 python tools/trace_gaps.py $OUT/small/small_kernel_trace.csv > $OUT/small_round_256x100000.txt
 SIZES=1024:125000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/small2 -o small -- $PY tools/small_timeline.py >> $OUT/small.log 2>&1
