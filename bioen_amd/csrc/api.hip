@@ -578,16 +578,12 @@ static ForcesRound make_forces_round(bioen_hip_ctx* c, const int* slots, int k, 
     return r;
 }
 
-static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr, int panel_sets = 0) {
+static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {     // streaming kernels (no row panels)
     MVec8 out{};
     for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
-    if (panel_sets > 0) {                     // M > 1024, row panels: the column sums on the strip kernel, uncentred
-        launch_adj_strip(c, fr.n, c->um, out, MVec8{}, panel_sets, true);
-    } else {
-        const int rc = ensure_rowmajor(c);    // streaming kernels: the row-major matrix (back from the strip copy if it was freed)
-        if (rc) return rc;
-        launch_adj(c, fr.n, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
-    }
+    const int rc = ensure_rowmajor(c);        // the row-major matrix (back from the strip copy if it was freed)
+    if (rc) return rc;
+    launch_adj(c, fr.n, c->um, out, false);   // F1: x_j = sum_i f_i yTilde_ij     [matrix pass 1]
     launch_forces_max(c, fr);
     launch_forces_exp(c, fr);
     launch_forces_norm(c, fr);                // w ; KL partials
@@ -628,11 +624,10 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         }
         return 0;
     }
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "forces on a sharded context need M <= 1024 (strip passes)");
     // M > 1024: four passes.  r03: on the strip kernels over row panels of <= 1024 rows (kernels_strip.hip) -- the two
     // column-sum passes uncentred, the two row-sum passes centred on the targets as in the two-pass path, T = sum_j t_j
     // taken off in the gradient's reduction -- with the r01 streaming kernels as the fallback (BIOEN_HIP_PANELS=0, or
-    // no memory for the panel copies)
+    // no memory for the panel copies; unsharded contexts only).
     int psets = strip_panels(c) ? fwd_strip_blocks(c) : 0;
     if (psets > 0) {
         rc = ensure_strip_copy(c);
@@ -640,36 +635,55 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         if (rc && !c->strips_unavailable) return rc;
         if (rc) psets = 0;
     }
-    if ((rc = enqueue_forces_weights(c, fr, psets))) return rc;
+    if (psets > 0) {
+        // r05: the panel path in canonical segments, on any number of ranks (two stage exchanges per evaluation, as in
+        // the two-pass path): the softmax is merged segment by segment (kernels_forces.hip: k_forces_seg_exp), the row
+        // sums of the two forward passes are the log-weights forward kernel's sets, shared out per segment
+        MVec8 out{};
+        Vec8 v{};
+        Round rx = r;
+        for (int a = 0; a < fr.n; ++a) {
+            out.p[a] = fr.a[a];
+            rx.x[a] = fr.a[a];
+            v.p[a] = fr.w[a];
+        }
+        const StripSets ss = strip_sets(c);
+        launch_adj_strip(c, fr.n, c->um, out, MVec8{}, psets, true);   // F1: x_j = sum_i f_i yTilde_ij   [matrix pass 1]
+        launch_max(c, rx);                                             //     block maxima of x per segment
+        launch_forces_seg_exp(c, fr);                                  //     e = w0 exp(x - m_v) -> w ; shares of sum e, sum e x
+        launch_fwd_strip(c, fr.n, v, psets);                           // F2: (yTilde - centre) . e      [matrix pass 2]
+        launch_fwd_rows_local(c, fr.n, true, psets, true);             //     the segments' shares + softmax totals
+        if ((rc = exchange(c, X_YBAR, (size_t)ybar_payload(c, fr.n, true)))) return rc;
+        launch_rows_combine(c, r, true, c->strip_center, false);       //     normalisation, ybar (centred), r, chi^2, KL, f
+        c->last_centered = true;
+        launch_scale_w(c, r);                                          //     w = e S_INV[v]: the weights
+        if (with_grad) {
+            launch_adj_strip(c, fr.n, c->r_c, out, MVec8{}, psets, true);   // F3: b = yTilde^T r  [matrix pass 3]
+            launch_forces_seg_t(c, fr, ss.gs * (ss.fold ? 1 : ss.nch));     //     t_j ; T_v = sum over segment v
+            for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
+            launch_fwd_strip(c, fr.n, v, psets);                            //     sum_j (yTilde_ij - c_i) t_j   [matrix pass 4]
+            launch_fwd_rows_forces_grad_share(c, fr.n, 0, &fr, false);      //     ... - (ybar_i - c_i) T_v, per segment
+            if ((rc = exchange(c, X_YBAR, (size_t)c->mp * fr.n))) return rc;
+            launch_forces_grad_sum_ranks(c, fr.n);                          //     added in segment order
+        }
+        return 0;
+    }
+    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "forces with M > 1024 on a sharded context need the row-panel copies");
+    if ((rc = enqueue_forces_weights(c, fr))) return rc;
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];
-    if (psets > 0) {
-        launch_fwd_strip(c, fr.n, v, psets);                       // F2: ybar - centre        [matrix pass 2]
-        launch_fwd_rows_local(c, fr.n, false, psets, true);
-        launch_rows_combine(c, r, false, c->strip_center, false);  //     ybar_c = ybar - centre; r, chi^2 from the raw averages
-        c->last_centered = true;
-    } else {
-        launch_fwd_partial(c, fr.n, v);       // F2: ybar                         [matrix pass 2]
-        launch_fwd_rows_local(c, fr.n, false);
-        launch_rows_combine(c, r, false);
-    }
+    launch_fwd_partial(c, fr.n, v);           // F2: ybar                         [matrix pass 2]
+    launch_fwd_rows_local(c, fr.n, false);
+    launch_rows_combine(c, r, false);
     launch_forces_scalars(c, fr);             //     f = theta KL + 0.5 chi^2
     if (with_grad) {
         MVec8 out{};
         for (int a = 0; a < fr.n; ++a) out.p[a] = fr.a[a];
-        if (psets > 0) {
-            launch_adj_strip(c, fr.n, c->r_c, out, MVec8{}, psets, true);   // F3: b = yTilde^T r  [matrix pass 3]
-            launch_forces_t(c, fr, psets);                                  //     t_j and T = sum_j t_j
-            for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
-            launch_fwd_strip(c, fr.n, v, psets);                            //     sum_j (yTilde_ij - c_i) t_j   [matrix pass 4]
-            launch_fwd_rows_forces_grad(c, fr.n, psets, &fr, true);         //     ... - (ybar_i - c_i) T
-        } else {
-            launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
-            launch_forces_t(c, fr);               //     t_j
-            for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
-            launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
-            launch_fwd_rows_forces_grad(c, fr.n, c->fwd_ctiles);
-        }
+        launch_adj(c, fr.n, c->r_c, out, false);   // F3: b = yTilde^T r          [matrix pass 3]
+        launch_forces_t(c, fr);               //     t_j
+        for (int a = 0; a < fr.n; ++a) v.p[a] = fr.t[a];
+        launch_fwd_partial(c, fr.n, v, true); //     gm_i = sum_j (yTilde_ij - ybar_i) t_j  [matrix pass 4]
+        launch_fwd_rows_forces_grad(c, fr.n, c->fwd_ctiles);
     }
     return 0;
 }
@@ -1200,9 +1214,14 @@ int bioen_hip_opt_lbfgs_logw(bioen_hip_ctx* c, const double* g0, const double* G
 // ---- forces ---------------------------------------------------------------------------
 static bool is_affine(const bioen_hip_ctx* c) { return c->affine; }
 
+// the forces evaluation in canonical segments: the two-pass strip kernels (M <= 1024) or the row panels (M > 1024)
+static bool forces_canonical(const bioen_hip_ctx* c) {
+    return forces_fused_blocks(c) > 0 || (strip_panels(c) && fwd_strip_blocks(c) > 0);
+}
+
 static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
-    // sharded contexts run the forces method through the strip passes only (M <= 1024)
-    if (c->world != 1 && !(strip_path_ok && forces_fused_blocks(c) > 0))
+    // sharded contexts run the forces method in canonical segments only (not on the r01 streaming kernels)
+    if (c->world != 1 && !(strip_path_ok && forces_canonical(c)))
         return fail(BIOEN_HIP_ESTATE, "not available on this structure-sharded context");
     if (is_affine(c)) return fail(BIOEN_HIP_ESTATE, "the affine observable model is implemented for the log-weights method");
     if (c->storage && !(strip_path_ok && forces_fused_blocks(c) > 0))
@@ -1213,8 +1232,8 @@ static int forces_guard(const bioen_hip_ctx* c, bool strip_path_ok = true) {
 int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const double* w0, double* w) {
     if (!c || !forces || !w0 || !w) return fail(BIOEN_HIP_EINVAL, "NULL argument");
     int rc;
-    if (forces_fused_blocks(c) > 0 && !c->storage) {
-        // M <= 1024 (r05): pass 1 of the strip evaluation IS _get_weights_from_forces -- x = yTilde^T f, the softmax over all
+    if (forces_canonical(c) && !c->storage) {
+        // r05: the first half of an evaluation IS _get_weights_from_forces -- x = yTilde^T f, the softmax over all
         // structures merged segment by segment -- so sharded contexts serve the call too (one stage exchange), and every rank
         // count returns the single-GPU bits
         if ((rc = forces_guard(c))) return rc;
@@ -1231,7 +1250,7 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
         BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
         return transport_error(c);
     }
-    rc = forces_guard(c, false);              // streaming kernels (M > 1024): unsharded contexts only
+    rc = forces_guard(c, false);              // streaming kernels (no strip copies): unsharded contexts only
     if (rc) return rc;
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     if ((rc = upload_n(c, c->fixed, w0))) return rc;

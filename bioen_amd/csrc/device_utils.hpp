@@ -120,6 +120,37 @@ __device__ __forceinline__ double sets_sum8(const double* __restrict__ P, size_t
             s = term(b + 24, v3, s);
         }
         for (; b < nsets; b += 8) s = term(b, P[(size_t)b * n], s);
+    } else if (fold <= 8) {
+        // (StripSets: at most eight chunks per group) all chunk loads of TWO of the part's groups in flight together -- one
+        // after the other (the trip count is a kernel argument) a rank of eight spent 10 us per round here; the adds in turn
+        int b = p;
+        for (; b + 8 < nsets; b += 16) {
+            double u[8], v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u[i] = i < fold ? P[((size_t)b * fold + i) * n] : 0.0;
+                v[i] = i < fold ? P[((size_t)(b + 8) * fold + i) * n] : 0.0;
+            }
+            double gu = 0.0, gv = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < fold) {
+                    gu += u[i];
+                    gv += v[i];
+                }
+            s = term(b, gu, s);
+            s = term(b + 8, gv, s);
+        }
+        for (; b < nsets; b += 8) {
+            double u[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u[i] = i < fold ? P[((size_t)b * fold + i) * n] : 0.0;
+            double gu = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < fold) gu += u[i];
+            s = term(b, gu, s);
+        }
     } else {
         for (int b = p; b < nsets; b += 8) {
             double gv = 0.0;

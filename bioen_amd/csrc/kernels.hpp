@@ -77,7 +77,7 @@ void launch_rows_combine(bioen_hip_ctx* c, const Round& r, bool logw,   // logw:
 int combine_grid(const bioen_hip_ctx* c);
 // forces gradient: gm_c[row*K + a] = reduced centred sums
 // tsum = true (strip passes on the centred copy): gm = sum of partials - ybar_c * T, T = sum of the blocks' P_KL shares
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles);
 // forces evaluation in TWO matrix passes over LDS-resident column strips (M <= 1024):
 //   xy: x = yTilde^T f (-> slot a), online softmax per block, raw ybar partials; block merge; ybar -> X_YBAR
 //   bt: b = yTilde^T r, t, and the centred yTilde . t together; partials -> fwd_partial[.. * nblk + block]
@@ -108,7 +108,9 @@ int forces_fused_blocks(const bioen_hip_ctx* c);       // sets per segment of th
 void launch_forces_xy(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_bt(bioen_hip_ctx* c, const struct ForcesRound& fr, int nblk);
 void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   // w = w0 exp(x - S_LOGS)
-void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int ctiles, const struct ForcesRound* tsum = nullptr, bool tposed = false);   // sharded: -> X_YBAR segment
+// every local segment's share of the forces gradient -> its part of X_YBAR.  tposed: the two-pass strip kernels' sets (seg_sets per
+// segment); else the log-weights forward kernel's sets (row panels, M > 1024)
+void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int seg_sets, const struct ForcesRound* tsum = nullptr, bool tposed = false);
 int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
 int set_storage_format(bioen_hip_ctx* c, int fmt);     // reduced-byte storage experiment of the log-weights passes (0 = FP64)
 int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
@@ -146,8 +148,11 @@ struct ForcesRound {
 void launch_forces_max(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_exp(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_norm(bioen_hip_ctx* c, const ForcesRound& r);
-void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r, int tsum_sets = 0);   // tsum_sets > 0: also T = sum_j t_j -> P_KL share 0 of that many (the rest zero)
+void launch_forces_t(bioen_hip_ctx* c, const ForcesRound& r);
 void launch_forces_scalars(bioen_hip_ctx* c, const ForcesRound& r);
+// canonical-segment forms of the row-panel path (M > 1024; any number of ranks)
+void launch_forces_seg_exp(bioen_hip_ctx* c, const ForcesRound& r);                 // e = w0 exp(x - m_v) -> w ; X_EXP shares (needs launch_max on x)
+void launch_forces_seg_t(bioen_hip_ctx* c, const ForcesRound& r, int seg_sets);     // t ; T_v -> share 0 of the segment's seg_sets P_KL shares
 
 // ---- assembly of yTilde = sim / sigma on the device ----------------------------------------
 void launch_rows_div(bioen_hip_ctx* c, const double* sigma);          // Y[i][:] /= sigma_i (device pointer)

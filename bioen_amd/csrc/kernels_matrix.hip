@@ -212,16 +212,18 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_local_t(const double* __res
 }
 
 // forces gradient from transposed partials (the strip kernels).  blockIdx.y = local segment v, whose sets are
-// [v * seg_sets, (v + 1) * seg_sets): the segment's share  sum_sets partial - ybar' T_v  (T_v = the sets' shares of
-// sum_j t_j, totalled in the same fixed order by every block) goes to out + v * out_stride -- the segment's part of the
-// X_YBAR stage (k_sum_ranks adds the segments up in order), or, with one "segment" holding every set, gm itself
-// (row panels of matrices taller than 1024 rows: unsharded contexts only).
-__global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double* __restrict__ partial, int seg_sets,
+// [v gs fold, (v + 1) gs fold) -- gs values of `fold` chunk sets each, as in k_fwd_rows_local_t (the two-pass strip
+// kernels: fold = 1, gs = the segment's sets): the segment's share  sum_sets partial - ybar' T_v  (T_v = the sets'
+// shares of sum_j t_j, totalled in the same fixed order by every block) goes to out + v * out_stride -- the segment's
+// part of the X_YBAR stage (k_sum_ranks adds the segments up in order), or, with one "segment" holding every set, gm
+// itself (the streaming-order fallback of unsharded contexts).
+__global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double* __restrict__ partial, int gs, int fold,
                                                                    int mp, int K, double* __restrict__ out, size_t out_stride,
                                                                    const double* __restrict__ ybar_c, MVec8 tpart) {
     __shared__ double lds[8][32];
     __shared__ double T[kMaxBatch];
     const int v = blockIdx.y;
+    const int seg_sets = gs * fold;
     if (ybar_c)
         for (int a = 0; a < K; ++a) {
             const double t = sum_partials(tpart.p[a] + (size_t)P_KL * kPartStride + (size_t)v * seg_sets, seg_sets, &lds[0][0]);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_rows_forces_grad_t(const double*
     const size_t n = (size_t)mp * K;
     const size_t idx = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
     const bool valid = idx < n;
-    const double s = sets_sum8(partial + (size_t)v * seg_sets * n + (valid ? idx : 0), n, seg_sets, 1, lds, TermAdd());
+    const double s = sets_sum8(partial + (size_t)v * seg_sets * n + (valid ? idx : 0), n, gs, fold, lds, TermAdd());
     if (threadIdx.x < 32 && valid) (out + (size_t)v * out_stride)[idx] = ybar_c ? fma(-ybar_c[idx], T[idx % K], s) : s;
 }
 
@@ -262,38 +264,82 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
     // thereby applied to the M sums instead of the N weights.
     __shared__ double fac[kShRed];     // LOGW: e^{m_v - M} / S per segment
     double gmax = 0.0, invS = 1.0;
+    const size_t tail_at = (size_t)mp * K + 3 * a;
+    // Up to eight segments (every world that divides 8, a single GPU included): their values are loaded TOGETHER and then
+    // used in segment order -- with the loops' trip count a kernel argument the loads went out one by one, and this
+    // one-block kernel is nothing but latency (r05: 14 us per round, twice r04's with one segment)
+    const bool few = xi.world <= kMaxSeg;
     if (LOGW) {
-        gmax = -DBL_MAX;
-        for (int r = 0; r < xi.world; ++r)
-            gmax = fmax(gmax, xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2]);
         double S = 0.0, PP = 0.0;
-        for (int r = 0; r < xi.world; ++r) {
-            const double* tail = xi.base + (size_t)r * xi.payload + (size_t)mp * K + 3 * a;
-            const double fr = exp(tail[2] - gmax);
-            S = fma(fr, tail[0], S);
-            PP = fma(fr, tail[1], PP);
+        if (few) {
+            double t0[kMaxSeg], t1[kMaxSeg], t2[kMaxSeg];
+#pragma unroll
+            for (int r = 0; r < kMaxSeg; ++r) {
+                const double* tail = xi.base + (size_t)(r < xi.world ? r : 0) * xi.payload + tail_at;
+                t0[r] = tail[0];
+                t1[r] = tail[1];
+                t2[r] = tail[2];
+            }
+            gmax = -DBL_MAX;
+#pragma unroll
+            for (int r = 0; r < kMaxSeg; ++r)
+                if (r < xi.world) gmax = fmax(gmax, t2[r]);
+#pragma unroll
+            for (int r = 0; r < kMaxSeg; ++r)
+                if (r < xi.world) {
+                    const double fr = exp(t2[r] - gmax);
+                    S = fma(fr, t0[r], S);
+                    PP = fma(fr, t1[r], PP);
+                }
+            invS = 1.0 / S;
+            if (threadIdx.x < kMaxSeg) {
+                double mine = t2[0];
+#pragma unroll
+                for (int r = 1; r < kMaxSeg; ++r)
+                    if ((int)threadIdx.x == r) mine = t2[r];
+                if ((int)threadIdx.x < xi.world) fac[threadIdx.x] = exp(mine - gmax) * invS;
+            }
+        } else {
+            gmax = -DBL_MAX;
+            for (int r = 0; r < xi.world; ++r) gmax = fmax(gmax, xi.base[(size_t)r * xi.payload + tail_at + 2]);
+            for (int r = 0; r < xi.world; ++r) {
+                const double* tail = xi.base + (size_t)r * xi.payload + tail_at;
+                const double fr = exp(tail[2] - gmax);
+                S = fma(fr, tail[0], S);
+                PP = fma(fr, tail[1], PP);
+            }
+            invS = 1.0 / S;
+            for (int r = threadIdx.x; r < xi.world; r += kBlock)
+                fac[r] = exp(xi.base[(size_t)r * xi.payload + tail_at + 2] - gmax) * invS;
         }
-        invS = 1.0 / S;
-        for (int r = threadIdx.x; r < xi.world; r += kBlock)
-            fac[r] = exp(xi.base[(size_t)r * xi.payload + (size_t)mp * K + 3 * a + 2] - gmax) * invS;
         __syncthreads();
         if (threadIdx.x == 0) {
             double* sc = rd.scal[a];
             sc[S_LOGS] = gmax + log(S);
             sc[S_P] = PP * invS;
-            for (int v = 0; v < xi.vr; ++v) {      // w = e * S_INV[v] in local segment v (its own shift m_v)
-                const double mown = xi.base[(size_t)(xi.rank + v) * xi.payload + (size_t)mp * K + 3 * a + 2];
-                sc[S_INV + v] = exp(mown - gmax) * invS;
-            }
         }
+        if ((int)threadIdx.x < xi.vr)      // w = e * S_INV[v] in local segment v (its own shift m_v): the factor of segment rank + v
+            rd.scal[a][S_INV + threadIdx.x] = fac[xi.rank + threadIdx.x];
     }
     double chi = 0.0, cc = 0.0, b0 = 0.0, uy = 0.0;
     for (int row = threadIdx.x; row < mp; row += kBlock) {
         double s = 0.0;
-        for (int r = 0; r < xi.world; ++r) {
-            const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
-            if (LOGW) s = fma(fac[r], v, s);
-            else s += v;
+        if (few) {
+            double v[kMaxSeg];
+#pragma unroll
+            for (int r = 0; r < kMaxSeg; ++r) v[r] = xi.base[(size_t)(r < xi.world ? r : 0) * xi.payload + (size_t)row * K + a];
+#pragma unroll
+            for (int r = 0; r < kMaxSeg; ++r)
+                if (r < xi.world) {
+                    if (LOGW) s = fma(fac[r], v[r], s);
+                    else s += v[r];
+                }
+        } else {
+            for (int r = 0; r < xi.world; ++r) {
+                const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
+                if (LOGW) s = fma(fac[r], v, s);
+                else s += v;
+            }
         }
         const double sc = row_scale[row];
         const double cen = center ? center[row] : 0.0;            // shares of the centred copy: ybar_raw = s + center
@@ -588,23 +634,25 @@ static MVec8 tsum_parts(const ForcesRound* fr) {
     return t;
 }
 
-void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles, const ForcesRound* tsum, bool tposed) {
-    if (tposed) {          // every set of the context as one run (unsharded contexts: row panels, M > 1024)
-        hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 31) / 32, 1), dim3(kBlock), 0, c->stream,
-                           c->fwd_partial, ctiles, c->mp, K, c->gm, (size_t)0, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
-        return;
-    }
+void launch_fwd_rows_forces_grad(bioen_hip_ctx* c, int K, int ctiles) {      // streaming fallback (unsharded contexts)
     hipLaunchKernelGGL(k_fwd_rows_forces_grad, dim3(rows_grid(c), K), dim3(kBlock), 0, c->stream, c->fwd_partial,
-                       ctiles, c->mp, K, c->gm, tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
+                       ctiles, c->mp, K, c->gm, static_cast<const double*>(nullptr), MVec8{});
 }
 
-// strip passes (M <= 1024): every local segment's share of the forces gradient -> its X_YBAR segment; after the
+// strip passes (M <= 1024) and row panels (M > 1024): every local segment's share of the forces gradient -> its X_YBAR segment; after the
 // exchange k_sum_ranks adds the shares in segment order (identical on every rank, and on every GPU count) -> gm
 void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int seg_sets, const ForcesRound* tsum, bool tposed) {
     const Xch xo = make_xch(c, X_YBAR, c->mp * K);
-    (void)tposed;
+    // tposed = false (r05): the sets of the log-weights forward kernel -- the row panels of a matrix taller than 1024
+    // rows -- whose groups are `nch` chunk sets each unless the kernel has folded them (kernels.hpp: StripSets)
+    int gs = seg_sets, fold = 1;
+    if (!tposed) {
+        const StripSets ss = strip_sets(c);
+        gs = ss.gs;
+        fold = ss.fold ? 1 : ss.nch;
+    }
     hipLaunchKernelGGL(k_fwd_rows_forces_grad_t, dim3((c->mp * K + 31) / 32, c->vr), dim3(kBlock), 0, c->stream,
-                       c->fwd_partial, seg_sets, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, (size_t)xo.payload,
+                       c->fwd_partial, gs, fold, c->mp, K, xo.base + (size_t)xo.rank * xo.payload, (size_t)xo.payload,
                        tsum ? c->ybar_c : nullptr, tsum_parts(tsum));
 }
 

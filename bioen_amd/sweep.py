@@ -520,7 +520,8 @@ def sweep_forces_sharded(ctx, thetas, w0, forces_init, lbfgs_params, verbose=Fal
     keeps a column block of yTilde and of w0, all thetas stay batched on every rank, and an
     evaluation needs two small all-gathers (the ranks' shares of ybar with their softmax totals, and
     of the gradient); the M force variables and the L-BFGS state are replicated and, fed with
-    identical numbers, take identical decisions on every rank.  Needs M <= 1024 (strip passes)."""
+    identical numbers, take identical decisions on every rank.  (M <= 1024: the two strip passes; beyond: the
+    four passes over row panels -- two all-gathers per evaluation either way.)"""
     thetas = [float(t) for t in thetas]
     _, w, infos = ctx.opt_lbfgs_forces_batch(thetas, forces_init, w0, lbfgs_params, max_batch=max_batch, verbose=verbose)
     return [{"theta": th, "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "iterations": i.iterations,

@@ -120,8 +120,9 @@ int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const doub
  * per stage through the peer-to-peer mailboxes (bioen_hip_p2p_attach), RCCL (bioen_hip_comm_init) or, for
  * processes that can share neither, a host callback.  Every rank must
  * issue the same calls in the same order.  Supported on sharded contexts: logw_weights, logw_fdf, chi_squared,
- * opt_lbfgs_logw(_batch), opt_gsl_logw, and for M <= 1024 the forces method (forces_weights, forces_fdf(_batch),
- * opt_lbfgs_forces(_batch), opt_gsl_forces). */
+ * opt_lbfgs_logw(_batch), opt_gsl_logw, and the forces method (forces_weights, forces_fdf(_batch),
+ * opt_lbfgs_forces(_batch), opt_gsl_forces) for every M served by strip copies (M <= 1024: two passes; beyond: four
+ * passes over row panels). */
 int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const double* YTilde,
                                  int device, int rank, int world, bioen_hip_ctx** ctx);
 int bioen_hip_ctx_create_synthetic_sharded(int m, long long n, const double* YTrue,
@@ -303,8 +304,10 @@ int bioen_hip_selftest_lbfgs(int kind, int n, const double* x0, const bioen_lbfg
                              double* x_out, bioen_opt_result* info);
 
 /* Forces method on structure-sharded contexts: bioen_hip_forces_weights (one all-gather), bioen_hip_forces_fdf and the
- * forces optimizers (two all-gathers per evaluation) work for M <= 1024 -- the strip passes; larger M
- * (row panels: four passes whose partial sums are not canonical segments) returns BIOEN_HIP_ESTATE there. */
+ * forces optimizers (two all-gathers per evaluation) -- the two strip passes for M <= 1024, the four
+ * passes over row panels beyond (r05: both in canonical segments, the bits of the single-GPU run).  Only the r01
+ * streaming kernels (no strip copies: BIOEN_HIP_PANELS=0, BIOEN_HIP_STRIP_TALL=0, or a device without the memory for
+ * them) remain unsharded-only: BIOEN_HIP_ESTATE there. */
 
 /* ---- yTilde assembled on the device from raw observables ---------------------------------
  * Replaces the host loops of bioen/analyze/observables/observables.py:110-143 (sim / sigma built

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import bioen_amd                      # noqa: E402
 from bioen_amd import sweep            # noqa: E402
-from conftest import load_golden, LBFGS_DEFAULTS, LBFGS_CONV   # noqa: E402
+from conftest import load_golden, tall_forces_problem, LBFGS_DEFAULTS, LBFGS_CONV   # noqa: E402
 
 
 def main():
@@ -117,6 +117,15 @@ def main():
     f6res, f6w, f6infos = fctx.opt_lbfgs_forces_batch([300.0, 100.0, 30.0, 10.0, 3.0, 1.0], fd["forces_init"], fd["w0"],
                                                       LBFGS_DEFAULTS, max_batch=6)
     fctx.close()
+    # r05: more than 1024 observables -- the four passes over row panels, in canonical segments like the two strip passes
+    td = tall_forces_problem()
+    tctx = bioen_amd.Context(td["yTilde"], td["YTilde"], device=0, rank=comm.rank, world=comm.world)
+    attach(tctx)
+    tw = tctx.forces_weights(td["f0"], td["w0"])
+    tf, tgrad = tctx.forces_fdf(td["f0"], td["w0"], 100.0)
+    tres, tww, tinfos = tctx.opt_lbfgs_forces_batch(td["thetas"], np.zeros(td["f0"].size), td["w0"],
+                                                    dict(LBFGS_DEFAULTS, max_iterations=25))
+    tctx.close()
     comm.barrier()
     np.savez(out_path % comm.rank, w=w, logs=logs, f=f, grad=grad, res=res, wopt=wopt,
              fmin=np.array([i.fmin for i in infos]), iters=np.array([i.iterations for i in infos]),
@@ -135,7 +144,9 @@ def main():
              nanb_res=nanb[0][[0, 2]], early_res=early[0], early_fmin=np.array([i.fmin for i in early[2]]),
              early_codes=np.array([i.lbfgs_code for i in early[2]]), early_evals=np.array([i.evaluations for i in early[2]]),
              ggsl=ggsl, wgsl=wgsl, gsl_stat=np.array([igsl.fmin, igsl.lbfgs_code, igsl.iterations, igsl.evaluations]),
-             gcg=gcg, cg_stat=np.array([icg.fmin, icg.lbfgs_code, icg.iterations, icg.evaluations]), fwts=fwts)
+             gcg=gcg, cg_stat=np.array([icg.fmin, icg.lbfgs_code, icg.iterations, icg.evaluations]), fwts=fwts,
+             tw=tw, tf=tf, tgrad=tgrad, tres=tres, tww=tww,
+             tstat=np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in tinfos]))
     comm.close()
 
 

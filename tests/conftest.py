@@ -52,6 +52,19 @@ LBFGS_CONV = dict(LBFGS_DEFAULTS, epsilon=1e-9, delta=0.0, past=0, max_iteration
 LBFGS_CONVMT = dict(LBFGS_CONV, linesearch=0)
 
 
+def tall_forces_problem(M=1100, N=2000, seed=20251):
+    """A forces problem with more than 1024 observables (the four passes over row panels), SURVEY 8(d)'s recipe."""
+    rng = np.random.default_rng(seed)
+    YTrue = rng.uniform(1, 10, M)
+    sig_exp, sig_sim = 0.1 * YTrue, 0.5 * YTrue
+    YTilde = rng.normal(YTrue, sig_exp) / sig_exp
+    yTilde = rng.normal(YTrue[:, None], sig_sim[:, None], (M, N)) / sig_exp[:, None]
+    w0 = rng.uniform(0.5, 1.5, N)
+    w0 /= w0.sum()
+    f0 = 1e-4 * rng.standard_normal(M)
+    return dict(yTilde=yTilde, YTilde=YTilde, w0=w0, f0=f0, thetas=[1000.0, 100.0])
+
+
 def require_reference():
     """-> oracle.ref_binding, the ctypes binding of the reference's own C path (oracle/_ref/libbioen_ref.so, git-ignored,
     built from /root/reference by oracle/Makefile in the build container; it travels to the GPU box with the repository).

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden, LBFGS_DEFAULTS
+from conftest import ROOT, load_golden, tall_forces_problem, LBFGS_DEFAULTS
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +61,7 @@ RESULT_KEYS = ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "c
                "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv", "f", "logs", "ff",
                "f6res", "f6w", "f6fmin", "nan_code", "nan_evals", "nanb_codes", "nanb_evals", "nanb_res",
                "early_res", "early_fmin", "early_codes", "early_evals",
-               "ggsl", "wgsl", "gsl_stat", "gcg", "cg_stat", "fwts")
+               "ggsl", "wgsl", "gsl_stat", "gcg", "cg_stat", "fwts", "tw", "tf", "tgrad", "tres", "tww", "tstat")
 
 
 # BIOEN_TEST_WORLDS="2,3,4,5": the ranks on the one GPU (2 and 4 divide the 8 canonical segments: their runs must equal the
@@ -120,7 +120,8 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
     for r in range(1, world):
         for key in ("w", "grad", "res", "wopt", "fmin", "iters", "evals", "codes", "chi2", "kl",
                     "fgrad", "fres", "fw", "ffmin", "fiters", "fcodes", "fkl", "fchi2", "wconv", "fwconv",
-                    "f6res", "f6w", "f6fmin", "ggsl", "wgsl", "gsl_stat", "gcg", "cg_stat", "fwts"):
+                    "f6res", "f6w", "f6fmin", "ggsl", "wgsl", "gsl_stat", "gcg", "cg_stat", "fwts", "tw", "tf", "tgrad", "tres", "tww",
+                    "tstat"):
             assert np.array_equal(z[0][key], z[r][key]), (key, r)
         assert z[0]["f"] == z[r]["f"] and z[0]["logs"] == z[r]["logs"] and z[0]["ff"] == z[r]["ff"]
 
@@ -245,6 +246,26 @@ def test_structure_sharded_run_matches_single_gpu(tmp_path, world):
         assert abs(z[0]["fw"][i].sum() - 1.0) < 1e-12
         assert abs(z[0]["ffmin"][i] - (fthetas[i] * z[0]["fkl"][i] + z[0]["fchi2"][i])) <= 1e-10 * abs(info.fmin)
 
+    # r05: more than 1024 observables (four passes over row panels) on the sharded context: the oracle, the single-GPU run
+    td = tall_forces_problem()
+    tw_o = O.forces_weights(td["f0"], td["w0"], td["yTilde"])
+    tf_o, tgrad_o, _ = O.forces_fdf(td["f0"], td["w0"], td["yTilde"], td["YTilde"], 100.0)
+    assert np.abs(z[0]["tw"] - tw_o).max() <= 1e-12 * tw_o.max() and abs(z[0]["tw"].sum() - 1.0) < 1e-12
+    assert abs(z[0]["tf"] - tf_o) <= 1e-12 * abs(tf_o)
+    assert np.abs(z[0]["tgrad"] - tgrad_o).max() <= 1e-9 * np.abs(tgrad_o).max()
+    with bioen_amd.Context(td["yTilde"], td["YTilde"]) as ctx:
+        tw1 = ctx.forces_weights(td["f0"], td["w0"])
+        tf1, tgrad1 = ctx.forces_fdf(td["f0"], td["w0"], 100.0)
+        tres1, tww1, tinfos1 = ctx.opt_lbfgs_forces_batch(td["thetas"], np.zeros(td["f0"].size), td["w0"],
+                                                          dict(LBFGS_DEFAULTS, max_iterations=25))
+    assert np.abs(z[0]["tgrad"] - tgrad1).max() <= 1e-10 * np.abs(tgrad1).max()
+    for i, info in enumerate(tinfos1):
+        assert abs(z[0]["tstat"][i][0] - info.fmin) <= 2e-5 * abs(info.fmin)
+    if canonical:
+        assert np.array_equal(z[0]["tw"], tw1) and float(z[0]["tf"]) == tf1 and np.array_equal(z[0]["tgrad"], tgrad1)
+        assert np.array_equal(z[0]["tres"], tres1) and np.array_equal(z[0]["tww"], tww1)
+        assert np.array_equal(z[0]["tstat"], np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in tinfos1]))
+
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.timeout(600)
@@ -295,7 +316,9 @@ def test_eight_ranks_equal_the_single_gpu_run_bit_for_bit():
     f0 = 1e-3 * np.random.default_rng(5).standard_normal(fd["yTilde"].shape[0])
     gsl_params = dict(step_size=0.01, tol=1e-3, max_iterations=120)
 
-    def workload(ctx, fctx):
+    td = tall_forces_problem()
+
+    def workload(ctx, fctx, tctx):
         out = {}
         out["w"], out["logs"] = ctx.logw_weights(g)
         out["f"], out["grad"] = ctx.logw_fdf(g, d["G"], d["theta"])
@@ -313,10 +336,18 @@ def test_eight_ranks_equal_the_single_gpu_run_bit_for_bit():
                                                        LBFGS_DEFAULTS, max_batch=6)
         out["fres"], out["fw"] = fres, fw
         out["fstat"] = np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in finfos])
+        # more than 1024 observables: the four passes over row panels
+        out["tw"] = tctx.forces_weights(td["f0"], td["w0"])
+        out["tf"], out["tgrad"] = tctx.forces_fdf(td["f0"], td["w0"], 100.0)
+        tres, tww, tinfos = tctx.opt_lbfgs_forces_batch(td["thetas"], np.zeros(td["f0"].size), td["w0"],
+                                                        dict(LBFGS_DEFAULTS, max_iterations=25))
+        out["tres"], out["tww"] = tres, tww
+        out["tstat"] = np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code) for i in tinfos])
         return out
 
-    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx, bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as fctx:
-        single = workload(ctx, fctx)
+    with bioen_amd.Context(d["yTilde"], d["YTilde"]) as ctx, bioen_amd.Context(fd["yTilde"], fd["YTilde"]) as fctx, \
+            bioen_amd.Context(td["yTilde"], td["YTilde"]) as tctx:
+        single = workload(ctx, fctx, tctx)
 
     comms = sweep.ThreadComm.create(world)
     results, errors = [None] * world, [None] * world
@@ -325,13 +356,16 @@ def test_eight_ranks_equal_the_single_gpu_run_bit_for_bit():
         try:
             ctx = bioen_amd.Context(d["yTilde"], d["YTilde"], device=0, rank=r, world=world)
             fctx = bioen_amd.Context(fd["yTilde"], fd["YTilde"], device=0, rank=r, world=world)
+            tctx = bioen_amd.Context(td["yTilde"], td["YTilde"], device=0, rank=r, world=world)
             try:
                 ctx.set_exchange(comms[r])
                 fctx.set_exchange(comms[r])
-                results[r] = workload(ctx, fctx)
+                tctx.set_exchange(comms[r])
+                results[r] = workload(ctx, fctx, tctx)
             finally:
                 ctx.close()
                 fctx.close()
+                tctx.close()
         except BaseException as e:          # noqa: B902 -- reported below; the other ranks leave through the barrier's bound
             errors[r] = e
             try:
