@@ -261,6 +261,15 @@ __device__ __forceinline__ double xmax_local(const Xch& x, int a, int q) {
 // finished per-segment totals (stages with npl = 1: X_GRAMR, the tail of X_YBAR): added in segment order from +0.0
 __device__ __forceinline__ double seg_order_sum(const double* __restrict__ first, size_t stride, int nseg) {
     double s = 0.0;
+    if (nseg <= kMaxSeg) {      // the loads together, the adds in order (a trip count from a kernel argument sends them one by one)
+        double v[kMaxSeg];
+#pragma unroll
+        for (int seg = 0; seg < kMaxSeg; ++seg) v[seg] = first[(size_t)(seg < nseg ? seg : 0) * stride];
+#pragma unroll
+        for (int seg = 0; seg < kMaxSeg; ++seg)
+            if (seg < nseg) s += v[seg];
+        return s;
+    }
     for (int seg = 0; seg < nseg; ++seg) s += first[(size_t)seg * stride];
     return s;
 }

@@ -322,36 +322,56 @@ __global__ __launch_bounds__(kBlock) void k_rows_combine(Xch xi, int mp, int K, 
             rd.scal[a][S_INV + threadIdx.x] = fac[xi.rank + threadIdx.x];
     }
     double chi = 0.0, cc = 0.0, b0 = 0.0, uy = 0.0;
-    for (int row = threadIdx.x; row < mp; row += kBlock) {
-        double s = 0.0;
-        if (few) {
-            double v[kMaxSeg];
-#pragma unroll
-            for (int r = 0; r < kMaxSeg; ++r) v[r] = xi.base[(size_t)(r < xi.world ? r : 0) * xi.payload + (size_t)row * K + a];
-#pragma unroll
-            for (int r = 0; r < kMaxSeg; ++r)
-                if (r < xi.world) {
-                    if (LOGW) s = fma(fac[r], v[r], s);
-                    else s += v[r];
-                }
-        } else {
-            for (int r = 0; r < xi.world; ++r) {
-                const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
-                if (LOGW) s = fma(fac[r], v, s);
-                else s += v;
-            }
-        }
-        const double sc = row_scale[row];
-        const double cen = center ? center[row] : 0.0;            // shares of the centred copy: ybar_raw = s + center
+    // a row's finish: the sums below run over a thread's rows in row order, whichever way the shares were fetched
+    auto finish_row = [&](int row, double s, double sc, double off, double yt, double cen) {
         const double raw = s + cen;
-        const double eff = fma(sc, raw, row_offset[row]);
-        const double res = eff - YT[row];
+        const double eff = fma(sc, raw, off);
+        const double res = eff - yt;
         ybar_c[(size_t)row * K + a] = store_raw ? raw : s;
         r_c[(size_t)row * K + a] = res * sc;
         chi = fma(res, res, chi);
         cc = fma(eff, res, cc);
         b0 = fma(cen, res * sc, b0);
         uy = fma(raw, res * sc, uy);
+    };
+    if (few) {
+        // four of the thread's rows at a time (all of them for M <= 1024): 32 shares and the rows' constants in flight together
+        constexpr int RB = 4;
+        for (int row0 = threadIdx.x; row0 < mp; row0 += RB * kBlock) {
+            double v[RB][kMaxSeg], sc[RB], off[RB], yt[RB], cen[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int row = row0 + i * kBlock < mp ? row0 + i * kBlock : row0;
+#pragma unroll
+                for (int r = 0; r < kMaxSeg; ++r) v[i][r] = xi.base[(size_t)(r < xi.world ? r : 0) * xi.payload + (size_t)row * K + a];
+                sc[i] = row_scale[row];
+                off[i] = row_offset[row];
+                yt[i] = YT[row];
+                cen[i] = center ? center[row] : 0.0;             // shares of the centred copy: ybar_raw = s + center
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                if (row0 + i * kBlock >= mp) break;
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < kMaxSeg; ++r)
+                    if (r < xi.world) {
+                        if (LOGW) s = fma(fac[r], v[i][r], s);
+                        else s += v[i][r];
+                    }
+                finish_row(row0 + i * kBlock, s, sc[i], off[i], yt[i], cen[i]);
+            }
+        }
+    } else {
+        for (int row = threadIdx.x; row < mp; row += kBlock) {
+            double s = 0.0;
+            for (int r = 0; r < xi.world; ++r) {
+                const double v = xi.base[(size_t)r * xi.payload + (size_t)row * K + a];
+                if (LOGW) s = fma(fac[r], v, s);
+                else s += v;
+            }
+            finish_row(row, s, row_scale[row], row_offset[row], YT[row], center ? center[row] : 0.0);
+        }
     }
     chi = block_sum(chi, sh);
     cc = block_sum(cc, sh);
