@@ -83,4 +83,24 @@ for (M, N) in sizes:
             t = sorted(times[n])
             print(("WORLD=%d rank share  " % world if world > 1 else "") + "M=%d N=%d %-16s best %.4f s  median %.4f s  rounds %d -> %.1f us/round" % (
                 M, N, n, t[0], t[len(t) // 2], rounds[n], 1e6 * t[0] / max(rounds[n], 1)))
+        if world > 1:
+            # the sweep's fixed cost (start-up, eight result deliveries with their gathers) weighs on the few hundred rounds of
+            # the mirrored problem: the same series cut after one iteration measures it; the rest is the rounds' own time
+            for k in KEYS:
+                os.environ.pop(k, None)
+            os.environ.update({k: v for k, v in VARIANTS[names[0]].items() if not k.startswith("_")})
+            short = dict(LBFGS_DEFAULTS, max_iterations=1)
+            t1 = []
+            for rep in range(4):
+                ctx.kernel_stats_enable(True)
+                ctx.kernel_stats_reset()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                sweep.sweep_log_weights(ctx, thetas, G, G, short)
+                ctx.synchronize()
+                t1.append(time.perf_counter() - t0)
+                r1 = ctx.kernel_stats()["forward"]["launches"]
+            t = sorted(times[names[0]])
+            print("WORLD=%d rank share  %-16s the series cut after one iteration: %.4f s for %d rounds -> net of that fixed cost "
+                  "%.1f us/round" % (world, names[0], min(t1[1:]), r1, 1e6 * (t[0] - min(t1[1:])) / max(rounds[names[0]] - r1, 1)))
         sys.stdout.flush()
