@@ -383,3 +383,15 @@ def test_eight_ranks_equal_the_single_gpu_run_bit_for_bit():
     for r in range(world):
         for key, val in single.items():
             assert np.array_equal(np.asarray(results[r][key]), np.asarray(val)), (r, key)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_randomised_problems_on_2_4_8_ranks_equal_the_single_gpu_run():
+    """tools/fuzz_canon.py as a test: random problems over every kernel geometry (M = 5 ... 1100, row panels included; N down
+    to one structure in the last segment), random series, line searches, caps, GSL algorithms, both methods -- sharded over
+    2, 4 or 8 ranks (threads of this process) they return the single-GPU run's bits.  (400 seeds clean in round 5.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_canon
+    bad = fuzz_canon.run(0, 12, [2, 4, 8])
+    assert not bad, bad
