@@ -668,7 +668,8 @@ static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Ro
         }
         return 0;
     }
-    if (c->world != 1) return fail(BIOEN_HIP_ESTATE, "forces with M > 1024 on a sharded context need the row-panel copies");
+    if (c->world != 1)      // (no strip copies: switched off by the environment, or no memory for them)
+        return fail(BIOEN_HIP_ESTATE, "the forces method on a sharded context needs the strip copies of the matrix (M > 1024: the row panels)");
     if ((rc = enqueue_forces_weights(c, fr))) return rc;
     Vec8 v{};
     for (int a = 0; a < fr.n; ++a) v.p[a] = fr.w[a];

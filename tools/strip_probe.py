@@ -1,6 +1,6 @@
 """Forces strip passes at BASELINE config 5 size (N = 1e6 x M = 512 by default): per-launch time of the two
 matrix passes at batch widths K = 1..8 through bioen_hip_forces_fdf_batch, and agreement of f / grad between
-batch widths.  BIOEN_HIP_STRIP_OLD=1 selects the r01 kernels for an A/B on the same box."""
+batch widths.  (An A/B against an earlier tree: build that tree beside this one and run its copy of this file.)"""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
