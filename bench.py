@@ -382,6 +382,13 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
         out["gpu_iterations"] = int(sum(r["iterations"] for r in res))
         out["gpu_iterations_per_theta"] = [int(r["iterations"]) for r in res]
         out["survey_iterations_theta10"] = {"8 threads": 409, "1 thread": 388}            # BASELINE.md 2 (orientation runs)
+        # r05: the optimum of every theta (converged settings: epsilon 1e-8, no plateau stop) -- what both sides' yaml-default
+        # stops are held against below, and what the reference is asked to confirm (started there, same settings)
+        eps = 1e-8
+        conv = dict(LBFGS_DEFAULTS, epsilon=eps, delta=0.0, past=0, max_iterations=60000)
+        t0 = time.perf_counter()
+        g_star, w_star, i_star = ctx.opt_lbfgs_logw_batch(thetas, G, G, conv, max_batch=8)
+        conv_s = time.perf_counter() - t0
     yTT = np.ascontiguousarray(yT.T)
     R.set_fast_openmp_flag(1)
     R.omp_set_num_threads(cores)
@@ -397,7 +404,26 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
     out.update({"cpu_sweep_s": cpu_s, "cpu_codes": codes, "speedup": cpu_s / out["gpu_sweep_s"],
                 "fmin_rel_diff_per_theta": rel, "fmin_rel_diff_max": max(rel),
                 "fmin_signed_rel_diff_per_theta": signed})
-    # The yardstick for those differences: the REFERENCE against itself.  At yaml defaults both codes stop on the plateau
+    # r05: both sides against the OPTIMUM (the device's converged runs above), and the reference's word on that optimum: its
+    # own _opt_lbfgs_logw started there under the same converged settings (status 0 / 2 = it takes the point for a minimum)
+    f_star = [i.fmin for i in i_star]
+    confirm = []
+    for k, th in enumerate(thetas):
+        g_c, f_c, c_c, _ = _ref_lbfgs_logw(R, yT, yTT, YTilde, G, th, dict(conv, max_iterations=25), g_start=g_star[k])
+        w_c = np.exp(g_c - g_c.max())
+        w_c /= w_c.sum()
+        confirm.append({"theta": float(th), "device_code": i_star[k].lbfgs_code, "device_iterations": i_star[k].iterations,
+                        "reference_code": c_c, "fmin_rel_diff": abs(f_c - f_star[k]) / abs(f_c),
+                        "w_diff_over_max_w": float(np.abs(w_c - w_star[k]).max() / w_c.max())})
+    out["optimum"] = {
+        "settings": "converged: epsilon %g, delta 0, past 0; device from the cold start (all thetas as one batch: %.2f s), reference "
+                    "started at the device's optimum" % (eps, conv_s),
+        "per_theta": confirm,
+        "within_north_star": bool(all(c["device_code"] in (0, 2) and c["reference_code"] in (0, 2) and c["fmin_rel_diff"] <= 1e-6 and
+                                      c["w_diff_over_max_w"] <= 1e-5 for c in confirm)),
+        "default_stop_above_optimum_rel": {"device": [(r["fmin"] - f) / abs(f) for r, f in zip(res, f_star)],
+                                           "reference": [(fr - f) / abs(f) for fr, f in zip(fref, f_star)]}}
+    # The yardstick for the differences between the two yaml-default stops: the REFERENCE against itself.  At yaml defaults both codes stop on the plateau
     # test (delta = 1e-6 over 10 iterations), and where exactly depends on the rounding of the sums: the same binary, the
     # same inputs, serial sums (fast_openmp = 0) instead of OpenMP reductions.
     variants = {"fast_openmp=0, %d threads" % cores: (0, cores)}
