@@ -34,6 +34,10 @@ def workload(ctx, p):
     fres, fwo, finfos = ctx.opt_lbfgs_forces_batch(p["thetas"], np.zeros(p["M"]), p["w0"], p["params"], max_batch=p["max_batch"])
     out["fres"], out["fwopt"] = fres, fwo
     out["fstat"] = np.array([(i.fmin, i.iterations, i.evaluations, i.lbfgs_code, i.chi2, i.kl) for i in finfos])
+    if p["gsl"]:
+        fg, fwg, fig = ctx.opt_gsl_forces(np.zeros(p["M"]), p["w0"], p["thetas"][0], p["gsl"], dict(step_size=0.01, tol=1e-3, max_iterations=8))
+        out["fgsl"], out["fwgsl"] = fg, fwg
+        out["fgslstat"] = np.array([fig.fmin, fig.iterations, fig.evaluations, fig.lbfgs_code])
     return out
 
 
