@@ -71,7 +71,7 @@ enum ScalarSlot : int {
 };
 static_assert(S_COUNT <= kScalStride, "scalar slots");
 
-// local (never exchanged) partial-reduction arrays, each kMaxPartials doubles, per problem slot
+// local (never exchanged) partial-reduction arrays, each kPartStride doubles (kernels.hpp), per problem slot
 enum PartSlot : int {
     P_MAX = 0, P_SUM, P_PP, P_CHI, P_C, P_KL,
     P_COUNT = 8
@@ -137,7 +137,7 @@ struct ProblemSlot {
     double* Yh[kHistory] = {};
     double* scal = nullptr;   // kScalStride doubles inside ctx->scal
     double *Ssp = nullptr, *Ysp = nullptr;   // spare (s, y) pair of the device-resident engine (kernels.hpp: DevSlot)
-    double* part = nullptr;   // P_COUNT * kMaxPartials doubles inside ctx->part (local partials)
+    double* part = nullptr;   // P_COUNT * kPartStride doubles inside ctx->part (local partials)
     double* gram = nullptr;   // kGramStride doubles inside ctx->gram
 };
 
@@ -243,7 +243,7 @@ struct bioen_hip_ctx {
     double* fwd_partial = nullptr;   // kMaxBatch * mp * fwd_ctiles, compact per round
     int fwd_ctiles = 0;              // column tiles of the forward pass
     int fwd_steps = 0;               // 128-column steps per tile
-    double* part = nullptr;          // kMaxBatch * P_COUNT * kMaxPartials
+    double* part = nullptr;          // kMaxBatch * P_COUNT * kPartStride
     double* scal = nullptr;          // kMaxBatch * kScalStride
     double* gram = nullptr;          // kMaxBatch * kGramStride
     int direction_mode = 0;          // 0 auto (= Gram form), 1 two-loop on the vectors, 2 Gram form

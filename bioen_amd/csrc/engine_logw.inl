@@ -640,7 +640,7 @@ struct LogwBatchEngine {
                             note(hipMemcpyAsync(sl.scal + rg[0], sh.scal + rg[0], rg[1] * sizeof(double),
                                                 hipMemcpyDeviceToDevice, c->stream), "adopt scalars");
                             // (the shadow keeps the owner's former values: a second adoption must not read them back)
-                            double tmp[8];
+                            double tmp[kScalStride];     // (the longest range is S_INV .. S_UY: kMaxSeg + 2 values)
                             std::memcpy(tmp, ho + rg[0], rg[1] * sizeof(double));
                             std::memcpy(ho + rg[0], hs + rg[0], rg[1] * sizeof(double));
                             std::memcpy(hs + rg[0], tmp, rg[1] * sizeof(double));
