@@ -167,6 +167,8 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     {
         const char* e = std::getenv("BIOEN_HIP_KEEP_ROWMAJOR");    // A/B: keep the row-major matrix beside the strip copies
         c->keep_rowmajor = (e && e[0] == '1') ? 1 : 0;
+        e = std::getenv("BIOEN_HIP_ONE_COPY");         // log-weights on ONE strip copy (ctx.hpp: one_copy)
+        c->one_copy_wanted = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_FWD_STREAM");       // A/B: the streaming forward kernel on the row-major matrix
         c->fwd_stream = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_PANELS");           // A/B: M > 1024 on the r01 streaming kernels instead of row panels
@@ -247,11 +249,41 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
     return 0;
 }
 
+// Host-to-device copy of a CALLER's (pageable) buffer.  r05, ROCm 7.2: the runtime pins a pageable source of this size for
+// the transfer, and refuses -- "invalid argument", from the asynchronous and the plain copy alike -- a buffer that took
+// (part of) the address range of one it has pinned before: a fresh numpy vector on the heap range of a freed one, in a
+// process that has already closed a context (tools/attic/onecopy_probe.py ran into it four times out of four).  The
+// transfer then goes through a pinned buffer of our own, 8 MB at a time: nothing of the caller's is pinned.
+static int h2d_staged(bioen_hip_ctx* c, char* dst, size_t dpitch, const char* src, size_t spitch, size_t width, size_t height) {
+    constexpr size_t kChunk = (size_t)8 << 20;
+    if (!c->stage_host) {
+        void* p = nullptr;
+        BIOEN_HIP_CHECK(hipHostMalloc(&p, kChunk, hipHostMallocDefault));
+        c->stage_host = static_cast<char*>(p);
+    }
+    for (size_t row = 0; row < height; ++row)
+        for (size_t off = 0; off < width; off += kChunk) {
+            const size_t nb = std::min(kChunk, width - off);
+            std::memcpy(c->stage_host, src + row * spitch + off, nb);
+            BIOEN_HIP_CHECK(hipMemcpyAsync(dst + row * dpitch + off, c->stage_host, nb, hipMemcpyHostToDevice, c->stream));
+            BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));      // the one buffer is written again
+        }
+    return 0;
+}
+
+static int h2d_user(bioen_hip_ctx* c, void* dst, const void* src, size_t bytes) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipErrorInvalidValue) {
+        (void)hipGetLastError();
+        return h2d_staged(c, static_cast<char*>(dst), bytes, static_cast<const char*>(src), bytes, bytes, 1);
+    }
+    BIOEN_HIP_CHECK(e);
+    return 0;
+}
+
 // host N-vectors are always GLOBAL (n_global long); a sharded context takes its slice
 static int upload_n(bioen_hip_ctx* c, double* dst, const double* src) {
-    BIOEN_HIP_CHECK(hipMemcpyAsync(dst, src + c->col0, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice,
-                                   c->stream));
-    return 0;
+    return h2d_user(c, dst, src + c->col0, (size_t)c->n * sizeof(double));
 }
 
 static int rccl_allgather_inplace(bioen_hip_ctx* c, double* base, size_t count);   // defined with the RCCL glue
@@ -782,6 +814,15 @@ int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const
     // this rank's column block [col0, col0 + n_local) of the host matrix
     hipError_t e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), yTilde + c->col0, (size_t)n * sizeof(double),
                                     (size_t)c->n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->stream);
+    if (e == hipErrorInvalidValue) {            // (h2d_staged: a caller's buffer the runtime will not pin)
+        (void)hipGetLastError();
+        if (h2d_staged(c, reinterpret_cast<char*>(c->Y), c->ld * sizeof(double), reinterpret_cast<const char*>(yTilde + c->col0),
+                       (size_t)n * sizeof(double), (size_t)c->n * sizeof(double), (size_t)m)) {
+            bioen_hip_ctx_destroy(c);
+            return BIOEN_HIP_EHIP;
+        }
+        e = hipSuccess;
+    }
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->YT, YTilde, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -816,14 +857,18 @@ int bioen_hip_ctx_create_raw(int m, long long n, int structure_major, const doub
     if (e == hipSuccess && !structure_major) {
         e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), sim, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
                              (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipErrorInvalidValue) {        // (h2d_staged: a caller's buffer the runtime will not pin)
+            (void)hipGetLastError();
+            e = h2d_staged(c, reinterpret_cast<char*>(c->Y), c->ld * sizeof(double), reinterpret_cast<const char*>(sim),
+                           (size_t)n * sizeof(double), (size_t)n * sizeof(double), (size_t)m) ? hipErrorUnknown : hipSuccess;
+        }
         if (e == hipSuccess) launch_rows_div(c, sigma);
     } else if (e == hipSuccess) {
         const long long chunk = std::max<long long>(1, std::min<long long>(n, (256ll << 20) / ((long long)m * 8)));
         e = hipMalloc(reinterpret_cast<void**>(&stage), (size_t)chunk * m * sizeof(double));
         for (long long j0 = 0; e == hipSuccess && j0 < n; j0 += chunk) {
             const long long nc = std::min(chunk, n - j0);
-            e = hipMemcpyAsync(stage, sim + (size_t)j0 * m, (size_t)nc * m * sizeof(double), hipMemcpyHostToDevice,
-                               c->stream);
+            e = h2d_user(c, stage, sim + (size_t)j0 * m, (size_t)nc * m * sizeof(double)) ? hipErrorUnknown : hipSuccess;
             if (e == hipSuccess) launch_transpose_div(c, stage, (int)nc, (size_t)j0, sigma);
         }
     }
@@ -952,6 +997,7 @@ int bioen_hip_ctx_destroy(bioen_hip_ctx* c) {
     for (int st = 0; st < X_COUNT; ++st)
         if (c->xbuf[st]) hipFree(c->xbuf[st]);
     if (c->exchange_host) hipHostFree(c->exchange_host);
+    if (c->stage_host) hipHostFree(c->stage_host);
     if (c->host_scal) hipHostFree(c->host_scal);
     if (c->live) hipHostFree(c->live);
     if (c->live2) hipHostFree(c->live2);

@@ -159,6 +159,7 @@ struct bioen_hip_ctx {
     int (*exchange_cb)(void* user, double* host_buf, size_t count_per_rank) = nullptr;
     void* exchange_user = nullptr;
     double* exchange_host = nullptr;
+    char* stage_host = nullptr;      // pinned, 8 MB, on first need: uploads of caller buffers the runtime refuses to pin (api.hip: h2d_staged)
     size_t exchange_host_count = 0;
     int exchange_error = 0;
     int force_exchange = 0;              // world == 1: run the stage exchanges all the same (through the communicator or the
@@ -214,6 +215,10 @@ struct bioen_hip_ctx {
     double* strip_stamps = nullptr;  // diagnostic builds only: [block][16 waves][8] phase-cycle sums of the last strip launch
     int fwd_stream = 0;              // BIOEN_HIP_FWD_STREAM=1: log-weights forward pass by k_fwd_partial (A/B)
     int strips_unavailable = 0;      // a strip copy could not be allocated: the streaming kernels serve this context
+    // r05: the log-weights method on ONE strip copy (the row-sum order one; the adjoint through the forces kernels' LDS image,
+    // kernels_strip.hip: k_strip<.., ADJ>): 1 x the matrix resident instead of 2 x.  wanted: BIOEN_HIP_ONE_COPY=1; taken
+    // by itself when the column-sum order copy cannot be allocated.  M <= 1024, FP64 storage.
+    int one_copy = 0, one_copy_wanted = 0;
     int strip_allocs = 0;            // strip-copy allocations attempted on this context (tests: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC=k fails the k-th)
     double* YT = nullptr;      // mp   experimental targets (YTilde)
     // affine observable model: yTilde_eff[i][j] = row_offset[i] + row_scale[i] * Y[i][j]

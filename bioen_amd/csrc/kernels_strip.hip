@@ -307,7 +307,10 @@ __device__ __forceinline__ ForcesSlot forces_slot(const StripArgs& q, int ps) {
 // strip s deferred behind the first barrier of strip s + 1, where it runs beside P2 of that strip on the waves P2 leaves
 // idle: ONE barrier per strip, P3 off the serial chain (the partial-sum, e | t and rescale buffers are doubled by strip
 // parity).  Same operands, same order of every sum: the bits of a problem do not depend on which form served it.
-template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH, int STORE = 0>
+// ADJ (r05): the column-sum half of pass 1 alone -- out_k[j] = sum_i Y'_ij u_ik + shift_k, the log-weights ADJOINT
+// (k_strip_adj's product) on the ROW-sum order copy: what lets the log-weights method run with ONE strip copy of the
+// matrix (ctx.hpp: one_copy).  No softmax, no row sums, no sets; instantiated with XY = true, DEPTH 2.
+template <int K, bool NT, bool XY, int DEPTH = STRIP_DEPTH, int STORE = 0, bool ADJ = false>
 __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q, ForcesRound fr) {
     constexpr int NK = (K + 3) / 4;                 // problem quads
     constexpr bool DEFER = DEPTH == 3;
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         logs = sck[S_LOGS];
         b0 = sck[S_B0];
         theta = thk;
+    }
+    double shift = 0.0;                             // ADJ: sum_i u_ik (center_i - ybar_ik), k_strip_adj's constant
+    if constexpr (ADJ) {
+        if (p2) shift = sck[S_B0] - sck[S_UY];
     }
 
     // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
@@ -534,20 +541,24 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(0)    // waited for the strip, copied it to LDS
-        if (flush_set >= 0) {                       // (block-uniform) the first strip of a segment: the set of the one before it
-            if constexpr (DEFER) {                  // ... whose last strip's deferred row sums run now
-                __syncthreads();                    // its e | t are in place
-                p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
+        if constexpr (!ADJ) {
+            if (flush_set >= 0) {                   // (block-uniform) the first strip of a segment: the set of the one before it
+                if constexpr (DEFER) {              // ... whose last strip's deferred row sums run now
+                    __syncthreads();                // its e | t are in place
+                    p3(a3old, tv + (par ^ 1) * 128, scale + (par ^ 1) * 16);
+                }
+                flush(flush_set);
             }
-            flush(flush_set);
         }
         // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
         // prefetch would wait for the whole strip after next
         const size_t col = (size_t)s * kStripCols + pc;
         double w0v = 0.0, xv = 0.0;
-        if (p2) {
-            w0v = q.w0[col];
-            if (!XY) xv = ak[col];
+        if constexpr (!ADJ) {
+            if (p2) {
+                w0v = q.w0[col];
+                if (!XY) xv = ak[col];
+            }
         }
         fetch(si + SETS < wk.total ? wk.strip(si + SETS) : s, pre);   // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
@@ -597,7 +608,14 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         __syncthreads();
         STAMP(2)    // first barrier
         // ---- P2 ----
-        if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
+        if constexpr (ADJ) {
+            if (p2) {                               // the waves' partial column sums in wave order, the constant, out
+                double colsum = 0.0;
+                const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
+                for (int wv = 0; wv < nown; ++wv) colsum += redp[wv * 128 + pk * 16 + pc];
+                __builtin_nontemporal_store(col < (size_t)q.n ? colsum + shift : 0.0, ak + col);
+            }
+        } else if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
             double colsum = 0.0;
             if (p2) {
                 const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
@@ -644,8 +662,8 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             STAMP(4)
         } else {
             __syncthreads();
-            STAMP(4)    // second barrier
-            p3(a3, tvp, scp);
+            STAMP(4)    // second barrier (ADJ: `red` may be rewritten)
+            if constexpr (!ADJ) p3(a3, tvp, scp);
         }
         STAMP(5)    // P3
         // no barrier here: the next strip's copy goes to the wave's own slice; red is rewritten only after
@@ -693,7 +711,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
             count();
         }
     }
-    flush((vloc - 1) * q.gs + wk.g);                              // the last segment's set
+    if constexpr (!ADJ) flush((vloc - 1) * q.gs + wk.g);           // the last segment's set
 #if STRIP_DIAG & 4
     if (q.stamps && lane == 0)
         for (int i = 0; i < 8; ++i) q.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + i] = tacc[i];
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
 #ifndef STRIP2_GB2
 #define STRIP2_GB2 2
 #endif
-template <int K, bool NT, bool XY, int STORE = 0>
+template <int K, bool NT, bool XY, int STORE = 0, bool ADJ = false>        // ADJ: as in k_strip
 __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) {
     constexpr int RH = 2;                           // 64-row halves per wave
     constexpr int WR = 64 * RH;                     // rows per wave
@@ -774,6 +792,10 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         logs = sck[S_LOGS];
         b0 = sck[S_B0];
         theta = thk;
+    }
+    double shift = 0.0;                             // ADJ: k_strip_adj's constant (k_strip)
+    if constexpr (ADJ) {
+        if (p2) shift = sck[S_B0] - sck[S_UY];
     }
 
     // the wave's 16 KB of the next strip travel in registers
@@ -876,15 +898,18 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
                 }
             }
         }
-        if (flush_set >= 0) flush(flush_set);      // (block-uniform) a segment's first strip: the set of the segment before it,
+        if constexpr (!ADJ)
+            if (flush_set >= 0) flush(flush_set);  // (block-uniform) a segment's first strip: the set of the segment before it,
                                                    // behind the wait for this strip's data and in front of its prefetch (k_strip)
         // P2's operands first, THEN the prefetch: vmcnt retires in order, a load issued behind the
         // prefetch would wait for the whole strip after next
         const size_t col = (size_t)s * kStripCols + pc;
         double w0v = 0.0, xv = 0.0;
-        if (p2) {
-            w0v = q.w0[col];
-            if (!XY) xv = ak[col];
+        if constexpr (!ADJ) {
+            if (p2) {
+                w0v = q.w0[col];
+                if (!XY) xv = ak[col];
+            }
         }
         const int nxt = si + 1 < wk.total ? wk.strip(si + 1) : s;
         fetch_part(nxt, 0, SPLIT);                 // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
@@ -950,7 +975,14 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         if (SPLIT < WR / 8) fetch_part(nxt, SPLIT, WR / 8);
         __syncthreads();
         // ---- P2 ----
-        if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
+        if constexpr (ADJ) {
+            if (p2) {                               // the waves' partial column sums in wave order, the constant, out
+                double colsum = 0.0;
+                const int nown = (q.mps + WR - 1) / WR;
+                for (int wv = 0; wv < nown; ++wv) colsum += red[wv * 128 + pk * 16 + pc];
+                __builtin_nontemporal_store(col < (size_t)q.n ? colsum + shift : 0.0, ak + col);
+            }
+        } else if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
             double colsum = 0.0;
             if (p2) {
                 const int nown = (q.mps + WR - 1) / WR;
@@ -987,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         __syncthreads();
         // ---- P3: acc[row][k] (+)= sum_c Y'[row][c] v[c][k] ----
         // A: lane (kk = lq, blk, i) = Y'[r0 + 4 blk + i = r0 + lr][c = 4 qq + lq]; B: lane (kk, blk, j) = v[4 qq + lq][4 kq + j]
-        {
+        if constexpr (!ADJ) {
             if (XY) {
 #pragma unroll
                 for (int kq = 0; kq < NK; ++kq) {
@@ -1023,7 +1055,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
             ++vloc;
         }
     }
-    flush((vloc - 1) * q.gs + wk.g);                              // the last segment's set
+    if constexpr (!ADJ) flush((vloc - 1) * q.gs + wk.g);           // the last segment's set
 }
 
 // ---- log-weights forward pass on the strip copy: partial[set mp K + row K + k] = sum_{j in the set's strips} Y'[row][j] e_k[j]
@@ -1692,6 +1724,31 @@ static void strip2_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRo
     BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, XY>), dim3(q.nblk), block, lds, q, fr);
 }
 
+// ADJ forms (the log-weights adjoint on the row-sum order copy: ctx.hpp, one_copy)
+template <int K, bool NT>
+static void strip_adj_launch_k(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds, bool tall) {
+    if (tall) {
+        allow_big_lds<&k_strip2<K, NT, true, 0, true>>(c);
+        BIOEN_LAUNCH_TIMED(c, (k_strip2<K, NT, true, 0, true>), dim3(q.nblk), block, lds, q, fr);
+    } else {
+        allow_big_lds<&k_strip<K, NT, true, 2, 0, true>>(c);
+        BIOEN_LAUNCH_TIMED(c, (k_strip<K, NT, true, 2, 0, true>), dim3(q.nblk), block, lds, q, fr);
+    }
+}
+template <bool NT>
+static void strip_adj_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds, bool tall) {
+    switch (fr.n) {
+        case 1: strip_adj_launch_k<1, NT>(c, q, fr, block, lds, tall); break;
+        case 2: strip_adj_launch_k<2, NT>(c, q, fr, block, lds, tall); break;
+        case 3: strip_adj_launch_k<3, NT>(c, q, fr, block, lds, tall); break;
+        case 4: strip_adj_launch_k<4, NT>(c, q, fr, block, lds, tall); break;
+        case 5: strip_adj_launch_k<5, NT>(c, q, fr, block, lds, tall); break;
+        case 6: strip_adj_launch_k<6, NT>(c, q, fr, block, lds, tall); break;
+        case 7: strip_adj_launch_k<7, NT>(c, q, fr, block, lds, tall); break;
+        default: strip_adj_launch_k<8, NT>(c, q, fr, block, lds, tall); break;
+    }
+}
+
 template <bool NT, bool XY>
 static void strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const ForcesRound& fr, dim3 block, size_t lds) {
     if (strip_tall(c)) {
@@ -1824,10 +1881,24 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     if (c->Ys1) return 0;
     int rc = ensure_strip_copy(c);                               // the centre is shared; the column-sum copy is cut from the row-sum one
     if (rc) return rc;
+    // ONE strip copy (r05; ctx.hpp: one_copy): asked for (BIOEN_HIP_ONE_COPY=1), or taken when the second copy does not
+    // fit -- the adjoint then runs on the row-sum order copy (launch_adj_strip) at the forces kernels' rate, instead of the
+    // whole context falling back to the streaming kernels on the row-major matrix
+    const bool can_one = forces_sets(c).gs > 0;                  // M <= 1024, the forces strip kernels apply
+    if (c->one_copy) return 0;
+    if (c->one_copy_wanted && can_one) {
+        c->one_copy = 1;
+        return 0;
+    }
     const int mps = strip_rows(c);
     const int nstrips = (int)(c->ld / kStripCols);
     double* ys = nullptr;
     hipError_t e = strip_malloc(c, &ys, (size_t)nstrips * mps * kStripCols * sizeof(double));
+    if (e != hipSuccess && can_one) {
+        (void)hipGetLastError();                                 // an out-of-memory error must not surface at the next launch check
+        c->one_copy = 1;
+        return 0;
+    }
     if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (column-sum strip copy of yTilde)");
     hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Ys, mps, ys, nstrips);
     e = hipGetLastError();
@@ -1873,6 +1944,38 @@ static void adj_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const MVec
 // out_a[j] = sum_i u_c[i K + a] (Y_ij - ybar_c[i K + a]) with the RAW ybar in ybar_c; needs S_B0 / S_UY of this
 // round in the problems' scalars (k_rows_combine with the strip centre)
 void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk, bool plain) {
+    if (c->one_copy && !paneled(c) && !plain && !c->storage) {
+        // ONE strip copy (r05): the product runs on the row-sum order copy through the forces kernels' LDS image (k_strip /
+        // k_strip2 in their ADJ form) -- no sum over columns: any assignment of strips to blocks gives the same bits
+        TimedLaunch tl(c, 1, K);
+        StripArgs q{};
+        q.Ys = c->Ys;
+        q.center = c->strip_center;
+        q.mps = strip_rows(c);
+        q.mp = c->mp;
+        q.nstrips = (int)(c->ld / kStripCols);
+        q.n = c->n;
+        q.K = K;
+        const StripSets ss = forces_sets(c);
+        q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = 1; q.fold = 0; q.slots = ss.gs;
+        q.nslots = ss.gs;
+        q.nlocal = c->vr;
+        q.nblk = q.nslots;
+        q.u_c = u_c;
+        q.w0 = c->fixed;
+        q.partial = c->fwd_partial;
+        ForcesRound fr{};
+        fr.n = K;
+        for (int a = 0; a < K; ++a) {
+            fr.a[a] = out.p[a];
+            fr.scal[a] = scal.p[a];
+        }
+        const dim3 block(strip_threads(c));
+        const size_t lds = strip_lds_bytes(c);
+        if (c->nontemporal) strip_adj_launch_nt<true>(c, q, fr, block, lds, strip_tall(c));
+        else strip_adj_launch_nt<false>(c, q, fr, block, lds, strip_tall(c));
+        return;
+    }
     for (int p = 0; p < panel_count(c); ++p) {
         TimedLaunch tl(c, 1, K);
         const int row0 = p * kPanelRows;

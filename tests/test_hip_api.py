@@ -720,9 +720,11 @@ def test_structures_reordered_in_place_are_not_served_from_the_cached_copy(optim
 @pytest.mark.parametrize("fail_at", [1, 2])
 def test_a_strip_copy_that_cannot_be_allocated_falls_back_to_the_streaming_kernels(M, N, fail_at, monkeypatch):
     """An exhausted device while the strip copies are built (the k-th allocation fails: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC) must
-    leave a context that still answers correctly -- on the streaming kernels over the row-major matrix, for good -- not one
-    that mixes kernel families inside an evaluation or holds half a copy: objective, gradient and short runs of both methods
-    against the restatement, the matrix still readable bit for bit, a second series the same as the first."""
+    leave a context that still answers correctly -- on the streaming kernels over the row-major matrix, for good; or, when
+    only the SECOND copy of a matrix of at most 1024 rows is missing, on the one strip copy there is (r05: the adjoint
+    through the forces kernels' LDS image) -- not one that mixes kernel families inside an evaluation or holds half a copy:
+    objective, gradient and short runs of both methods against the restatement, the matrix still readable bit for bit, a
+    second series the same as the first."""
     import bioen_amd
     from oracle import oracle_binding as O
     from conftest import LBFGS_DEFAULTS
@@ -754,7 +756,52 @@ def test_a_strip_copy_that_cannot_be_allocated_falls_back_to_the_streaming_kerne
         assert (a[2][k].lbfgs_code, a[2][k].iterations) == (code_o, it_o) and abs(a[2][k].fmin - fmin_o) <= 1e-8 * abs(fmin_o)
         _, ffmin_o, fcode_o, fit_o, fev_o = O.opt_lbfgs_forces(f0, w0, y, YT, th, params)
         assert (b[2][k].lbfgs_code, b[2][k].iterations) == (fcode_o, fit_o) and abs(b[2][k].fmin - ffmin_o) <= 1e-8 * abs(ffmin_o)
-    assert "rowmajor" in forms                      # what the streaming kernels read
+    if fail_at == 2 and M <= 1024:
+        assert forms == {"strips"}                  # one strip copy serves both matrix passes
+    else:
+        assert "rowmajor" in forms                  # what the streaming kernels read
+
+
+@pytest.mark.parametrize("M,N", [(37, 1000), (205, 4099), (512, 3000), (600, 2000), (1024, 1500)])
+def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
+    """BIOEN_HIP_ONE_COPY=1 (r05): the log-weights method with ONE strip copy of the matrix resident -- the forward pass as
+    always, the adjoint on the same row-sum order copy through the forces kernels' LDS image (k_strip / k_strip2, ADJ form).
+    Objective and gradient against the restatement at every batch width, capped series step for step, and against the
+    two-copy default (another order of the sums over rows: last bits only)."""
+    import bioen_amd
+    from oracle import oracle_binding as O
+    from conftest import LBFGS_DEFAULTS
+    rng = np.random.default_rng(3 * M + 1)
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    g = G + 0.2 * rng.standard_normal(N)
+    thetas = [300.0, 100.0, 30.0, 10.0, 3.0, 1.0, 0.3, 0.1]
+    params = dict(LBFGS_DEFAULTS, max_iterations=10)
+    with bioen_amd.Context(y, YT) as ctx:
+        two = ctx.opt_lbfgs_logw_batch(thetas, g, G, params)
+        f2, grad2 = ctx.logw_fdf(g, G, 5.0)
+        assert ctx.footprint()[0] == {"strips", "strips_colsum"}
+    monkeypatch.setenv("BIOEN_HIP_ONE_COPY", "1")
+    with bioen_amd.Context(y, YT) as ctx:
+        f, grad = ctx.logw_fdf(g, G, 5.0)
+        one = ctx.opt_lbfgs_logw_batch(thetas, g, G, params)                     # K = 8: the two-quad form
+        one3 = ctx.opt_lbfgs_logw_batch(thetas[:3], g, G, params)
+        gg, wg, ig = ctx.opt_gsl_logw(g, G, 5.0, "bfgs2", dict(step_size=0.01, tol=1e-3, max_iterations=10))
+        assert ctx.footprint()[0] == {"strips"}
+        assert np.array_equal(ctx.read_ytilde(), y)
+    f_o, grad_o, _ = O.logw_fdf(g, G, y, YT, 5.0)
+    assert abs(f - f_o) <= 1e-12 * abs(f_o) and np.abs(grad - grad_o).max() <= 1e-10 * np.abs(grad_o).max()
+    assert f == f2 and np.abs(grad - grad2).max() <= 1e-12 * np.abs(grad2).max()
+    for k, th in enumerate(thetas):
+        _, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_logw(g, G, y, YT, th, params)
+        assert (one[2][k].lbfgs_code, one[2][k].iterations, one[2][k].evaluations) == (code_o, it_o, ev_o)
+        assert abs(one[2][k].fmin - fmin_o) <= 1e-8 * abs(fmin_o)
+        assert abs(one[2][k].fmin - two[2][k].fmin) <= 1e-9 * abs(two[2][k].fmin)
+    for k in range(3):                               # a problem's bits do not depend on the width of its batch
+        assert np.array_equal(one3[0][k], one[0][k]) and one3[2][k].fmin == one[2][k].fmin
+    assert np.isfinite(ig.fmin) and abs(wg.sum() - 1.0) < 1e-12
 
 
 def test_randomised_last_average_is_that_of_the_returned_weights():

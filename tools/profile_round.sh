@@ -12,11 +12,11 @@ mkdir -p $OUT
 # preloaded library has initialised the GPU by then, and an exec after that is forbidden on this pool)
 PY=$(readlink -f "$(command -v python3)")
 head -c 4 "$PY" | grep -q ELF || { echo "profile_round.sh: $PY is not an ELF binary" >&2; exit 2; }
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $PY bench.py --no-cpu-baseline --no-api > $OUT/stats.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $PY bench.py --no-cpu-baseline --no-api --no-one-copy > $OUT/stats.log 2>&1
 echo "stats done"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- $PY bench.py --no-cpu-baseline --no-api --no-deer --no-ala5 --no-storage-experiment --warmup 0 > $OUT/fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o $TAG -- $PY bench.py --no-cpu-baseline --no-api --no-deer --no-ala5 --no-storage-experiment --no-one-copy --warmup 0 > $OUT/fetch.log 2>&1
 echo "fetch done"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- $PY bench.py --no-cpu-baseline --no-api --no-deer --no-ala5 --no-storage-experiment --warmup 0 > $OUT/write.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o $TAG -- $PY bench.py --no-cpu-baseline --no-api --no-deer --no-ala5 --no-storage-experiment --no-one-copy --warmup 0 > $OUT/write.log 2>&1
 echo "write done"
 mkdir -p $OUT/profiles
 cp profiles/traffic.json $OUT/profiles/ 2>/dev/null || true
