@@ -77,6 +77,7 @@ _SIGNATURES = {
     "bioen_hip_ctx_set_affine": (C.c_int, [ctx_p, dp, dp]),
     "bioen_hip_ctx_set_direction_mode": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_ctx_set_storage": (C.c_int, [ctx_p, C.c_int]),
+    "bioen_hip_ctx_set_one_copy": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_synchronize": (C.c_int, [ctx_p]),
     "bioen_hip_logw_weights": (C.c_int, [ctx_p, dp, dp, dp]),
     "bioen_hip_logw_fdf": (C.c_int, [ctx_p, dp, dp, C.c_double, dp, dp]),
@@ -451,6 +452,13 @@ class Context(object):
         fused strip passes (forces_fdf(_batch), the forces optimizers); everything else of the forces method (forces_weights)
         raises BioenHipError (invalid state) while a reduced format is selected (the contract as implemented)."""
         check(lib().bioen_hip_ctx_set_storage(self._h, self.STORAGE_FORMATS[fmt]))
+
+    def set_one_copy(self, on=True):
+        """The log-weights method with ONE strip copy of the matrix resident (M <= 1024; 1 x instead of 2 x the matrix): the
+        adjoint runs on the row-sum order copy, 1-3 % slower per launch; same minima, last bits differ from the two-copy
+        default.  Call before the context's first gradient evaluation.  (Also: BIOEN_HIP_ONE_COPY=1 at creation; and a context
+        takes this form by itself when the second copy does not fit.)"""
+        check(lib().bioen_hip_ctx_set_one_copy(self._h, int(bool(on))))
 
     def synchronize(self):
         check(lib().bioen_hip_synchronize(self._h))

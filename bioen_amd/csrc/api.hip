@@ -1120,6 +1120,17 @@ int bioen_hip_ctx_set_storage(bioen_hip_ctx* c, int format) {
     return rc;
 }
 
+int bioen_hip_ctx_set_one_copy(bioen_hip_ctx* c, int on) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    if (c->mp > 1024) return fail(BIOEN_HIP_ESTATE, "one strip copy serves M <= 1024 (beyond: row panels in both orders)");
+    if (on && c->Ys1) return fail(BIOEN_HIP_ESTATE, "the column-sum order copy exists already: ask before the first gradient evaluation");
+    if (!on && c->one_copy) {        // back to two copies: the second one is built at the next gradient evaluation
+        c->one_copy = 0;
+    }
+    c->one_copy_wanted = on ? 1 : 0;
+    return 0;
+}
+
 int bioen_hip_ctx_set_direction_mode(bioen_hip_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) return fail(BIOEN_HIP_EINVAL, "mode must be 0 (auto), 1 (two-loop) or 2 (Gram form)");
     c->direction_mode = mode;

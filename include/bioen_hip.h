@@ -166,6 +166,9 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, 
  * from the two-copy default: the sums over rows are formed in another order). */
 /* (bit 3: copies of the reduced-storage experiment, bioen_hip_ctx_set_storage, beside the FP64 row-major matrix) */
 int bioen_hip_ctx_footprint(const bioen_hip_ctx* ctx, int* forms, long long* bytes);
+/* r05: ask for (1) / give up (0) the ONE-copy form of the log-weights method described above; to be called before the
+ * context's first gradient evaluation (BIOEN_HIP_ESTATE once the column-sum order copy exists, and for M > 1024). */
+int bioen_hip_ctx_set_one_copy(bioen_hip_ctx* ctx, int on);
 int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
 /* Affine observable model: the optimizer sees yTilde_eff[i][j] = row_offset[i] + row_scale[i] * yTilde[i][j]
  * without the resident matrix being touched.  This is how DEER (modulation depth m:

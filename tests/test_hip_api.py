@@ -783,9 +783,16 @@ def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
         two = ctx.opt_lbfgs_logw_batch(thetas, g, G, params)
         f2, grad2 = ctx.logw_fdf(g, G, 5.0)
         assert ctx.footprint()[0] == {"strips", "strips_colsum"}
+        with pytest.raises(bioen_amd.BioenHipError):
+            ctx.set_one_copy(True)                   # too late: the second copy exists
+    with bioen_amd.Context(y, YT) as ctx:           # the switch on a live context, before its first gradient evaluation
+        ctx.set_one_copy(True)
+        fs, grads = ctx.logw_fdf(g, G, 5.0)
+        assert ctx.footprint()[0] == {"strips"}
     monkeypatch.setenv("BIOEN_HIP_ONE_COPY", "1")
     with bioen_amd.Context(y, YT) as ctx:
         f, grad = ctx.logw_fdf(g, G, 5.0)
+        assert f == fs and np.array_equal(grad, grads)
         one = ctx.opt_lbfgs_logw_batch(thetas, g, G, params)                     # K = 8: the two-quad form
         one3 = ctx.opt_lbfgs_logw_batch(thetas[:3], g, G, params)
         gg, wg, ig = ctx.opt_gsl_logw(g, G, 5.0, "bfgs2", dict(step_size=0.01, tol=1e-3, max_iterations=10))
