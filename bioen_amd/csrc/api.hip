@@ -1122,8 +1122,7 @@ int bioen_hip_ctx_set_storage(bioen_hip_ctx* c, int format) {
 
 int bioen_hip_ctx_set_one_copy(bioen_hip_ctx* c, int on) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
-    if (c->mp > 1024) return fail(BIOEN_HIP_ESTATE, "one strip copy serves M <= 1024 (beyond: row panels in both orders)");
-    if (on && c->Ys1) return fail(BIOEN_HIP_ESTATE, "the column-sum order copy exists already: ask before the first gradient evaluation");
+    if (on && (c->Ys1 || c->Y1p[0])) return fail(BIOEN_HIP_ESTATE, "the column-sum order copy exists already: ask before the first gradient evaluation");
     if (!on && c->one_copy) {        // back to two copies: the second one is built at the next gradient evaluation
         c->one_copy = 0;
     }

@@ -379,8 +379,8 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
         theta = thk;
     }
     double shift = 0.0;                             // ADJ: sum_i u_ik (center_i - ybar_ik), k_strip_adj's constant
-    if constexpr (ADJ) {
-        if (p2) shift = sck[S_B0] - sck[S_UY];
+    if constexpr (ADJ) {                            // (accumulate: 0 = start at the shift, 1 = continue the panels before, 2 = start at 0)
+        if (p2 && q.accumulate == 0) shift = sck[S_B0] - sck[S_UY];
     }
 
     // the wave's 8 KB of the next TWO strips travel in registers (two sets, used alternately)
@@ -559,6 +559,8 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
                 w0v = q.w0[col];
                 if (!XY) xv = ak[col];
             }
+        } else {
+            if (p2 && q.accumulate == 1) xv = ak[col];            // the column sums of the row panels before this one
         }
         fetch(si + SETS < wk.total ? wk.strip(si + SETS) : s, pre);   // unconditional, see k_strip_adj
         // ---- P1: D1[c][k] = sum_{i in the wave's rows} Y'[i][c] u[i][k] ----
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
                 double colsum = 0.0;
                 const int nown = (q.mps + kWaveRows - 1) / kWaveRows;
                 for (int wv = 0; wv < nown; ++wv) colsum += redp[wv * 128 + pk * 16 + pc];
-                __builtin_nontemporal_store(col < (size_t)q.n ? colsum + shift : 0.0, ak + col);
+                __builtin_nontemporal_store(col < (size_t)q.n ? colsum + (q.accumulate == 1 ? xv : shift) : 0.0, ak + col);
             }
         } else if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
             double colsum = 0.0;
@@ -794,8 +796,8 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
         theta = thk;
     }
     double shift = 0.0;                             // ADJ: k_strip_adj's constant (k_strip)
-    if constexpr (ADJ) {
-        if (p2) shift = sck[S_B0] - sck[S_UY];
+    if constexpr (ADJ) {                            // (accumulate: 0 = start at the shift, 1 = continue the panels before, 2 = start at 0)
+        if (p2 && q.accumulate == 0) shift = sck[S_B0] - sck[S_UY];
     }
 
     // the wave's 16 KB of the next strip travel in registers
@@ -910,6 +912,8 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
                 w0v = q.w0[col];
                 if (!XY) xv = ak[col];
             }
+        } else {
+            if (p2 && q.accumulate == 1) xv = ak[col];            // the column sums of the row panels before this one
         }
         const int nxt = si + 1 < wk.total ? wk.strip(si + 1) : s;
         fetch_part(nxt, 0, SPLIT);                 // unconditional, see k_strip_adj; `pre` is free: a3 holds the strip
@@ -980,7 +984,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
                 double colsum = 0.0;
                 const int nown = (q.mps + WR - 1) / WR;
                 for (int wv = 0; wv < nown; ++wv) colsum += red[wv * 128 + pk * 16 + pc];
-                __builtin_nontemporal_store(col < (size_t)q.n ? colsum + shift : 0.0, ak + col);
+                __builtin_nontemporal_store(col < (size_t)q.n ? colsum + (q.accumulate == 1 ? xv : shift) : 0.0, ak + col);
             }
         } else if (t < kStripCols * K || (XY && wave < (kStripCols * K + 63) / 64)) {      // whole waves: the shuffles below
             double colsum = 0.0;
@@ -1860,6 +1864,11 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
         if (c->Y1p[0]) return 0;
         int rc = ensure_strip_copy(c);
         if (rc) return rc;
+        if (c->one_copy) return 0;                                // (below: the one-copy form, asked for or taken)
+        if (c->one_copy_wanted) {
+            c->one_copy = 1;
+            return 0;
+        }
         const int nstrips = (int)(c->ld / kStripCols);
         double* made[bioen_hip_ctx::kMaxPanels] = {};
         for (int p = 0; p < panel_count(c); ++p) {
@@ -1872,7 +1881,9 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
             if (e != hipSuccess) {
                 for (int q = 0; q <= p; ++q)
                     if (made[q]) (void)hipFree(made[q]);
-                return strip_copy_failed(c, nullptr, e, "column-sum strip copies of the row panels");
+                (void)hipGetLastError();
+                c->one_copy = 1;                                  // the row-sum order panels serve both products
+                return 0;
             }
         }
         for (int p = 0; p < panel_count(c); ++p) c->Y1p[p] = made[p];
@@ -1884,7 +1895,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     // ONE strip copy (r05; ctx.hpp: one_copy): asked for (BIOEN_HIP_ONE_COPY=1), or taken when the second copy does not
     // fit -- the adjoint then runs on the row-sum order copy (launch_adj_strip) at the forces kernels' rate, instead of the
     // whole context falling back to the streaming kernels on the row-major matrix
-    const bool can_one = forces_sets(c).gs > 0;                  // M <= 1024, the forces strip kernels apply
+    const bool can_one = true;                                   // (the ADJ forms of k_strip / k_strip2 serve every strip height)
     if (c->one_copy) return 0;
     if (c->one_copy_wanted && can_one) {
         c->one_copy = 1;
@@ -1944,36 +1955,46 @@ static void adj_strip_launch_nt(bioen_hip_ctx* c, const StripArgs& q, const MVec
 // out_a[j] = sum_i u_c[i K + a] (Y_ij - ybar_c[i K + a]) with the RAW ybar in ybar_c; needs S_B0 / S_UY of this
 // round in the problems' scalars (k_rows_combine with the strip centre)
 void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& out, const MVec8& scal, int nblk, bool plain) {
-    if (c->one_copy && !paneled(c) && !plain && !c->storage) {
+    if (c->one_copy && !c->storage) {
         // ONE strip copy (r05): the product runs on the row-sum order copy through the forces kernels' LDS image (k_strip /
-        // k_strip2 in their ADJ form) -- no sum over columns: any assignment of strips to blocks gives the same bits
-        TimedLaunch tl(c, 1, K);
-        StripArgs q{};
-        q.Ys = c->Ys;
-        q.center = c->strip_center;
-        q.mps = strip_rows(c);
-        q.mp = c->mp;
-        q.nstrips = (int)(c->ld / kStripCols);
-        q.n = c->n;
-        q.K = K;
-        const StripSets ss = forces_sets(c);
-        q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = 1; q.fold = 0; q.slots = ss.gs;
-        q.nslots = ss.gs;
-        q.nlocal = c->vr;
-        q.nblk = q.nslots;
-        q.u_c = u_c;
-        q.w0 = c->fixed;
-        q.partial = c->fwd_partial;
-        ForcesRound fr{};
-        fr.n = K;
-        for (int a = 0; a < K; ++a) {
-            fr.a[a] = out.p[a];
-            fr.scal[a] = scal.p[a];
+        // k_strip2 in their ADJ form; a matrix taller than 1024 rows: panel by panel, continuing the column sums) -- no sum
+        // over columns: any assignment of strips to blocks gives the same bits
+        for (int p = 0; p < panel_count(c); ++p) {
+            TimedLaunch tl(c, 1, K);
+            const int row0 = p * kPanelRows;
+            StripArgs q{};
+            q.Ys = paneled(c) ? c->Yp[p] : c->Ys;
+            q.center = (plain ? c->zero_center : c->strip_center) + row0;
+            q.mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+            q.mp = panel_mp(c, p);
+            q.nstrips = (int)(c->ld / kStripCols);
+            q.n = c->n;
+            q.K = K;
+            q.sps = c->segcols / kStripCols;
+            q.gs = std::max(1, std::min(q.sps, 256));          // one block per CU (the kernels' register and LDS budget)
+            q.tc = (q.sps + q.gs - 1) / q.gs;
+            q.nch = 1; q.fold = 0; q.slots = q.gs;
+            q.nslots = q.gs;
+            q.nlocal = c->vr;
+            q.nblk = q.nslots;
+            q.u_c = u_c + (size_t)row0 * K;
+            q.accumulate = p > 0 ? 1 : (plain ? 2 : 0);
+            q.w0 = c->fixed;
+            q.partial = c->fwd_partial;
+            ForcesRound fr{};
+            fr.n = K;
+            for (int a = 0; a < K; ++a) {
+                fr.a[a] = out.p[a];
+                fr.scal[a] = scal.p[a];
+            }
+            const bool tall = q.mp > 512;                       // k_strip2: 128 rows per wave
+            const int waves = std::max(2, tall ? (q.mps + 2 * kWaveRows - 1) / (2 * kWaveRows) : (q.mps + kWaveRows - 1) / kWaveRows);
+            const dim3 block(64 * waves);
+            const size_t lds = tall ? ((size_t)waves * kWaveRows * kStripCols + (size_t)waves * 2 * kWaveRows * (8 + 1) + (size_t)waves * 128 + 128 + 16) * sizeof(double)
+                                    : ((size_t)waves * kWaveRows * (kStripCols + 8 + 1) + (size_t)waves * 128 + 128 + 16) * sizeof(double);
+            if (c->nontemporal) strip_adj_launch_nt<true>(c, q, fr, block, lds, tall);
+            else strip_adj_launch_nt<false>(c, q, fr, block, lds, tall);
         }
-        const dim3 block(strip_threads(c));
-        const size_t lds = strip_lds_bytes(c);
-        if (c->nontemporal) strip_adj_launch_nt<true>(c, q, fr, block, lds, strip_tall(c));
-        else strip_adj_launch_nt<false>(c, q, fr, block, lds, strip_tall(c));
         return;
     }
     for (int p = 0; p < panel_count(c); ++p) {

@@ -160,14 +160,14 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, 
  * arrive in; the operand of the streaming kernels for M > 1024), bit 1 the strip-major copy in row-sum operand order,
  * bit 2 the one in column-sum operand order.  For M <= 1024 the strip copies hold the raw numbers and REPLACE the
  * row-major matrix once built: log-weights 2 x the matrix (bits 1 + 2), forces method 1 x (bit 1; beyond 1024 rows,
- * where the copies are kept as row panels of <= 1024 rows, 2 x: both orders).  Log-weights with ONE copy (r05, M <= 1024:
- * bit 1 alone): environment BIOEN_HIP_ONE_COPY=1 at context creation, or taken by itself when the second copy cannot
+ * where the copies are kept as row panels of <= 1024 rows, 2 x: both orders).  ONE copy (r05: bit 1 alone; log-weights at every M, and the forces method's row panels beyond 1024 rows): environment BIOEN_HIP_ONE_COPY=1 at context creation, or taken by itself when the second copy cannot
  * be allocated -- the adjoint then runs on the row-sum order copy (1-3 % slower per launch, same minima, last bits differ
  * from the two-copy default: the sums over rows are formed in another order). */
 /* (bit 3: copies of the reduced-storage experiment, bioen_hip_ctx_set_storage, beside the FP64 row-major matrix) */
 int bioen_hip_ctx_footprint(const bioen_hip_ctx* ctx, int* forms, long long* bytes);
-/* r05: ask for (1) / give up (0) the ONE-copy form of the log-weights method described above; to be called before the
- * context's first gradient evaluation (BIOEN_HIP_ESTATE once the column-sum order copy exists, and for M > 1024). */
+/* r05: ask for (1) / give up (0) the ONE-copy form described above; to be called before the context's first gradient
+ * evaluation (BIOEN_HIP_ESTATE once the column-sum order copy exists).  Beyond 1024 rows it serves both methods: one set
+ * of row panels instead of two. */
 int bioen_hip_ctx_set_one_copy(bioen_hip_ctx* ctx, int on);
 int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
 /* Affine observable model: the optimizer sees yTilde_eff[i][j] = row_offset[i] + row_scale[i] * yTilde[i][j]

@@ -762,12 +762,13 @@ def test_a_strip_copy_that_cannot_be_allocated_falls_back_to_the_streaming_kerne
         assert "rowmajor" in forms                  # what the streaming kernels read
 
 
-@pytest.mark.parametrize("M,N", [(37, 1000), (205, 4099), (512, 3000), (600, 2000), (1024, 1500)])
+@pytest.mark.parametrize("M,N", [(37, 1000), (205, 4099), (512, 3000), (600, 2000), (1024, 1500), (1100, 1500), (2100, 1000)])
 def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
     """BIOEN_HIP_ONE_COPY=1 (r05): the log-weights method with ONE strip copy of the matrix resident -- the forward pass as
     always, the adjoint on the same row-sum order copy through the forces kernels' LDS image (k_strip / k_strip2, ADJ form).
     Objective and gradient against the restatement at every batch width, capped series step for step, and against the
-    two-copy default (another order of the sums over rows: last bits only)."""
+    two-copy default (another order of the sums over rows: last bits only).  Beyond 1024 rows: panel by panel, the column
+    sums continued from panel to panel -- both methods on the one set of row panels."""
     import bioen_amd
     from oracle import oracle_binding as O
     from conftest import LBFGS_DEFAULTS
@@ -796,8 +797,13 @@ def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
         one = ctx.opt_lbfgs_logw_batch(thetas, g, G, params)                     # K = 8: the two-quad form
         one3 = ctx.opt_lbfgs_logw_batch(thetas[:3], g, G, params)
         gg, wg, ig = ctx.opt_gsl_logw(g, G, 5.0, "bfgs2", dict(step_size=0.01, tol=1e-3, max_iterations=10))
+        w0 = rng.dirichlet(np.ones(N) * 2.0)
+        f0 = 1e-3 * rng.standard_normal(M)
+        ff, fgrad = ctx.forces_fdf(f0, w0, 5.0)      # beyond 1024 rows: the forces method's four passes on the one set of panels
         assert ctx.footprint()[0] == {"strips"}
         assert np.array_equal(ctx.read_ytilde(), y)
+    ff_o, fgrad_o, _ = O.forces_fdf(f0, w0, y, YT, 5.0)
+    assert abs(ff - ff_o) <= 1e-12 * abs(ff_o) and np.abs(fgrad - fgrad_o).max() <= 1e-9 * np.abs(fgrad_o).max()
     f_o, grad_o, _ = O.logw_fdf(g, G, y, YT, 5.0)
     assert abs(f - f_o) <= 1e-12 * abs(f_o) and np.abs(grad - grad_o).max() <= 1e-10 * np.abs(grad_o).max()
     assert f == f2 and np.abs(grad - grad2).max() <= 1e-12 * np.abs(grad2).max()
