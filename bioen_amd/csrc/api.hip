@@ -271,8 +271,16 @@ static int h2d_staged(bioen_hip_ctx* c, char* dst, size_t dpitch, const char* sr
     return 0;
 }
 
+// tests: BIOEN_HIP_TEST_STAGED_UPLOAD=1 sends every such copy through the staging buffer (the refusal itself cannot be
+// provoked at will)
+static bool staged_upload_forced() {
+    const char* e = std::getenv("BIOEN_HIP_TEST_STAGED_UPLOAD");
+    return e && e[0] == '1';
+}
+
 static int h2d_user(bioen_hip_ctx* c, void* dst, const void* src, size_t bytes) {
-    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    const hipError_t e = staged_upload_forced() ? hipErrorInvalidValue
+                                                : hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
         return h2d_staged(c, static_cast<char*>(dst), bytes, static_cast<const char*>(src), bytes, bytes, 1);
@@ -812,8 +820,9 @@ int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const
     int rc = ctx_alloc(m, n, device, rank, world, &c);
     if (rc) return rc;
     // this rank's column block [col0, col0 + n_local) of the host matrix
-    hipError_t e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), yTilde + c->col0, (size_t)n * sizeof(double),
-                                    (size_t)c->n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = staged_upload_forced() ? hipErrorInvalidValue
+                                          : hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), yTilde + c->col0, (size_t)n * sizeof(double),
+                                                             (size_t)c->n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->stream);
     if (e == hipErrorInvalidValue) {            // (h2d_staged: a caller's buffer the runtime will not pin)
         (void)hipGetLastError();
         if (h2d_staged(c, reinterpret_cast<char*>(c->Y), c->ld * sizeof(double), reinterpret_cast<const char*>(yTilde + c->col0),
@@ -855,8 +864,9 @@ int bioen_hip_ctx_create_raw(int m, long long n, int structure_major, const doub
     if (e == hipSuccess) e = hipMemcpyAsync(sigma, exp_err, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->YT, yt.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && !structure_major) {
-        e = hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), sim, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
-                             (size_t)m, hipMemcpyHostToDevice, c->stream);
+        e = staged_upload_forced() ? hipErrorInvalidValue
+                                   : hipMemcpy2DAsync(c->Y, c->ld * sizeof(double), sim, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                                                      (size_t)m, hipMemcpyHostToDevice, c->stream);
         if (e == hipErrorInvalidValue) {        // (h2d_staged: a caller's buffer the runtime will not pin)
             (void)hipGetLastError();
             e = h2d_staged(c, reinterpret_cast<char*>(c->Y), c->ld * sizeof(double), reinterpret_cast<const char*>(sim),

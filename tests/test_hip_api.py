@@ -817,6 +817,50 @@ def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
     assert np.isfinite(ig.fmin) and abs(wg.sum() - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_uploads_through_the_staging_buffer_change_nothing(world, monkeypatch):
+    """api.hip: h2d_staged -- the path uploads of a caller's buffers take when the runtime refuses to pin them (ROCm 7.2: a
+    pageable buffer on the address range of one it pinned before; tools/attic/onecopy_probe.py ran into it).  Forced here
+    (BIOEN_HIP_TEST_STAGED_UPLOAD=1): the matrix (row-major and assembled from raw observables in both layouts), N-vectors
+    larger than one 8 MB chunk, a column block of a sharded context -- the same bits as the direct copies."""
+    import bioen_amd
+    from conftest import LBFGS_DEFAULTS
+    rng = np.random.default_rng(77)
+    M, N = 40, 1200000                               # an N-vector of 9.6 MB: two chunks
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    g = G + 0.2 * rng.standard_normal(N)
+    params = dict(LBFGS_DEFAULTS, max_iterations=5)
+
+    def run():
+        out = []
+        kw = dict(device=0, rank=0, world=world) if world > 1 else {}
+        with bioen_amd.Context(y, YT, **kw) as ctx:
+            if world > 1:
+                ctx.set_mirror_exchange(True)
+            out.append(ctx.read_ytilde(0, M, 0, min(ctx.n_local, 5000)))
+            f, grad = ctx.logw_fdf(g, G, 5.0)
+            out += [np.float64(f), grad]
+            r = ctx.opt_lbfgs_logw_batch([50.0, 5.0], g, G, params)
+            out += [r[0], r[1], np.array([i.fmin for i in r[2]])]
+        if world == 1:
+            sim = y * (0.1 * YTrue[:, None])
+            for major in (False, True):
+                with bioen_amd.Context.from_raw(sim.T.copy() if major else sim, YT * 0.1 * YTrue, 0.1 * YTrue,
+                                                structure_major=major) as ctx:
+                    out.append(ctx.read_ytilde(0, M, 0, 4000))
+        return out
+
+    direct = run()
+    monkeypatch.setenv("BIOEN_HIP_TEST_STAGED_UPLOAD", "1")
+    staged = run()
+    assert len(direct) == len(staged)
+    for a, b in zip(direct, staged):
+        assert np.array_equal(a, b)
+
+
 def test_randomised_last_average_is_that_of_the_returned_weights():
     """tools/fuzz_last_average.py as a test: 50 random single-problem runs of both methods ending in every status (converged,
     plateau, budget, failed and refused searches that revert to the previous point), either engine, with and without an
