@@ -271,8 +271,8 @@ static int h2d_staged(bioen_hip_ctx* c, char* dst, size_t dpitch, const char* sr
     return 0;
 }
 
-// tests: BIOEN_HIP_TEST_STAGED_UPLOAD=1 sends every such copy through the staging buffer (the refusal itself cannot be
-// provoked at will)
+// tests: BIOEN_HIP_TEST_STAGED_UPLOAD=1 sends every such copy -- uploads and downloads of caller buffers -- through the
+// staging buffers (the refusal itself cannot be provoked at will)
 static bool staged_upload_forced() {
     const char* e = std::getenv("BIOEN_HIP_TEST_STAGED_UPLOAD");
     return e && e[0] == '1';
@@ -287,6 +287,37 @@ static int h2d_user(bioen_hip_ctx* c, void* dst, const void* src, size_t bytes) 
     }
     BIOEN_HIP_CHECK(e);
     return 0;
+}
+
+// The same towards a caller's buffer: device -> host.  The staged form is synchronous on `stream` and brings its own pinned
+// chunk (the result deliveries run on threads of their own: nothing shared).
+static hipError_t d2h_user(hipStream_t stream, void* dst, const void* src, size_t bytes) {
+    hipError_t e = staged_upload_forced() ? hipErrorInvalidValue : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    if (e != hipErrorInvalidValue) return e;
+    (void)hipGetLastError();
+    constexpr size_t kChunk = (size_t)8 << 20;
+    void* stage = nullptr;
+    e = hipHostMalloc(&stage, std::min(kChunk, std::max<size_t>(bytes, 1)), hipHostMallocDefault);
+    for (size_t off = 0; e == hipSuccess && off < bytes; off += kChunk) {
+        const size_t nb = std::min(kChunk, bytes - off);
+        e = hipMemcpyAsync(stage, static_cast<const char*>(src) + off, nb, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) std::memcpy(static_cast<char*>(dst) + off, stage, nb);
+    }
+    if (stage) (void)hipHostFree(stage);
+    return e;
+}
+
+static hipError_t d2h_user_2d(hipStream_t stream, char* dst, size_t dpitch, const char* src, size_t spitch, size_t width, size_t height) {
+    hipError_t e = staged_upload_forced() ? hipErrorInvalidValue
+                                          : hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, stream);
+    if (e != hipErrorInvalidValue) return e;
+    (void)hipGetLastError();
+    e = hipSuccess;
+    for (size_t row = 0; row < height && e == hipSuccess; ++row) {
+        e = d2h_user(stream, dst + row * dpitch, src + row * spitch, width);      // row by row: each tries the direct copy first
+    }
+    return e;
 }
 
 // host N-vectors are always GLOBAL (n_global long); a sharded context takes its slice
@@ -447,8 +478,7 @@ static int exchange_raw(bioen_hip_ctx* c, int stage, size_t payload) {      // p
 // gather a sharded device N-vector into a GLOBAL host vector (world == 1: plain download)
 static int download_n(bioen_hip_ctx* c, double* dst_global, const double* src_local) {
     if (c->world == 1) {
-        BIOEN_HIP_CHECK(hipMemcpyAsync(dst_global, src_local, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost,
-                                       c->stream));
+        BIOEN_HIP_CHECK(d2h_user(c->stream, dst_global, src_local, (size_t)c->n * sizeof(double)));
         return 0;
     }
     double* base = c->xbuf[X_VEC];
@@ -460,8 +490,7 @@ static int download_n(bioen_hip_ctx* c, double* dst_global, const double* src_lo
         long long col0, nl;
         rank_columns(c, r, &col0, &nl);
         if (nl > 0)
-            BIOEN_HIP_CHECK(hipMemcpyAsync(dst_global + col0, base + (size_t)r * c->ld, (size_t)nl * sizeof(double),
-                                           hipMemcpyDeviceToHost, c->stream));
+            BIOEN_HIP_CHECK(d2h_user(c->stream, dst_global + col0, base + (size_t)r * c->ld, (size_t)nl * sizeof(double)));
     }
     return 0;
 }
@@ -1040,9 +1069,9 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* c, int row0, int rows, int col0, in
         return fail(BIOEN_HIP_EINVAL, "block out of range");
     BIOEN_HIP_CHECK(hipSetDevice(c->device));
     if (c->Y) {
-        BIOEN_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(double), c->Y + (size_t)row0 * c->ld + col0,
-                                         c->ld * sizeof(double), (size_t)cols * sizeof(double), (size_t)rows,
-                                         hipMemcpyDeviceToHost, c->stream));
+        BIOEN_HIP_CHECK(d2h_user_2d(c->stream, reinterpret_cast<char*>(out), (size_t)cols * sizeof(double),
+                                    reinterpret_cast<const char*>(c->Y + (size_t)row0 * c->ld + col0), c->ld * sizeof(double),
+                                    (size_t)cols * sizeof(double), (size_t)rows));
         BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
         return 0;
     }
@@ -1057,8 +1086,8 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* c, int row0, int rows, int col0, in
         const int nc = std::min(chunk, cols - c0);
         rc = gather_block(c, row0, rows, (size_t)col0 + c0, nc, stage);
         if (!rc) {
-            e = hipMemcpy2DAsync(out + c0, (size_t)cols * sizeof(double), stage, (size_t)nc * sizeof(double),
-                                 (size_t)nc * sizeof(double), (size_t)rows, hipMemcpyDeviceToHost, c->stream);
+            e = d2h_user_2d(c->stream, reinterpret_cast<char*>(out + c0), (size_t)cols * sizeof(double),
+                            reinterpret_cast<const char*>(stage), (size_t)nc * sizeof(double), (size_t)nc * sizeof(double), (size_t)rows);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) rc = hip_fail(e, "read-back", __FILE__, __LINE__);
         }
@@ -1325,7 +1354,7 @@ int bioen_hip_forces_weights(bioen_hip_ctx* c, const double* forces, const doubl
     const int one[1] = {0};
     if ((rc = enqueue_forces_weights(c, make_forces_round(c, one, 1, nullptr)))) return rc;
     if ((rc = check_launch())) return rc;
-    BIOEN_HIP_CHECK(hipMemcpyAsync(w, c->slot[0].w, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BIOEN_HIP_CHECK(d2h_user(c->stream, w, c->slot[0].w, (size_t)c->n * sizeof(double)));
     BIOEN_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -109,8 +109,8 @@ struct LogwBatchEngine {
         auto work = [=]() {
             hipError_t e = hipSetDevice(dev);
             if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(dst_x, src_x, bytes, hipMemcpyDeviceToHost, cs);
-            if (e == hipSuccess && dst_w) e = hipMemcpyAsync(dst_w, src_w, bytes, hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess) e = d2h_user(cs, dst_x, src_x, bytes);          // (api.hip: a caller's buffer the runtime will not pin is staged)
+            if (e == hipSuccess && dst_w) e = d2h_user(cs, dst_w, src_w, bytes);
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             (void)hipEventDestroy(ev);
             d->rc = e == hipSuccess ? 0 : BIOEN_HIP_EHIP;
@@ -172,8 +172,7 @@ struct LogwBatchEngine {
                     long long col0, nl;
                     rank_columns(cc, r, &col0, &nl);
                     if (nl > 0)
-                        e = hipMemcpyAsync(dsts[v] + col0, gb + (size_t)v * ld * world + (size_t)r * ld,
-                                           (size_t)nl * sizeof(double), hipMemcpyDeviceToHost, cs);
+                        e = d2h_user(cs, dsts[v] + col0, gb + (size_t)v * ld * world + (size_t)r * ld, (size_t)nl * sizeof(double));
                 }
             }
             if (e == hipSuccess) e = hipStreamSynchronize(cs);

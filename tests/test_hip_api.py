@@ -821,8 +821,9 @@ def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
 def test_uploads_through_the_staging_buffer_change_nothing(world, monkeypatch):
     """api.hip: h2d_staged -- the path uploads of a caller's buffers take when the runtime refuses to pin them (ROCm 7.2: a
     pageable buffer on the address range of one it pinned before; tools/attic/onecopy_probe.py ran into it).  Forced here
-    (BIOEN_HIP_TEST_STAGED_UPLOAD=1): the matrix (row-major and assembled from raw observables in both layouts), N-vectors
-    larger than one 8 MB chunk, a column block of a sharded context -- the same bits as the direct copies."""
+    (BIOEN_HIP_TEST_STAGED_UPLOAD=1), in both directions: the matrix (row-major and assembled from raw observables in both
+    layouts), N-vectors larger than one 8 MB chunk up and down (starts, priors; points, weights, read-back blocks), a column
+    block of a sharded context -- the same bits as the direct copies."""
     import bioen_amd
     from conftest import LBFGS_DEFAULTS
     rng = np.random.default_rng(77)
@@ -845,6 +846,12 @@ def test_uploads_through_the_staging_buffer_change_nothing(world, monkeypatch):
             out += [np.float64(f), grad]
             r = ctx.opt_lbfgs_logw_batch([50.0, 5.0], g, G, params)
             out += [r[0], r[1], np.array([i.fmin for i in r[2]])]
+            one = ctx.opt_lbfgs_logw(g, G, 5.0, params)             # the single-problem call: its own delivery of point and weights
+            out += [one[0], one[1]]
+            w0 = np.full(N, 1.0 / N)
+            out.append(ctx.forces_weights(1e-3 * np.ones(M), w0))
+            fr = ctx.opt_lbfgs_forces_batch([50.0, 5.0], np.zeros(M), w0, params)
+            out += [fr[0], fr[1]]
         if world == 1:
             sim = y * (0.1 * YTrue[:, None])
             for major in (False, True):
