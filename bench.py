@@ -5,9 +5,12 @@ One "step" = one complete pass of the hot path over the workload: the 8-point
 theta series (np.logspace(3, -0.5, 8), every theta cold-started, liblbfgs yaml
 defaults) of the log-weights optimizer on a synthetic N = 1e6 x M = 1024 ensemble
 (BASELINE.json configs[2]; the matrix is generated in HBM, so inputs are resident
-when the timed region starts).  With --gpus N the thetas are sharded over the N
-ranks (one process per GPU, launched by torch.distributed.run; this script itself
-is torch-free) and the per-theta results are all-gathered over RCCL/xGMI.
+when the timed region starts).  With --gpus N the work is sharded over N ranks, one
+process per GPU: `python3 bench.py --gpus N` starts them itself (plain subprocesses,
+before any HIP call: launch_ranks), `python -m torch.distributed.run ... bench.py
+--gpus N` is taken as it comes (this script is torch-free either way); the per-theta
+results are all-gathered over RCCL/xGMI.  A line labelled n_gpus: N is N ranks on N
+devices -- fewer devices than ranks is refused unless --share-devices (a test mode).
 
 value = (L-BFGS iterations of the whole job) * N * M / wall-clock, max over ranks.
 
@@ -16,6 +19,7 @@ lock-step batch; with --gpus N the structures are split over the ranks, two smal
 
     python bench.py                      # 1 GPU, 1 warm-up + 1 timed sweep
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus 8             # 8 ranks started by this script
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29511 bench.py --gpus 8 --steps 1 --warmup 1
 """
@@ -955,6 +959,100 @@ def choose_transport(ctx, comm, sweep, nshard, transport, count, xinfo, HipError
     return gather, rccl
 
 
+def visible_devices(python=None, root=ROOT, timeout=180.0):
+    """Number of GPUs HIP shows -- asked in a CHILD process, so that the caller (the rank launcher below) never initialises
+    the GPU itself.  -> (count, None) or (None, reason)"""
+    import subprocess
+    code = "import sys; sys.path.insert(0, %r); import bioen_amd; print('BIOEN_DEVICES', bioen_amd.device_count())" % root
+    try:
+        p = subprocess.run([python or os.path.realpath(sys.executable), "-c", code], capture_output=True, text=True, timeout=timeout)
+    except Exception as e:
+        return None, repr(e)
+    for ln in p.stdout.splitlines():
+        if ln.startswith("BIOEN_DEVICES "):
+            return int(ln.split()[1]), None
+    return None, "device probe: exit %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:].strip())
+
+
+def launch_ranks(nranks, child_argv, timeout, out=None, err=None, port=None, poll=0.05):
+    """`python3 bench.py --gpus N` without a launcher around it (r06): this process becomes the launcher.  It starts N fresh
+    child processes of `child_argv` -- one rank each, the environment torchrun would give them (RANK, LOCAL_RANK, WORLD_SIZE,
+    LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT, a run id) -- relays rank 0's stdout (the ONE JSON line; the
+    other ranks' stdout goes to stderr), and returns the exit status: 0 if every rank left with 0, else the FIRST non-zero
+    status seen (the remaining ranks are terminated at once: nothing waits on a dead peer), 124 after `timeout` seconds
+    (all ranks killed).  No HIP call, no torch, no bioen_amd import happens in this process: the children own the GPUs.
+    Replaces the serial theta loop of the reference (bioen/analyze/procedure.py:62-63) on the launcher side."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    out = out or sys.stdout
+    err = err or sys.stderr
+    if port is None:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    run_id = "bench_%d_%d" % (os.getpid(), int(time.time()))
+    children, pumps = [], []
+
+    def pump(src, dst):
+        for ln in iter(src.readline, ""):
+            dst.write(ln)
+            dst.flush()
+        src.close()
+
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID=run_id, BIOEN_BENCH_LAUNCHED="1")
+        p = subprocess.Popen(child_argv, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+        children.append(p)
+        t = threading.Thread(target=pump, args=(p.stdout, out if r == 0 else err), daemon=True)
+        t.start()
+        pumps.append(t)
+
+    def stop_all(sig):
+        for p in children:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)          # the rank and whatever it started (its rocprofv3 passes)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    deadline = time.time() + timeout
+    status = 0
+    try:
+        while True:
+            codes = [p.poll() for p in children]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                status = bad[0] if bad[0] > 0 else 128 - bad[0]      # (a rank killed by signal s: 128 + s, as a shell reports it)
+                which = codes.index(bad[0])
+                print("bench.py: rank %d left with status %d; stopping the other ranks" % (which, status), file=err)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                status = 124
+                print("bench.py: the ranks did not finish within %.0f s; killing them" % timeout, file=err)
+                break
+            time.sleep(poll)
+    finally:
+        if any(p.poll() is None for p in children):
+            stop_all(signal.SIGTERM)
+            t_end = time.time() + 5.0
+            while time.time() < t_end and any(p.poll() is None for p in children):
+                time.sleep(poll)
+            stop_all(signal.SIGKILL)
+        for p in children:
+            try:
+                p.wait(timeout=10.0)
+            except Exception:
+                pass
+        for t in pumps:
+            t.join(timeout=5.0)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -991,13 +1089,40 @@ def main():
                     help="skip the api_end_to_end record (the kept Python API on a host numpy matrix, upload included)")
     ap.add_argument("--no-cpu-fullsize", action="store_true",
                     help="skip the reference run on the FULL headline matrix (two cheapest thetas, ~1 minute)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="allow more ranks than visible GPUs (rank r on device r %% devices): a TEST mode for one-GPU boxes -- "
+                         "without it a run with fewer devices than --gpus exits with status 5 and one line saying so")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="seconds after which the self-launched ranks of --gpus N > 1 are killed (exit status 124)")
+    ap.add_argument("--budget", type=float, default=240.0,
+                    help="wall budget in seconds for the SIDE records after the timed region; they are dropped lowest priority "
+                         "first with \"skipped\": \"budget\" -- roofline and cpu_baseline are never dropped")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # r06: no launcher around us -- become it.  Nothing below this branch runs in this process: no HIP call, no
+        # bioen_amd import; the N children re-enter main() with the rank environment set.
+        ndev, why = visible_devices()
+        if ndev is None:
+            print("bench.py: cannot count the GPUs (%s)" % why, file=sys.stderr)
+            sys.exit(5)
+        if ndev < args.gpus and not args.share_devices:
+            print("bench.py: --gpus %d but only %d device(s) visible to HIP; not running (--share-devices puts several ranks "
+                  "on one device: a test mode, labelled as such in the line)" % (args.gpus, ndev), file=sys.stderr)
+            sys.exit(5)
+        sys.exit(launch_ranks(args.gpus, [os.path.realpath(sys.executable), os.path.abspath(__file__)] + sys.argv[1:],
+                              args.launch_timeout))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        # the label and the ranks must agree: a line saying n_gpus: N is N ranks, never fewer
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to run under a wrong label" % (args.gpus, world), file=sys.stderr)
+        sys.exit(5)
 
     import bioen_amd
     from bioen_amd import sweep
@@ -1012,6 +1137,11 @@ def main():
     ndev = bioen_amd.device_count()
     if ndev < 1:
         raise SystemExit("bench.py: no MI355X visible to HIP -- this benchmark has no CPU path")
+    if ndev < world and not args.share_devices:
+        if rank == 0:
+            print("bench.py: %d ranks but only %d device(s) visible to HIP; not running (--share-devices: test mode)"
+                  % (world, ndev), file=sys.stderr)
+        sys.exit(5)
     xinfo = {}     # what the stage exchanges of the sharded context go through, and what each transport measured
 
     def build(nshard):
@@ -1119,12 +1249,19 @@ def main():
     # is reported in the line, never fatal.
     final_gather = None
     if world > 1:
+        # only the gather itself may fail on a rank; the two control-plane collectives behind it run on EVERY rank whatever
+        # happened, so that no rank waits in them for one that left through the except branch
         try:
             final_gather = sweep.gather_results(ctx, results, comm, rccl=bool(rccl))
-            final_gather["seconds"] = comm.max(final_gather["seconds"])
-            final_gather["consistent"] = bool(all(comm.allgather_object(final_gather["consistent"])))
         except bioen_amd.BioenHipError as e:
-            final_gather = {"error": str(e), "via": "rccl" if rccl else "tcp"}
+            final_gather = {"error": str(e), "via": "rccl" if rccl else "tcp", "seconds": 0.0, "consistent": False}
+        final_gather["seconds"] = comm.max(final_gather["seconds"])
+        states = comm.allgather_object([bool(final_gather["consistent"]), final_gather.get("error")])
+        final_gather["consistent"] = bool(all(s_[0] for s_ in states))
+        errors = [s_[1] for s_ in states if s_[1]]
+        if errors:
+            final_gather["error"] = errors[0]
+            final_gather["ranks_failed"] = len(errors)
 
     iters_per_sweep = sum(r["iterations"] for r in results)
     evals_per_sweep = sum(r["evaluations"] for r in results)
@@ -1323,6 +1460,9 @@ def main():
                        "exchange_us": xinfo.get("exchange_us") if xinfo else (decision or {}).get("exchange_us"),
                        "exchange_us_by_transport": {k[:-3]: xinfo[k] for k in ("p2p_us", "rccl_us", "host_us") if k in xinfo},
                        "decomposition": ("structures" if nshard else "thetas") if world > 1 else "single GPU",
+                       "devices_visible": ndev, "ranks_share_devices": bool(world > ndev),
+                       "launched_by": "bench.py itself (subprocess ranks)" if os.environ.get("BIOEN_BENCH_LAUNCHED") == "1"
+                                      else ("an outer launcher (torchrun environment)" if world > 1 else "single process"),
                        "sharding_fallback": bool(world > 1 and ((decision or {}).get("fallback") or
                                                                 not (nshard and xinfo.get("transport") in ("p2p", "rccl"))))},
             "roofline": roofline,

@@ -180,3 +180,117 @@ def test_the_slowest_ranks_probe_counts_and_a_failed_probe_is_reported():
 def test_theta_dealing_only_wants_a_gather():
     ctx, sw, x, gather, rccl = _choose("auto", _Sweep(), {"p2p": 5.0, "rccl": 25.0, "host": 90.0}, nshard=False)
     assert sw.calls == ["init_rccl"] and rccl and gather == "rccl-allgather" and x == {}
+
+
+# ---- r06: `python3 bench.py --gpus N` launches its own ranks (bench.launch_ranks), no torchrun, no HIP call in the launcher ----
+_CHILD = r'''
+import json, os, sys, time
+r = int(os.environ["RANK"])
+d = os.environ["FAKE_DIR"]
+with open(os.path.join(d, "env_%d.json" % r), "w") as fp:
+    json.dump({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                               "TORCHELASTIC_RUN_ID", "BIOEN_BENCH_LAUNCHED")}, fp)
+print("line of rank %d" % r)
+sys.stdout.flush()
+time.sleep(float(os.environ.get("FAKE_SLEEP_%d" % r, "0")))
+sys.exit(int(os.environ.get("FAKE_EXIT_%d" % r, "0")))
+'''
+
+
+def _launch(tmp_path, monkeypatch, n, timeout=30.0, **env):
+    import io
+    import json
+    child = tmp_path / "child.py"
+    child.write_text(_CHILD)
+    monkeypatch.setenv("FAKE_DIR", str(tmp_path))
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    out, err = io.StringIO(), io.StringIO()
+    rc = bench.launch_ranks(n, [sys.executable, str(child)], timeout, out=out, err=err)
+    envs = {}
+    for r in range(n):
+        f = tmp_path / ("env_%d.json" % r)
+        if f.exists():
+            envs[r] = json.loads(f.read_text())
+    return rc, out.getvalue(), err.getvalue(), envs
+
+
+def test_launcher_starts_n_ranks_with_the_rank_environment_and_relays_rank_zero(tmp_path, monkeypatch):
+    rc, out, err, envs = _launch(tmp_path, monkeypatch, 4)
+    assert rc == 0 and sorted(envs) == [0, 1, 2, 3]
+    for r, e in envs.items():
+        assert e["RANK"] == str(r) and e["LOCAL_RANK"] == str(r) and e["WORLD_SIZE"] == "4" and e["LOCAL_WORLD_SIZE"] == "4"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["BIOEN_BENCH_LAUNCHED"] == "1"
+    assert len({e["MASTER_PORT"] for e in envs.values()}) == 1 and len({e["TORCHELASTIC_RUN_ID"] for e in envs.values()}) == 1
+    assert out == "line of rank 0\n"                                  # stdout carries rank 0's line and nothing else
+    assert all(("line of rank %d" % r) in err for r in (1, 2, 3))
+
+
+def test_launcher_propagates_the_first_failure_and_stops_the_other_ranks(tmp_path, monkeypatch):
+    import time
+    t0 = time.time()
+    rc, out, err, envs = _launch(tmp_path, monkeypatch, 3, FAKE_EXIT_1=7, FAKE_SLEEP_0=60, FAKE_SLEEP_2=60)
+    assert rc == 7 and "rank 1 left with status 7" in err
+    assert time.time() - t0 < 30.0                                    # ranks 0 and 2 were not waited for
+
+
+def test_launcher_kills_the_ranks_at_its_time_bound(tmp_path, monkeypatch):
+    rc, out, err, envs = _launch(tmp_path, monkeypatch, 2, timeout=1.0, FAKE_SLEEP_0=60, FAKE_SLEEP_1=60)
+    assert rc == 124 and "did not finish" in err
+
+
+_FAKE_PKG = r'''
+import json, os, sys
+def device_count():
+    return int(os.environ.get("FAKE_NDEV", "1"))
+if os.environ.get("BIOEN_BENCH_LAUNCHED") == "1" or "RANK" in os.environ:      # a rank of the bench: record, answer, leave
+    r = int(os.environ.get("RANK", "0"))
+    with open(os.path.join(os.environ["FAKE_DIR"], "rank_%d.json" % r), "w") as fp:
+        json.dump({"world": os.environ.get("WORLD_SIZE"), "argv": sys.argv[1:]}, fp)
+    if r == 0:
+        print(json.dumps({"n_gpus": int(os.environ["WORLD_SIZE"])}))
+    sys.exit(int(os.environ.get("FAKE_EXIT_%d" % r, "0")))
+'''
+
+
+def _bench_copy(tmp_path, args, **env):
+    """bench.py itself, run as a program beside a FAKE bioen_amd (no GPU, no library): what does `--gpus N` do?"""
+    import shutil
+    import subprocess
+    shutil.copy(os.path.join(ROOT, "bench.py"), tmp_path / "bench.py")
+    pkg = tmp_path / "bioen_amd"
+    pkg.mkdir(exist_ok=True)
+    (pkg / "__init__.py").write_text(_FAKE_PKG)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(FAKE_DIR=str(tmp_path), PYTHONPATH="")
+    e.update({k: str(v) for k, v in env.items()})
+    p = subprocess.run([sys.executable, str(tmp_path / "bench.py")] + args, env=e, capture_output=True, text=True, timeout=120)
+    ranks = sorted(int(f.name[5:-5]) for f in tmp_path.glob("rank_*.json"))
+    return p, ranks
+
+
+def test_bench_with_gpus_n_and_no_launcher_becomes_the_launcher(tmp_path):
+    import json
+    p, ranks = _bench_copy(tmp_path, ["--gpus", "3", "--steps", "2"], FAKE_NDEV=4)
+    assert p.returncode == 0, p.stderr
+    assert ranks == [0, 1, 2]
+    assert json.loads(p.stdout.strip().splitlines()[-1]) == {"n_gpus": 3}
+    rec = json.loads((tmp_path / "rank_2.json").read_text())
+    assert rec["world"] == "3" and rec["argv"] == ["--gpus", "3", "--steps", "2"]          # the ranks get the caller's arguments
+
+
+def test_bench_refuses_fewer_devices_than_ranks_unless_told_to_share(tmp_path):
+    p, ranks = _bench_copy(tmp_path, ["--gpus", "2"], FAKE_NDEV=1)
+    assert p.returncode == 5 and ranks == [] and "only 1 device(s) visible" in p.stderr and p.stdout == ""
+    p, ranks = _bench_copy(tmp_path, ["--gpus", "2", "--share-devices"], FAKE_NDEV=1)
+    assert p.returncode == 0 and ranks == [0, 1]
+
+
+def test_bench_passes_a_ranks_failure_on(tmp_path):
+    p, ranks = _bench_copy(tmp_path, ["--gpus", "2"], FAKE_NDEV=2, FAKE_EXIT_1=4)
+    assert p.returncode == 4
+
+
+def test_bench_refuses_a_label_that_is_not_the_rank_count(tmp_path):
+    p, ranks = _bench_copy(tmp_path, ["--gpus", "4"], FAKE_NDEV=8, WORLD_SIZE=2, RANK=0)
+    assert p.returncode == 5 and "refusing to run under a wrong label" in p.stderr
