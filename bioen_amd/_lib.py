@@ -100,6 +100,7 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_speculation_stats": (C.c_int, [ctx_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_debug_strip_stamps": (C.c_int, [ctx_p, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
+    "bioen_hip_debug_pass_probe": (C.c_int, [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bioen_hip_ctx_create_raw": (C.c_int, [C.c_int, C.c_longlong, C.c_int, dp, dp, dp, C.c_int, C.POINTER(ctx_p)]),
     "bioen_hip_gsl_strerror": (C.c_char_p, [C.c_int]),
     "bioen_hip_opt_gsl_logw": (C.c_int, [ctx_p, dp, dp, C.c_double, C.POINTER(GslConfig), C.POINTER(VisualParams),

@@ -1399,6 +1399,52 @@ int bioen_hip_debug_strip_stamps(bioen_hip_ctx* c, int enable, long long* out, i
     return 0;
 }
 
+// Measurement aid (tools/pass_probe.py): the two log-weights matrix passes alone, `reps` launches each at batch width k on
+// whatever the slots' vectors hold, timed with events on the context's stream.  No result is produced or changed.
+int bioen_hip_debug_pass_probe(bioen_hip_ctx* c, int k, int reps, double* fwd_ms, double* adj_ms) {
+    if (!c || !fwd_ms || !adj_ms || reps <= 0) return fail(BIOEN_HIP_EINVAL, "bad argument");
+    if (k < 1 || k > kMaxBatch) return fail(BIOEN_HIP_EINVAL, "k must be in [1, 8]");
+    BIOEN_HIP_CHECK(hipSetDevice(c->device));
+    int rc;
+    for (int s = 0; s < k; ++s)
+        if ((rc = alloc_slot(c, s, false))) return rc;
+    const int nblk = fwd_strip_blocks(c);
+    if (nblk <= 0) return fail(BIOEN_HIP_ESTATE, "the strip passes do not serve this context");
+    if ((rc = ensure_strip_copy(c)) || (rc = ensure_strip_copy_colsum(c))) return rc;
+    Vec8 w{};
+    MVec8 out{}, sc{};
+    for (int a = 0; a < k; ++a) {
+        w.p[a] = c->slot[a].w;
+        out.p[a] = c->slot[a].a;
+        sc.p[a] = c->slot[a].scal;
+    }
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
+    float f_ms = 0.f, a_ms = 0.f;
+    if (e == hipSuccess) {
+        for (int i = 0; i < 2; ++i) {
+            launch_fwd_strip(c, k, w, nblk);
+            launch_adj_strip(c, k, c->r_c, out, sc, nblk);
+        }
+        e = hipEventRecord(ev[0], c->stream);
+        for (int i = 0; i < reps; ++i) launch_fwd_strip(c, k, w, nblk);
+        if (e == hipSuccess) e = hipEventRecord(ev[1], c->stream);
+        for (int i = 0; i < reps; ++i) launch_adj_strip(c, k, c->r_c, out, sc, nblk);
+        if (e == hipSuccess) e = hipEventRecord(ev[2], c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(ev[2]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&f_ms, ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&a_ms, ev[1], ev[2]);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    for (int i = 0; i < 3; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (e != hipSuccess) return hip_fail(e, "pass probe", __FILE__, __LINE__);
+    *fwd_ms = f_ms / reps;
+    *adj_ms = a_ms / reps;
+    return 0;
+}
+
 int bioen_hip_forces_fdf_batch(bioen_hip_ctx* c, int k, const double* forces, const double* w0, const double* thetas,
                                double* f, double* grad) {
     if (!c || !forces || !w0 || !thetas) return fail(BIOEN_HIP_EINVAL, "NULL argument");

@@ -58,6 +58,9 @@
 #ifndef STRIP_DIAG
 #define STRIP_DIAG 0      // diagnostic builds: 1 = no MFMAs, 2 = no matrix loads
 #endif
+#ifndef FWD_DIAG
+#define FWD_DIAG 0        // diagnostic builds of k_strip_fwd (timing only, results are garbage): 1 = the blocks sweep the copy as ONE
+#endif                    // front (slot s takes strips s, s + slots, ...: the r04 pattern), 2 = no chunk fold
 #ifndef STRIP_PRECENTERED
 #define STRIP_PRECENTERED 0   // diagnostic builds: 1 = the r02 layout (copies hold Y - centre, no subtraction in the kernels;
 #endif                        // read_ytilde is then off by the centre): A/B of what the in-kernel centring costs
@@ -1182,8 +1185,12 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
             }
         // unconditional (see k_strip_adj); the operands are consumed at issue.  Past its last strip a wave re-reads a
         // strip it may touch (its last one, or strip 0) against e = 0
+#if FWD_DIAG & 1
+        fetch(min((int)(blockIdx.x * q.spb + sub + (it + 1) * gridDim.x * q.spb), q.nstrips - 1));
+#else
         fetch(it + 1 < mw.count ? mw.first + q.gs * (it + 1) : (mw.count > 0 ? mw.first + q.gs * (mw.count - 1) : 0));
-        if (q.fold && ++tcnt == q.tc) {                            // a chunk ends (block-uniform; registers only)
+#endif
+        if (!(FWD_DIAG & 2) && q.fold && ++tcnt == q.tc) {                            // a chunk ends (block-uniform; registers only)
             tcnt = 0;
 #pragma unroll
             for (int h = 0; h < kWaveRows / 16; ++h)

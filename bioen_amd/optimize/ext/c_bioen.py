@@ -121,6 +121,10 @@ class hold(object):
         ctx, cached = _context_for(self.obj, YT)
         if not hasattr(ctx, "_YT_host"):
             ctx._YT_host = _lib.as_f64(YT).ravel().copy()
+        if cached:
+            # the hold OWNS the context while it lasts (r06): out of the LRU cache, so that calls on other matrices
+            # inside the block -- or clear_cache() -- cannot evict and close the copy the block is served from
+            _CACHE.pop(id(self.obj), None)
         _HELD[id(self.obj)] = [self.obj, ctx, cached, 1]
         return self
 
@@ -131,9 +135,21 @@ class hold(object):
         e[3] -= 1
         if e[3] == 0:
             del _HELD[id(self.obj)]
-            if not e[2]:
+            if e[2] and _CACHE_MAX > 0 and getattr(e[1], "_h", None):
+                _cache_insert(id(self.obj), e[1])        # back under the cache's rules (checked again on its next use)
+            else:
                 e[1].close()
         return False
+
+
+def _cache_insert(key, ctx):
+    stale = _CACHE.pop(key, None)
+    if stale is not None and stale is not ctx:
+        stale.close()
+    _CACHE[key] = ctx
+    while len(_CACHE) > _CACHE_MAX:
+        _, old = _CACHE.popitem(last=False)
+        old.close()
 
 
 def _context_for(yTilde, YTilde):
@@ -176,10 +192,7 @@ def _context_for(yTilde, YTilde):
     ctx._YT_host = YT.copy()
     ctx._fingerprint = fp
     ctx._host_ref = weakref.ref(yTilde)
-    _CACHE[key] = ctx
-    while len(_CACHE) > _CACHE_MAX:
-        _, old = _CACHE.popitem(last=False)
-        old.close()
+    _cache_insert(key, ctx)
     return ctx, True
 
 

@@ -301,6 +301,11 @@ int bioen_hip_speculation_stats(bioen_hip_ctx* ctx, long long* issued, long long
  * launch, out[nblocks][16 waves][8 phases]; a normal build leaves the buffer untouched. */
 int bioen_hip_debug_strip_stamps(bioen_hip_ctx* ctx, int enable, long long* out, int nblocks);
 
+/* Measurement aid (tools/pass_probe.py): the two matrix passes of a log-weights evaluation alone --
+ * `reps` launches each at batch width k (1..8) over whatever the problem slots hold -- mean milliseconds per launch,
+ * HIP events on the context's stream.  Produces and changes no result. */
+int bioen_hip_debug_pass_probe(bioen_hip_ctx* ctx, int k, int reps, double* fwd_ms, double* adj_ms);
+
 /* ---- host self-test of the L-BFGS driver (no GPU needed) ------------------------------
  * Runs the SAME driver + line-search code as the optimizers above on a built-in analytic
  * objective evaluated on the host: kind 0 = extended Rosenbrock, kind 1 = ill-conditioned

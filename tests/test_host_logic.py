@@ -271,3 +271,50 @@ def test_context_cache_needs_the_same_live_object_and_the_same_content(monkeypat
     assert not cached8
     c_bioen.clear_cache()
     assert all(c.closed for c in made if c is not c8)
+
+
+def test_a_held_matrix_survives_evictions_and_clear_cache(monkeypatch):
+    """`with optimize.resident(A):` looping over A, B and C.  The hold owns A's context while it lasts -- calls on
+    other matrices inside the block (LRU evictions, BIOEN_HIP_CACHE = 2) and clear_cache() must not close it; after the
+    block it is back in the cache."""
+    made = []
+
+    class FakeContext(object):
+        def __init__(self, yT, YT):
+            self._h = object()
+            made.append(self)
+
+        def set_target(self, YT):
+            pass
+
+        def close(self):
+            self._h = None
+
+    monkeypatch.setattr(c_bioen._lib, "Context", FakeContext)
+    c_bioen.clear_cache()
+    YT = np.ones(4)
+    A, B, Cm, D = (np.arange(20.0).reshape(4, 5) + i for i in range(4))
+    a0, _ = c_bioen._context_for(A, YT)                       # cached before the block: the hold takes it over
+    with optimize.resident(A, YT):
+        assert id(A) not in c_bioen._CACHE
+        for other in (B, Cm, D):                               # three more matrices through a cache of two
+            c_bioen._context_for(other, YT)
+            a, cached = c_bioen._context_for(A, YT)
+            assert a is a0 and cached and a._h is not None
+        c_bioen.clear_cache()
+        a, _ = c_bioen._context_for(A, YT)
+        assert a is a0 and a._h is not None                    # still alive, still the same upload
+        with optimize.resident(A, YT):                         # nested
+            assert c_bioen._context_for(A, YT)[0] is a0
+        assert c_bioen._HELD
+    assert not c_bioen._HELD
+    assert c_bioen._CACHE.get(id(A)) is a0 and a0._h is not None      # handed back to the cache
+    assert len(made) == 1 + 3
+    big = np.zeros((4, 5))
+    monkeypatch.setattr(c_bioen, "_FULL_CHECK_BYTES", 8)       # a matrix the cache refuses: the hold closes it at the end
+    with optimize.resident(big, YT):
+        held = c_bioen._context_for(big, YT)[0]
+        c_bioen.clear_cache()
+        assert held._h is not None
+    assert held._h is None
+    c_bioen.clear_cache()
