@@ -1218,6 +1218,8 @@ def main():
     for _ in range(max(args.warmup - warm_done, 0)):
         results = step()
 
+    # (structure-sharded: did a rank fall back to the one-copy form alone?  then the bits are not those of other GPU counts)
+    forms = sweep.check_common_form(ctx, comm) if nshard else None
     ctx.kernel_stats_enable(True)
     ctx.kernel_stats_reset()
     comm.barrier()
@@ -1242,6 +1244,7 @@ def main():
     dt = comm.max(time.perf_counter() - t0)
     stats = ctx.kernel_stats()
     ctx.kernel_stats_enable(False)
+    ctx_layout = ctx.layout()
 
     # r05: the final (S, chi^2, weights) per theta once more through ONE RCCL all-gather over all ranks -- in a
     # structure-sharded run the cross-rank consistency check (every rank must hold the same bytes), after the timed region;
@@ -1460,6 +1463,7 @@ def main():
                        "exchange_us": xinfo.get("exchange_us") if xinfo else (decision or {}).get("exchange_us"),
                        "exchange_us_by_transport": {k[:-3]: xinfo[k] for k in ("p2p_us", "rccl_us", "host_us") if k in xinfo},
                        "decomposition": ("structures" if nshard else "thetas") if world > 1 else "single GPU",
+                       "strip_copy_forms": forms, "strip_layout": ctx_layout,
                        "devices_visible": ndev, "ranks_share_devices": bool(world > ndev),
                        "launched_by": "bench.py itself (subprocess ranks)" if os.environ.get("BIOEN_BENCH_LAUNCHED") == "1"
                                       else ("an outer launcher (torchrun environment)" if world > 1 else "single process"),

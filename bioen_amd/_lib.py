@@ -100,6 +100,7 @@ _SIGNATURES = {
     "bioen_hip_kernel_stats_enable": (C.c_int, [ctx_p, C.c_int]),
     "bioen_hip_speculation_stats": (C.c_int, [ctx_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bioen_hip_debug_strip_stamps": (C.c_int, [ctx_p, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
+    "bioen_hip_ctx_layout": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bioen_hip_debug_pass_probe": (C.c_int, [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bioen_hip_ctx_create_raw": (C.c_int, [C.c_int, C.c_longlong, C.c_int, dp, dp, dp, C.c_int, C.POINTER(ctx_p)]),
     "bioen_hip_gsl_strerror": (C.c_char_p, [C.c_int]),
@@ -423,6 +424,13 @@ class Context(object):
         check(lib().bioen_hip_ctx_footprint(self._h, C.byref(f), C.byref(b)))
         names = {1: "rowmajor", 2: "strips", 4: "strips_colsum", 8: "reduced"}
         return {names[k] for k in names if f.value & k}, b.value
+
+    def layout(self):
+        """How the strip copies are held: {"one_copy": 0 | 1, "interleave": segments interleaved in the row-sum order copy,
+        "relayouts": times that copy was moved to the other method's layout} (bioen_hip_ctx_layout)"""
+        a, b, c_ = C.c_int(0), C.c_int(1), C.c_int(0)
+        check(lib().bioen_hip_ctx_layout(self._h, C.byref(a), C.byref(b), C.byref(c_)))
+        return {"one_copy": a.value, "interleave": b.value, "relayouts": c_.value}
 
     def set_target(self, YTilde):
         check(lib().bioen_hip_ctx_set_ytilde_target(self._h, ptr(self._mvec(YTilde, "YTilde"))))

@@ -586,7 +586,7 @@ static int enqueue_logw_eval(bioen_hip_ctx* c, const Round& r, bool with_grad) {
     if (nblk > 0) {
         // both strip copies before the first pass, so that one evaluation never mixes the two kernel families; a
         // copy that cannot be allocated switches the context to the streaming kernels for good (strips_unavailable)
-        rc = ensure_strip_copy(c);
+        rc = ensure_strip_copy(c, 0);
         if (!rc && with_grad) rc = ensure_strip_copy_colsum(c);
         if (rc && !c->strips_unavailable) return rc;
         if (rc) nblk = 0;
@@ -662,7 +662,7 @@ static int enqueue_forces_weights(bioen_hip_ctx* c, const ForcesRound& fr) {    
 static int enqueue_forces_eval(bioen_hip_ctx* c, const ForcesRound& fr, const Round& r, bool with_grad) {
     int nblk = forces_fused_blocks(c);
     int rc;
-    if (nblk > 0 && (rc = ensure_strip_copy(c))) {
+    if (nblk > 0 && (rc = ensure_strip_copy(c, 1))) {
         if (!c->strips_unavailable) return rc;
         nblk = forces_fused_blocks(c);        // = 0 now: the kernels on the row-major matrix take over
     }
@@ -1096,6 +1096,14 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* c, int row0, int rows, int col0, in
     return rc;
 }
 
+int bioen_hip_ctx_layout(const bioen_hip_ctx* c, int* one_copy, int* interleave, int* relayouts) {
+    if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
+    if (one_copy) *one_copy = c->one_copy;
+    if (interleave) *interleave = std::max(1, c->strip_ilv);
+    if (relayouts) *relayouts = c->strip_relayouts;
+    return 0;
+}
+
 int bioen_hip_ctx_footprint(const bioen_hip_ctx* c, int* forms, long long* bytes) {
     if (!c) return fail(BIOEN_HIP_EINVAL, "ctx is NULL");
     const long long rowmajor = (long long)c->mp * (long long)c->ld * 8;
@@ -1410,7 +1418,7 @@ int bioen_hip_debug_pass_probe(bioen_hip_ctx* c, int k, int reps, double* fwd_ms
         if ((rc = alloc_slot(c, s, false))) return rc;
     const int nblk = fwd_strip_blocks(c);
     if (nblk <= 0) return fail(BIOEN_HIP_ESTATE, "the strip passes do not serve this context");
-    if ((rc = ensure_strip_copy(c)) || (rc = ensure_strip_copy_colsum(c))) return rc;
+    if ((rc = ensure_strip_copy(c, 0)) || (rc = ensure_strip_copy_colsum(c))) return rc;
     Vec8 w{};
     MVec8 out{}, sc{};
     for (int a = 0; a < k; ++a) {

@@ -370,7 +370,7 @@ int LogwBatchEngine::run_device(int ntheta, const double* thetas, const double* 
         launch_dev_exp(c, r);
         int nblk = fwd_strip_blocks(c);
         if (nblk > 0) {
-            int e = ensure_strip_copy(c);
+            int e = ensure_strip_copy(c, 0);
             if (!e) e = ensure_strip_copy_colsum(c);
             if (e && !c->strips_unavailable) note(e);
             if (e) nblk = 0;

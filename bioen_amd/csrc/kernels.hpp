@@ -111,7 +111,9 @@ void launch_forces_w_from_x(bioen_hip_ctx* c, const struct ForcesRound& fr);   /
 // every local segment's share of the forces gradient -> its part of X_YBAR.  tposed: the two-pass strip kernels' sets (seg_sets per
 // segment); else the log-weights forward kernel's sets (row panels, M > 1024)
 void launch_fwd_rows_forces_grad_share(bioen_hip_ctx* c, int K, int seg_sets, const struct ForcesRound* tsum = nullptr, bool tposed = false);
-int ensure_strip_copy(bioen_hip_ctx* c);               // builds ctx->Ys on first use
+// builds ctx->Ys on first use; method 0 / 1: the log-weights / the forces passes come next and want the copy in their
+// layout (kernels_strip.hip: strip_phys; an existing copy is moved, best effort), -1: whatever is there
+int ensure_strip_copy(bioen_hip_ctx* c, int method = -1);
 int set_storage_format(bioen_hip_ctx* c, int fmt);     // reduced-byte storage experiment of the log-weights passes (0 = FP64)
 int fwd_strip_blocks(const bioen_hip_ctx* c);          // > 0: the log-weights forward pass runs on the strip copy
 void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool plain = false);

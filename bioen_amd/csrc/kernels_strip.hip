@@ -75,6 +75,20 @@ constexpr int kWaveRows = 64;
 // physical column of logical column c in row r:  c ^ strip_swz(r)
 __device__ __forceinline__ int strip_swz(int row) { return (((row >> 1) & 7) << 1) ^ ((row >> 4) & 1); }
 
+// Where strip s of the row-sum order copy lives (r06).  A context that holds ilv > 1 canonical segments (one GPU: all
+// eight) stores the strips of its segments INTERLEAVED: strip r of local segment v at position r ilv + v.  The row-sum
+// passes give every slot the strips g, g + gs, ... of ONE segment (kernels.hpp: StripSets), so in segment order the 256
+// slots of a launch read eight windows of the copy a segment (1 GB at the headline) apart; interleaved, the same slots at
+// the same moment read ONE contiguous window, as the whole-matrix sweep of r04 did -- which strips a set is summed over,
+// and in which order, does not change (same bits), only where they lie.  Measured (tools/pass_probe.py, profiles/
+// r06_fwd_ab.txt): 1.5-3 % of the forward pass on boxes whose memory system does not mind the eight windows, 7 % on those
+// that do (r04's kernel 1.155-1.169 ms in the headline sweep against 1.247-1.253 ms for r05's on the same box).
+__device__ __forceinline__ int strip_phys(int s, int sps, int ilv) {
+    if (ilv <= 1) return s;
+    const int v = s / sps;
+    return (s - v * sps) * ilv + v;
+}
+
 // ---- one-time construction of the strip-major copy -------------------------------------------------
 // Within a strip the 64-row slice of wave w is stored in the order the ROW-SUM product wants its matrix
 // operand, so a wave-load (1 KiB, 16 B per lane) lands in the operand registers with no further movement:
@@ -104,9 +118,9 @@ __device__ __forceinline__ size_t strip_pos_colsum(int row, int col) {
 template <bool COLSUM>
 __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__ Y, size_t ld, int mp, int mps, int n,
                                                       double* __restrict__ Ys, int nstrips,
-                                                      const double* __restrict__ center_diag) {
+                                                      const double* __restrict__ center_diag, int sps, int ilv) {
     for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
-        double* dst = Ys + (size_t)s * mps * kStripCols;
+        double* dst = Ys + (size_t)strip_phys(s, sps, ilv) * mps * kStripCols;
         for (int p = threadIdx.x; p < mps * 8; p += 256) {
             const int row = p >> 3, part = p & 7;
             d2 v{0.0, 0.0};
@@ -128,9 +142,9 @@ __global__ __launch_bounds__(256) void k_build_strips(const double* __restrict__
 
 // row-sum order copy -> column-sum order copy (the log-weights adjoint's), strip by strip through LDS-free index maps
 __global__ __launch_bounds__(256) void k_restripe(const double* __restrict__ Ys, int mps, double* __restrict__ Ys1,
-                                                  int nstrips) {
+                                                  int nstrips, int sps, int ilv) {
     for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
-        const double* src = Ys + (size_t)s * mps * kStripCols;
+        const double* src = Ys + (size_t)strip_phys(s, sps, ilv) * mps * kStripCols;    // (the column-sum copy: strip order)
         double* dst = Ys1 + (size_t)s * mps * kStripCols;
         for (int p = threadIdx.x; p < mps * kStripCols; p += 256) {
             const int row = p >> 4, col = p & 15;
@@ -139,14 +153,25 @@ __global__ __launch_bounds__(256) void k_restripe(const double* __restrict__ Ys,
     }
 }
 
+// row-sum order copy, segments interleaved by ilv_from -> the same strips interleaved by ilv_to (whole strips move)
+__global__ __launch_bounds__(256) void k_relayout(const double* __restrict__ from, double* __restrict__ to, int mps, int nstrips,
+                                                  int sps, int ilv_from, int ilv_to) {
+    for (int s = blockIdx.x; s < nstrips; s += gridDim.x) {
+        const d2* src = reinterpret_cast<const d2*>(from + (size_t)strip_phys(s, sps, ilv_from) * mps * kStripCols);
+        d2* dst = reinterpret_cast<d2*>(to + (size_t)strip_phys(s, sps, ilv_to) * mps * kStripCols);
+        for (int p = threadIdx.x; p < mps * (kStripCols / 2); p += 256) dst[p] = src[p];
+    }
+}
+
 // row-sum order copy -> row-major block out[rows][cols] (device), rows [row0, row0 + rows), columns [col0, col0 + cols)
 __global__ __launch_bounds__(256) void k_gather_strips(const double* __restrict__ Ys, int mps, int row0, int rows,
-                                                       size_t col0, int cols, double* __restrict__ out, size_t ldo) {
+                                                       size_t col0, int cols, double* __restrict__ out, size_t ldo,
+                                                       int sps, int ilv) {
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)rows * cols; p += (size_t)gridDim.x * 256) {
         const int r = (int)(p / cols);
         const size_t cc = col0 + (p - (size_t)r * cols);
         out[(size_t)r * ldo + (p - (size_t)r * cols)] =
-            Ys[(cc / kStripCols) * (size_t)mps * kStripCols + strip_pos(row0 + r, (int)(cc % kStripCols))];
+            Ys[(size_t)strip_phys((int)(cc / kStripCols), sps, ilv) * mps * kStripCols + strip_pos(row0 + r, (int)(cc % kStripCols))];
     }
 }
 
@@ -245,6 +270,7 @@ struct StripArgs {
     int sps, gs, tc, nch, fold, slots;
     int nslots;             // physical slots of the launch = slots x local segments (forces passes: = gs)
     int nlocal;             // local segments (forces passes: a block runs its group through all of them)
+    int ilv;                // row-sum order FP64 copies: segments interleaved by this many (strip_phys); <= 1: strip order
     const double* u_c;      // [row * K + k]: forces (xy) | residuals (bt)
     const double* w0;
     double* partial;        // [block * mp K + row * K + k]  (transposed: device_utils.hpp, tiles_sum16)
@@ -397,7 +423,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     auto fetch = [&](int strip, Regs& pre) {
 #if !(STRIP_DIAG & 2)
         if constexpr (STORE == 0) {
-            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+            const double* src = q.Ys + (size_t)strip_phys(strip, q.sps, q.ilv) * q.mps * kStripCols + wave_off;
 #pragma unroll
             for (int i = 0; i < kWaveRows / 8; ++i) pre.v[i] = ldg2<NT>(src + choff[i]);
         } else {                                    // reduced-storage experiment: centred, rows padded to 64
@@ -814,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     }
     auto fetch_part = [&](int strip, int lo, int hi) {
         if constexpr (STORE == 0) {
-            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+            const double* src = q.Ys + (size_t)strip_phys(strip, q.sps, q.ilv) * q.mps * kStripCols + wave_off;
 #pragma unroll
             for (int i = 0; i < WR / 8; ++i)
                 if (i >= lo && i < hi) pre.v[i] = ldg2<NT>(src + choff[i]);
@@ -1121,7 +1147,7 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
     strip_chunk_offsets(q.mps, rsrc, choff);
     auto fetch = [&](int strip) {
         if constexpr (STORE == 0) {
-            const double* src = q.Ys + (size_t)strip * q.mps * kStripCols + wave_off;
+            const double* src = q.Ys + (size_t)strip_phys(strip, q.sps, q.ilv) * q.mps * kStripCols + wave_off;
 #pragma unroll
             for (int i = 0; i < kWaveRows / 8; ++i) pre[i] = ldg2<NT>(src + choff[i]);
         } else {
@@ -1227,6 +1253,12 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 // geometry as in the forward pass; u = r (compact [row K + k]) sits in an LDS table in B-operand reach, the partial
 // column sums of a slot's waves meet in LDS (two buffers by strip parity: one barrier per iteration), 16 K threads per
 // slot add the shift and store.
+// One register set, as in the forward pass.  r06 tried two here (the strip after next requested before the products of the
+// next one start, loop unrolled by two, same bits; profiles/r06_adj_depth_ab.txt): K <= 4: 1.18-1.21 ms per launch at
+// N = 1e6 x M = 1024 against 1.17-1.21 (nothing), K > 4: 1.71 ms against 1.21-1.26 (the second set does not fit beside
+// 2 x 16 operand registers of u).  What a launch takes moves by 4-5 % with the process and the box (the first 0.2 s of a
+// process, where the copy landed in HBM: tools/pass_probe.py shows it for both passes and for the plain read probe alike),
+// not with bytes in flight.
 template <int K, bool NT, int STORE = 0>
 __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec8 scal) {
     constexpr int NK = (K + 3) / 4;
@@ -1384,6 +1416,19 @@ static size_t strip_lds_bytes(const bioen_hip_ctx* c) {
     return (waves * kWaveRows * (kStripCols + 8 + 1) + waves * 128 + 128 + 16) * sizeof(double);   // 64 rows per wave
 }
 
+static int env_flag(const char* name, int dflt);
+// segments interleaved in the row-sum order FP64 copies of this context (strip_phys); BIOEN_HIP_STRIP_INTERLEAVE=0: strip
+// order as until r05 (A/B; read once per context at the first copy)
+static int strip_ilv(const bioen_hip_ctx* c) { return std::max(1, c->strip_ilv); }      // the layout the copies ARE in
+// the layout a method wants: the log-weights passes (k_strip_fwd's folded groups, one slot per (segment, group)) the
+// interleaved one; the forces passes (a block runs its group through the segments one after the other: already one window)
+// strip order -- interleaved they read every ilv-th strip of an ilv times wider window, 2-4 % slower at K >= 6
+static int strip_ilv_wanted(const bioen_hip_ctx* c, bool forces) {
+    if (forces) return 1;
+    return env_flag("BIOEN_HIP_STRIP_INTERLEAVE", 1) != 0 ? std::max(1, c->vr) : 1;
+}
+static int strip_sps(const bioen_hip_ctx* c) { return c->segcols / kStripCols; }
+
 static int env_flag(const char* name, int dflt) {
     const char* e = std::getenv(name);
     return e ? std::atoi(e) : dflt;
@@ -1475,7 +1520,7 @@ int ensure_rowmajor(bioen_hip_ctx* c) {
         const int mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
         const double* src = paneled(c) ? c->Yp[p] : c->Ys;
         hipLaunchKernelGGL(k_gather_strips, dim3(4096), dim3(256), 0, c->stream, src, mps, 0, std::min(mps, panel_mp(c, p)),
-                           (size_t)0, (int)c->ld, y + (size_t)p * kPanelRows * c->ld, c->ld);
+                           (size_t)0, (int)c->ld, y + (size_t)p * kPanelRows * c->ld, c->ld, strip_sps(c), strip_ilv(c));
         e = hipGetLastError();
         if (e != hipSuccess) rc = hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
     }
@@ -1503,7 +1548,7 @@ int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, do
             const size_t total = (size_t)(hi - lo) * cols;
             hipLaunchKernelGGL(k_gather_strips, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
                                c->stream, c->Yp[p], panel_mps(c, p), lo - p * kPanelRows, hi - lo, col0, cols,
-                               out + (size_t)(lo - row0) * cols, (size_t)cols);
+                               out + (size_t)(lo - row0) * cols, (size_t)cols, strip_sps(c), strip_ilv(c));
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
         }
@@ -1512,7 +1557,7 @@ int gather_block(bioen_hip_ctx* c, int row0, int rows, size_t col0, int cols, do
     if (!c->Ys) return BIOEN_HIP_ESTATE;
     const size_t total = (size_t)rows * cols;
     hipLaunchKernelGGL(k_gather_strips, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0, c->stream,
-                       c->Ys, strip_rows(c), row0, rows, col0, cols, out, (size_t)cols);
+                       c->Ys, strip_rows(c), row0, rows, col0, cols, out, (size_t)cols, strip_sps(c), strip_ilv(c));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "k_gather_strips", __FILE__, __LINE__);
 }
@@ -1601,8 +1646,50 @@ int set_storage_format(bioen_hip_ctx* c, int fmt) {
     return 0;
 }
 
-int ensure_strip_copy(bioen_hip_ctx* c) {
+// The existing row-sum order copies into the layout `want` (strip_phys), best effort: new buffers, whole strips moved, the old
+// ones freed -- 2 x the copy's bytes of traffic (3 ms at the headline) and, for the moment of the move, a second copy's
+// memory; if that is not to be had the copies stay as they are (every kernel reads either layout).
+static void relayout_strip_copies(bioen_hip_ctx* c, int want) {
+    if (strip_ilv(c) == want) return;
+    const int nstrips = (int)(c->ld / kStripCols);
+    const int np = paneled(c) ? panel_count(c) : 1;
+    double* made[bioen_hip_ctx::kMaxPanels] = {};
+    for (int p = 0; p < np; ++p) {
+        const int mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
+        const double* from = paneled(c) ? c->Yp[p] : c->Ys;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&made[p]), (size_t)nstrips * mps * kStripCols * sizeof(double));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_relayout, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, from, made[p], mps, nstrips,
+                               strip_sps(c), strip_ilv(c), want);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->stream);
+            for (int q = 0; q <= p; ++q)
+                if (made[q]) (void)hipFree(made[q]);
+            return;
+        }
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {          // (reported by the next launch check)
+        for (int p = 0; p < np; ++p) (void)hipFree(made[p]);
+        return;
+    }
+    for (int p = 0; p < np; ++p) {
+        double*& slot = paneled(c) ? c->Yp[p] : c->Ys;
+        (void)hipFree(slot);
+        slot = made[p];
+    }
+    c->strip_ilv = want;
+    ++c->strip_relayouts;
+}
+
+// method: 0 = the log-weights passes are about to run on the copy, 1 = the forces passes, -1 = any layout will do
+int ensure_strip_copy(bioen_hip_ctx* c, int method) {
     if (c->storage) return ensure_reduced_copy(c, false);
+    if (method >= 0 && (paneled(c) ? c->Yp[0] : c->Ys) != nullptr)
+        relayout_strip_copies(c, strip_ilv_wanted(c, method == 1));
+    if (!(paneled(c) ? c->Yp[0] : c->Ys)) c->strip_ilv = strip_ilv_wanted(c, method == 1);     // the layout they are built in
     if (paneled(c)) {                                   // row panels of a matrix taller than 1024 rows; Y stays
         if (c->Yp[0]) return 0;
         if (c->strips_unavailable) return BIOEN_HIP_ENOMEM;
@@ -1618,7 +1705,7 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream,
                                    c->Y + (size_t)p * kPanelRows * c->ld, c->ld, panel_mp(c, p), mps, c->n, made[p], nstrips,
-                                   c->strip_center + (size_t)p * kPanelRows);
+                                   c->strip_center + (size_t)p * kPanelRows, strip_sps(c), strip_ilv(c));
                 e = hipGetLastError();
             }
             if (e != hipSuccess) {
@@ -1656,7 +1743,7 @@ int ensure_strip_copy(bioen_hip_ctx* c) {
     }
     if (ensure_zero_center(c)) return strip_copy_failed(c, ys, hipErrorOutOfMemory, "zero centre");
     hipLaunchKernelGGL(k_build_strips<false>, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Y, c->ld, c->mp, mps,
-                       c->n, ys, nstrips, c->strip_center);
+                       c->n, ys, nstrips, c->strip_center, strip_sps(c), strip_ilv(c));
     e = hipGetLastError();
     if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_build_strips");
     c->Ys = ys;
@@ -1849,6 +1936,7 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
         (void)nblk;
         const StripSets ss = strip_sets(c);
         q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = ss.nch; q.fold = ss.fold; q.slots = ss.slots;
+        q.ilv = c->storage ? 1 : strip_ilv(c);          // (the reduced-format copies are kept in strip order)
         q.nslots = ss.slots * c->vr;
         q.partial = c->fwd_partial + (size_t)row0 * K;
         q.pstride = c->mp;
@@ -1882,7 +1970,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
             const int mps = panel_mps(c, p);
             hipError_t e = strip_malloc(c, &made[p], (size_t)nstrips * mps * kStripCols * sizeof(double));
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Yp[p], mps, made[p], nstrips);
+                hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Yp[p], mps, made[p], nstrips, strip_sps(c), strip_ilv(c));
                 e = hipGetLastError();
             }
             if (e != hipSuccess) {
@@ -1918,7 +2006,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
         return 0;
     }
     if (e != hipSuccess) return strip_copy_failed(c, nullptr, e, "hipMalloc (column-sum strip copy of yTilde)");
-    hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Ys, mps, ys, nstrips);
+    hipLaunchKernelGGL(k_restripe, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, c->Ys, mps, ys, nstrips, strip_sps(c), strip_ilv(c));
     e = hipGetLastError();
     if (e != hipSuccess) return strip_copy_failed(c, ys, e, "k_restripe");
     c->Ys1 = ys;
@@ -1983,6 +2071,7 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
             q.nch = 1; q.fold = 0; q.slots = q.gs;
             q.nslots = q.gs;
             q.nlocal = c->vr;
+            q.ilv = strip_ilv(c);
             q.nblk = q.nslots;
             q.u_c = u_c + (size_t)row0 * K;
             q.accumulate = p > 0 ? 1 : (plain ? 2 : 0);
@@ -2051,6 +2140,7 @@ static void strip_launch(bioen_hip_ctx* c, const ForcesRound& fr, int nblk, cons
     q.sps = ss.sps; q.gs = ss.gs; q.tc = ss.tc; q.nch = 1; q.fold = 0; q.slots = ss.gs;
     q.nslots = ss.gs;                                  // one block per group; it runs the local segments in turn
     q.nlocal = c->vr;
+    q.ilv = c->storage ? 1 : strip_ilv(c);
     q.nblk = q.nslots;
     q.u_c = u_c;
     q.w0 = c->fixed;

@@ -471,6 +471,22 @@ def gather_results(ctx, results, comm, rccl=True):
             "via": "rccl" if rccl else "tcp"}
 
 
+def check_common_form(ctx, comm):
+    """A structure-sharded context promises the SAME bits on 1, 2, 4 and 8 ranks -- as long as every rank runs the same
+    kernels.  A rank that could not allocate its second strip copy takes the one-copy form by itself
+    (bioen_hip_ctx_layout: one_copy), whose adjoint rounds differently in the last bits: compare the form over the ranks
+    and say so.  -> {"one_copy": [per rank], "common": bool}"""
+    import warnings
+    forms = comm.allgather_object(int(ctx.layout()["one_copy"])) if comm is not None and comm.world > 1 \
+        else [int(ctx.layout()["one_copy"])]
+    common = len(set(forms)) == 1
+    if not common:
+        warnings.warn("bioen_amd: ranks %s run the log-weights adjoint on ONE strip copy, the others on two: results agree to "
+                      "rounding, not bit for bit, with runs on another number of GPUs (BIOEN_HIP_ONE_COPY=1 on every rank "
+                      "gives one common form)" % [r for r, f in enumerate(forms) if f], RuntimeWarning)
+    return {"one_copy": forms, "common": common}
+
+
 def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=False, verbose=False, max_batch=8):
     """Cold-started log-weights series (every theta starts from g_init, as
     procedure.py:46,66 does for generic data).  The thetas of a rank run as ONE lock-step
@@ -487,14 +503,18 @@ def sweep_log_weights(ctx, thetas, G, g_init, lbfgs_params, comm=None, rccl=Fals
     return theta_sweep(ctx, thetas, None, comm=comm, rccl=rccl, presolved=solved)
 
 
-def sweep_log_weights_sharded(ctx, thetas, G, g_init, lbfgs_params, verbose=False, max_batch=8):
+def sweep_log_weights_sharded(ctx, thetas, G, g_init, lbfgs_params, verbose=False, max_batch=8, comm=None):
     """The same series on a STRUCTURE-sharded context (``Context(..., rank, world)``): every rank
     keeps a column block of yTilde and all ranks work on every theta together -- each matrix
     pass, each N-vector kernel and each L-BFGS vector lives 1/world per GPU, and the reductions
     over structures are completed by one in-place all-gather per stage (RCCL over xGMI).  All
-    ranks return the same list (results are gathered inside the library)."""
+    ranks return the same list (results are gathered inside the library).  `comm` (a control-plane communicator, the
+    same on every rank): the ranks' strip-copy forms are compared afterwards (check_common_form: a RuntimeWarning when one
+    rank fell back to the one-copy form alone)."""
     thetas = [float(t) for t in thetas]
     _, w, infos = ctx.opt_lbfgs_logw_batch(thetas, g_init, G, lbfgs_params, max_batch=max_batch, verbose=verbose)
+    if comm is not None:
+        check_common_form(ctx, comm)          # (a control-plane collective: every rank passes the same `comm` or none)
     return [{"theta": th, "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "iterations": i.iterations,
              "evaluations": i.evaluations, "code": i.lbfgs_code, "seconds": i.seconds, "rank": -1, "w": w[k]}
             for k, (th, i) in enumerate(zip(thetas, infos))]

@@ -165,6 +165,14 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, 
  * from the two-copy default: the sums over rows are formed in another order). */
 /* (bit 3: copies of the reduced-storage experiment, bioen_hip_ctx_set_storage, beside the FP64 row-major matrix) */
 int bioen_hip_ctx_footprint(const bioen_hip_ctx* ctx, int* forms, long long* bytes);
+/* r06: HOW the strip copies are held.  one_copy: 1 = the log-weights adjoint runs on the row-sum order copy (asked for, or
+ * taken by THIS rank because the second copy could not be allocated -- its last bits then differ from a two-copy rank's:
+ * sharded drivers compare this value across ranks, bioen_amd/sweep.py).  interleave: the local segments' strips are stored
+ * interleaved by this many in the row-sum order copy (1: strip order) -- the log-weights passes want the context's local
+ * segment count (one contiguous window of the copy is read at any moment), the forces passes 1; the copy is moved when the
+ * other method starts on the context (relayouts counts the moves; results never depend on the layout).
+ * BIOEN_HIP_STRIP_INTERLEAVE=0: strip order always (A/B). */
+int bioen_hip_ctx_layout(const bioen_hip_ctx* ctx, int* one_copy, int* interleave, int* relayouts);
 /* r05: ask for (1) / give up (0) the ONE-copy form described above; to be called before the context's first gradient
  * evaluation (BIOEN_HIP_ESTATE once the column-sum order copy exists).  Beyond 1024 rows it serves both methods: one set
  * of row panels instead of two. */

@@ -3,6 +3,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -294,3 +295,35 @@ def test_bench_passes_a_ranks_failure_on(tmp_path):
 def test_bench_refuses_a_label_that_is_not_the_rank_count(tmp_path):
     p, ranks = _bench_copy(tmp_path, ["--gpus", "4"], FAKE_NDEV=8, WORLD_SIZE=2, RANK=0)
     assert p.returncode == 5 and "refusing to run under a wrong label" in p.stderr
+
+
+def test_check_common_form_warns_when_one_rank_fell_back_alone():
+    """a rank that takes the one-copy form by itself leaves the bit-identity across GPU counts -- the sharded
+    drivers compare the form over the ranks (sweep.check_common_form)."""
+    import warnings
+    from bioen_amd import sweep
+
+    class Ctx(object):
+        def __init__(self, one):
+            self.one = one
+
+        def layout(self):
+            return {"one_copy": self.one, "interleave": 1, "relayouts": 0}
+
+    class Comm(object):
+        world = 4
+
+        def __init__(self, forms):
+            self.forms = forms
+
+        def allgather_object(self, obj):
+            return list(self.forms)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert sweep.check_common_form(Ctx(0), Comm([0, 0, 0, 0])) == {"one_copy": [0, 0, 0, 0], "common": True}
+        assert sweep.check_common_form(Ctx(1), Comm([1, 1, 1, 1]))["common"]
+        assert sweep.check_common_form(Ctx(1), None) == {"one_copy": [1], "common": True}
+    with pytest.warns(RuntimeWarning, match="ranks \\[2\\]"):
+        out = sweep.check_common_form(Ctx(0), Comm([0, 0, 1, 0]))
+    assert out == {"one_copy": [0, 0, 1, 0], "common": False}

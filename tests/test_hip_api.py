@@ -817,6 +817,63 @@ def test_log_weights_on_one_strip_copy(M, N, monkeypatch):
     assert np.isfinite(ig.fmin) and abs(wg.sum() - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("M,N", [(37, 1000), (205, 20000), (512, 3000), (1024, 5000), (1100, 1500)])
+def test_strip_layout_follows_the_method_and_changes_no_bit(M, N, monkeypatch):
+    """r06: the row-sum order strip copy holds the local segments' strips INTERLEAVED for the log-weights passes (one
+    contiguous window of the copy is read at any moment, kernels_strip.hip: strip_phys) and in strip order for the forces
+    passes; a context that changes method moves the copy.  Which layout served a call must not show in any bit: objective,
+    gradient, capped batches of both methods, the matrix read back -- against a context that never interleaves
+    (BIOEN_HIP_STRIP_INTERLEAVE=0, the r05 layout) and across the moves."""
+    import bioen_amd
+    from conftest import LBFGS_DEFAULTS
+    rng = np.random.default_rng(5 * M + 3)
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    g = G + 0.2 * rng.standard_normal(N)
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    f0 = 1e-3 * rng.standard_normal(M)
+    thetas = [100.0, 10.0, 1.0, 0.3, 30.0, 3.0]
+    params = dict(LBFGS_DEFAULTS, max_iterations=8)
+
+    def run(ctx, order):
+        out = {}
+        for what in order:
+            if what == "logw":
+                out["logw"] = (ctx.logw_fdf(g, G, 5.0), ctx.opt_lbfgs_logw_batch(thetas, g, G, params))
+                out["layout_logw"] = ctx.layout()
+            else:
+                out["forces"] = (ctx.forces_fdf(f0, w0, 5.0), ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params))
+                out["layout_forces"] = ctx.layout()
+            assert np.array_equal(ctx.read_ytilde(), y)              # the caller's numbers, whichever layout holds them
+        return out
+
+    def same(a, b):
+        (fa, ga), (xa, wa, ia) = a
+        (fb, gb), (xb, wb, ib) = b
+        assert fa == fb and np.array_equal(ga, gb)
+        for k in range(len(thetas)):
+            assert np.array_equal(xa[k], xb[k]) and np.array_equal(wa[k], wb[k])
+            assert (ia[k].fmin, ia[k].iterations, ia[k].evaluations, ia[k].lbfgs_code) == \
+                   (ib[k].fmin, ib[k].iterations, ib[k].evaluations, ib[k].lbfgs_code)
+
+    with bioen_amd.Context(y, YT) as ctx:
+        a = run(ctx, ["logw", "forces", "logw"])
+        assert a["layout_logw"]["interleave"] == 8                  # one GPU holds the eight canonical segments
+        if M <= 1024:                                                # (beyond: the forces method runs the log-weights kernels on row panels)
+            assert a["layout_forces"]["interleave"] == 1 and a["layout_logw"]["relayouts"] == 2
+    with bioen_amd.Context(y, YT) as ctx:
+        b = run(ctx, ["forces", "logw"])
+    monkeypatch.setenv("BIOEN_HIP_STRIP_INTERLEAVE", "0")
+    with bioen_amd.Context(y, YT) as ctx:
+        c = run(ctx, ["logw", "forces"])
+        assert c["layout_logw"] == {"one_copy": 0, "interleave": 1, "relayouts": 0}
+    for other in (b, c):
+        same(a["logw"], other["logw"])
+        same(a["forces"], other["forces"])
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_uploads_through_the_staging_buffer_change_nothing(world, monkeypatch):
     """api.hip: h2d_staged -- the path uploads of a caller's buffers take when the runtime refuses to pin them (ROCm 7.2: a

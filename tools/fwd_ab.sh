@@ -1,11 +1,12 @@
 set -e
-mkdir -p gpurun_out/r06_fwd_ab
-for rep in 1 2; do
-for v in default fwddiag1 fwddiag2 fwddiag3; do
-  if [ $v = default ]; then unset BIOEN_HIP_LIBRARY; else export BIOEN_HIP_LIBRARY=$PWD/build/libbioen_$v.so; fi
-  timeout -k 10 200 python3 tools/pass_probe.py 1024 1000000 30 >> gpurun_out/r06_fwd_ab/$v.json
-done
-unset BIOEN_HIP_LIBRARY
-BIOEN_HIP_STRIP_FOLD=0 timeout -k 10 200 python3 tools/pass_probe.py 1024 1000000 30 >> gpurun_out/r06_fwd_ab/default_nofold.json
-done
-cat gpurun_out/r06_fwd_ab/*.json
+mkdir -p gpurun_out/r06_ilv2
+timeout -k 10 300 python3 tools/strip_probe.py > gpurun_out/r06_ilv2/forces.json
+FORCES_M=1024 timeout -k 10 300 python3 tools/strip_probe.py > gpurun_out/r06_ilv2/forces1024.json
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r06_ilv2/forces*.json')):
+    for ln in open(f):
+        d=json.loads(ln)
+        print(f.split('/')[-1][:-5].ljust(16), ' '.join('K%s xy %.3f bt %.3f eq %s |'%(k,v['xy_ms'],v['bt_ms'],v['bitwise_equal_to_single']) for k,v in d['K'].items()))
+PY
+timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -8
