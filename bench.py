@@ -465,17 +465,20 @@ def cpu_matched(bioen_amd, thetas, seed, budget_iters_1t=60):
     return out
 
 
-def one_copy_record(bioen_amd, M, N, YTrue, sig_sim, sig_exp, YTilde, thetas, max_batch, base_results, base_sweep_s, base_stats):
-    """The same sweep with ONE strip copy of the matrix resident (BIOEN_HIP_ONE_COPY=1; r05): the forward pass as always,
-    the adjoint on the same row-sum order copy through the forces kernels' LDS image.  A side record -- never `value`: what
-    half the footprint costs in time, and that the results are the same minima (another order of the adjoint's sums over
-    rows: the plateau stop may fall a few iterations elsewhere)."""
+def one_copy_record(bioen_amd, M, N, YTrue, sig_sim, sig_exp, YTilde, thetas, max_batch, base_results, base_sweep_s, base_stats,
+                    base_one_copy):
+    """The same sweep in the OTHER strip-copy form (r06: a matrix above 1 GiB keeps ONE strip copy by default -- the adjoint
+    on the row-sum order copy through the forces kernels' LDS image; BIOEN_HIP_ONE_COPY=0 / 1 asks for two / one).  A side
+    record -- never `value`: what the second copy's 8.2 GB buy in time (nothing, within the run-to-run spread), and that
+    both forms stop at the same minima (another order of the adjoint's sums over rows: the plateau stop may fall a few
+    iterations elsewhere)."""
     from bioen_amd import sweep
-    os.environ["BIOEN_HIP_ONE_COPY"] = "1"
+    other = "0" if base_one_copy else "1"
+    os.environ["BIOEN_HIP_ONE_COPY"] = other
     try:
         with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=SEED) as ctx:
             G = np.zeros(N)
-            sweep.sweep_log_weights(ctx, thetas[:2], G, G, LBFGS_DEFAULTS, max_batch=max_batch)       # the copy, warm-up
+            sweep.sweep_log_weights(ctx, thetas[:2], G, G, LBFGS_DEFAULTS, max_batch=max_batch)       # the copies, warm-up
             ctx.kernel_stats_enable(True)
             ctx.kernel_stats_reset()
             ctx.synchronize()
@@ -489,15 +492,20 @@ def one_copy_record(bioen_amd, M, N, YTrue, sig_sim, sig_exp, YTilde, thetas, ma
         os.environ.pop("BIOEN_HIP_ONE_COPY", None)
     rounds = max(st["forward"]["launches"], 1)
     base_rounds = max(base_stats["forward"]["launches"], 1)
-    return {"note": "opt-in (BIOEN_HIP_ONE_COPY=1), and what a context falls back to when the second copy does not fit; not the graded path",
-            "resident": sorted(forms), "resident_bytes": nbytes, "default_resident_bytes": 2 * nbytes,
+    one_adj = "k_strip<K, nt, ADJ>" if M <= 512 else "k_strip2<K, nt, ADJ>"
+    return {"note": "the form that is NOT this matrix's default (BIOEN_HIP_ONE_COPY=%s); the headline runs on %s" %
+                    (other, "one strip copy" if base_one_copy else "two strip copies"),
+            "form": "one copy" if other == "1" else "two copies",
+            "resident": sorted(forms), "resident_bytes": nbytes,
+            "default_resident_bytes": nbytes // 2 if base_one_copy else 2 * nbytes,
             "sweep_s": dt, "default_sweep_s": base_sweep_s, "rounds": rounds, "default_rounds": base_rounds,
             "ms_per_round": 1e3 * dt / rounds, "default_ms_per_round": 1e3 * base_sweep_s / base_rounds,
             "iterations": int(sum(r["iterations"] for r in res)),
             "fwd_ms": st["forward"]["total_ms"] / rounds, "adj_ms": st["adjoint"]["total_ms"] / max(st["adjoint"]["launches"], 1),
             "default_fwd_ms": base_stats["forward"]["total_ms"] / base_rounds,
             "default_adj_ms": base_stats["adjoint"]["total_ms"] / max(base_stats["adjoint"]["launches"], 1),
-            "adjoint_kernel": "k_strip<K, nt, ADJ>" if M <= 512 else "k_strip2<K, nt, ADJ>",
+            "adjoint_kernel": one_adj if other == "1" else "k_strip_adj",
+            "default_adjoint_kernel": one_adj if base_one_copy else "k_strip_adj",
             "fmin_rel_diff_max_vs_default": max(abs(a["fmin"] - b["fmin"]) / abs(b["fmin"]) for a, b in zip(res, base_results))}
 
 
@@ -627,12 +635,20 @@ def forces_record(bioen_amd, thetas, seed, max_batch, with_cpu=True, with_split=
                            "fmin": i.fmin, "chi2": i.chi2, "S": -i.kl, "seconds": i.seconds} for t, i in zip(thetas, infos)]}
 
 
-def forces_failed_thetas(bioen_amd, ctx, M, N, YTilde, thetas, results):
+def forces_failed_thetas(bioen_amd, ctx, M, N, YTilde, thetas, results, seconds=60.0):
     """The thetas of configs[4]'s series whose runs end outside liblbfgs' success codes (-998: the line search has used
-    its max_linesearch trials; at large theta the start is the optimum to rounding) -- like for like against the
-    reference's own _opt_lbfgs_forces (c_bioen_kernels_forces.c:574-662, lbfgs.c:645-734) on the SAME full matrix
-    (read back from HBM; the reference builds its transposed cache per call): status and fmin of both.  Is the ending
-    the reference's behaviour on this problem, or the device's own?"""
+    its max_linesearch trials) -- like for like against the reference's own _opt_lbfgs_forces
+    (c_bioen_kernels_forces.c:574-662, lbfgs.c:645-734) on the SAME full matrix (read back from HBM; the reference builds
+    its transposed cache per call), in BOTH of its summation modes (fast_openmp 1 / 0, c_bioen_common.c:46-55) while
+    `seconds` last: status and fmin of all three.
+
+    r06 finding (tools/forces_status_probe.py -> profiles/r06_forces_status_probe_full.txt; the reference's spread on a
+    configs[4]-shaped problem in tests/golden/forces_status_cfg4_M512xN100000.json): at large theta these runs end where
+    the decrease the line search still asks for (1/2 g^2 / (theta var) ~ 1e-15) lies below the rounding noise of the
+    objective (f ~ 250: ~5e-13), so 0 (the gradient test met by a last lucky step) or -998 is decided by rounding -- the
+    reference's own status changes with its summation mode, its thread count and from run to run; liblbfgs' own binary
+    driven by the DEVICE's objective and gradient (100 x closer to the 80-bit values than the reference's) flips the same
+    way.  Equal minima, not equal statuses, are what the two sides can be held to here."""
     from oracle import ref_binding as R
     from oracle import cpus
     if not thetas or not R.available():
@@ -644,22 +660,41 @@ def forces_failed_thetas(bioen_amd, ctx, M, N, YTilde, thetas, results):
         avail = 0
     if avail < 1.3 * need:
         return {"skipped": "host memory: %.1f GB free, %.1f GB needed" % (avail / 1e9, 1.3 * need / 1e9)}
-    R.set_fast_openmp_flag(1)
-    R.omp_set_num_threads(cpus.usable_cpus())
+    cores = cpus.usable_cpus()
+    R.omp_set_num_threads(cores)
     yT = ctx.read_ytilde()
     w0 = np.full(N, 1.0 / N)
-    out = {"sample": "the full %d x %d matrix, forces_init = 0, yaml-default liblbfgs, %d OpenMP threads" % (M, N, cpus.usable_cpus()),
+    out = {"sample": "the full %d x %d matrix, forces_init = 0, yaml-default liblbfgs, %d OpenMP threads, fast_openmp = 1 "
+                     "and (while %.0f s last) 0" % (M, N, cores, seconds),
+           "evidence": ["profiles/r06_forces_status_probe_full.txt", "tests/golden/forces_status_cfg4_M512xN100000.json"],
            "per_theta": []}
+    t_all = time.perf_counter()
+    floor_codes = (0, -998, -1000, -1001)       # converged | the line search's three ways of giving up at the rounding floor
     for th in thetas:
-        t0 = time.perf_counter()
-        _, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, yT, YTilde, th, LBFGS_DEFAULTS)
         dev = results[th]
-        out["per_theta"].append({"theta": th, "reference_code": int(code_ref), "device_code": int(dev.lbfgs_code),
-                                 "reference_fmin": float(fmin_ref), "device_fmin": float(dev.fmin),
-                                 "fmin_rel_diff": abs(dev.fmin - fmin_ref) / abs(fmin_ref),
-                                 "device_iterations": dev.iterations, "device_evaluations": dev.evaluations,
-                                 "reference_seconds": time.perf_counter() - t0})
+        rec = {"theta": th, "device_code": int(dev.lbfgs_code), "device_fmin": float(dev.fmin),
+               "device_iterations": dev.iterations, "device_evaluations": dev.evaluations, "reference": []}
+        for flag in (1, 0):
+            if flag == 0 and time.perf_counter() - t_all > seconds:
+                break
+            R.set_fast_openmp_flag(flag)
+            t0 = time.perf_counter()
+            _, fmin_ref, code_ref = R.opt_lbfgs_forces(np.zeros(M), w0, yT, YTilde, th, LBFGS_DEFAULTS)
+            rec["reference"].append({"fast_openmp": flag, "code": int(code_ref), "fmin": float(fmin_ref),
+                                     "seconds": time.perf_counter() - t0})
+        R.set_fast_openmp_flag(1)
+        rec["reference_code"] = rec["reference"][0]["code"]
+        rec["reference_fmin"] = rec["reference"][0]["fmin"]
+        rec["fmin_rel_diff"] = max(abs(dev.fmin - r["fmin"]) / abs(r["fmin"]) for r in rec["reference"])
+        codes = {r["code"] for r in rec["reference"]}
+        rec["status_in_reference_spread"] = int(dev.lbfgs_code) in codes
+        rec["rounding_floor_ending"] = bool((codes | {int(dev.lbfgs_code)}) <= set(floor_codes) and rec["fmin_rel_diff"] <= 1e-12)
+        out["per_theta"].append(rec)
     out["same_status_everywhere"] = all(r["reference_code"] == r["device_code"] for r in out["per_theta"])
+    out["status_in_reference_spread_everywhere"] = all(r["status_in_reference_spread"] for r in out["per_theta"])
+    out["same_minimum_everywhere"] = all(r["fmin_rel_diff"] <= 1e-12 for r in out["per_theta"])
+    out["every_difference_at_the_rounding_floor"] = all(r["rounding_floor_ending"] for r in out["per_theta"]
+                                                        if r["reference_code"] != r["device_code"])
     return out
 
 
@@ -708,7 +743,7 @@ def deer_inputs(N, seed, sigma=0.01):
     return Ft, z["signal"] / sigma, np.full(M, 1.0 / sigma)
 
 
-def deer_record(bioen_amd, seed):
+def deer_record(bioen_amd, seed, with_cpu=True):
     """BASELINE configs[3] on one GPU: DEER refinement with a modulation-depth nuisance parameter, N = 5e5 rotamers
     x M = 205 time points of the measured trace exp-370-292 (y~(m) = 1/sigma + m (F - 1)/sigma, F the Fresnel
     form of the reference's rotamer example).  The m-independent matrix (F - 1)/sigma is resident; per theta the
@@ -727,20 +762,97 @@ def deer_record(bioen_amd, seed):
     thetas, iterations = [100.0, 10.0, 1.0], 10
     with bioen_amd.Context(Ft, YT) as ctx:
         nuisance.series(ctx, thetas[:1], G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=1)      # warm-up, builds the strip copies
+        ctx.kernel_stats_enable(True)
+        ctx.kernel_stats_reset()
         ctx.synchronize()
         t0 = time.perf_counter()
         res = nuisance.series(ctx, thetas, G, G, LBFGS_DEFAULTS, YT, row_offset=off, scale0=m0, iterations=iterations)
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        stats = ctx.kernel_stats()
+        ctx.kernel_stats_enable(False)
+        try:
+            ceil_gbs = ctx.read_probe(reps=10)[0]
+        except Exception:
+            ceil_gbs = None
     its = int(sum(sum(x["iterations"] for x in r["trace"]) for r in res))
     evs = int(sum(sum(x["evaluations"] for x in r["trace"]) for r in res))
-    return {"workload": "DEER rotamer refinement, N=%d x M=%d (trace exp-370-292, Fresnel kernel), thetas %s, %d optimise/refit "
+    # roofline of the matrix kernels at M = 205 (one problem per launch: the series runs theta by theta): algorithmic bytes
+    # of a launch = the matrix once + one N-vector and one M-vector in, one out, as at the headline
+    kern = {}
+    for name, kname in (("forward", "k_strip_fwd"), ("adjoint", "k_strip_adj")):
+        st = stats[name]
+        launches = max(st["launches"], 1)
+        avg_ms = st["total_ms"] / launches
+        avg_k = st["problem_passes"] / launches
+        alg = float(M) * N * 8 + avg_k * (8.0 * N + 8.0 * M)
+        kern[name] = {"kernel": kname, "launches": st["launches"], "avg_ms": avg_ms, "avg_batch_width": avg_k,
+                      "algorithmic_bytes": alg, "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
+    dom = max(kern, key=lambda k: kern[k]["avg_ms"])
+    roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "kernels": kern,
+                "note": "M = 205 is stored as 208 rows per strip (the 16-row operand block): 1.5 % more bytes are read than "
+                        "the algorithmic count credits",
+                "read_ceiling_GBs": ceil_gbs}
+    cpu = None
+    if with_cpu:
+        try:
+            cpu = deer_cpu_baseline(Ft, YT, off, m0)
+        except Exception as e:
+            cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
+    return {"roofline": roofline, "cpu_baseline": cpu, "workload": "DEER rotamer refinement, N=%d x M=%d (trace exp-370-292, Fresnel kernel), thetas %s, %d optimise/refit "
                         "iterations each (cold-started weights, modulation depth carried over), yaml-default liblbfgs, "
                         "modulation depth refitted on the resident matrix" % (N, M, thetas, iterations),
             "seconds": dt, "iterations": its, "evaluations": evs, "value": its * float(N) * M / dt, "unit": "iter*N*M/s",
             "refits": len(thetas) * iterations, "moddepth_start": m0, "input_synthesis_s": t_inputs,
             "moddepth_fit": [r["scales"][0] for r in res], "fmin": [r["fmin"] for r in res],
             "chi2": [r["chi2"] for r in res]}
+
+
+def deer_cpu_baseline(Ft, YT, off, m0, cols=131072, theta=10.0, iterations=2, cap=60):
+    """configs[3]'s protocol the way the reference runs it (observables.py:110-171, 205-210; procedure.py:62-83), on a
+    BOUNDED sample: the first `cols` rotamers, one theta, `iterations` optimise/refit rounds -- every round REBUILDS
+    yTilde(m) = 1/sigma + m (F - 1)/sigma on the host, runs the reference's own _opt_lbfgs_logw (oracle/_ref; capped at
+    `cap` iterations) on it with its transposed cache built per call (c_bioen.pyx:471-473), and refits m on chi^2 from a
+    host GEMV.  value = L-BFGS iterations * cols * M / wall, rebuilds and refits included."""
+    from oracle import ref_binding as R
+    from oracle import cpus
+    from bioen_amd import nuisance
+    if not R.available():
+        return None
+    cores = cpus.usable_cpus()
+    R.set_fast_openmp_flag(1)
+    R.omp_set_num_threads(cores)
+    F = np.ascontiguousarray(Ft[:, :cols])
+    M, n = F.shape
+    G = np.zeros(n)
+    params = dict(LBFGS_DEFAULTS, max_iterations=cap)
+    R.logw_f(G, G, F, YT, theta)                      # thread pool up
+    m, its, t_rebuild, t_opt, uncounted = m0, 0, 0.0, 0.0, []
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        t1 = time.perf_counter()
+        explicit = off[:, None] + m * F               # the host rebuild of yTilde(m)
+        t_rebuild += time.perf_counter() - t1
+        t1 = time.perf_counter()
+        g, fmin, code = R.opt_lbfgs_logw(G, G, explicit, YT, theta, params)
+        t_opt += time.perf_counter() - t1
+        # (the reference's driver counts its iterations in a C global it does not return: -997 <=> the cap was reached, else
+        # the restatement's count on the same inputs, untimed -- as cpu_baseline above)
+        uncounted.append(None if code == -997 else explicit)
+        its += cap if code == -997 else 0
+        w = R.get_weights(g)[0]
+        m = float(nuisance.refit_scales(F.dot(w), YT, off, [np.arange(M)])[0])
+    dt = time.perf_counter() - t0
+    for explicit in uncounted:
+        if explicit is not None:
+            from oracle import oracle_binding as O
+            its += O.opt_lbfgs_logw(G, G, explicit, YT, theta, params)[3]
+    return {"value": its * float(n) * M / dt, "unit": "iter*N*M/s", "cores": cores, "kind": "reference",
+            "sample": "first %d of the rotamers x M=%d, theta=%g, %d optimise/refit rounds of at most %d L-BFGS iterations each "
+                      "(%d in all), host rebuild of yTilde(m) every round: %.2f s (rebuilds %.2f s, _opt_lbfgs_logw %.2f s)"
+                      % (n, M, theta, iterations, cap, its, dt, t_rebuild, t_opt),
+            "seconds": dt, "iterations": its, "moddepth_fit": m}
 
 
 ALA5_LBFGS = dict(linesearch=2, max_iterations=20000, delta=1e-6, epsilon=1e-5, ftol=1e-4, gtol=0.9, wolfe=0.9, past=10,
@@ -957,6 +1069,44 @@ def choose_transport(ctx, comm, sweep, nshard, transport, count, xinfo, HipError
         if isinstance(xinfo[k], float) and not np.isfinite(xinfo[k]):
             xinfo[k] = None
     return gather, rccl
+
+
+class WallBudget(object):
+    """Wall budget of bench.py's side records (r06): `seconds` from its creation; `reserve` = what the records that are
+    never dropped still need.  take(name, estimate) -> may this droppable record still run; timed(name) times one;
+    report() -> what ran for how long and what was left out."""
+
+    def __init__(self, seconds, reserve=0.0, clock=time.perf_counter):
+        self.clock, self.t0, self.seconds, self.reserve = clock, clock(), float(seconds), float(reserve)
+        self.spent, self.dropped = {}, []
+
+    def left(self):
+        return self.seconds - (self.clock() - self.t0)
+
+    def take(self, name, estimate):
+        if self.left() - self.reserve < estimate:
+            self.dropped.append(name)
+            return False
+        return True
+
+    def skipped(self, estimate):
+        return {"skipped": "budget", "estimate_s": estimate, "budget_left_s": round(self.left(), 1), "reserved_s": round(self.reserve, 1)}
+
+    def timed(self, name):
+        budget = self
+
+        class _T(object):
+            def __enter__(self_):
+                self_.t = budget.clock()
+
+            def __exit__(self_, *exc):
+                budget.spent[name] = round(budget.spent.get(name, 0.0) + budget.clock() - self_.t, 2)
+                return False
+        return _T()
+
+    def report(self):
+        return {"budget_s": self.seconds, "used_s": round(self.clock() - self.t0, 1), "seconds": dict(self.spent),
+                "skipped_for_budget": list(self.dropped)}
 
 
 def visible_devices(python=None, root=ROOT, timeout=180.0):
@@ -1245,6 +1395,7 @@ def main():
     stats = ctx.kernel_stats()
     ctx.kernel_stats_enable(False)
     ctx_layout = ctx.layout()
+    resident_forms, resident_bytes = ctx.footprint()        # (r06: one strip copy of a matrix above 1 GiB -- 8.2 GB at the headline, not 16.4)
 
     # r05: the final (S, chi^2, weights) per theta once more through ONE RCCL all-gather over all ranks -- in a
     # structure-sharded run the cross-rank consistency check (every rank must hold the same bytes), after the timed region;
@@ -1291,8 +1442,9 @@ def main():
                 kname = "%s<K, nt, %s>" % ("k_strip" if M <= 512 else "k_strip2", "true" if name == "adjoint" else "false") if M <= 1024 else \
                         ("k_adj + k_fwd_partial" if name == "adjoint" else "k_fwd_partial")
             else:
+                one_adj = "k_strip" if M <= 512 else "k_strip2"          # the one-copy adjoint: the forces kernels' ADJ form
                 kname = ("k_strip_fwd" if strip else "k_fwd_partial") if name == "forward" else \
-                        ("k_strip_adj" if strip else "k_adj")
+                        ((one_adj if ctx_layout["one_copy"] else "k_strip_adj") if strip else "k_adj")
             kern[name] = {"kernel": kname,
                           "launches": s["launches"], "avg_ms": avg_ms, "avg_batch_width": avg_k,
                           "algorithmic_bytes": alg,
@@ -1323,110 +1475,156 @@ def main():
         except Exception as e:
             roofline["read_ceiling"] = {"error": repr(e)}
 
+        # ---- side records, under a wall budget (r06) -------------------------------------------------------------
+        # Everything below is reported BESIDE the headline; the driver's clock runs on.  `--budget` seconds (default 240)
+        # from here: the records run in priority order and one that no longer fits -- by its estimate, with the time the
+        # never-dropped ones still need held back -- is left out with "skipped": "budget".  Never dropped: cpu_baseline
+        # (the bounded sample) and roofline.traffic (the live counter passes).
+        budget = WallBudget(args.budget, reserve=0.0)
+        single = world == 1
+        want_pmc = single and not args.no_pmc and M <= 1024
+        budget.reserve = (20.0 if want_pmc else 0.0) + (25.0 if single and not args.no_cpu_baseline else 0.0)
+        stats_per_sweep = {k: {kk: vv / max(args.steps, 1) for kk, vv in stats[k].items()} for k in stats}
+
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                if forces_mode:
-                    cpu = cpu_baseline_forces(ctx, M, N, YTilde, 10.0, min(args.cpu_cols, 262144), 40)
-                else:
-                    cpu = cpu_baseline(ctx, M, N, YTilde, 10.0, args.cpu_cols, args.cpu_iters)
-            except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
-                cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
-            if cpu is not None and not forces_mode and not args.no_cpu_fullsize and N * float(M) >= 5e8:
-                try:     # the same CONFIG on the CPU, not a sample: the two cheapest thetas of the series
-                    cheap = sorted(results, key=lambda r: r["evaluations"])[:2]
-                    # the mid-series thetas nearest 31.6 first (the cheap ones above excluded)
-                    mids = [] if args.no_cpu_mid else sorted((r["theta"] for r in results if r not in cheap and 2.0 < r["theta"] < 60.0),
-                                                           key=lambda t: abs(np.log(t / 31.6)))
-                    cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap], mid_thetas=mids)
-                except Exception as e:
-                    cpu["full_size"] = {"error": repr(e)}
+        if single and not args.no_cpu_baseline:
+            with budget.timed("cpu_baseline"):
+                try:
+                    if forces_mode:
+                        cpu = cpu_baseline_forces(ctx, M, N, YTilde, 10.0, min(args.cpu_cols, 262144), 40)
+                    else:
+                        cpu = cpu_baseline(ctx, M, N, YTilde, 10.0, args.cpu_cols, args.cpu_iters)
+                except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+                    cpu = {"value": None, "unit": "iter*N*M/s", "cores": 0, "kind": "error", "sample": repr(e)}
+            budget.reserve -= 25.0
 
-        api = None
-        host_matrix = None
-        if world == 1 and not forces_mode and not args.no_api:
-            try:      # the headline matrix on the host, as a caller of the Python API holds it (read back: the same numbers)
-                host_matrix = ctx.read_ytilde()
-            except Exception as e:
-                api = {"error": repr(e)}
-        storage = None
-        if world == 1 and not forces_mode and M <= 1024 and not args.no_storage_experiment:
-            try:
-                sweep_s = dt / max(args.steps, 1)
-                storage = storage_record(ctx, thetas, G, g0, args.max_batch, results,
-                                         {k: {kk: vv / max(args.steps, 1) for kk, vv in stats[k].items()} for k in stats})
-                storage["f64"]["sweep_s"] = sweep_s
-                storage["f64"]["ms_per_round"] = 1e3 * sweep_s / max(storage["f64"]["rounds"], 1)
-            except Exception as e:
-                storage = {"error": repr(e)}
-
-        one_copy = None
-        if world == 1 and not forces_mode and M <= 1024 and not args.no_one_copy:
-            try:
-                one_copy = one_copy_record(bioen_amd, M, N, YTrue, sig_sim, sig_exp, YTilde, thetas, args.max_batch, results, dt / max(args.steps, 1),
-                                           {k: {kk: vv / max(args.steps, 1) for kk, vv in stats[k].items()} for k in stats})
-            except Exception as e:
-                one_copy = {"error": repr(e)}
-
-        forces = None
-        if world == 1 and not args.no_forces and not forces_mode:
-            ctx.close()              # 8 GB back before the second workload (closed again below: idempotent)
-            try:
-                forces = forces_record(bioen_amd, thetas, SEED, args.max_batch, with_cpu=not args.no_cpu_baseline,
-                                        with_split=not args.no_storage_experiment)
-                tj_f = None
-                if os.path.isfile(tpath):
-                    with open(tpath) as fp:
-                        tj_f = json.load(fp)
-                if tj_f and tj_f.get("_source_sha") == kernel_source_sha():
-                    forces["roofline"]["traffic"] = tj_f.get("k_strip_N1000000_M512")
-            except Exception as e:
-                forces = {"error": repr(e)}
-        if host_matrix is not None:
-            ctx.close()
-            try:
-                api = {"headline": api_record(bioen_amd, host_matrix, YTilde, thetas, "BASELINE configs[2]", False)}
-                del host_matrix
-                y1, Y1 = survey_inputs(256, 100000)
-                api["configs1"] = api_record(bioen_amd, y1, Y1, thetas, "BASELINE configs[1] (SURVEY 8(d)'s numpy stream)", True)
-                del y1
-                api["kernel_only_sweep_s"] = dt / max(args.steps, 1)
-            except Exception as e:
-                api = dict(api or {}, error=repr(e))
-        deer = None
-        if world == 1 and not args.no_deer and not args.no_forces and not forces_mode:
-            try:
-                deer = deer_record(bioen_amd, SEED)
-            except Exception as e:
-                deer = {"error": repr(e)}
-        ala5 = None
-        if world == 1 and not args.no_ala5 and not args.no_forces and not forces_mode:
-            try:
-                ala5 = ala5_record(bioen_amd, SEED, with_cpu=not args.no_cpu_baseline)
-            except Exception as e:
-                ala5 = {"error": repr(e)}
-        if cpu is not None and world == 1 and not args.no_matched and not args.no_cpu_baseline and not forces_mode:
-            try:
-                cpu["matched_sweep"] = cpu_matched(bioen_amd, thetas, SEED)
-                if cpu["matched_sweep"] and "single_thread" in cpu["matched_sweep"]:
-                    cpu["single_thread"] = cpu["matched_sweep"].pop("single_thread")
-            except Exception as e:
-                cpu["matched_sweep"] = {"error": repr(e)}
-
-        if world == 1 and not args.no_pmc and M <= 1024:
-            # roofline.traffic from counters read on THIS box, in this run (the committed profiles/traffic.json stays the
-            # fallback): child processes, after every context of this one is closed
-            ctx.close()
-            base = roofline["kernel"].split("<")[0]
-            t_live, src = live_traffic(args.method, M, N, base)
-            if t_live is not None:
-                roofline["traffic"], roofline["traffic_source"] = t_live, src
+        forces = None                    # priority 1: configs[4]
+        if single and not args.no_forces and not forces_mode:
+            if budget.take("forces", 60.0):
+                with budget.timed("forces"):
+                    try:
+                        forces = forces_record(bioen_amd, thetas, SEED, args.max_batch, with_cpu=not args.no_cpu_baseline,
+                                                with_split=not args.no_storage_experiment and budget.left() - budget.reserve > 120.0)
+                        tj_f = None
+                        if os.path.isfile(tpath):
+                            with open(tpath) as fp:
+                                tj_f = json.load(fp)
+                        if tj_f and tj_f.get("_source_sha") == kernel_source_sha():
+                            forces["roofline"]["traffic"] = tj_f.get("k_strip_N1000000_M512")
+                    except Exception as e:
+                        forces = {"error": repr(e)}
             else:
-                roofline["traffic_live_error"] = src
-            if forces and "roofline" in forces:
-                t_live, src = live_traffic("forces", 512, 1000000, "k_strip")
+                forces = budget.skipped(60.0)
+
+        deer = None                      # priority 2: configs[3]
+        if single and not args.no_deer and not args.no_forces and not forces_mode:
+            if budget.take("deer", 15.0):
+                with budget.timed("deer"):
+                    try:
+                        deer = deer_record(bioen_amd, SEED, with_cpu=not args.no_cpu_baseline)
+                    except Exception as e:
+                        deer = {"error": repr(e)}
+            else:
+                deer = budget.skipped(15.0)
+
+        if cpu is not None and single and not args.no_matched and not args.no_cpu_baseline and not forces_mode:
+            if budget.take("matched_sweep", 45.0):          # priority 3: configs[1], numpy's stream to the letter, against the reference
+                with budget.timed("matched_sweep"):
+                    try:
+                        cpu["matched_sweep"] = cpu_matched(bioen_amd, thetas, SEED)
+                        if cpu["matched_sweep"] and "single_thread" in cpu["matched_sweep"]:
+                            cpu["single_thread"] = cpu["matched_sweep"].pop("single_thread")
+                    except Exception as e:
+                        cpu["matched_sweep"] = {"error": repr(e)}
+            else:
+                cpu["matched_sweep"] = budget.skipped(45.0)
+
+        if cpu is not None and single and not forces_mode and not args.no_cpu_fullsize and N * float(M) >= 5e8:
+            if budget.take("cpu_full_size", 60.0):          # priority 4: the same CONFIG on the CPU, not a sample
+                with budget.timed("cpu_full_size"):
+                    try:     # the two cheapest thetas of the series; then, while the budget lasts, a mid-series one
+                        cheap = sorted(results, key=lambda r: r["evaluations"])[:2]
+                        # the mid-series thetas nearest 31.6 first (the cheap ones above excluded)
+                        mids = [] if args.no_cpu_mid else sorted((r["theta"] for r in results if r not in cheap and 2.0 < r["theta"] < 60.0),
+                                                               key=lambda t: abs(np.log(t / 31.6)))
+                        mid_budget = max(0.0, min(170.0, budget.left() - budget.reserve - 60.0 - 45.0))     # (after the cheap thetas; the records below keep 45 s)
+                        cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap], mid_thetas=mids,
+                                                        mid_budget_s=mid_budget)
+                    except Exception as e:
+                        cpu["full_size"] = {"error": repr(e)}
+            else:
+                cpu["full_size"] = budget.skipped(60.0)
+
+        api = None                       # priority 5: the kept Python API on a host matrix, upload included
+        if single and not forces_mode and not args.no_api:
+            if budget.take("api_end_to_end", 20.0):
+                with budget.timed("api_end_to_end"):
+                    try:      # the headline matrix on the host, as a caller of the Python API holds it (read back: the same numbers)
+                        host_matrix = ctx.read_ytilde()
+                        api = {"headline": api_record(bioen_amd, host_matrix, YTilde, thetas, "BASELINE configs[2]", False)}
+                        del host_matrix
+                        y1, Y1 = survey_inputs(256, 100000)
+                        api["configs1"] = api_record(bioen_amd, y1, Y1, thetas, "BASELINE configs[1] (SURVEY 8(d)'s numpy stream)", True)
+                        del y1
+                        api["kernel_only_sweep_s"] = dt / max(args.steps, 1)
+                    except Exception as e:
+                        api = dict(api or {}, error=repr(e))
+            else:
+                api = budget.skipped(20.0)
+
+        one_copy = None                  # priority 6
+        if single and not forces_mode and M <= 1024 and not args.no_one_copy:
+            if budget.take("one_copy", 5.0):
+                with budget.timed("one_copy"):
+                    try:
+                        one_copy = one_copy_record(bioen_amd, M, N, YTrue, sig_sim, sig_exp, YTilde, thetas, args.max_batch, results,
+                                                   dt / max(args.steps, 1), stats_per_sweep, bool(ctx_layout["one_copy"]))
+                    except Exception as e:
+                        one_copy = {"error": repr(e)}
+            else:
+                one_copy = budget.skipped(5.0)
+
+        storage = None                   # priority 7: the reduced-byte storage experiment
+        if single and not forces_mode and M <= 1024 and not args.no_storage_experiment:
+            if budget.take("storage_experiment", 12.0):
+                with budget.timed("storage_experiment"):
+                    try:
+                        sweep_s = dt / max(args.steps, 1)
+                        storage = storage_record(ctx, thetas, G, g0, args.max_batch, results, stats_per_sweep)
+                        storage["f64"]["sweep_s"] = sweep_s
+                        storage["f64"]["ms_per_round"] = 1e3 * sweep_s / max(storage["f64"]["rounds"], 1)
+                    except Exception as e:
+                        storage = {"error": repr(e)}
+            else:
+                storage = budget.skipped(12.0)
+
+        ala5 = None                      # priority 8
+        if single and not args.no_ala5 and not args.no_forces and not forces_mode:
+            if budget.take("ala5", 5.0):
+                with budget.timed("ala5"):
+                    try:
+                        ala5 = ala5_record(bioen_amd, SEED, with_cpu=not args.no_cpu_baseline)
+                    except Exception as e:
+                        ala5 = {"error": repr(e)}
+            else:
+                ala5 = budget.skipped(5.0)
+
+        if want_pmc:
+            # roofline.traffic from counters read on THIS box, in this run (the committed profiles/traffic.json stays the
+            # fallback): child processes, after every context of this one is closed.  Never dropped.
+            budget.reserve = 0.0
+            ctx.close()
+            with budget.timed("roofline_traffic"):
+                base = roofline["kernel"].split("<")[0]
+                t_live, src = live_traffic(args.method, M, N, base)
                 if t_live is not None:
-                    forces["roofline"]["traffic"], forces["roofline"]["traffic_source"] = t_live, src
+                    roofline["traffic"], roofline["traffic_source"] = t_live, src
+                else:
+                    roofline["traffic_live_error"] = src
+                if forces and "roofline" in forces and budget.left() > 25.0:
+                    t_live, src = live_traffic("forces", 512, 1000000, "k_strip")
+                    if t_live is not None:
+                        forces["roofline"]["traffic"], forces["roofline"]["traffic_source"] = t_live, src
 
         line = {
             "metric": "L-BFGS iterations/sec x (N structures * M observables), %s theta sweep"
@@ -1464,6 +1662,7 @@ def main():
                        "exchange_us_by_transport": {k[:-3]: xinfo[k] for k in ("p2p_us", "rccl_us", "host_us") if k in xinfo},
                        "decomposition": ("structures" if nshard else "thetas") if world > 1 else "single GPU",
                        "strip_copy_forms": forms, "strip_layout": ctx_layout,
+                       "resident": sorted(resident_forms), "resident_bytes": resident_bytes,
                        "devices_visible": ndev, "ranks_share_devices": bool(world > ndev),
                        "launched_by": "bench.py itself (subprocess ranks)" if os.environ.get("BIOEN_BENCH_LAUNCHED") == "1"
                                       else ("an outer launcher (torchrun environment)" if world > 1 else "single process"),
@@ -1477,6 +1676,7 @@ def main():
             "api_end_to_end": api,
             "deer": deer,
             "ala5": ala5,
+            "side_records": budget.report(),
             "sweep_wall_s": dt / max(args.steps, 1),
             "iterations_per_sweep": iters_per_sweep,
             "evaluations_per_sweep": evals_per_sweep,

@@ -187,6 +187,8 @@ def column_segments(n, world=1):
     structures then has ONE shape on 1, 2, 4 and 8 GPUs, and their results are bit-identical --, else world;
     segcols = ceil(n / nseg) rounded up to 128; a rank holds nseg / world consecutive segments."""
     nseg = 8 if (world <= 8 and 8 % world == 0) else world
+    if world == 1 and os.environ.get("BIOEN_HIP_SEGMENTS") == "1":      # the single-GPU opt-out (api.hip: segment_geometry)
+        nseg = 1
     segcols = (-(-n // nseg) + 127) // 128 * 128
     return nseg, segcols, segcols * (nseg // world)
 

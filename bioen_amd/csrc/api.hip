@@ -107,8 +107,16 @@ static int alloc_slot(bioen_hip_ctx* c, int s, bool with_history, bool with_spar
 
 // Canonical segments (ctx.hpp): nseg = 8 whenever `world` divides 8, else world; segcols = ceil(n / nseg) rounded up
 // to 128; rank r holds the vr = nseg / world segments [r vr, (r + 1) vr), i.e. the columns [r vr segcols, ...).
+// BIOEN_HIP_SEGMENTS=1 (r06, unsharded contexts only): ONE segment -- the opt-out from the canonical shape for a caller
+// who will never compare with a run on another number of GPUs: every sum over structures is then one tree over the whole
+// matrix, the forces passes write one partial set per block instead of eight (3-7 % of a pass, profiles/
+// r05_forces_ab_vs_r04.txt), the N-vector kernels one total instead of eight.  The results are those of ONE GPU only.
 static void segment_geometry(long long n_global, int world, int* nseg, int* vr, long long* segcols) {
     *nseg = (world <= kMaxSeg && kMaxSeg % world == 0) ? kMaxSeg : world;
+    if (world == 1) {
+        const char* e = std::getenv("BIOEN_HIP_SEGMENTS");
+        if (e && e[0] == '1' && e[1] == 0) *nseg = 1;
+    }
     *vr = *nseg / world;
     *segcols = (long long)round_up((size_t)((n_global + *nseg - 1) / *nseg), kColAlign);
 }
@@ -168,7 +176,7 @@ static int ctx_alloc(int m, long long n_global, int device, int rank, int world,
         const char* e = std::getenv("BIOEN_HIP_KEEP_ROWMAJOR");    // A/B: keep the row-major matrix beside the strip copies
         c->keep_rowmajor = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_ONE_COPY");         // log-weights on ONE strip copy (ctx.hpp: one_copy)
-        c->one_copy_wanted = (e && e[0] == '1') ? 1 : 0;
+        c->one_copy_wanted = (e && e[0] == '1') ? 1 : (e && e[0] == '0') ? 0 : -1;     // (-1: by size, kernels_strip.hip: one_copy_by_default)
         e = std::getenv("BIOEN_HIP_FWD_STREAM");       // A/B: the streaming forward kernel on the row-major matrix
         c->fwd_stream = (e && e[0] == '1') ? 1 : 0;
         e = std::getenv("BIOEN_HIP_PANELS");           // A/B: M > 1024 on the r01 streaming kernels instead of row panels

@@ -218,7 +218,7 @@ struct bioen_hip_ctx {
     // r05: the log-weights method on ONE strip copy (the row-sum order one; the adjoint through the forces kernels' LDS image,
     // kernels_strip.hip: k_strip<.., ADJ>): 1 x the matrix resident instead of 2 x.  wanted: BIOEN_HIP_ONE_COPY=1; taken
     // by itself when the column-sum order copy cannot be allocated.  M <= 1024, FP64 storage.
-    int one_copy = 0, one_copy_wanted = 0;
+    int one_copy = 0, one_copy_wanted = -1;      // wanted: 1 / 0 asked for / refused, -1 (r06 default): by the matrix's size -- ONE copy above 1 GiB
     int strip_ilv = 0;               // r06: segments interleaved in the row-sum order FP64 copies (kernels_strip.hip: strip_phys); 0: none built yet
     int strip_relayouts = 0;         // times the copies were moved to another method's layout
     int strip_allocs = 0;            // strip-copy allocations attempted on this context (tests: BIOEN_HIP_TEST_FAIL_STRIP_ALLOC=k fails the k-th)

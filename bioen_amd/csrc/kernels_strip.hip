@@ -311,16 +311,30 @@ __device__ __forceinline__ SlotWork strip_slot(const StripArgs& q, int ps) {
 // number i is strip (i / tg) sps + g + gs (i % tg), tg = the group's strips per segment.
 struct ForcesSlot {
     int g, tg, total, sps, gs;
+    int flat;           // > 1 (ADJ on an interleaved copy): the slot's strips are POSITIONS g, g + gs, ... of the copy
     __device__ __forceinline__ int strip(int i) const {
+        if (flat > 1) {                             // position p holds strip p / flat of local segment p % flat (strip_phys)
+            const int p = g + gs * i;
+            return (p % flat) * sps + p / flat;
+        }
         const int v = i / tg;
         return v * sps + g + gs * (i - v * tg);
     }
 };
-__device__ __forceinline__ ForcesSlot forces_slot(const StripArgs& q, int ps) {
+// adj: the column-sum form on the one-copy path -- no sum over strips, so any assignment of strips to blocks gives the same
+// bits; on a copy whose segments are interleaved (strip_phys) the blocks take the copy's positions in order, and at any
+// moment read one contiguous window of it instead of every ilv-th strip of a window ilv times as wide
+__device__ __forceinline__ ForcesSlot forces_slot(const StripArgs& q, int ps, bool adj = false) {
     ForcesSlot w;
     w.g = ps;
     w.sps = q.sps;
     w.gs = q.gs;
+    w.flat = (adj && q.ilv > 1) ? q.ilv : 0;
+    if (w.flat > 1) {
+        w.total = (q.nstrips - ps + q.gs - 1) / q.gs;      // (ps < gs <= nstrips: at least one)
+        w.tg = w.total + 1;                                 // never a segment's end: nothing is flushed in this form
+        return w;
+    }
     w.tg = (q.sps - ps + q.gs - 1) / q.gs;      // (ps < gs <= sps: at least one)
     w.total = w.tg * q.nlocal;
     return w;
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(512, STRIP_WAVES_PER_SIMD) void k_strip(StripArgs q
     const int rbase = wave * kWaveRows;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
-    const ForcesSlot wk = forces_slot(q, blockIdx.x);
+    const ForcesSlot wk = forces_slot(q, blockIdx.x, ADJ);
 
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
@@ -781,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     const int rbase = wave * WR;
     const int rsrc = rbase < q.mps ? rbase : 0;     // rows the wave loads
     const int lq = lane >> 4, lr = lane & 15, lj = lane & 3;
-    const ForcesSlot wk = forces_slot(q, blockIdx.x);
+    const ForcesSlot wk = forces_slot(q, blockIdx.x, ADJ);
 
     for (int i = t; i < lrows * 8; i += blockDim.x) {
         const int row = i >> 3, k = i & 7;
@@ -1949,6 +1963,20 @@ void launch_fwd_strip(bioen_hip_ctx* c, int K, const Vec8& v, int nblk, bool pla
     }
 }
 
+// ONE strip copy or two?  (r06: the default depends on the size.)  one_copy_wanted: 1 / 0 = asked for / refused
+// (BIOEN_HIP_ONE_COPY, bioen_hip_ctx_set_one_copy), -1 = by size: a second copy of more than 1 GiB is not made.  With the
+// one-copy adjoint taking the copy's positions in order (forces_slot: flat) it runs at the two-copy kernel's time wherever
+// the matrix is large (profiles/r06_onecopy_ab.txt: headline sweep 1.306-1.316 s on one copy against 1.307-1.315 s on two,
+// adjoint 1.203-1.209 against 1.201-1.212 ms; M = 512 x 1e6, 1024 x 1.25e5, 256 x 1e5: equal; M <= 128: a launch of the
+// LDS-image kernel costs 12 us against 6), so the 8.2 GB the headline's second copy took are no longer spent by default;
+// small problems keep the faster dedicated kernel.  Decided on the GLOBAL matrix (every rank of a sharded context takes
+// the same form: the bits of a result must not depend on the GPU count).
+static bool one_copy_by_default(const bioen_hip_ctx* c) {
+    if (c->one_copy_wanted >= 0) return c->one_copy_wanted == 1;
+    const double global_copy_bytes = (double)round_up((size_t)c->m, 16) * (double)c->n_global * sizeof(double);
+    return global_copy_bytes > 1024.0 * 1024.0 * 1024.0;
+}
+
 // adjoint pass of the log-weights method on the column-sum copy (built on first use)
 int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     if (c->storage) {
@@ -1960,7 +1988,7 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
         int rc = ensure_strip_copy(c);
         if (rc) return rc;
         if (c->one_copy) return 0;                                // (below: the one-copy form, asked for or taken)
-        if (c->one_copy_wanted) {
+        if (one_copy_by_default(c)) {
             c->one_copy = 1;
             return 0;
         }
@@ -1987,12 +2015,13 @@ int ensure_strip_copy_colsum(bioen_hip_ctx* c) {
     if (c->Ys1) return 0;
     int rc = ensure_strip_copy(c);                               // the centre is shared; the column-sum copy is cut from the row-sum one
     if (rc) return rc;
-    // ONE strip copy (r05; ctx.hpp: one_copy): asked for (BIOEN_HIP_ONE_COPY=1), or taken when the second copy does not
+    // ONE strip copy (r05; ctx.hpp: one_copy): asked for (BIOEN_HIP_ONE_COPY=1), the default of a large matrix (r06:
+    // one_copy_by_default), or taken when the second copy does not
     // fit -- the adjoint then runs on the row-sum order copy (launch_adj_strip) at the forces kernels' rate, instead of the
     // whole context falling back to the streaming kernels on the row-major matrix
     const bool can_one = true;                                   // (the ADJ forms of k_strip / k_strip2 serve every strip height)
     if (c->one_copy) return 0;
-    if (c->one_copy_wanted && can_one) {
+    if (one_copy_by_default(c) && can_one) {
         c->one_copy = 1;
         return 0;
     }
@@ -2066,7 +2095,8 @@ void launch_adj_strip(bioen_hip_ctx* c, int K, const double* u_c, const MVec8& o
             q.n = c->n;
             q.K = K;
             q.sps = c->segcols / kStripCols;
-            q.gs = std::max(1, std::min(q.sps, 256));          // one block per CU (the kernels' register and LDS budget)
+            // as many blocks per CU as the forces passes run (M <= 128: four of two waves, <= 256: two of four, else one)
+            q.gs = std::max(1, std::min(q.sps, 256 * (paneled(c) ? 1 : forces_per_cu(c))));
             q.tc = (q.sps + q.gs - 1) / q.gs;
             q.nch = 1; q.fold = 0; q.slots = q.gs;
             q.nslots = q.gs;

@@ -159,7 +159,7 @@ int bioen_hip_ctx_read_ytilde(bioen_hip_ctx* ctx, int row0, int rows, int col0, 
 /* Which forms of the matrix are resident and what they occupy.  forms: bit 0 the row-major matrix (the form data
  * arrive in; the operand of the streaming kernels for M > 1024), bit 1 the strip-major copy in row-sum operand order,
  * bit 2 the one in column-sum operand order.  For M <= 1024 the strip copies hold the raw numbers and REPLACE the
- * row-major matrix once built: log-weights 2 x the matrix (bits 1 + 2), forces method 1 x (bit 1; beyond 1024 rows,
+ * row-major matrix once built: log-weights 2 x the matrix (bits 1 + 2; r06: 1 x, bit 1 alone, once a copy exceeds 1 GiB), forces method 1 x (bit 1; beyond 1024 rows,
  * where the copies are kept as row panels of <= 1024 rows, 2 x: both orders).  ONE copy (r05: bit 1 alone; log-weights at every M, and the forces method's row panels beyond 1024 rows): environment BIOEN_HIP_ONE_COPY=1 at context creation, or taken by itself when the second copy cannot
  * be allocated -- the adjoint then runs on the row-sum order copy (1-3 % slower per launch, same minima, last bits differ
  * from the two-copy default: the sums over rows are formed in another order). */
@@ -175,7 +175,11 @@ int bioen_hip_ctx_footprint(const bioen_hip_ctx* ctx, int* forms, long long* byt
 int bioen_hip_ctx_layout(const bioen_hip_ctx* ctx, int* one_copy, int* interleave, int* relayouts);
 /* r05: ask for (1) / give up (0) the ONE-copy form described above; to be called before the context's first gradient
  * evaluation (BIOEN_HIP_ESTATE once the column-sum order copy exists).  Beyond 1024 rows it serves both methods: one set
- * of row panels instead of two. */
+ * of row panels instead of two.
+ * r06: without this call (and without BIOEN_HIP_ONE_COPY=0 / 1 in the environment) the form follows the matrix's size:
+ * a strip copy of the WHOLE matrix (all ranks' columns) above 1 GiB is kept once -- the one-copy adjoint then runs at the
+ * two-copy kernel's time (the headline: 8.2 GB resident instead of 16.4, the sweep within its run-to-run spread) --
+ * smaller matrices keep the dedicated second copy, whose kernel is the faster one where launches are short. */
 int bioen_hip_ctx_set_one_copy(bioen_hip_ctx* ctx, int on);
 int bioen_hip_ctx_set_ytilde_target(bioen_hip_ctx* ctx, const double* YTilde);
 /* Affine observable model: the optimizer sees yTilde_eff[i][j] = row_offset[i] + row_scale[i] * yTilde[i][j]

@@ -327,3 +327,26 @@ def test_check_common_form_warns_when_one_rank_fell_back_alone():
     with pytest.warns(RuntimeWarning, match="ranks \\[2\\]"):
         out = sweep.check_common_form(Ctx(0), Comm([0, 0, 1, 0]))
     assert out == {"one_copy": [0, 0, 1, 0], "common": False}
+
+
+def test_wall_budget_drops_lowest_priority_records_and_keeps_the_reserve():
+    """r06: the side records of bench.py run under a wall budget -- a droppable record that no longer
+    fits (its estimate plus what the never-dropped ones still need) is left out and named; the never-dropped ones run."""
+    now = [0.0]
+    b = bench.WallBudget(100.0, reserve=30.0, clock=lambda: now[0])
+    assert b.take("first", 50.0)                     # 100 - 30 >= 50
+    with b.timed("first"):
+        now[0] += 55.0
+    assert not b.take("second", 20.0)                # 45 left, 30 reserved: 15 < 20
+    sk = b.skipped(20.0)
+    assert sk["skipped"] == "budget" and sk["budget_left_s"] == 45.0 and sk["reserved_s"] == 30.0
+    assert b.take("third", 10.0)                     # a cheaper one still fits
+    with b.timed("third"):
+        now[0] += 8.0
+    b.reserve = 0.0                                  # the never-dropped record runs now, whatever is left
+    with b.timed("never_dropped"):
+        now[0] += 50.0
+    rep = b.report()
+    assert rep["skipped_for_budget"] == ["second"] and rep["used_s"] == 113.0
+    assert rep["seconds"] == {"first": 55.0, "third": 8.0, "never_dropped": 50.0}
+    assert not b.take("late", 1.0) and b.left() == -13.0

@@ -155,12 +155,17 @@ def _generated_columns(bioen_amd, M, N, targets, seed, cols, world=64):
     return out
 
 
-def test_logw_beyond_2_pow_32_matrix_elements():
+@pytest.mark.parametrize("copies", [1, 2])
+def test_logw_beyond_2_pow_32_matrix_elements(copies, monkeypatch):
     """Maximum sizes: M x N = 1024 x 4.3e6 = 4.4e9 elements (35 GB a copy) -- every element offset beyond 2^31 and 2^32
     has to come out of 64-bit index arithmetic, in the row-major matrix, in both strip copies, in the read-back and in
     the passes.  The columns on either side of those boundaries are checked against the generator run at small local
-    indices (another decomposition's ranks), the passes against those columns."""
+    indices (another decomposition's ranks), the passes against those columns.  Both forms: ONE strip copy (r06: the
+    default of a matrix this large -- the segments' strips interleaved, the adjoint through the LDS-image kernel) and two
+    (BIOEN_HIP_ONE_COPY=0: the column-sum order copy and its kernel)."""
     import bioen_amd
+    if copies == 2:
+        monkeypatch.setenv("BIOEN_HIP_ONE_COPY", "0")
     M, N = 1024, 4300032
     assert M * N > 2 ** 32
     targets = _targets(M)
@@ -186,7 +191,8 @@ def test_logw_beyond_2_pow_32_matrix_elements():
         g = G + 0.3 * rng.standard_normal(N)
         f, grad = ctx.logw_fdf(g, G, theta)                                 # ... and the column-sum order copy
         forms, _ = ctx.footprint()
-        assert "rowmajor" not in forms and {"strips", "strips_colsum"} <= forms    # the copies have replaced the matrix
+        assert forms == ({"strips"} if copies == 1 else {"strips", "strips_colsum"})    # the copies have replaced the matrix
+        assert ctx.layout()["interleave"] == 8
         assert np.array_equal(_columns(ctx, cols), Y)                       # read-back out of the strip copy
         wg, logs = ctx.logw_weights(g)
         chi2g, ybar = ctx.chi_squared(wg)
@@ -313,8 +319,20 @@ def test_deer_nuisance_series_at_config4_scale():
 # them and must update them here, together with profiles/.
 # ---------------------------------------------------------------------------------------
 BENCH_PINNED = [   # theta, iterations, evaluations, fmin
-    # r05: the canonical 8-segment reduction shape -- these are the bits of 1, 2, 4 AND 8 GPUs.  (r02-r04, one-GPU
-    # shape: 1605 iterations, the smallest theta stopping on an early plateau at 111.626; sharded runs took 1702-1758.)
+    # r06: ONE strip copy is the default of a matrix this large (include/bioen_hip.h: bioen_hip_ctx_set_one_copy) -- the
+    # adjoint sums over rows in the LDS-image kernel's order, last bits differ from the two-copy form below.  Canonical
+    # 8-segment reduction shape: these are the bits of 1, 2, 4 AND 8 GPUs.
+    (1000.0, 8, 13, 502.23205525980626),
+    (316.2277660168379, 76, 127, 477.09441969228806),
+    (100.0, 43, 63, 411.9475274073285),
+    (31.622776601683793, 203, 235, 291.058383858162),
+    (10.0, 324, 368, 181.45436663275478),
+    (3.1622776601683795, 367, 407, 133.27496797041636),
+    (1.0, 286, 323, 116.9335766404019),
+    (0.31622776601683794, 471, 530, 111.56954022348951),
+]
+BENCH_PINNED_TWO_COPIES = [   # BIOEN_HIP_ONE_COPY=0: the r05 default, bit for bit what r05 pinned
+    # (r02-r04, one-GPU shape: 1605 iterations, the smallest theta stopping on an early plateau at 111.626; sharded runs took 1702-1758.)
     (1000.0, 8, 13, 502.2320552598044),
     (316.2277660168379, 76, 129, 477.094413061891),
     (100.0, 43, 63, 411.9475274073507),
@@ -326,7 +344,7 @@ BENCH_PINNED = [   # theta, iterations, evaluations, fmin
 ]
 
 
-def test_bench_workload_is_pinned():
+def test_bench_workload_is_pinned(monkeypatch):
     import bioen_amd
     from bioen_amd import sweep
     M, N = 1024, 1000000
@@ -335,6 +353,7 @@ def test_bench_workload_is_pinned():
     G = np.zeros(N)
     with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
         res = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=8)
+        assert ctx.footprint()[0] == {"strips"} and ctx.layout()["one_copy"] == 1       # 8.2 GB resident, not 16.4
         again = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=3)     # another batch schedule, same bits
         import os
         os.environ["BIOEN_HIP_DEVICE_LS"] = "1"      # the device-resident engine (the default below 4 GB per round): same bits
@@ -342,7 +361,7 @@ def test_bench_workload_is_pinned():
             dev = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=8)
         finally:
             os.environ.pop("BIOEN_HIP_DEVICE_LS", None)
-    assert sum(r["iterations"] for r in res) == sum(p[1] for p in BENCH_PINNED) == 1763
+    assert sum(r["iterations"] for r in res) == sum(p[1] for p in BENCH_PINNED) == 1778
     for r, r2, (theta, it, ev, fmin) in zip(res, again, BENCH_PINNED):
         assert rel(r["theta"], theta) < 1e-15 and r["code"] in (0, 1)
         assert (r["iterations"], r["evaluations"]) == (it, ev), (theta, r["iterations"], r["evaluations"])
@@ -352,6 +371,14 @@ def test_bench_workload_is_pinned():
         assert (r3["iterations"], r3["evaluations"], r3["fmin"], r3["chi2"], r3["S"]) == \
                (r["iterations"], r["evaluations"], r["fmin"], r["chi2"], r["S"])
         assert np.array_equal(r["w"], r3["w"])
+    monkeypatch.setenv("BIOEN_HIP_ONE_COPY", "0")     # two copies, as until r05: its pinned bits, and the same minima to the plateau stops' spread
+    with bioen_amd.Context.synthetic(M, N, YTrue, sig_sim, sig_exp, YTilde, seed=12345) as ctx:
+        two = sweep.sweep_log_weights(ctx, thetas, G, G, LBFGS_DEFAULTS, max_batch=8)
+        assert ctx.footprint()[0] == {"strips", "strips_colsum"}
+    for r, (theta, it, ev, fmin) in zip(two, BENCH_PINNED_TWO_COPIES):
+        assert (r["iterations"], r["evaluations"], r["fmin"]) == (it, ev, fmin), (theta, r["iterations"], r["evaluations"], repr(r["fmin"]))
+    for r, r2 in zip(res, two):
+        assert rel(r["fmin"], r2["fmin"]) < 3e-4
 
 
 _AT_OPTIMUM = (0, -998, -1000, -1001)      # epsilon test | line search out of trials / below min_step / rounding errors
@@ -511,3 +538,53 @@ def test_objective_and_gradient_against_the_reference_binary(M, N):
             fgrad_ref = np.asarray(R.forces_df(forces, w0, yT, YTilde, theta)).ravel()
             assert rel(ff, ff_ref) < 1e-12, (theta, ff, ff_ref)
             assert np.abs(fgrad - fgrad_ref).max() <= 1e-10 * np.abs(fgrad_ref).max(), theta
+
+
+def test_configs4_shape_forces_endings_against_the_reference_golden():
+    """how the forces-method runs of a configs[4]-shaped problem END -- status, minimum, iteration
+    count per theta -- against what the REFERENCE's own binary does with the same inputs (tests/golden/
+    forces_status_cfg4_M512xN100000.json, made by make_golden_forces_status.py from oracle/_ref: SURVEY 8(d)'s numpy
+    stream, M = 512 x N = 1e5, the 8 thetas of the series, yaml-default liblbfgs, every summation mode x thread count x
+    repetition recorded).
+
+    Where the reference is unanimous (theta <= 31.6: the plateau test, status 1) the device must end with the same status
+    after the same number of iterations where the reference's own count is unanimous too.  At theta >= 100 the reference is NOT a function of its inputs:
+    the runs end where the decrease the line search still asks for (1/2 g^2 / (theta var) ~ 1e-15) lies below the rounding
+    noise of the objective (f ~ 250: 5e-13), so 0 or -998 (or -1000) is decided by rounding, and the golden holds both
+    for the same inputs (fast_openmp 0 / 1, 8 / 4 / 2 / 1 threads, repeated runs).  There the two sides are held to what IS
+    determined: the same minimum to 1e-12, and an ending out of the rounding-floor set.  (profiles/
+    r06_forces_status_probe_full.txt: the same at N = 1e6, with liblbfgs' own binary on the device's objective.)"""
+    import json
+    import os
+    import bioen_amd
+    from bench import survey_inputs
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "forces_status_cfg4_M512xN100000.json")) as fp:
+        gold = json.load(fp)
+    M, N = gold["M"], gold["N"]
+    assert len(gold["per_theta"]) == 8
+    y, YT = survey_inputs(M, N, gold["seed"])
+    w0 = np.full(N, 1.0 / N)
+    thetas = [p["theta"] for p in gold["per_theta"]]
+    with bioen_amd.Context(y, YT) as ctx:
+        _, _, infos = ctx.opt_lbfgs_forces_batch(thetas, np.zeros(M), w0, gold["lbfgs"], want_weights=False)
+        for k in (0, 1, 2):                          # the large thetas one by one: the bits of the batch
+            _, _, one = ctx.opt_lbfgs_forces(np.zeros(M), w0, thetas[k], gold["lbfgs"], want_weights=False)
+            assert (one.lbfgs_code, one.iterations, one.evaluations, one.fmin) == \
+                   (infos[k].lbfgs_code, infos[k].iterations, infos[k].evaluations, infos[k].fmin)
+    floor = {0, -998, -1000, -1001}                  # converged | the line search's three ways of giving up at the rounding floor
+    undetermined = 0
+    for g, i in zip(gold["per_theta"], infos):
+        codes = set(g["codes"])
+        its = {r["iterations"] for r in g["runs"]}
+        tol = max(1e-12, 10.0 * g["fmin_rel_spread"])      # (a plateau stop moves with the summation order: the reference's own spread)
+        assert rel(i.fmin, g["fmin_min"]) <= tol, (g["theta"], i.fmin, g["fmin_min"], tol)
+        if len(codes) == 1:
+            assert i.lbfgs_code in codes, (g["theta"], i.lbfgs_code, codes)
+            if len(its) == 1:
+                assert i.iterations in its, (g["theta"], i.iterations, its)
+        else:
+            undetermined += 1
+            assert g["theta"] >= 99.0 and codes <= floor and i.lbfgs_code in floor, (g["theta"], i.lbfgs_code, codes)
+            assert rel(i.fmin, g["fmin_min"]) <= 1e-12
+    assert undetermined == 3                         # theta = 1000, 316, 100: the reference's own coin flips (the golden's content)

@@ -183,3 +183,29 @@ def test_non_finite_inputs_end_as_in_the_reference_binary(case):
     assert not np.isfinite(f_r) and not np.isfinite(f_o) and np.isnan(f_r) == np.isnan(f_o)
     assert np.array_equal(np.asarray(x_r).ravel(), start, equal_nan=True)
     assert np.array_equal(np.asarray(x_o).ravel(), start, equal_nan=True)
+
+
+def test_forces_status_golden_records_the_references_own_coin_flips():
+    """tests/golden/forces_status_cfg4_M512xN100000.json (made by make_golden_forces_status.py from the reference's binary):
+    on the SAME inputs the reference ends a large-theta forces run with 0 in one configuration (summation mode, thread
+    count, repetition) and with -998 in another -- the GPU test that holds the device to this golden
+    (test_hip_fullsize.py) rests on that content."""
+    import json
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "forces_status_cfg4_M512xN100000.json")
+    with open(path) as fp:
+        gold = json.load(fp)
+    assert (gold["M"], gold["N"], gold["seed"]) == (512, 100000, 12345)
+    thetas = [p["theta"] for p in gold["per_theta"]]
+    assert np.allclose(thetas, np.logspace(3, -0.5, 8))
+    for p in gold["per_theta"]:
+        codes = set(p["codes"])
+        assert codes == {r["code"] for r in p["runs"]} | {r["driver_code"] for r in p["runs"]}
+        if p["theta"] >= 99.0:
+            assert {0, -998} <= codes <= {0, -998, -1000, -1001}          # both endings, same inputs
+            assert p["fmin_rel_spread"] < 1e-12                           # ... at one and the same minimum
+            modes = {(r["fast_openmp"], r["threads"]) for r in p["runs"]}
+            assert len(modes) >= 6
+        else:
+            assert codes == {1}                                           # the plateau test, unanimously

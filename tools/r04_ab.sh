@@ -1,16 +1,15 @@
 set -e
-mkdir -p gpurun_out/r06_r04_ab
-rm -f gpurun_out/r06_r04_ab/*.json
-FLAGS="--no-cpu-baseline --no-forces --no-api --no-deer --no-ala5 --no-matched --no-pmc --no-storage-experiment --no-one-copy"
-for rep in 1 2; do
-  (cd build/r04tree && timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-forces --no-deer --no-ala5 --no-matched --no-pmc --no-storage-experiment --steps 2) > gpurun_out/r06_r04_ab/r04_$rep.json
-  BIOEN_HIP_STRIP_INTERLEAVE=0 timeout -k 10 300 python3 bench.py $FLAGS --steps 2 > gpurun_out/r06_r04_ab/r06_ilv0_$rep.json
-  timeout -k 10 300 python3 bench.py $FLAGS --steps 2 > gpurun_out/r06_r04_ab/r06_ilv1_$rep.json
+mkdir -p gpurun_out/r06_onecopy2
+rm -f gpurun_out/r06_onecopy2/*.json
+for shape in "256 100000" "205 500000" "28 50001" "64 20000" "512 1000000" "1024 125000" "600 200000" "2100 100000"; do
+  for oc in 0 1; do
+    BIOEN_HIP_ONE_COPY=$oc KS=1,4,8 timeout -k 10 200 python3 tools/pass_probe.py $shape 40 >> gpurun_out/r06_onecopy2/oc$oc.json
+  done
 done
 python3 - <<'PY'
 import json,glob
-for f in sorted(glob.glob("gpurun_out/r06_r04_ab/*.json")):
-    d=json.loads(open(f).read().strip().splitlines()[-1])
-    k=d["roofline"]["kernels"]
-    print(f.split('/')[-1].ljust(18), "sweep %.1f ms"%d["ms_per_step"], d["iterations_per_sweep"], {n:(round(v["avg_ms"],4), round(v["avg_batch_width"],2), v["launches"]) for n,v in k.items()}, "read ceiling %.0f"%d["roofline"]["read_ceiling"]["GB/s"])
+for f in sorted(glob.glob('gpurun_out/r06_onecopy2/*.json')):
+    for ln in open(f):
+        d=json.loads(ln)
+        print(f.split('/')[-1][:-5].ljust(6), ("%dx%d"%(d['M'],d['N'])).ljust(14), ' '.join('K%s fwd %s adj %s |'%(k,'/'.join('%.4f'%x['fwd_ms'] for x in v),'/'.join('%.4f'%x['adj_ms'] for x in v)) for k,v in d['K'].items()))
 PY

@@ -66,7 +66,7 @@ def main():
         N, M = int(sys.argv[i + 1]), int(sys.argv[i + 2])
         tpath = os.path.join(out_dir, "traffic.json")
         tj = json.load(open(tpath)) if os.path.isfile(tpath) else {}
-        for base in ("k_fwd_partial", "k_adj", "k_strip_fwd", "k_strip_adj"):      # launch-weighted mean over the batch-width variants
+        for base in ("k_fwd_partial", "k_adj", "k_strip_fwd", "k_strip_adj", "k_strip2"):     # (k_strip2: the one-copy adjoint at 512 < M <= 1024)      # launch-weighted mean over the batch-width variants
             sel = [v for k, v in traffic.items() if k.split("<")[0] == base]
             if sel:
                 tj["%s_N%d_M%d" % (base, N, M)] = sum(b * n for b, n in sel) / max(sum(n for _, n in sel), 1)
