@@ -189,7 +189,7 @@ def cpu_baseline(ctx, M, N, YTilde, theta, budget_cols, cap_iterations):
     }
 
 
-def cpu_fullsize(ctx, M, N, YTilde, thetas, mid_thetas=(), mid_budget_s=170.0):
+def cpu_fullsize(ctx, M, N, YTilde, thetas, mid_thetas=(), mid_budget_s=170.0, ms_per_eval=None):
     """A direct CPU number ON the headline config: the reference's own _opt_lbfgs_logw on the FULL matrix (read back
     from HBM, transposed cache built blockwise) for the cheapest thetas of the series, next to the device solving the
     same single problem.  Skipped when the host lacks the memory for matrix + transposed cache."""
@@ -232,7 +232,8 @@ def cpu_fullsize(ctx, M, N, YTilde, thetas, mid_thetas=(), mid_budget_s=170.0):
                                  "fmin_rel_diff": abs(info.fmin - fmin) / abs(fmin), "speedup": cpu_s / gpu_s})
     out["cpu_s"] = sum(r["cpu_s"] for r in out["per_theta"])
     out["gpu_s"] = sum(r["gpu_s"] for r in out["per_theta"])
-    out["speedup"] = out["cpu_s"] / out["gpu_s"]
+    out["speedup"] = out["cpu_s"] / out["gpu_s"] if out["gpu_s"] > 0 else None
+    out["cpu_ms_per_evaluation"] = 1e3 * out["cpu_s"] / max(sum(r["gpu_evaluations"] for r in out["per_theta"]), 1) if thetas else ms_per_eval
     if mid_thetas:
         # r05: parity ON the headline config for a theta that matters (the six slow thetas carry 95 % of the sweep's
         # iterations).  The problem is flat at this size: under the converged settings (delta 0, past 0: no plateau stop)
@@ -249,7 +250,7 @@ def cpu_fullsize(ctx, M, N, YTilde, thetas, mid_thetas=(), mid_budget_s=170.0):
         # this matrix a trial point reaches max g = 712 in the fourth iteration, the objective is NaN from there on, and its
         # -ffast-math liblbfgs returns that as status 0.  (The device shifts by the maximum and walks on: same trajectory
         # to 1e-12 up to that point.)  Such a theta is recorded as what it is and the next one is taken.
-        ms_it = 1e3 * out["cpu_s"] / max(sum(r["gpu_evaluations"] for r in out["per_theta"]), 1)
+        ms_it = out["cpu_ms_per_evaluation"] or 130.0
         eps = 1e-8
         conv = dict(LBFGS_DEFAULTS, epsilon=eps, delta=0.0, past=0, max_iterations=15000)
         out["mid_theta"] = {"reference_failures": []}
@@ -945,7 +946,9 @@ def api_record(bioen_amd, yTilde, YTilde, thetas, label, with_unheld):
     out, dt, up = timed(lambda: optimize.log_weights.find_optimum_series(G, G, yTilde, yTilde, YT, thetas, cfg))
     its = sum(i.iterations for i in c_bioen.last_opt_info)
     rec["series"] = {"wall_s": dt, "uploads": up, "iterations": int(its), "value_incl_upload": its * float(N) * M / dt,
-                     "fmin": [float(o[4]) for o in out]}
+                     "fmin": [float(o[4]) for o in out],
+                     "per_theta": [{"theta": float(t), "iterations": int(i.iterations), "evaluations": int(i.evaluations),
+                                    "code": int(i.lbfgs_code)} for t, i in zip(thetas, c_bioen.last_opt_info)]}
     c_bioen.clear_cache()
 
     def loop(held):
@@ -1539,29 +1542,35 @@ def main():
             else:
                 cpu["matched_sweep"] = budget.skipped(45.0)
 
+        mids = []
         if cpu is not None and single and not forces_mode and not args.no_cpu_fullsize and N * float(M) >= 5e8:
-            if budget.take("cpu_full_size", 60.0):          # priority 4: the same CONFIG on the CPU, not a sample
+            if budget.take("cpu_full_size", 35.0):          # priority 4: the same CONFIG on the CPU, not a sample
                 with budget.timed("cpu_full_size"):
                     try:     # the two cheapest thetas of the series; then, while the budget lasts, a mid-series one
                         cheap = sorted(results, key=lambda r: r["evaluations"])[:2]
                         # the mid-series thetas nearest 31.6 first (the cheap ones above excluded)
                         mids = [] if args.no_cpu_mid else sorted((r["theta"] for r in results if r not in cheap and 2.0 < r["theta"] < 60.0),
                                                                key=lambda t: abs(np.log(t / 31.6)))
-                        mid_budget = max(0.0, min(170.0, budget.left() - budget.reserve - 60.0 - 45.0))     # (after the cheap thetas; the records below keep 45 s)
-                        cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap], mid_thetas=mids,
-                                                        mid_budget_s=mid_budget)
+                        cpu["full_size"] = cpu_fullsize(ctx, M, N, YTilde, [r["theta"] for r in cheap])      # (a mid-series theta: last record below)
                     except Exception as e:
                         cpu["full_size"] = {"error": repr(e)}
             else:
-                cpu["full_size"] = budget.skipped(60.0)
+                cpu["full_size"] = budget.skipped(35.0)
 
         api = None                       # priority 5: the kept Python API on a host matrix, upload included
         if single and not forces_mode and not args.no_api:
-            if budget.take("api_end_to_end", 20.0):
+            if budget.take("api_end_to_end", 45.0):
                 with budget.timed("api_end_to_end"):
-                    try:      # the headline matrix on the host, as a caller of the Python API holds it (read back: the same numbers)
-                        host_matrix = ctx.read_ytilde()
-                        api = {"headline": api_record(bioen_amd, host_matrix, YTilde, thetas, "BASELINE configs[2]", False)}
+                    try:
+                        # the headline SIZE on the host as a caller of the Python API holds it -- r06: SURVEY 8(d)'s numpy
+                        # stream to the letter (PCG64(12345), row-wise normals: 1.02e9 draws on one host thread, ~15 s), so that
+                        # iteration counts on the survey's own inputs stand beside the device generator's of the headline
+                        t_gen = time.perf_counter()
+                        host_matrix, host_YT = survey_inputs(M, N)
+                        t_gen = time.perf_counter() - t_gen
+                        api = {"headline": api_record(bioen_amd, host_matrix, host_YT, thetas,
+                                                      "BASELINE configs[2] on SURVEY 8(d)'s numpy stream (PCG64 seed %d, row-wise normals)" % SEED, False)}
+                        api["headline"]["host_generation_s"] = t_gen
                         del host_matrix
                         y1, Y1 = survey_inputs(256, 100000)
                         api["configs1"] = api_record(bioen_amd, y1, Y1, thetas, "BASELINE configs[1] (SURVEY 8(d)'s numpy stream)", True)
@@ -1570,7 +1579,7 @@ def main():
                     except Exception as e:
                         api = dict(api or {}, error=repr(e))
             else:
-                api = budget.skipped(20.0)
+                api = budget.skipped(45.0)
 
         one_copy = None                  # priority 6
         if single and not forces_mode and M <= 1024 and not args.no_one_copy:
@@ -1608,6 +1617,23 @@ def main():
                         ala5 = {"error": repr(e)}
             else:
                 ala5 = budget.skipped(5.0)
+
+        # priority 9, with whatever the budget has left: a theta of the series' expensive half on the FULL matrix, the device's
+        # converged optimum put before the reference (cpu_fullsize: mid_theta) -- ~35 s of the reference's yaml-default run,
+        # 30 s of the device's converged one, two short reference runs at the optimum
+        if (cpu is not None and isinstance(cpu.get("full_size"), dict) and "per_theta" in cpu["full_size"] and mids
+                and not args.no_cpu_mid):
+            if budget.take("cpu_mid_theta", 85.0):
+                with budget.timed("cpu_mid_theta"):
+                    try:
+                        more = cpu_fullsize(ctx, M, N, YTilde, [], mid_thetas=mids,
+                                            mid_budget_s=max(0.0, budget.left() - budget.reserve - 45.0),
+                                            ms_per_eval=cpu["full_size"].get("cpu_ms_per_evaluation"))
+                        cpu["full_size"]["mid_theta"] = (more or {}).get("mid_theta")
+                    except Exception as e:
+                        cpu["full_size"]["mid_theta"] = {"error": repr(e)}
+            else:
+                cpu["full_size"]["mid_theta"] = budget.skipped(85.0)
 
         if want_pmc:
             # roofline.traffic from counters read on THIS box, in this run (the committed profiles/traffic.json stays the

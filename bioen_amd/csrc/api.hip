@@ -1709,7 +1709,7 @@ static int rccl_async_error(bioen_hip_ctx* c) {
     return 0;
 }
 
-static std::atomic<int> g_comm_init_abandoned{0};      // a bounded ncclCommInitRank was given up and its helper thread is still inside RCCL
+static std::atomic<int> g_comm_init_abandoned{0};      // helper threads of given-up (bounded) ncclCommInitRank calls that are still inside RCCL
 
 static void rccl_abort(bioen_hip_ctx* c) {
     if (!c->comm) return;
@@ -1746,11 +1746,17 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
     // before, or died) would keep the others here for good.  It runs on a helper thread; this thread waits for it for three
     // times the context's wait bound (topology detection on a full node takes seconds) and then gives the transport up --
     // the helper stays behind, blocked, in a process that goes on without RCCL (the callers fall back).
+    // One state word per job decides who owns the outcome (two release / acquire flags read crosswise are a
+    // Dekker pattern -- both sides could miss each other, and a late-successful communicator was then neither adopted nor
+    // aborted): RUNNING -> DONE by the helper, RUNNING -> ABANDONED by the caller, one sequentially consistent
+    // compare-exchange each -- whoever LOSES the exchange knows the other side's move and acts on it.  The process-wide
+    // count of helpers still blocked inside RCCL goes up when a job is abandoned and down whenever such a helper returns,
+    // successful or not.
     struct InitJob {
+        enum { RUNNING = 0, DONE = 1, ABANDONED = 2 };
         ncclComm_t comm = nullptr;
         ncclResult_t r = ncclSuccess;
-        std::atomic<int> done{0};
-        std::atomic<int> abandoned{0};      // the caller has given up: a late success is nobody's communicator
+        std::atomic<int> state{RUNNING};
     };
     auto job = std::make_shared<InitJob>();
     const int dev = c->device;
@@ -1758,30 +1764,36 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
         std::thread([job, nranks, u, rank, dev]() {
             if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
             job->r = g_rccl.CommInitRank(&job->comm, nranks, u, rank);
-            job->done.store(1, std::memory_order_release);
-            // a peer that arrived late completes the init after this rank has walked away: the orphan is aborted here, so
-            // that the peers' collectives on it fail fast instead of waiting for a rank that will never join them
-            if (job->abandoned.load(std::memory_order_acquire) && job->r == ncclSuccess && job->comm) {
+            int expected = InitJob::RUNNING;
+            if (job->state.compare_exchange_strong(expected, InitJob::DONE)) return;      // the caller is still waiting: it adopts the result
+            // ABANDONED: the caller walked away (and counted this helper as blocked).  A peer that arrived late completes
+            // the init now: the orphan is aborted here, so that the peers' collectives on it fail fast instead of waiting
+            // for a rank that will never join them; then this helper is no longer inside RCCL, whatever the init returned
+            if (job->r == ncclSuccess && job->comm) {
                 if (g_rccl.CommAbort) g_rccl.CommAbort(job->comm);
                 else if (g_rccl.CommDestroy) g_rccl.CommDestroy(job->comm);
-                g_comm_init_abandoned.store(0, std::memory_order_release);      // nothing is blocked inside RCCL any more
             }
+            g_comm_init_abandoned.fetch_sub(1);
         }).detach();
     } catch (...) {
         return fail(BIOEN_HIP_ERCCL, "could not start the thread that initialises the RCCL communicator");
     }
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(3.0 * std::max(c->wait_timeout_s, 1.0));
-    while (!job->done.load(std::memory_order_acquire)) {
+    while (job->state.load() == InitJob::RUNNING) {
         if (std::chrono::steady_clock::now() > deadline) {
-            char buf[200];
-            std::snprintf(buf, sizeof buf, "ncclCommInitRank (rank %d of %d) did not return within %g s: a rank is missing "
-                          "(3 x BIOEN_HIP_WAIT_TIMEOUT)", rank, nranks, 3.0 * std::max(c->wait_timeout_s, 1.0));
             // A helper thread stays behind, blocked inside RCCL: static destructors of librccl / HIP running under it at
-            // interpreter teardown can hang or crash.  The process-wide flag (bioen_hip_comm_init_abandoned) tells the
+            // interpreter teardown can hang or crash.  The process-wide count (bioen_hip_comm_init_abandoned) tells the
             // host layer to leave through os._exit after flushing its output (bioen_amd/_lib.py: leave_process).
-            job->abandoned.store(1, std::memory_order_release);
-            if (!job->done.load(std::memory_order_acquire)) g_comm_init_abandoned.store(1, std::memory_order_release);
-            return fail(BIOEN_HIP_ERCCL, buf);
+            g_comm_init_abandoned.fetch_add(1);                      // before the exchange: the helper's decrement comes after it
+            int expected = InitJob::RUNNING;
+            if (job->state.compare_exchange_strong(expected, InitJob::ABANDONED)) {
+                char buf[200];
+                std::snprintf(buf, sizeof buf, "ncclCommInitRank (rank %d of %d) did not return within %g s: a rank is missing "
+                              "(3 x BIOEN_HIP_WAIT_TIMEOUT)", rank, nranks, 3.0 * std::max(c->wait_timeout_s, 1.0));
+                return fail(BIOEN_HIP_ERCCL, buf);
+            }
+            g_comm_init_abandoned.fetch_sub(1);                      // the helper finished in that very moment: its result is ours
+            break;
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
@@ -1794,7 +1806,7 @@ int bioen_hip_comm_init(bioen_hip_ctx* c, const unsigned char id[128], int rank,
     return 0;
 }
 
-int bioen_hip_comm_init_abandoned(void) { return g_comm_init_abandoned.load(std::memory_order_acquire); }
+int bioen_hip_comm_init_abandoned(void) { return g_comm_init_abandoned.load() > 0 ? 1 : 0; }
 
 int bioen_hip_comm_allgather(bioen_hip_ctx* c, const double* send, size_t count, double* recv) {
     if (!c || !send || !recv || count == 0) return fail(BIOEN_HIP_EINVAL, "bad argument");

@@ -122,7 +122,10 @@ int bioen_hip_ctx_create_synthetic(int m, int n, const double* YTrue, const doub
  * issue the same calls in the same order.  Supported on sharded contexts: logw_weights, logw_fdf, chi_squared,
  * opt_lbfgs_logw(_batch), opt_gsl_logw, and the forces method (forces_weights, forces_fdf(_batch),
  * opt_lbfgs_forces(_batch), opt_gsl_forces) for every M served by strip copies (M <= 1024: two passes; beyond: four
- * passes over row panels). */
+ * passes over row panels).
+ * Minimum size: the LAST rank must still own a column, (world - 1) * P < n -- n > 512 for two ranks, > 768 for four,
+ * > 896 for eight (S is at least 128); BIOEN_HIP_EINVAL ("too few structures to shard") on EVERY rank otherwise, so that
+ * none waits in a collective for one that failed.  The leading dimension of the local data is segments-per-rank * S. */
 int bioen_hip_ctx_create_sharded(int m, long long n, const double* yTilde, const double* YTilde,
                                  int device, int rank, int world, bioen_hip_ctx** ctx);
 int bioen_hip_ctx_create_synthetic_sharded(int m, long long n, const double* YTrue,
