@@ -875,7 +875,14 @@ __global__ __launch_bounds__(512, 2) void k_strip2(StripArgs q, ForcesRound fr) 
     auto fetch = [&](int strip) { fetch_part(strip, 0, WR / 8); };
     // K > 4: the operand batches of the column-sum product do not fit beside a3 AND the whole prefetch (7-12 registers
     // spilled per strip); the second half of the prefetch is issued behind that product instead
-    constexpr int SPLIT = NK > 1 ? WR / 16 : WR / 8;
+    // (r06) The ADJ form has no row-sum accumulators and no second operand table: the WHOLE prefetch fits in front of the
+    // product at every K (174 registers, no spill) -- K = 5 / 8 at N = 1e6 x M = 1024: 1.167 / 1.19 ms per launch against
+    // 1.222 / 1.235 with the split (three alternations, one box: profiles/r06_adj_prefetch_ab.txt); -DSTRIP2_ADJ_SPLIT=1
+    // brings the split back for an A/B.  The order of the loads changes no bit.
+#ifndef STRIP2_ADJ_SPLIT
+#define STRIP2_ADJ_SPLIT 0
+#endif
+    constexpr int SPLIT = (NK > 1 && (!ADJ || STRIP2_ADJ_SPLIT)) ? WR / 16 : WR / 8;
     auto flush = [&](int set) {                                    // a segment's sums leave as one set; then everything starts from zero (k_strip)
         // result lane 16 i + 4 blk + j: row rbase + 16 h + 4 blk + i, problem 4 kq + j.  Row block by row block (16 rows x K
         // sums = one run of <= 128 doubles of the set) through the wave's own slice of `red` -- free here: the column sums of

@@ -874,6 +874,57 @@ def test_strip_layout_follows_the_method_and_changes_no_bit(M, N, monkeypatch):
         same(a["forces"], other["forces"])
 
 
+@pytest.mark.parametrize("M,N", [(37, 3000), (512, 20000), (1024, 6000), (1100, 3000)])
+def test_single_segment_opt_out_on_one_gpu(M, N, monkeypatch):
+    """BIOEN_HIP_SEGMENTS=1 (r06): an unsharded context with ONE column segment instead of the canonical eight -- every
+    sum over structures one tree over the whole matrix (r04's shape: the forces passes write one partial set per block).
+    The same mathematics in another summation order: objective and gradient of both methods against the restatement at the
+    default context's tolerances, against the default context to rounding, batched = single bit for bit, and capped series
+    step for step with the restatement."""
+    import bioen_amd
+    from oracle import oracle_binding as O
+    from conftest import LBFGS_DEFAULTS
+    rng = np.random.default_rng(11 * M + 5)
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    g = G + 0.2 * rng.standard_normal(N)
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    f0 = 1e-3 * rng.standard_normal(M)
+    thetas = [100.0, 10.0, 1.0, 30.0, 3.0]
+    params = dict(LBFGS_DEFAULTS, max_iterations=8)
+    with bioen_amd.Context(y, YT) as ctx:
+        f8, g8 = ctx.logw_fdf(g, G, 5.0)
+        ff8, fg8 = ctx.forces_fdf(f0, w0, 5.0)
+    assert bioen_amd._lib.column_segments(N)[0] == 8
+    monkeypatch.setenv("BIOEN_HIP_SEGMENTS", "1")
+    assert bioen_amd._lib.column_segments(N)[0] == 1
+    with bioen_amd.Context(y, YT) as ctx:
+        f1, g1 = ctx.logw_fdf(g, G, 5.0)
+        ff1, fg1 = ctx.forces_fdf(f0, w0, 5.0)
+        assert ctx.layout()["interleave"] == 1
+        lw = ctx.opt_lbfgs_logw_batch(thetas, g, G, params)
+        lf = ctx.opt_lbfgs_forces_batch(thetas, f0, w0, params)
+        xs, ws, one = ctx.opt_lbfgs_logw(g, G, thetas[1], params)
+        fs, wfs, onef = ctx.opt_lbfgs_forces(f0, w0, thetas[1], params)
+        assert np.array_equal(ctx.read_ytilde(), y)
+    assert np.array_equal(lw[0][1], xs) and lw[2][1].fmin == one.fmin            # a problem's bits do not depend on its batch
+    assert np.array_equal(lf[0][1], fs) and lf[2][1].fmin == onef.fmin
+    f_o, g_o, _ = O.logw_fdf(g, G, y, YT, 5.0)
+    ff_o, fg_o, _ = O.forces_fdf(f0, w0, y, YT, 5.0)
+    assert abs(f1 - f_o) <= 1e-12 * abs(f_o) and np.abs(g1 - g_o).max() <= 1e-10 * np.abs(g_o).max()
+    assert abs(ff1 - ff_o) <= 1e-12 * abs(ff_o) and np.abs(fg1 - fg_o).max() <= 1e-9 * np.abs(fg_o).max()
+    assert abs(f1 - f8) <= 1e-13 * abs(f8) and np.abs(g1 - g8).max() <= 1e-11 * np.abs(g8).max()      # another order of the same sums
+    assert abs(ff1 - ff8) <= 1e-13 * abs(ff8) and np.abs(fg1 - fg8).max() <= 1e-10 * np.abs(fg8).max()
+    for k, th in enumerate(thetas):
+        _, fmin_o, code_o, it_o, ev_o = O.opt_lbfgs_logw(g, G, y, YT, th, params)
+        assert (lw[2][k].lbfgs_code, lw[2][k].iterations, lw[2][k].evaluations) == (code_o, it_o, ev_o)
+        assert abs(lw[2][k].fmin - fmin_o) <= 1e-8 * abs(fmin_o)
+        _, ffmin_o, fcode_o, fit_o, fev_o = O.opt_lbfgs_forces(f0, w0, y, YT, th, params)
+        assert (lf[2][k].lbfgs_code, lf[2][k].iterations) == (fcode_o, fit_o) and abs(lf[2][k].fmin - ffmin_o) <= 1e-8 * abs(ffmin_o)
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_uploads_through_the_staging_buffer_change_nothing(world, monkeypatch):
     """api.hip: h2d_staged -- the path uploads of a caller's buffers take when the runtime refuses to pin them (ROCm 7.2: a
