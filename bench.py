@@ -1629,7 +1629,7 @@ def main():
                 with budget.timed("cpu_mid_theta"):
                     try:
                         more = cpu_fullsize(ctx, M, N, YTilde, [], mid_thetas=mids,
-                                            mid_budget_s=max(0.0, budget.left() - budget.reserve - 45.0),
+                                            mid_budget_s=max(0.0, budget.left() - budget.reserve - 35.0),      # (its own device runs: ~35 s)
                                             ms_per_eval=cpu["full_size"].get("cpu_ms_per_evaluation"))
                         cpu["full_size"]["mid_theta"] = (more or {}).get("mid_theta")
                     except Exception as e:
