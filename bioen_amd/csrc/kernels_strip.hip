@@ -1678,7 +1678,7 @@ static void relayout_strip_copies(bioen_hip_ctx* c, int want) {
     for (int p = 0; p < np; ++p) {
         const int mps = paneled(c) ? panel_mps(c, p) : strip_rows(c);
         const double* from = paneled(c) ? c->Yp[p] : c->Ys;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&made[p]), (size_t)nstrips * mps * kStripCols * sizeof(double));
+        hipError_t e = strip_malloc(c, &made[p], (size_t)nstrips * mps * kStripCols * sizeof(double));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_relayout, dim3(std::min(nstrips, 4096)), dim3(256), 0, c->stream, from, made[p], mps, nstrips,
                                strip_sps(c), strip_ilv(c), want);

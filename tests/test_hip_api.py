@@ -874,6 +874,37 @@ def test_strip_layout_follows_the_method_and_changes_no_bit(M, N, monkeypatch):
         same(a["forces"], other["forces"])
 
 
+def test_a_strip_copy_that_cannot_be_moved_stays_and_serves(monkeypatch):
+    """The move of the row-sum order copy into the other method's layout is best effort: when the buffer for it cannot be
+    allocated (forced here: the context's third strip allocation fails) the copy stays as it is -- every kernel reads
+    either layout -- and not a bit of the results changes."""
+    import bioen_amd
+    M, N = 300, 6000
+    rng = np.random.default_rng(99)
+    YTrue = rng.uniform(1, 10, M)
+    y = rng.normal(YTrue[:, None], 0.5 * YTrue[:, None], (M, N)) / (0.1 * YTrue[:, None])
+    YT = rng.normal(YTrue, 0.1 * YTrue) / (0.1 * YTrue)
+    G = np.log(rng.dirichlet(np.ones(N) * 2.0))
+    g = G + 0.2 * rng.standard_normal(N)
+    w0 = rng.dirichlet(np.ones(N) * 2.0)
+    f0 = 1e-3 * rng.standard_normal(M)
+    with bioen_amd.Context(y, YT) as ctx:
+        ref_l = ctx.logw_fdf(g, G, 5.0)
+        ref_f = ctx.forces_fdf(f0, w0, 5.0)
+        assert ctx.layout() == {"one_copy": 0, "interleave": 1, "relayouts": 1}
+    monkeypatch.setenv("BIOEN_HIP_TEST_FAIL_STRIP_ALLOC", "3")          # 1, 2: the two strip copies; 3: the move's buffer
+    with bioen_amd.Context(y, YT) as ctx:
+        got_l = ctx.logw_fdf(g, G, 5.0)
+        got_f = ctx.forces_fdf(f0, w0, 5.0)                              # wants strip order, cannot have it
+        assert ctx.layout() == {"one_copy": 0, "interleave": 8, "relayouts": 0}
+        again = ctx.forces_fdf(f0, w0, 5.0)                              # (tries again: this time the buffer is there)
+        assert ctx.layout()["interleave"] == 1
+        assert np.array_equal(ctx.read_ytilde(), y)
+    assert got_l[0] == ref_l[0] and np.array_equal(got_l[1], ref_l[1])
+    for r in (got_f, again):
+        assert r[0] == ref_f[0] and np.array_equal(r[1], ref_f[1])
+
+
 @pytest.mark.parametrize("M,N", [(37, 3000), (512, 20000), (1024, 6000), (1100, 3000)])
 def test_single_segment_opt_out_on_one_gpu(M, N, monkeypatch):
     """BIOEN_HIP_SEGMENTS=1 (r06): an unsharded context with ONE column segment instead of the canonical eight -- every
