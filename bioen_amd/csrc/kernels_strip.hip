@@ -1279,7 +1279,9 @@ __global__ __launch_bounds__(1024) void k_strip_fwd(StripArgs q, Vec8 v) {
 // N = 1e6 x M = 1024 against 1.17-1.21 (nothing), K > 4: 1.71 ms against 1.21-1.26 (the second set does not fit beside
 // 2 x 16 operand registers of u).  What a launch takes moves by 4-5 % with the process and the box (the first 0.2 s of a
 // process, where the copy landed in HBM: tools/pass_probe.py shows it for both passes and for the plain read probe alike),
-// not with bytes in flight.
+// not with bytes in flight.  Nor does it help at K > 4 to move the 16 centred operands out of the load registers first and
+// request the next strip before the 32 products (what the one-copy form k_strip2<ADJ> gains 4 % from, below): 1.231-1.258 ms
+// either way at N = 1e6 x M = 1024, K = 8 (three alternations, one box).
 template <int K, bool NT, int STORE = 0>
 __global__ __launch_bounds__(1024) void k_strip_adj(StripArgs q, MVec8 out, MVec8 scal) {
     constexpr int NK = (K + 3) / 4;
